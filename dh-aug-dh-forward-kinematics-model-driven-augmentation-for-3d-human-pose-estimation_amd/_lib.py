@@ -1,0 +1,68 @@
+"""ctypes binding of libdhaug.so (include/dhaug.h).  Loaded lazily; never falls back to anything else."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("DHAUG_LIB", os.path.join(_HERE, "lib", "libdhaug.so"))
+
+_vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+
+# name -> argtypes, in the order of include/dhaug.h
+SIGNATURES = {
+    "dhaug_fk_forward": [_vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    "dhaug_fk_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "dhaug_gen_tail_forward": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    "dhaug_gen_tail_backward": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    "dhaug_bone_length": [_vp, _vp, _i64, _vp],
+    "dhaug_kcs_forward": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "dhaug_kcs_backward": [_vp, _vp, _vp, _i64, _i32, _vp],
+    "dhaug_kcs_jvp": [_vp, _vp, _vp, _i64, _i32, _vp],
+    "dhaug_world_to_camera_project": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "dhaug_world_to_camera_project_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "dhaug_camera_to_world": [_vp, _vp, _vp, _vp, _i64, _vp],
+    "dhaug_center_flip": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    "dhaug_center_flip_backward": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    "dhaug_gemm_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i32,
+                        _f32, _vp],
+    "dhaug_gemm_tn_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
+    "dhaug_cast_pad_bf16": [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp],
+    "dhaug_cast_transpose_bf16": [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp],
+    "dhaug_split3_bf16": [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp],
+    "dhaug_colsum_f32": [_vp, _i64, _vp, _i64, _i64, _i32, _vp],
+    "dhaug_colsum_bf16": [_vp, _i64, _vp, _i64, _i64, _i32, _vp],
+    "dhaug_act_backward_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i32, _f32, _vp],
+    "dhaug_act_backward_f32": [_vp, _vp, _vp, _i64, _i32, _f32, _vp],
+    "dhaug_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp],
+}
+
+ERRORS = {-1: "DHAUG_EINVAL (bad argument)", -2: "DHAUG_EALIGN (alignment contract violated)",
+          -3: "DHAUG_EUNSUPPORTED (shape not implemented)"}
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises RuntimeError if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libdhaug.so not found at %s: build it with `python __graft_entry__.py build` "
+                               "(there is no fallback path)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.dhaug_version.restype = ctypes.c_int
+        L.dhaug_arch.restype = ctypes.c_char_p
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc, name):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (name, ERRORS.get(rc, "hipError_t %d" % rc)))
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)

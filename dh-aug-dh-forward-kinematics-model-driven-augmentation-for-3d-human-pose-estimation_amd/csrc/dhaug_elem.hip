@@ -1,0 +1,239 @@
+// Streaming helpers of the training step: operand packing (fp32 -> bf16, transposed, bf16x3 split), column
+// sums (bias gradients), activation backward, fused Adam.  All HBM-bound; 16-byte accesses where the layout
+// allows, grid-stride loops over >= 2048 workgroups.
+#include "dhaug_common.h"
+
+namespace {
+
+int grid1d(long long items, int block) {
+    long long b = (items + block - 1) / block;
+    if (b > 256 * 16) b = 256 * 16;
+    return (int)(b < 1 ? 1 : b);
+}
+
+// dst (rows, ld_dst) bf16 <- src (rows, cols) fp32, zero in [cols, pad_cols).  One thread per packed pair.
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, long long ld_src,
+                                                       uint16_t* __restrict__ dst, long long ld_dst, long long rows,
+                                                       long long cols, long long pad_cols) {
+    const long long ppr = pad_cols >> 1;                       // pad_cols is even
+    const long long total = rows * ppr;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / ppr, c = (i - r * ppr) * 2;
+        const float a = c < cols ? src[r * ld_src + c] : 0.0f;
+        const float b = c + 1 < cols ? src[r * ld_src + c + 1] : 0.0f;
+        *reinterpret_cast<uint32_t*>(dst + r * ld_dst + c) =
+            (uint32_t)dhaug_f32_to_bf16(a) | ((uint32_t)dhaug_f32_to_bf16(b) << 16);
+    }
+}
+
+// dst (cols, ld_dst) bf16 <- src (rows, cols)^T through a 32x33 LDS tile; zero in [rows, pad_cols).
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, long long ld_src,
+                                                             uint16_t* __restrict__ dst, long long ld_dst,
+                                                             long long rows, long long cols, long long pad_cols) {
+    __shared__ float t[32][33];
+    const long long tiles_r = (pad_cols + 31) / 32, tiles_c = (cols + 31) / 32;
+    for (long long tile = blockIdx.x; tile < tiles_r * tiles_c; tile += gridDim.x) {
+        const long long r0 = (tile / tiles_c) * 32, c0 = (tile % tiles_c) * 32;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int k = ty; k < 32; k += 8) {
+            const long long r = r0 + k, c = c0 + tx;
+            t[k][tx] = (r < rows && c < cols) ? src[r * ld_src + c] : 0.0f;
+        }
+        __syncthreads();
+        for (int k = ty; k < 32; k += 8) {
+            const long long c = c0 + k, r = r0 + tx;           // dst[c][r]
+            if (c < cols && r < pad_cols) dst[c * ld_dst + r] = dhaug_f32_to_bf16(t[tx][k]);
+        }
+        __syncthreads();
+    }
+}
+
+// bf16x3: x = hi + lo; activation side [hi|hi|lo], weight side [hi|lo|hi]
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, long long ld_src,
+                                                     uint16_t* __restrict__ dst, long long rows, long long cols,
+                                                     long long pad_cols, int mode) {
+    const long long total = rows * pad_cols;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / pad_cols, c = i - r * pad_cols;
+        const float x = c < cols ? src[r * ld_src + c] : 0.0f;
+        const uint16_t hi = dhaug_f32_to_bf16(x);
+        const uint16_t lo = dhaug_f32_to_bf16(x - dhaug_bf16_to_f32(hi));
+        uint16_t* row = dst + r * 3 * pad_cols;
+        row[c] = hi;
+        row[pad_cols + c] = mode == 0 ? hi : lo;
+        row[2 * pad_cols + c] = mode == 0 ? lo : hi;
+    }
+}
+
+// column sums: block (x) covers 64 columns, (y) a slab of rows; 4 row-lanes per column, LDS combine, atomics out
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ src, long long ld, float* __restrict__ dst,
+                                                     long long M, long long N, long long rows_per_block) {
+    __shared__ float part[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const long long col = (long long)blockIdx.x * 64 + cx;
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float s = 0.0f;
+    if (col < N) {
+        for (long long r = r0 + ry; r < r1; r += 4) {
+            if constexpr (sizeof(T) == 2) s += dhaug_bf16_to_f32((uint16_t)src[r * ld + col]);
+            else s += (float)src[r * ld + col];
+        }
+    }
+    part[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && col < N) atomicAdd(dst + col, part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx]);
+}
+
+__global__ __launch_bounds__(256) void act_backward_kernel(const uint16_t* __restrict__ g, long long ld_g,
+                                                           const uint16_t* __restrict__ y, long long ld_y,
+                                                           uint16_t* __restrict__ dst, long long ld_dst, long long M,
+                                                           long long N8, int act, float slope) {
+    // N8 = 16-byte chunks per row
+    const long long total = M * N8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / N8, c = (i - r * N8) * 8;
+        const uint4 gv = *reinterpret_cast<const uint4*>(g + r * ld_g + c);
+        const uint4 yv = *reinterpret_cast<const uint4*>(y + r * ld_y + c);
+        const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+        uint32_t ow[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float g0 = __builtin_bit_cast(float, gw[e] << 16), g1 = __builtin_bit_cast(float, gw[e] & 0xffff0000u);
+            const float y0 = __builtin_bit_cast(float, yw[e] << 16), y1 = __builtin_bit_cast(float, yw[e] & 0xffff0000u);
+            const float neg = act == DHAUG_ACT_RELU ? 0.0f : (act == DHAUG_ACT_LRELU ? slope : 1.0f);
+            g0 = y0 > 0.0f ? g0 : g0 * neg;
+            g1 = y1 > 0.0f ? g1 : g1 * neg;
+            ow[e] = (uint32_t)dhaug_f32_to_bf16(g0) | ((uint32_t)dhaug_f32_to_bf16(g1) << 16);
+        }
+        *reinterpret_cast<uint4*>(dst + r * ld_dst + c) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void act_backward_f32_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                               float* __restrict__ dst, long long n, int act, float slope) {
+    const float neg = act == DHAUG_ACT_RELU ? 0.0f : (act == DHAUG_ACT_LRELU ? slope : 1.0f);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        dst[i] = y[i] > 0.0f ? g[i] : g[i] * neg;
+}
+
+// torch.optim.Adam (no amsgrad, no weight decay): m,v update, bias correction, p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long long n, float lr,
+                                                   float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                   float gscale) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i] * gscale;
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);            // lerp form used by ATen
+        const float vi = v[i] * b2 + gi * gi * (1.0f - b2);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - (lr / bc1) * (mi / denom);
+    }
+}
+
+}  // namespace
+
+template <typename T>
+static int colsum_impl(const T* src, int64_t ld, float* dst, int64_t M, int64_t N, int accumulate, void* stream) {
+    DHAUG_CHECK(M >= 0 && N >= 1 && ld >= N, DHAUG_EINVAL);
+    DHAUG_CHECK_PTR(dst);
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(dst, 0, (size_t)N * 4, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (M == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(src);
+    const long long col_blocks = (N + 63) / 64;
+    long long slabs = 1024 / col_blocks;
+    if (slabs < 1) slabs = 1;
+    long long rpb = (M + slabs - 1) / slabs;
+    if (rpb < 64) rpb = 64;
+    slabs = (M + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colsum_kernel<T>, dim3((unsigned)col_blocks, (unsigned)slabs), dim3(256), 0, s, src, (long long)ld,
+                       dst, (long long)M, (long long)N, rpb);
+    return dhaug_launch_status();
+}
+
+extern "C" {
+
+int dhaug_version(void) { return DHAUG_VERSION; }
+const char* dhaug_arch(void) { return "gfx950"; }
+
+int dhaug_cast_pad_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int64_t rows, int64_t cols,
+                        int64_t pad_cols, void* stream) {
+    DHAUG_CHECK(rows >= 0 && cols >= 1 && pad_cols >= cols && ld_src >= cols && ld_dst >= pad_cols, DHAUG_EINVAL);
+    if (rows == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(src); DHAUG_CHECK_PTR(dst);
+    DHAUG_CHECK((pad_cols & 1) == 0 && (ld_dst & 1) == 0 && (reinterpret_cast<uintptr_t>(dst) & 3) == 0, DHAUG_EALIGN);
+    hipLaunchKernelGGL(cast_pad_kernel, dim3(grid1d(rows * (pad_cols / 2), 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (long long)ld_src, dst, (long long)ld_dst, (long long)rows, (long long)cols, (long long)pad_cols);
+    return dhaug_launch_status();
+}
+
+int dhaug_cast_transpose_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int64_t rows,
+                              int64_t cols, int64_t pad_cols, void* stream) {
+    DHAUG_CHECK(rows >= 1 && cols >= 1 && pad_cols >= rows && ld_src >= cols && ld_dst >= pad_cols, DHAUG_EINVAL);
+    DHAUG_CHECK_PTR(src); DHAUG_CHECK_PTR(dst);
+    const long long tiles = ((pad_cols + 31) / 32) * ((cols + 31) / 32);
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3(grid1d(tiles, 1)), dim3(256), 0, (hipStream_t)stream, src,
+                       (long long)ld_src, dst, (long long)ld_dst, (long long)rows, (long long)cols, (long long)pad_cols);
+    return dhaug_launch_status();
+}
+
+int dhaug_split3_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t rows, int64_t cols, int64_t pad_cols,
+                      int mode, void* stream) {
+    DHAUG_CHECK(rows >= 0 && cols >= 1 && pad_cols >= cols && ld_src >= cols && (mode == 0 || mode == 1), DHAUG_EINVAL);
+    if (rows == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(src); DHAUG_CHECK_PTR(dst);
+    hipLaunchKernelGGL(split3_kernel, dim3(grid1d(rows * pad_cols, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (long long)ld_src, dst, (long long)rows, (long long)cols, (long long)pad_cols, mode);
+    return dhaug_launch_status();
+}
+
+int dhaug_colsum_f32(const float* src, int64_t ld, float* dst, int64_t M, int64_t N, int accumulate, void* stream) {
+    return colsum_impl<float>(src, ld, dst, M, N, accumulate, stream);
+}
+int dhaug_colsum_bf16(const uint16_t* src, int64_t ld, float* dst, int64_t M, int64_t N, int accumulate, void* stream) {
+    return colsum_impl<uint16_t>(src, ld, dst, M, N, accumulate, stream);
+}
+
+int dhaug_act_backward_bf16(const uint16_t* g, int64_t ld_g, const uint16_t* y, int64_t ld_y, uint16_t* dst,
+                            int64_t ld_dst, int64_t M, int64_t N, int act, float slope, void* stream) {
+    DHAUG_CHECK(M >= 0 && N >= 8, DHAUG_EINVAL);
+    DHAUG_CHECK(act >= DHAUG_ACT_NONE && act <= DHAUG_ACT_LRELU, DHAUG_EINVAL);
+    if (M == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(g); DHAUG_CHECK_PTR(y); DHAUG_CHECK_PTR(dst);
+    DHAUG_CHECK(N % 8 == 0 && ld_g % 8 == 0 && ld_y % 8 == 0 && ld_dst % 8 == 0, DHAUG_EALIGN);
+    DHAUG_CHECK(dhaug_aligned16(g) && dhaug_aligned16(y) && dhaug_aligned16(dst), DHAUG_EALIGN);
+    hipLaunchKernelGGL(act_backward_kernel, dim3(grid1d(M * (N / 8), 256)), dim3(256), 0, (hipStream_t)stream, g,
+                       (long long)ld_g, y, (long long)ld_y, dst, (long long)ld_dst, (long long)M, (long long)(N / 8), act,
+                       slope);
+    return dhaug_launch_status();
+}
+
+int dhaug_act_backward_f32(const float* g, const float* y, float* dst, int64_t n, int act, float slope, void* stream) {
+    DHAUG_CHECK(n >= 0 && act >= DHAUG_ACT_NONE && act <= DHAUG_ACT_LRELU, DHAUG_EINVAL);
+    if (n == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(g); DHAUG_CHECK_PTR(y); DHAUG_CHECK_PTR(dst);
+    hipLaunchKernelGGL(act_backward_f32_kernel, dim3(grid1d(n, 256)), dim3(256), 0, (hipStream_t)stream, g, y, dst,
+                       (long long)n, act, slope);
+    return dhaug_launch_status();
+}
+
+int dhaug_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                    float beta2, float eps, int step, float grad_scale, void* stream) {
+    DHAUG_CHECK(n >= 0 && step >= 1, DHAUG_EINVAL);
+    if (n == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(param); DHAUG_CHECK_PTR(grad); DHAUG_CHECK_PTR(exp_avg); DHAUG_CHECK_PTR(exp_avg_sq);
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, (long long)n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+    return dhaug_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,299 @@
+// Fused DH forward-kinematics kernels (forward, generator-tail forward, and their reverse modes).
+//
+// Mapping: one wave (64 lanes) = one tile of 64 poses; one lane = one pose, whole skeleton in registers
+// (dhaug_fk_math.h).  A workgroup is a single wave so that LDS (the occupancy limiter here) is allocated
+// in 14.5 KB units: up to 10 workgroups per CU.
+//
+// HBM <-> lane transposition goes through LDS: the tile's input rows are contiguous in memory
+// (64 x 37 angles, 64 x 15 lengths, 64 x 3 root), so the wave copies them with 16-byte-per-lane coalesced
+// loads into an LDS image with the same layout; lane i then reads row i (row strides 37 / 15 / 3 / 35 / 8
+// dwords are odd -> conflict-free ds_read_b32).  Results are written to LDS with an odd row stride (49 / 97 /
+// 37 ...) and leave as fully coalesced stores.  Algorithmic HBM traffic: 220 B in + 192 B out = 412 B/pose.
+#include "dhaug_fk_math.h"
+
+using namespace dhaug_fk;
+
+namespace {
+
+constexpr int TILE = 64;
+
+// coalesced copy of `count` floats global -> LDS (same linear layout); base of g is 16-byte aligned
+__device__ __forceinline__ void stage_in(const float* __restrict__ g, float* __restrict__ l, int count, int lane) {
+    const int n4 = count >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* l4 = reinterpret_cast<float4*>(l);
+    for (int i = lane; i < n4; i += TILE) l4[i] = g4[i];
+    const int rem = count & 3;
+    if (lane < rem) l[(n4 << 2) + lane] = g[(n4 << 2) + lane];
+}
+
+// LDS image with row stride LSTRIDE (odd) -> contiguous global rows of W floats
+template <int W, int LSTRIDE>
+__device__ __forceinline__ void stage_out(const float* __restrict__ l, float* __restrict__ g, int rows, int lane) {
+    const int count = rows * W;
+    for (int e = lane; e < count; e += TILE) {
+        const int r = e / W, j = e - r * W;
+        g[e] = l[r * LSTRIDE + j];
+    }
+}
+template <int W, int LSTRIDE>
+__device__ __forceinline__ void stage_in_strided(const float* __restrict__ g, float* __restrict__ l, int rows, int lane) {
+    const int count = rows * W;
+    for (int e = lane; e < count; e += TILE) {
+        const int r = e / W, j = e - r * W;
+        l[r * LSTRIDE + j] = g[e];
+    }
+}
+
+__device__ __forceinline__ float tanh_acc(float x) { return tanhf(x); }
+
+// MODE 0: in0 = angles (N,37), in2 = root (N,3).      MODE 1: in0 = head (N,35), in2 = scaler (N,8) or null.
+template <int MODE> struct InLayout;
+template <> struct InLayout<0> { static constexpr int W0 = 37, W2 = 3; };
+template <> struct InLayout<1> { static constexpr int W0 = 35, W2 = 8; };
+
+// Loads this lane's pose from the LDS image and produces ang[37], bl[15], root.
+template <int MODE, bool PREANGLE>
+__device__ __forceinline__ void load_pose(const float* __restrict__ l0, const float* __restrict__ l1,
+                                          const float* __restrict__ l2, bool has2, int lane,
+                                          float* __restrict__ ang, float* __restrict__ bl, V3& root,
+                                          float* __restrict__ th /*35, MODE 1 only*/) {
+    if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 37; ++j) ang[j] = l0[lane * 37 + j];
+#pragma unroll
+        for (int j = 0; j < 15; ++j) bl[j] = l1[lane * 15 + j];
+        root = mk(l2[lane * 3 + 0], l2[lane * 3 + 1], l2[lane * 3 + 2]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 35; ++j) th[j] = tanh_acc(l0[lane * 35 + j]);
+        tail_angles<PREANGLE>(th, ang);
+        root = mk(th[32] * 10.0f, th[33] * 10.0f, th[34] * 10.0f);
+        float sc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sc[j] = has2 ? l2[lane * 8 + j] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 15; ++j) {
+            const float len = l1[lane * 15 + j];
+            bl[j] = kJitterCol[j] < 0 ? len : len * (1.0f + sc[kJitterCol[j] < 0 ? 0 : kJitterCol[j]]);
+        }
+    }
+}
+
+constexpr int kTo32[16] = {0, 1, 2, 3, 6, 7, 8, 12, 13, 15, 17, 18, 19, 25, 26, 27};
+
+template <int MODE, int OUTJ, bool PREANGLE>
+__global__ __launch_bounds__(TILE) void fk_forward_kernel(const float* __restrict__ in0,
+                                                          const float* __restrict__ bone_len,
+                                                          const float* __restrict__ in2,
+                                                          float* __restrict__ out, float* __restrict__ angles_out,
+                                                          long long N) {
+    using L = InLayout<MODE>;
+    constexpr int OW = OUTJ * 3, OS = OW + 1;                  // output row width / odd LDS stride
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const long long ntiles = (N + TILE - 1) / TILE;
+    float* l0 = smem;                                          // 64 x W0
+    float* l1 = l0 + TILE * L::W0 + ((TILE * L::W0) & 3 ? 4 - ((TILE * L::W0) & 3) : 0);
+    float* l2 = l1 + TILE * 15;
+    const bool has2 = in2 != nullptr;
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long base = tile * TILE;
+        const int rows = (int)((N - base) < TILE ? (N - base) : TILE);
+        stage_in(in0 + base * L::W0, l0, rows * L::W0, lane);
+        stage_in(bone_len + base * 15, l1, rows * 15, lane);
+        if (has2) stage_in(in2 + base * L::W2, l2, rows * L::W2, lane);
+        __syncthreads();
+
+        float ang[37], bl[15], th[35];
+        V3 root, p[16];
+        const int src = lane < rows ? lane : 0;                // idle lanes recompute row 0 (never stored)
+        load_pose<MODE, PREANGLE>(l0, l1, l2, has2, src, ang, bl, root, th);
+        if (MODE == 0 && !has2) root = mk(0.f, 0.f, 0.f);
+        fk_pose(ang, bl, p);
+        __syncthreads();                                       // all lanes have consumed the input image
+
+        float* lo = smem;
+        if (OUTJ == 16) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                lo[lane * OS + 3 * j + 0] = p[j].x + root.x;
+                lo[lane * OS + 3 * j + 1] = p[j].y + root.y;
+                lo[lane * OS + 3 * j + 2] = p[j].z + root.z;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {                     // rows the reference never writes stay = root
+                lo[lane * OS + 3 * j + 0] = root.x; lo[lane * OS + 3 * j + 1] = root.y; lo[lane * OS + 3 * j + 2] = root.z;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int s = kTo32[j];
+                lo[lane * OS + 3 * s + 0] = p[j].x + root.x;
+                lo[lane * OS + 3 * s + 1] = p[j].y + root.y;
+                lo[lane * OS + 3 * s + 2] = p[j].z + root.z;
+            }
+            // slot 14 ('Neck/Nose') = slot 15 ('Head'), forward_kinematics_DH_model.py:787-793
+            lo[lane * OS + 42] = p[9].x + root.x; lo[lane * OS + 43] = p[9].y + root.y; lo[lane * OS + 44] = p[9].z + root.z;
+        }
+        __syncthreads();
+        stage_out<OW, OS>(lo, out + base * OW, rows, lane);
+        if (MODE == 1 && angles_out != nullptr) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 37; ++j) lo[lane * 37 + j] = ang[j];
+            __syncthreads();
+            stage_out<37, 37>(lo, angles_out + base * 37, rows, lane);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------
+// LDS: [in0 64xW0 | bone 64x15 | in2 64xW2]  reused for the gradient image, then [grad_out 64 x 49].
+template <int MODE, bool PREANGLE>
+__global__ __launch_bounds__(TILE) void fk_backward_kernel(const float* __restrict__ in0,
+                                                           const float* __restrict__ bone_len,
+                                                           const float* __restrict__ in2,
+                                                           const float* __restrict__ grad_out,
+                                                           float* __restrict__ g0 /*grad angles | grad head*/,
+                                                           float* __restrict__ g1 /*grad bone_len (MODE 0)*/,
+                                                           float* __restrict__ g2 /*grad root (MODE 0)*/,
+                                                           long long N) {
+    using L = InLayout<MODE>;
+    constexpr int GS = 49;
+    constexpr int A_FLOATS = TILE * 64;                        // region A: >= 64 x (37+15+8), 16-byte multiple
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const long long ntiles = (N + TILE - 1) / TILE;
+    float* l0 = smem;
+    float* l1 = l0 + TILE * L::W0 + ((TILE * L::W0) & 3 ? 4 - ((TILE * L::W0) & 3) : 0);
+    float* l2 = l1 + TILE * 15;
+    float* lg = smem + A_FLOATS;                               // 64 x 49
+    const bool has2 = in2 != nullptr;
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long base = tile * TILE;
+        const int rows = (int)((N - base) < TILE ? (N - base) : TILE);
+        stage_in(in0 + base * L::W0, l0, rows * L::W0, lane);
+        stage_in(bone_len + base * 15, l1, rows * 15, lane);
+        if (MODE == 1 && has2) stage_in(in2 + base * L::W2, l2, rows * L::W2, lane);
+        stage_in_strided<48, GS>(grad_out + base * 48, lg, rows, lane);
+        __syncthreads();
+
+        float ang[37], bl[15], th[35], gang[37], gbl[15];
+        V3 root, groot;
+        const int src = lane < rows ? lane : 0;
+        load_pose<MODE, PREANGLE>(l0, l1, l2, has2, src, ang, bl, root, th);
+        const float* mine = lg + src * GS;
+        fk_pose_backward(ang, bl, [&](int j) { return mk(mine[3 * j], mine[3 * j + 1], mine[3 * j + 2]); },
+                         gang, gbl, groot);
+        __syncthreads();
+        if (MODE == 0) {
+            float* o0 = smem;                                  // 64 x 37 | 64 x 15 | 64 x 3
+            float* o1 = o0 + TILE * 37;
+            float* o2 = o1 + TILE * 15;
+#pragma unroll
+            for (int j = 0; j < 37; ++j) o0[lane * 37 + j] = gang[j];
+#pragma unroll
+            for (int j = 0; j < 15; ++j) o1[lane * 15 + j] = gbl[j];
+            o2[lane * 3 + 0] = groot.x; o2[lane * 3 + 1] = groot.y; o2[lane * 3 + 2] = groot.z;
+            __syncthreads();
+            stage_out<37, 37>(o0, g0 + base * 37, rows, lane);
+            stage_out<15, 15>(o1, g1 + base * 15, rows, lane);
+            stage_out<3, 3>(o2, g2 + base * 3, rows, lane);
+        } else {
+            float* o0 = smem;                                  // 64 x 35
+            float gh[35];
+#pragma unroll
+            for (int c = 0; c < 35; ++c) gh[c] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 37; ++i) {
+                const int col = kSlotCol[i];
+                if (col >= 0) gh[col] = gang[i] * tail_scale<PREANGLE>(i);
+            }
+            gh[32] = groot.x * 10.0f; gh[33] = groot.y * 10.0f; gh[34] = groot.z * 10.0f;
+#pragma unroll
+            for (int c = 0; c < 35; ++c) o0[lane * 35 + c] = gh[c] * fmaf(-th[c], th[c], 1.0f);
+            __syncthreads();
+            stage_out<35, 35>(o0, g0 + base * 35, rows, lane);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename K, typename... Args>
+int launch_tiles(K kernel, size_t lds_bytes, long long N, void* stream, Args... args) {
+    if (N == 0) return DHAUG_OK;
+    const long long ntiles = (N + TILE - 1) / TILE;
+    const int grid = dhaug_stream_grid(ntiles, 1, 256 * 10 * 4);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(TILE), lds_bytes, (hipStream_t)stream, args..., N);
+    return dhaug_launch_status();
+}
+
+constexpr size_t fwd_lds(int w_in, int w_out) {
+    size_t a = (size_t)TILE * (w_in + 3) * 4, b = (size_t)TILE * (w_out + 1) * 4;   // +3: 16-byte padding slack
+    return a > b ? a : b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dhaug_fk_forward(const float* angles, const float* bone_len, const float* root, float* out, int64_t N,
+                     int out_joints, void* stream) {
+    DHAUG_CHECK(N >= 0, DHAUG_EINVAL);
+    DHAUG_CHECK(out_joints == 16 || out_joints == 32, DHAUG_EINVAL);
+    if (N == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(angles); DHAUG_CHECK_PTR(bone_len); DHAUG_CHECK_PTR(out);
+    DHAUG_CHECK(dhaug_aligned16(angles) && dhaug_aligned16(bone_len) && dhaug_aligned16(root) && dhaug_aligned16(out),
+                DHAUG_EALIGN);
+    if (out_joints == 16)
+        return launch_tiles(fk_forward_kernel<0, 16, true>, fwd_lds(55, 48), N, stream, angles, bone_len, root, out,
+                            (float*)nullptr);
+    return launch_tiles(fk_forward_kernel<0, 32, true>, fwd_lds(55, 96), N, stream, angles, bone_len, root, out,
+                        (float*)nullptr);
+}
+
+int dhaug_fk_backward(const float* angles, const float* bone_len, const float* grad_out16, float* grad_angles,
+                      float* grad_bone_len, float* grad_root, int64_t N, void* stream) {
+    DHAUG_CHECK(N >= 0, DHAUG_EINVAL);
+    if (N == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(angles); DHAUG_CHECK_PTR(bone_len); DHAUG_CHECK_PTR(grad_out16);
+    DHAUG_CHECK_PTR(grad_angles); DHAUG_CHECK_PTR(grad_bone_len); DHAUG_CHECK_PTR(grad_root);
+    DHAUG_CHECK(dhaug_aligned16(angles) && dhaug_aligned16(bone_len), DHAUG_EALIGN);
+    return launch_tiles(fk_backward_kernel<0, true>, (size_t)TILE * (64 + 49) * 4, N, stream, angles, bone_len,
+                        (const float*)nullptr, grad_out16, grad_angles, grad_bone_len, grad_root);
+}
+
+int dhaug_gen_tail_forward(const float* head, const float* bone_len, const float* scaler, float* fake16,
+                           float* angles_out, int64_t N, int use_preangle, void* stream) {
+    DHAUG_CHECK(N >= 0, DHAUG_EINVAL);
+    if (N == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(head); DHAUG_CHECK_PTR(bone_len); DHAUG_CHECK_PTR(fake16);
+    DHAUG_CHECK(dhaug_aligned16(head) && dhaug_aligned16(bone_len) && dhaug_aligned16(scaler), DHAUG_EALIGN);
+    if (use_preangle)
+        return launch_tiles(fk_forward_kernel<1, 16, true>, fwd_lds(58, 48), N, stream, head, bone_len, scaler, fake16,
+                            angles_out);
+    return launch_tiles(fk_forward_kernel<1, 16, false>, fwd_lds(58, 48), N, stream, head, bone_len, scaler, fake16,
+                        angles_out);
+}
+
+int dhaug_gen_tail_backward(const float* head, const float* bone_len, const float* scaler, const float* grad_fake16,
+                            float* grad_head, int64_t N, int use_preangle, void* stream) {
+    DHAUG_CHECK(N >= 0, DHAUG_EINVAL);
+    if (N == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(head); DHAUG_CHECK_PTR(bone_len); DHAUG_CHECK_PTR(grad_fake16); DHAUG_CHECK_PTR(grad_head);
+    DHAUG_CHECK(dhaug_aligned16(head) && dhaug_aligned16(bone_len) && dhaug_aligned16(scaler), DHAUG_EALIGN);
+    const size_t lds = (size_t)TILE * (64 + 49) * 4;
+    if (use_preangle)
+        return launch_tiles(fk_backward_kernel<1, true>, lds, N, stream, head, bone_len, scaler, grad_fake16, grad_head,
+                            (float*)nullptr, (float*)nullptr);
+    return launch_tiles(fk_backward_kernel<1, false>, lds, N, stream, head, bone_len, scaler, grad_fake16, grad_head,
+                        (float*)nullptr, (float*)nullptr);
+}
+
+}  // extern "C"

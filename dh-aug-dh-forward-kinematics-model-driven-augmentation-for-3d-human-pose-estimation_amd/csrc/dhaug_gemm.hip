@@ -1,0 +1,414 @@
+// bf16 MFMA GEMMs for the generator / critic dense layers (gfx950: v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+//
+//   gemm_nt : C[M,N] = act(A[M,K] * B[N,K]^T + bias + residual)     forward layers and input gradients
+//             (nn.Linear weight layout [out,in]: both operands contraction-contiguous)
+//   gemm_tn : C[N1,N2] += A[M,N1]^T * B[M,N2]                        weight gradients (contraction over the batch)
+//
+// Orientation.  The MFMA is issued "swapped": its A operand is the weight fragment (rows = output
+// features n) and its B operand the activation fragment (columns = batch rows m), so a lane of the
+// accumulator owns one batch row and 4 consecutive features per register quad.  That makes the epilogue's LDS
+// write a conflict-free ds_write_b128 and keeps the layout that a fused multi-layer kernel can feed straight
+// back as the next MFMA's B operand (cdna_hip_programming.md section 3, accumulator-as-operand).
+//
+// LDS images.  NT tiles are [rows][64 k] bf16 (128-B rows); the 16-byte chunk index is XOR-swizzled with
+// (row >> 1) & 7 so that every ds_read_b128 lane group touches all 64 banks exactly once (two rows share a
+// 256-B bank row; eight row pairs take eight different chunks).  TN tiles keep the global row-major layout
+// [64 m][160] (320-B rows: consecutive rows shift by 16 banks) and are read with ds_read_b64_tr_b16, the
+// hardware transpose read, because the contraction index m is the slow axis in memory.
+#include "dhaug_common.h"
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct GemmArgs {
+    const uint16_t* A; long long lda;
+    const uint16_t* B; long long ldb;
+    const float* bias;
+    const uint16_t* res; long long ld_res;
+    const float* resf; long long ld_resf;
+    uint16_t* cb; long long ldcb; long long npad;
+    float* cf; long long ldcf;
+    long long M, N, K, W;          // W = output width covered by tiles (N, or the zero-padded width)
+    int act; float slope;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    if (act == DHAUG_ACT_RELU) return v > 0.0f ? v : 0.0f;
+    if (act == DHAUG_ACT_LRELU) return v > 0.0f ? v : v * slope;
+    return v;
+}
+
+constexpr int BK = 64;
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_CH = BM * 8 / 256, B_CH = (BN * 8 + 255) / 256;
+    constexpr int CS = BN + 4;                                  // fp32 C-tile row stride (16-byte multiple, 4 mod 32)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint16_t* sA = reinterpret_cast<uint16_t*>(smem_raw);      // [2][BM*BK]
+    uint16_t* sB = sA + 2 * BM * BK;                            // [2][BN*BK]
+    float* sC = reinterpret_cast<float*>(smem_raw);             // [BM][CS], reuses the staging buffers
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const long long ntn = (p.W + BN - 1) / BN;
+    const long long m0 = (long long)(blockIdx.x / ntn) * BM;
+    const long long n0 = (long long)(blockIdx.x % ntn) * BN;
+
+    uint4 ra[A_CH], rb[B_CH];
+    auto gload = [&](int kt) {
+        const long long k0 = (long long)kt * BK;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int q = tid + 256 * i, row = q >> 3, c = q & 7;
+            const long long gm = m0 + row, kk = k0 + c * 8;
+            ra[i] = (gm < p.M && kk < p.K) ? *reinterpret_cast<const uint4*>(p.A + gm * p.lda + kk) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) {
+            const int q = tid + 256 * i, row = q >> 3, c = q & 7;
+            const long long gn = n0 + row, kk = k0 + c * 8;
+            rb[i] = (row < BN && gn < p.N && kk < p.K) ? *reinterpret_cast<const uint4*>(p.B + gn * p.ldb + kk)
+                                                       : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int q = tid + 256 * i, row = q >> 3, c = q & 7;
+            *reinterpret_cast<uint4*>(sA + buf * BM * BK + row * BK + ((c ^ ((row >> 1) & 7)) << 3)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) {
+            const int q = tid + 256 * i, row = q >> 3, c = q & 7;
+            if (row < BN) *reinterpret_cast<uint4*>(sB + buf * BN * BK + row * BK + ((c ^ ((row >> 1) & 7)) << 3)) = rb[i];
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nkt = (int)((p.K + BK - 1) / BK);
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) gload(kt + 1);
+        const uint16_t* bufA = sA + (kt & 1) * BM * BK;
+        const uint16_t* bufB = sB + (kt & 1) * BN * BK;
+        const int ksteps = (int)(((p.K - (long long)kt * BK) < BK ? (p.K - (long long)kt * BK) : BK) >> 4);
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const int chunk = 2 * ks + (lane >> 5);
+            bf16x8 fw[TN], fx[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int row = wn * WN + 32 * i + (lane & 31);
+                fw[i] = *reinterpret_cast<const bf16x8*>(bufB + row * BK + ((chunk ^ ((row >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int row = wm * WM + 32 * j + (lane & 31);
+                fx[j] = *reinterpret_cast<const bf16x8*>(bufA + row * BK + ((chunk ^ ((row >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // accumulators -> fp32 C tile in LDS.  D[n][m]: lane owns m = lane&31, register quad g owns
+    // n = 8g + 4*(lane>>5) .. +3
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = wm * WM + 32 * j + (lane & 31);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = wn * WN + 32 * i + 8 * g + 4 * (lane >> 5);
+                f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(sC + m * CS + n) = v;
+            }
+        }
+    __syncthreads();
+
+    // coalesced epilogue: each thread owns 8 consecutive features of one batch row
+    constexpr int PIECES = BM * BN / 8;
+    for (int q = tid; q < PIECES; q += 256) {
+        const int row = q / (BN / 8), pc = q % (BN / 8);
+        const long long gm = m0 + row, n = n0 + pc * 8;
+        if (gm >= p.M) continue;
+        const bool any_out = n < p.N || (p.cb != nullptr && n < p.npad);
+        if (!any_out) continue;
+        float v[8];
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(sC + row * CS + pc * 8);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(sC + row * CS + pc * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = c0[e]; v[4 + e] = c1[e]; }
+        const bool full = n + 8 <= p.N;
+        if (p.bias != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (full || n + e < p.N) v[e] += p.bias[n + e];
+        }
+        if (p.resf != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (full || n + e < p.N) v[e] += p.resf[gm * p.ld_resf + n + e];
+        }
+        if (p.res != nullptr) {
+            if (full) {
+                const uint4 rr = *reinterpret_cast<const uint4*>(p.res + gm * p.ld_res + n);
+                const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += __builtin_bit_cast(float, w[e] << 16);
+                    v[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] += dhaug_bf16_to_f32(p.res[gm * p.ld_res + n + e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (full || n + e < p.N) ? apply_act(v[e], p.act, p.slope) : 0.0f;
+        if (p.cb != nullptr) {
+            if (n + 8 <= p.npad || full) {
+                uint4 o;
+                o.x = (uint32_t)dhaug_f32_to_bf16(v[0]) | ((uint32_t)dhaug_f32_to_bf16(v[1]) << 16);
+                o.y = (uint32_t)dhaug_f32_to_bf16(v[2]) | ((uint32_t)dhaug_f32_to_bf16(v[3]) << 16);
+                o.z = (uint32_t)dhaug_f32_to_bf16(v[4]) | ((uint32_t)dhaug_f32_to_bf16(v[5]) << 16);
+                o.w = (uint32_t)dhaug_f32_to_bf16(v[6]) | ((uint32_t)dhaug_f32_to_bf16(v[7]) << 16);
+                *reinterpret_cast<uint4*>(p.cb + gm * p.ldcb + n) = o;
+            } else {
+                const long long lim = p.npad > p.N ? p.npad : p.N;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (n + e < lim) p.cb[gm * p.ldcb + n + e] = dhaug_f32_to_bf16(v[e]);
+            }
+        }
+        if (p.cf != nullptr) {
+            if (full && (p.ldcf & 3) == 0) {
+                f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                *reinterpret_cast<f32x4*>(p.cf + gm * p.ldcf + n) = o0;
+                *reinterpret_cast<f32x4*>(p.cf + gm * p.ldcf + n + 4) = o1;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (n + e < p.N) p.cf[gm * p.ldcf + n + e] = v[e];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// TN (weight gradient): C[N1,N2] += sum_m A[m,N1] * B[m,N2]
+// ---------------------------------------------------------------------------------------------------
+struct TnArgs {
+    const uint16_t* A; long long lda;
+    const uint16_t* B; long long ldb;
+    float* C; long long ldc;
+    long long M, N1, N2;
+    long long rows_per_split;
+};
+
+constexpr int TN_BN = 128;          // tile edge in both output dimensions
+constexpr int TN_LD = 160;          // LDS row stride (elements): 320 B = 16 banks shift per row
+
+// 8 consecutive contraction rows k = kbase..kbase+7 of column (col0 + lane&15) : two hardware transpose reads.
+__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* tile, int kbase, int col0, int lane) {
+    const int li = lane & 15, q = li >> 2, pp = li & 3;
+    const uint16_t* a0 = tile + (kbase + q) * TN_LD + col0 + 4 * pp;
+    typedef bf16x4 __attribute__((address_space(3))) * lds_ptr;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0 + 4 * TN_LD));
+    bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f;
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint16_t* sA = reinterpret_cast<uint16_t*>(smem_raw);      // [2][64*TN_LD]
+    uint16_t* sB = sA + 2 * BK * TN_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w1 = wave >> 1, w2 = wave & 1;                    // 2 x 2 waves, 64 x 64 each
+    const long long nt2 = (p.N2 + TN_BN - 1) / TN_BN;
+    const long long tile = blockIdx.x;
+    const long long n1_0 = (tile / nt2) * TN_BN, n2_0 = (tile % nt2) * TN_BN;
+    const long long ms = (long long)blockIdx.y * p.rows_per_split;
+    long long me = ms + p.rows_per_split;
+    if (me > p.M) me = p.M;
+    if (ms >= me) return;
+
+    uint4 ra[4], rb[4];
+    auto gload = [&](long long mrow0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + 256 * i, row = q >> 4, c = q & 15;
+            const long long gm = mrow0 + row;
+            const long long ca = n1_0 + c * 8, cb = n2_0 + c * 8;
+            ra[i] = (gm < me && ca < p.N1) ? *reinterpret_cast<const uint4*>(p.A + gm * p.lda + ca) : make_uint4(0, 0, 0, 0);
+            rb[i] = (gm < me && cb < p.N2) ? *reinterpret_cast<const uint4*>(p.B + gm * p.ldb + cb) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + 256 * i, row = q >> 4, c = q & 15;
+            *reinterpret_cast<uint4*>(sA + buf * BK * TN_LD + row * TN_LD + c * 8) = ra[i];
+            *reinterpret_cast<uint4*>(sB + buf * BK * TN_LD + row * TN_LD + c * 8) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nkt = (int)((me - ms + BK - 1) / BK);
+    gload(ms);
+    lstore(0);
+    __syncthreads();
+    const int grp = lane >> 4;                                  // 16-lane group: columns 16*(grp&1), k half grp>>1
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) gload(ms + (long long)(kt + 1) * BK);
+        const uint16_t* bufA = sA + (kt & 1) * BK * TN_LD;
+        const uint16_t* bufB = sB + (kt & 1) * BK * TN_LD;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kbase = 16 * ks + 8 * (grp >> 1);
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = tr_frag(bufA, kbase, w1 * 64 + 32 * i + 16 * (grp & 1), lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = tr_frag(bufB, kbase, w2 * 64 + 32 * j + 16 * (grp & 1), lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+    // D[n1][n2]: lane owns column n2 = lane&31, rows n1 = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long n2 = n2_0 + w2 * 64 + 32 * j + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long n1 = n1_0 + w1 * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (n1 < p.N1 && n2 < p.N2) atomicAdd(p.C + n1 * p.ldc + n2, acc[i][j][r]);
+            }
+        }
+}
+
+template <typename Kern>
+int launch_nt(Kern kern, long long grid, size_t lds, hipStream_t s, const GemmArgs& p) {
+    static bool configured = false;          // one attribute call per kernel instantiation
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, p);
+    return dhaug_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int dhaug_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias,
+                    const uint16_t* residual, int64_t ld_res, const float* residual_f32, int64_t ld_res_f32,
+                    uint16_t* c_bf16, int64_t ldc_bf16, int64_t n_pad_zero,
+                    float* c_f32, int64_t ldc_f32, int64_t M, int64_t N, int64_t K, int act, float slope, void* stream) {
+    DHAUG_CHECK(M >= 0 && N >= 1 && K >= 16, DHAUG_EINVAL);
+    DHAUG_CHECK(act >= DHAUG_ACT_NONE && act <= DHAUG_ACT_LRELU, DHAUG_EINVAL);
+    if (M == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(A); DHAUG_CHECK_PTR(B);
+    DHAUG_CHECK(c_bf16 != nullptr || c_f32 != nullptr, DHAUG_EINVAL);
+    DHAUG_CHECK(K % 16 == 0, DHAUG_EUNSUPPORTED);
+    DHAUG_CHECK(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K, DHAUG_EALIGN);
+    DHAUG_CHECK(dhaug_aligned16(A) && dhaug_aligned16(B), DHAUG_EALIGN);
+    if (residual) DHAUG_CHECK(ld_res % 8 == 0 && ld_res >= N && dhaug_aligned16(residual), DHAUG_EALIGN);
+    if (residual_f32) DHAUG_CHECK(ld_res_f32 >= N, DHAUG_EINVAL);
+    if (c_bf16) DHAUG_CHECK(ldc_bf16 % 8 == 0 && ldc_bf16 >= N && n_pad_zero <= ldc_bf16 && dhaug_aligned16(c_bf16), DHAUG_EALIGN);
+    if (c_f32) DHAUG_CHECK(ldc_f32 >= N && ((ldc_f32 & 3) != 0 || dhaug_aligned16(c_f32)), DHAUG_EALIGN);
+    GemmArgs p{A, lda, B, ldb, bias, residual, ld_res, residual_f32, ld_res_f32, c_bf16, ldc_bf16, c_bf16 ? (n_pad_zero > N ? n_pad_zero : N) : 0,
+               c_f32, ldc_f32, M, N, K, N, act, slope};
+    hipStream_t s = (hipStream_t)stream;
+    const long long width = (c_bf16 && p.npad > N) ? p.npad : N;
+    p.W = width;
+    if (width > 64) {
+        constexpr int BM = 128, BN = 128;
+        const long long grid = ((M + BM - 1) / BM) * ((width + BN - 1) / BN);
+        size_t lds = (size_t)2 * (BM + BN) * BK * 2, ctile = (size_t)BM * (BN + 4) * 4;
+        return launch_nt(gemm_nt_kernel<BM, BN, 2, 2>, grid, lds > ctile ? lds : ctile, s, p);
+    } else if (width > 32) {
+        constexpr int BM = 128, BN = 64;
+        const long long grid = ((M + BM - 1) / BM);
+        size_t lds = (size_t)2 * (BM + BN) * BK * 2, ctile = (size_t)BM * (BN + 4) * 4;
+        return launch_nt(gemm_nt_kernel<BM, BN, 2, 2>, grid, lds > ctile ? lds : ctile, s, p);
+    } else {
+        constexpr int BM = 128, BN = 32;
+        const long long grid = ((M + BM - 1) / BM);
+        size_t lds = (size_t)2 * (BM + BN) * BK * 2, ctile = (size_t)BM * (BN + 4) * 4;
+        return launch_nt(gemm_nt_kernel<BM, BN, 4, 1>, grid, lds > ctile ? lds : ctile, s, p);
+    }
+}
+
+int dhaug_gemm_tn_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                       int64_t N1, int64_t N2, int accumulate, void* stream) {
+    DHAUG_CHECK(M >= 0 && N1 >= 1 && N2 >= 1, DHAUG_EINVAL);
+    DHAUG_CHECK_PTR(C);
+    DHAUG_CHECK(ldc >= N2, DHAUG_EINVAL);
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) {
+        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N2 * 4, (size_t)N1, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (M == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(A); DHAUG_CHECK_PTR(B);
+    // columns are fetched in 16-byte chunks: the operand rows must be readable up to ceil8(N)
+    DHAUG_CHECK(lda % 8 == 0 && ldb % 8 == 0 && lda >= ((N1 + 7) & ~7LL) && ldb >= ((N2 + 7) & ~7LL), DHAUG_EALIGN);
+    DHAUG_CHECK(dhaug_aligned16(A) && dhaug_aligned16(B), DHAUG_EALIGN);
+    const long long tiles = ((N1 + TN_BN - 1) / TN_BN) * ((N2 + TN_BN - 1) / TN_BN);
+    long long splits = 512 / tiles;
+    if (splits < 1) splits = 1;
+    long long rows = (M + splits - 1) / splits;
+    rows = (rows + BK - 1) / BK * BK;
+    if (rows < 4 * BK) rows = 4 * BK;
+    splits = (M + rows - 1) / rows;
+    TnArgs p{A, lda, B, ldb, C, ldc, M, N1, N2, rows};
+    {
+        static bool configured = false;
+        if (!configured) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BK * TN_LD * 2);
+            if (e != hipSuccess) return (int)e;
+            configured = true;
+        }
+    }
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(256), (size_t)4 * BK * TN_LD * 2, s, p);
+    return dhaug_launch_status();
+}
+
+}  // extern "C"

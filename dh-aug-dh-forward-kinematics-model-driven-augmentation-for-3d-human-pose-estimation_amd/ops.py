@@ -1,0 +1,259 @@
+"""Tensor-level wrappers of the C-ABI (no autograd here): allocate outputs with torch, pass raw device pointers and
+the current HIP stream to libdhaug.so.  Every function requires CUDA(HIP) tensors and raises otherwise."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_vp = ctypes.c_void_p
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else _vp(t.data_ptr())
+
+
+def _dev(t, dtype, name):
+    if not t.is_cuda:
+        raise RuntimeError("dhaug op `%s` needs a GPU tensor (no CPU fallback exists)" % name)
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def _host3(x, n):
+    """small host-side float arrays (camera parameters) -> ctypes float[n]"""
+    if torch.is_tensor(x):
+        x = x.detach().reshape(-1).cpu().tolist()
+    x = [float(v) for v in (x.reshape(-1).tolist() if hasattr(x, "reshape") else x)]
+    assert len(x) == n, (len(x), n)
+    return (ctypes.c_float * n)(*x)
+
+
+def ceil_to(v, m):
+    return (v + m - 1) // m * m
+
+
+# ---------------------------------------------------------------------------------------------- FK
+def fk_forward(angles, bone_len, root, out_joints=16):
+    a = _dev(angles, torch.float32, "fk_forward").reshape(-1, 37)
+    b = _dev(bone_len, torch.float32, "fk_forward").reshape(-1, 15)
+    r = None if root is None else _dev(root, torch.float32, "fk_forward").reshape(-1, 3)
+    N = a.shape[0]
+    assert b.shape[0] == N and (r is None or r.shape[0] == N), "FK inputs disagree on the number of poses"
+    out = torch.empty((N, out_joints, 3), dtype=torch.float32, device=a.device)
+    _lib.call("dhaug_fk_forward", _p(a), _p(b), _p(r), _p(out), N, out_joints, _stream())
+    return out
+
+
+def fk_backward(angles, bone_len, grad_out16):
+    a = _dev(angles, torch.float32, "fk_backward").reshape(-1, 37)
+    b = _dev(bone_len, torch.float32, "fk_backward").reshape(-1, 15)
+    g = _dev(grad_out16, torch.float32, "fk_backward").reshape(-1, 48)
+    N = a.shape[0]
+    ga = torch.empty((N, 37), dtype=torch.float32, device=a.device)
+    gb = torch.empty((N, 15), dtype=torch.float32, device=a.device)
+    gr = torch.empty((N, 3), dtype=torch.float32, device=a.device)
+    _lib.call("dhaug_fk_backward", _p(a), _p(b), _p(g), _p(ga), _p(gb), _p(gr), N, _stream())
+    return ga, gb, gr
+
+
+def gen_tail_forward(head, bone_len, scaler, use_preangle=True, want_angles=False):
+    h = _dev(head, torch.float32, "gen_tail_forward").reshape(-1, 35)
+    b = _dev(bone_len, torch.float32, "gen_tail_forward").reshape(-1, 15)
+    s = None if scaler is None else _dev(scaler, torch.float32, "gen_tail_forward").reshape(-1, 8)
+    N = h.shape[0]
+    assert b.shape[0] == N and (s is None or s.shape[0] == N)
+    fake = torch.empty((N, 16, 3), dtype=torch.float32, device=h.device)
+    ang = torch.empty((N, 37), dtype=torch.float32, device=h.device) if want_angles else None
+    _lib.call("dhaug_gen_tail_forward", _p(h), _p(b), _p(s), _p(fake), _p(ang), N, int(bool(use_preangle)), _stream())
+    return fake, ang
+
+
+def gen_tail_backward(head, bone_len, scaler, grad_fake16, use_preangle=True):
+    h = _dev(head, torch.float32, "gen_tail_backward").reshape(-1, 35)
+    b = _dev(bone_len, torch.float32, "gen_tail_backward").reshape(-1, 15)
+    s = None if scaler is None else _dev(scaler, torch.float32, "gen_tail_backward").reshape(-1, 8)
+    g = _dev(grad_fake16, torch.float32, "gen_tail_backward").reshape(-1, 48)
+    N = h.shape[0]
+    gh = torch.empty((N, 35), dtype=torch.float32, device=h.device)
+    _lib.call("dhaug_gen_tail_backward", _p(h), _p(b), _p(s), _p(g), _p(gh), N, int(bool(use_preangle)), _stream())
+    return gh
+
+
+# ------------------------------------------------------------------------------------- pose features
+def bone_length(pose16):
+    x = _dev(pose16, torch.float32, "bone_length").reshape(-1, 48)
+    out = torch.empty((x.shape[0], 15), dtype=torch.float32, device=x.device)
+    _lib.call("dhaug_bone_length", _p(x), _p(out), x.shape[0], _stream())
+    return out
+
+
+def kcs_forward(pose16, with_lengths=True, f32=True, bf16_ld=0):
+    x = _dev(pose16, torch.float32, "kcs_forward").reshape(-1, 48)
+    N, W = x.shape[0], (30 if with_lengths else 15)
+    of = torch.empty((N, W), dtype=torch.float32, device=x.device) if f32 else None
+    ob = torch.empty((N, bf16_ld), dtype=BF16, device=x.device) if bf16_ld else None
+    _lib.call("dhaug_kcs_forward", _p(x), _p(of), _p(ob), bf16_ld, N, int(with_lengths), _stream())
+    return of, ob
+
+
+def kcs_backward(pose16, grad_feat, with_lengths=True):
+    x = _dev(pose16, torch.float32, "kcs_backward").reshape(-1, 48)
+    g = _dev(grad_feat, torch.float32, "kcs_backward").reshape(x.shape[0], 30 if with_lengths else 15)
+    out = torch.empty((x.shape[0], 48), dtype=torch.float32, device=x.device)
+    _lib.call("dhaug_kcs_backward", _p(x), _p(g), _p(out), x.shape[0], int(with_lengths), _stream())
+    return out
+
+
+def kcs_jvp(pose16, tangent, with_lengths=True):
+    x = _dev(pose16, torch.float32, "kcs_jvp").reshape(-1, 48)
+    t = _dev(tangent, torch.float32, "kcs_jvp").reshape(-1, 48)
+    out = torch.empty((x.shape[0], 30 if with_lengths else 15), dtype=torch.float32, device=x.device)
+    _lib.call("dhaug_kcs_jvp", _p(x), _p(t), _p(out), x.shape[0], int(with_lengths), _stream())
+    return out
+
+
+# -------------------------------------------------------------------------------------------- camera
+def world_to_camera_project(pose16, quat, trans, cam9, want3d=True, want2d=True):
+    x = _dev(pose16, torch.float32, "world_to_camera_project").reshape(-1, 48)
+    N = x.shape[0]
+    c3 = torch.empty((N, 16, 3), dtype=torch.float32, device=x.device) if want3d else None
+    p2 = torch.empty((N, 16, 2), dtype=torch.float32, device=x.device) if want2d else None
+    _lib.call("dhaug_world_to_camera_project", _p(x), _host3(quat, 4), _host3(trans, 3),
+              None if cam9 is None else _host3(cam9, 9), _p(c3), _p(p2), N, _stream())
+    return c3, p2
+
+
+def world_to_camera_project_backward(pose16, quat, trans, cam9, grad3d, grad2d):
+    x = _dev(pose16, torch.float32, "w2c_backward").reshape(-1, 48)
+    g3 = None if grad3d is None else _dev(grad3d, torch.float32, "w2c_backward").reshape(-1, 48)
+    g2 = None if grad2d is None else _dev(grad2d, torch.float32, "w2c_backward").reshape(-1, 32)
+    out = torch.empty((x.shape[0], 16, 3), dtype=torch.float32, device=x.device)
+    _lib.call("dhaug_world_to_camera_project_backward", _p(x), _host3(quat, 4), _host3(trans, 3),
+              None if cam9 is None else _host3(cam9, 9), _p(g3), _p(g2), _p(out), x.shape[0], _stream())
+    return out
+
+
+def camera_to_world(cam3d, quat, trans):
+    x = _dev(cam3d, torch.float32, "camera_to_world").reshape(-1, 48)
+    q = _dev(quat, torch.float32, "camera_to_world").reshape(-1, 4)
+    t = _dev(trans, torch.float32, "camera_to_world").reshape(-1, 3)
+    assert q.shape[0] == x.shape[0] and t.shape[0] == x.shape[0]
+    out = torch.empty((x.shape[0], 16, 3), dtype=torch.float32, device=x.device)
+    _lib.call("dhaug_camera_to_world", _p(x), _p(q), _p(t), _p(out), x.shape[0], _stream())
+    return out
+
+
+def center_flip(x, center, flip, adjoint=False):
+    C = x.shape[-1]
+    v = _dev(x, torch.float32, "center_flip").reshape(-1, 16 * C)
+    out = torch.empty_like(v)
+    _lib.call("dhaug_center_flip_backward" if adjoint else "dhaug_center_flip", _p(v), _p(out), v.shape[0], C,
+              int(bool(center)), int(bool(flip)), _stream())
+    return out.reshape(-1, 16, C)
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+def cast_pad_bf16(src, pad_cols=None):
+    s = _dev(src, torch.float32, "cast_pad_bf16")
+    s = s.reshape(-1, s.shape[-1])
+    rows, cols = s.shape
+    pad_cols = ceil_to(cols, 16) if pad_cols is None else pad_cols
+    dst = torch.empty((rows, pad_cols), dtype=BF16, device=s.device)
+    _lib.call("dhaug_cast_pad_bf16", _p(s), cols, _p(dst), pad_cols, rows, cols, pad_cols, _stream())
+    return dst
+
+
+def cast_transpose_bf16(src, pad_cols=None):
+    s = _dev(src, torch.float32, "cast_transpose_bf16")
+    rows, cols = s.shape
+    pad_cols = ceil_to(rows, 16) if pad_cols is None else pad_cols
+    dst = torch.empty((cols, pad_cols), dtype=BF16, device=s.device)
+    _lib.call("dhaug_cast_transpose_bf16", _p(s), cols, _p(dst), pad_cols, rows, cols, pad_cols, _stream())
+    return dst
+
+
+def split3_bf16(src, mode, pad_cols=None):
+    """fp32 (rows, cols) -> bf16 (rows, 3*pad): mode 0 [hi|hi|lo] (activation side), mode 1 [hi|lo|hi] (weight side)."""
+    s = _dev(src, torch.float32, "split3_bf16")
+    s = s.reshape(-1, s.shape[-1])
+    rows, cols = s.shape
+    pad_cols = ceil_to(cols, 16) if pad_cols is None else pad_cols
+    dst = torch.empty((rows, 3 * pad_cols), dtype=BF16, device=s.device)
+    _lib.call("dhaug_split3_bf16", _p(s), cols, _p(dst), rows, cols, pad_cols, mode, _stream())
+    return dst
+
+
+def gemm_nt(A, B, N, K, bias=None, res_bf16=None, res_f32=None, act=0, slope=0.0, out_bf16=False, n_pad=0,
+            out_f32=False, lda=None, ldb=None):
+    """C[M,N] = act(A[M,K] B[N,K]^T + bias + residual).  A, B bf16 (row strides lda/ldb default to their widths).
+    Returns (c_bf16 (M, max(n_pad, ceil8(N))) | None, c_f32 (M,N) | None)."""
+    assert A.dtype == BF16 and B.dtype == BF16 and A.is_cuda and B.is_cuda
+    M = A.shape[0]
+    lda = A.stride(0) if lda is None else lda
+    ldb = B.stride(0) if ldb is None else ldb
+    cb = cf = None
+    ldcb = 0
+    if out_bf16:
+        ldcb = max(n_pad, ceil_to(N, 8))
+        cb = torch.empty((M, ldcb), dtype=BF16, device=A.device)
+        n_pad = ldcb
+    if out_f32:
+        cf = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    if bias is not None:
+        bias = _dev(bias, torch.float32, "gemm_nt")
+    _lib.call("dhaug_gemm_bf16", _p(A), lda, _p(B), ldb, _p(bias), _p(res_bf16),
+              0 if res_bf16 is None else res_bf16.stride(0), _p(res_f32), 0 if res_f32 is None else res_f32.stride(0),
+              _p(cb), ldcb, n_pad, _p(cf), N, M, N, K, act, float(slope), _stream())
+    return cb, cf
+
+
+def gemm_tn(A, B, N1, N2, out=None, accumulate=False, M=None, lda=None, ldb=None):
+    """C[N1,N2] (+)= A[M,N1]^T B[M,N2], bf16 operands, fp32 result."""
+    assert A.dtype == BF16 and B.dtype == BF16
+    M = A.shape[0] if M is None else M
+    if out is None:
+        out = torch.empty((N1, N2), dtype=torch.float32, device=A.device)
+        accumulate = False
+    _lib.call("dhaug_gemm_tn_bf16", _p(A), A.stride(0) if lda is None else lda, _p(B), B.stride(0) if ldb is None else ldb,
+              _p(out), out.stride(0), M, N1, N2, int(accumulate), _stream())
+    return out
+
+
+def colsum(src, N=None, out=None, accumulate=False):
+    N = src.shape[1] if N is None else N
+    if out is None:
+        out = torch.empty((N,), dtype=torch.float32, device=src.device)
+        accumulate = False
+    name = "dhaug_colsum_bf16" if src.dtype == BF16 else "dhaug_colsum_f32"
+    _lib.call(name, _p(src), src.stride(0), _p(out), src.shape[0], N, int(accumulate), _stream())
+    return out
+
+
+def act_backward(g, y, act, slope=0.0):
+    """g * act'(y), same dtype/shape as g (bf16: widths multiple of 8; fp32: any)."""
+    assert g.dtype == y.dtype and g.shape == y.shape
+    out = torch.empty_like(g)
+    if g.dtype == BF16:
+        _lib.call("dhaug_act_backward_bf16", _p(g), g.stride(0), _p(y), y.stride(0), _p(out), out.stride(0), g.shape[0],
+                  g.shape[1], act, float(slope), _stream())
+    else:
+        _lib.call("dhaug_act_backward_f32", _p(g), _p(y), _p(out), g.numel(), act, float(slope), _stream())
+    return out
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-4, betas=(0.5, 0.9), eps=1e-8, grad_scale=1.0):
+    n = param.numel()
+    assert param.is_contiguous() and grad.is_contiguous() and grad.numel() == n
+    _lib.call("dhaug_adam_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, lr, betas[0], betas[1], eps,
+              int(step), float(grad_scale), _stream())

@@ -1,0 +1,218 @@
+/*
+ * dhaug.h -- C-ABI of libdhaug.so: hand-written HIP (gfx950 / MI355X) kernels for the DH-AUG hot path
+ * (DH forward kinematics + MLP GAN generator / critic step).
+ *
+ * The reference (R/ = DH-AUG_master/) is pure Python on stock PyTorch ops; it has no FFI layer.  Each entry
+ * point below therefore names the reference *Python* symbol whose arithmetic it replaces (file:line).  The
+ * Python drop-in classes in the package bind these through ctypes.
+ *
+ * Conventions
+ *   - plain C: raw device pointers + sizes; no torch / C++ types cross the boundary.
+ *   - the caller owns every buffer; the library allocates nothing and keeps no state.
+ *   - all work is enqueued on the caller's HIP stream (`stream`, a hipStream_t passed as void*); no
+ *     synchronisation inside, safe for hipGraph capture.
+ *   - return value: 0 on success; a negative DHAUG_E* code for an argument error detected on the host
+ *     (nothing was launched); a positive hipError_t value if the launch failed.  Never throws.
+ *   - fp32 tensors are contiguous row-major.  bf16 tensors are row-major with an explicit leading dimension
+ *     (elements); rows must start 16-byte aligned (ld % 8 == 0, base 16-byte aligned).
+ *   - angle layout (degrees), 37 columns = `generator_angle` of R/models_Fk_GAN/Fk_generator.py:179-186:
+ *       [0:5] right leg, [5:10] left leg, [10:23] body, [23:28] right arm, [28:33] left arm,
+ *       [33] unused, [34:37] global rotation x,y,z.
+ *   - bone_len layout, 15 columns = used_16key_15bone_len_table order
+ *       (R/models_Fk_GAN/forward_kinematics_DH_model.py:46-49).
+ *   - out16 = the 16 H36M joints of R/common/h36m_dataset.py:37-38, (N,16,3).
+ */
+#ifndef DHAUG_H
+#define DHAUG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DHAUG_VERSION 100            /* major*10000 + minor*100 + patch */
+
+#define DHAUG_OK             0
+#define DHAUG_EINVAL        -1       /* null pointer / negative size / bad enum */
+#define DHAUG_EALIGN        -2       /* pointer or leading dimension violates the alignment contract */
+#define DHAUG_EUNSUPPORTED  -3       /* shape outside what the kernels implement */
+
+/* activation kinds for dhaug_gemm_bf16 epilogues */
+#define DHAUG_ACT_NONE   0
+#define DHAUG_ACT_RELU   1
+#define DHAUG_ACT_LRELU  2           /* LeakyReLU, slope passed separately (reference uses 0.01) */
+
+int dhaug_version(void);
+/* name of the code-object architecture the library was built for ("gfx950") */
+const char* dhaug_arch(void);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Forward kinematics
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* Fused DH forward kinematics: 33 local DH matrices, 5 chain products, global rotation, root add,
+ * 32->16 joint gather -- one kernel, one HBM read of the inputs, one write of the joints.
+ * Replaces Forward_Kinematics_DH_Model.change_3d_joint_angle (torch branch)
+ *   R/models_Fk_GAN/forward_kinematics_DH_model.py:562-822 (+ dh_matrix :80-116, rotationMatrix :141-191)
+ * followed by the H36M_32_To_16_Table gather of R/models_Fk_GAN/Fk_generator.py:259.
+ *   angles (N,37) deg, bone_len (N,15) m, root (N,3) m  ->  out (N,out_joints,3), out_joints in {16,32}.
+ * out_joints == 32 reproduces the reference's (N,32,3) tensor exactly (unused rows = root). */
+int dhaug_fk_forward(const float* angles, const float* bone_len, const float* root, float* out,
+                     int64_t N, int out_joints, void* stream);
+
+/* Reverse-mode gradient of dhaug_fk_forward(out_joints=16) w.r.t. all three inputs (the G step
+ * back-propagates through FK: R/models_Fk_GAN/model_fk_gan_train.py:431-480).
+ *   grad_out16 (N,16,3) -> grad_angles (N,37), grad_bone_len (N,15), grad_root (N,3).
+ * grad_angles columns that cannot move any joint (4,9,22,27,32,33) are written as 0. */
+int dhaug_fk_backward(const float* angles, const float* bone_len, const float* grad_out16,
+                      float* grad_angles, float* grad_bone_len, float* grad_root, int64_t N, void* stream);
+
+/* Generator tail fused in front of FK: tanh on the 35 head columns (x10 on the root columns), scatter of the
+ * 31 live columns into the 37 angle slots, joint-limit affine map (use_preangle) or x180, bone-length
+ * jitter len*(1+s[pair]), FK, 32->16 gather.
+ * Replaces R/models_Fk_GAN/Fk_generator.py:121-259 (Fk_Generator.forward after deconv_out) and :310-453.
+ *   head (N,35) fp32 pre-activation, bone_len (N,15), scaler (N,8) (may be NULL = no jitter)
+ *   -> fake16 (N,16,3); angles_out (N,37) optional (NULL to skip) = `generator_angle`. */
+int dhaug_gen_tail_forward(const float* head, const float* bone_len, const float* scaler, float* fake16,
+                           float* angles_out, int64_t N, int use_preangle, void* stream);
+
+/* Gradient of dhaug_gen_tail_forward w.r.t. head: grad_fake16 (N,16,3) -> grad_head (N,35)
+ * (column 31 = 0).  Recomputes the forward from head. */
+int dhaug_gen_tail_backward(const float* head, const float* bone_len, const float* scaler,
+                            const float* grad_fake16, float* grad_head, int64_t N, int use_preangle,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Pose features
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* Bone lengths of 16-joint poses: (N,16,3) -> (N,15).  Replaces
+ * Fk_Generator.GAN_generator_get_bone_length, R/models_Fk_GAN/Fk_generator.py:107-111
+ * (Fk_get_boneVecByPose3d, R/models_Fk_GAN/special_operate.py:513-539, + norm). */
+int dhaug_bone_length(const float* pose16, float* bone_len, int64_t N, void* stream);
+
+/* KCS features: 15 adjacent-bone cosines (+ the 15 bone lengths when with_lengths != 0).
+ * Replaces special_KCS_Input_transform R/models_Fk_GAN/Fk_discriminator.py:36-146 and the video variant
+ * :269-377.  pose16 (N,16,3) fp32.
+ *   out_f32 : optional (N, 30|15) fp32, contiguous.
+ *   out_bf16: optional (N, ld_bf16) bf16 with columns [30|15, ld_bf16) zero-filled (GEMM operand). */
+int dhaug_kcs_forward(const float* pose16, float* out_f32, uint16_t* out_bf16, int64_t ld_bf16,
+                      int64_t N, int with_lengths, void* stream);
+
+/* VJP of dhaug_kcs_forward: grad_feat (N,30|15) fp32 -> grad_pose16 (N,16,3). */
+int dhaug_kcs_backward(const float* pose16, const float* grad_feat, float* grad_pose16, int64_t N,
+                       int with_lengths, void* stream);
+
+/* JVP (forward-mode) of dhaug_kcs_forward along tangent (N,16,3): -> tan_feat (N,30|15).  Used by the
+ * analytic WGAN-GP gradient (R/models_Fk_GAN/Fk_discriminator.py:205-231 with create_graph=True). */
+int dhaug_kcs_jvp(const float* pose16, const float* tangent, float* tan_feat, int64_t N, int with_lengths,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Camera / projection ("next" row N1): between the FK output and the 2D critic on every iteration
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* world -> camera by quaternion (qinverse, qrot) + H36M non-linear projection, one shared camera.
+ * Replaces GAN_torch_world_to_camera R/common/camera.py:36-38 (+ R/common/quaternion.py:6-35) and
+ * project_to_2d R/common/camera.py:62-94 as called at R/models_Fk_GAN/model_fk_gan_train.py:374-376.
+ *   pose16 (N,16,3) world; quat[4] (w,x,y,z), trans[3], cam9[9] = f(2) c(2) k(3) p(2)  (host arrays)
+ *   -> cam3d (N,16,3) optional, proj2d (N,16,2) optional. */
+int dhaug_world_to_camera_project(const float* pose16, const float* quat, const float* trans,
+                                  const float* cam9, float* cam3d, float* proj2d, int64_t N, void* stream);
+
+/* VJP of the above w.r.t. pose16: grad_cam3d / grad_proj2d (either may be NULL) -> grad_pose16. */
+int dhaug_world_to_camera_project_backward(const float* pose16, const float* quat, const float* trans,
+                                           const float* cam9, const float* grad_cam3d,
+                                           const float* grad_proj2d, float* grad_pose16, int64_t N,
+                                           void* stream);
+
+/* camera -> world with per-sample quaternion/translation (N,4),(N,3):
+ * GAN_torch_camera_to_world_batch R/common/camera.py:53-59. */
+int dhaug_camera_to_world(const float* cam3d, const float* quat, const float* trans, float* world,
+                          int64_t N, void* stream);
+
+/* Root-centre and/or left/right flip of (N,16,C) poses, C in {2,3}:
+ * x - x[:, :1] (R/models_Fk_GAN/model_fk_gan_train.py:295,312) and the flip of :320-331
+ * (negate coordinate 0, swap joints [4,5,6,10,11,12] <-> [1,2,3,13,14,15]). */
+int dhaug_center_flip(const float* in, float* out, int64_t N, int C, int center, int flip, void* stream);
+/* transpose (VJP) of the linear map above */
+int dhaug_center_flip_backward(const float* grad_out, float* grad_in, int64_t N, int C, int center, int flip,
+                               void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Dense layers: bf16 MFMA GEMM with fused epilogue
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* C[M,N] = act( A[M,K] * B[N,K]^T + bias[N] + residual[M,N] )      (v_mfma_f32_32x32x16_bf16, fp32 acc)
+ * A, B bf16 row-major, contraction dimension contiguous in both (nn.Linear weight layout [out,in]).
+ * Replaces nn.Linear + ReLU/LeakyReLU + residual add of myResNet (R/models_Fk_GAN/special_operate.py:490-510)
+ * and the Linear stacks of R/models_Fk_GAN/Fk_generator.py:95-103, Fk_discriminator.py:156-178,243-249.
+ *   K % 16 == 0 (operands zero-padded by their producers); lda, ldb, ld_res, ldc_* in elements, % 8 == 0.
+ *   bias     : fp32 [N] or NULL.
+ *   residual : bf16 (M, ld_res) or NULL, added before the activation.
+ *   residual_f32 : fp32 (M, ld_res_f32) or NULL, same role (fp32-grade "bf16x3" path).
+ *   c_bf16   : optional bf16 output (M, ldc_bf16); columns [N, n_pad_zero) are written as 0 so the result
+ *              can feed the next GEMM as a zero-padded operand.
+ *   c_f32    : optional fp32 output (M, ldc_f32).
+ * At least one output must be given. */
+int dhaug_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
+                    const float* bias, const uint16_t* residual, int64_t ld_res,
+                    const float* residual_f32, int64_t ld_res_f32,
+                    uint16_t* c_bf16, int64_t ldc_bf16, int64_t n_pad_zero,
+                    float* c_f32, int64_t ldc_f32,
+                    int64_t M, int64_t N, int64_t K, int act, float slope, void* stream);
+
+/* Weight-gradient GEMM: C[N1,N2] (+)= A[M,N1]^T * B[M,N2], contraction over the batch dimension M
+ * (split across workgroups, fp32 atomics into C).  bf16 operands, fp32 result.  `accumulate` != 0 adds
+ * into C, otherwise C is overwritten (zeroed by the library on the stream first). */
+int dhaug_gemm_tn_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
+                       float* C, int64_t ldc, int64_t M, int64_t N1, int64_t N2, int accumulate,
+                       void* stream);
+
+/* fp32 -> bf16 (round-to-nearest-even) with zero padding: src (rows, cols) ld_src -> dst (rows, ld_dst),
+ * columns [cols, pad_cols) zero-filled.  Used to pack weights / inputs as GEMM operands. */
+int dhaug_cast_pad_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst,
+                        int64_t rows, int64_t cols, int64_t pad_cols, void* stream);
+
+/* Same with transposition: src (rows, cols) -> dst (cols, ld_dst) = src^T, columns [rows, pad_cols) zero. */
+int dhaug_cast_transpose_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst,
+                              int64_t rows, int64_t cols, int64_t pad_cols, void* stream);
+
+/* "bf16x3" operand split for fp32-grade products on the bf16 MFMA path: x = hi + lo (both bf16).
+ * mode 0 (activation side): dst row = [hi | hi | lo]; mode 1 (weight side): dst row = [hi | lo | hi],
+ * each segment pad_cols wide (zero padded), so that A3 * B3^T = hi*hi + hi*lo + lo*hi.
+ * dst is (rows, 3*pad_cols) contiguous. */
+int dhaug_split3_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t rows, int64_t cols,
+                      int64_t pad_cols, int mode, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Elementwise / reductions used by the training step
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* column sums: src (M, N) fp32|bf16 -> dst[N] fp32 (bias gradients). */
+int dhaug_colsum_f32(const float* src, int64_t ld, float* dst, int64_t M, int64_t N, int accumulate,
+                     void* stream);
+int dhaug_colsum_bf16(const uint16_t* src, int64_t ld, float* dst, int64_t M, int64_t N, int accumulate,
+                      void* stream);
+
+/* dst = g * act'(y)  (y = the saved activation output; relu: y>0, lrelu: y>0 ? 1 : slope), bf16 in/out,
+ * optional second output g_res (same values) is the gradient flowing into a residual branch. */
+int dhaug_act_backward_bf16(const uint16_t* g, int64_t ld_g, const uint16_t* y, int64_t ld_y,
+                            uint16_t* dst, int64_t ld_dst, int64_t M, int64_t N, int act, float slope,
+                            void* stream);
+
+/* fp32 variant on flat arrays of n elements. */
+int dhaug_act_backward_f32(const float* g, const float* y, float* dst, int64_t n, int act, float slope,
+                           void* stream);
+
+/* Fused Adam step on a flat fp32 parameter vector (torch.optim.Adam semantics, eps outside the sqrt,
+ * bias correction; R/models_Fk_GAN/model_fk_gan_train.py:112-118: lr 1e-4, betas (0.5, 0.9)).
+ * grad_scale multiplies the gradient first (1/world_size after an all-reduce sum). */
+int dhaug_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                    float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DHAUG_H */

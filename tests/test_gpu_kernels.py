@@ -1,0 +1,289 @@
+"""GPU parity tests, kernel level: every C-ABI entry point against the oracle on seeded inputs.
+Tolerances: FK joints <= 1e-5 abs (north_star); gradients <= 1e-4 relative to the gradient scale; bf16 GEMMs are
+compared with an fp32 matmul of the *bf16-rounded* operands (fp32 accumulate both sides): <= 2e-5 relative to the
+row scale, plus the bf16 rounding of the stored output where the output is bf16."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as GU
+from oracle import dhaug_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import dhaug_amd
+    from dhaug_amd import ops as _ops
+    dhaug_amd._lib.lib()            # fail loudly if the HIP extension is missing
+    return _ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+def maxabs(a, b):
+    return (a.double().cpu() - b.double().cpu()).abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------ FK
+@pytest.mark.parametrize("name", ["fk_N1", "fk_N8", "fk_N1024", "fk_single_dof", "fk_video_B16_R9"])
+def test_fk_forward_golden(ops, golden, name):
+    g = golden(name)
+    root = g["root"].reshape(-1, 3)
+    out32 = ops.fk_forward(dev(g["angles"]), dev(g["bone_len"]), dev(root), out_joints=32)
+    assert out32.shape == g["out32"].shape
+    assert maxabs(out32, g["out32"]) <= 1e-5                      # reference (N,32,3), incl. the unused rows
+    out16 = ops.fk_forward(dev(g["angles"]), dev(g["bone_len"]), dev(root), out_joints=16)
+    assert maxabs(out16, g["out32"][:, O.H36M_32_TO_16]) <= 1e-5
+
+
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 1000, 65536 + 17])
+def test_fk_forward_ragged_sizes(ops, N):
+    a, bl, rt = GU.synth_fk_inputs(N, seed=100 + N)
+    out = ops.fk_forward(dev(a), dev(bl), dev(rt))
+    ref = O.fk_forward16(a, bl, rt)
+    assert maxabs(out, ref) <= 1e-5
+    # fp64 oracle: the GPU result is as close to exact arithmetic as the fp32 reference is
+    if N <= 1000:
+        ref64 = O.fk_forward16(a.double(), bl.double(), rt.double())
+        assert maxabs(out, ref64) <= 4e-6
+
+
+def test_fk_forward_empty_and_misuse(ops):
+    e = torch.empty((0, 37)).cuda()
+    out = ops.fk_forward(e, torch.empty((0, 15)).cuda(), torch.empty((0, 3)).cuda())
+    assert out.shape == (0, 16, 3)
+    with pytest.raises(RuntimeError):
+        ops.fk_forward(torch.zeros(4, 37), torch.zeros(4, 15), torch.zeros(4, 3))      # CPU tensors: no fallback
+
+
+def test_fk_properties_full_size(ops):
+    """size-independent properties at the BASELINE batch (65 536): bone-length invariance, dead angle slots,
+    root translation equivariance."""
+    N = 65536
+    a, bl, rt = GU.synth_fk_inputs(N, seed=7)
+    out = ops.fk_forward(dev(a), dev(bl), dev(rt))
+    assert maxabs(ops.bone_length(out), bl) <= 2e-6
+    a2 = a.clone(); a2[:, [4, 9, 22, 27, 32, 33]] += 77.0
+    assert maxabs(ops.fk_forward(dev(a2), dev(bl), dev(rt)), out) <= 1e-6
+    shift = torch.tensor([0.5, -0.25, 2.0])
+    out_s = ops.fk_forward(dev(a), dev(bl), dev(rt + shift))
+    assert maxabs(out_s - shift.cuda(), out) <= 2e-6
+    assert maxabs(out[:, 0], rt) == 0.0                          # Hip == root exactly
+
+
+@pytest.mark.parametrize("N", [5, 64, 1000])
+def test_fk_backward(ops, N):
+    a, bl, rt = GU.synth_fk_inputs(N, seed=200 + N)
+    g = torch.randn(N, 16, 3, generator=torch.Generator().manual_seed(N))
+    ad, bd, rd = (t.double().requires_grad_(True) for t in (a, bl, rt))
+    (O.fk_forward16(ad, bd, rd) * g.double()).sum().backward()
+    ga, gb, gr = ops.fk_backward(dev(a), dev(bl), dev(g))
+    for got, ref in ((ga, ad.grad), (gb, bd.grad), (gr, rd.grad)):
+        assert maxabs(got, ref) <= 1e-4 * ref.abs().max().item()
+    assert ga[:, [4, 9, 22, 27, 32, 33]].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("name,pre", [("gen_D32", True), ("gen_D256", True), ("gen_D32_nopre", False)])
+def test_gen_tail_forward_golden(ops, golden, name, pre):
+    src = golden("gen_D32" if name == "gen_D32_nopre" else name)
+    g = golden(name)
+    fake, ang = ops.gen_tail_forward(dev(src["head"]), dev(src["bone_len"]), dev(src["scaler"]), use_preangle=pre,
+                                     want_angles=True)
+    assert maxabs(ang, g["angle37"]) <= 2e-4                      # degrees (tanhf on device vs ATen tanh)
+    assert maxabs(fake.reshape(-1, 48), g["fake"]) <= 1e-5
+
+
+def test_gen_tail_video_golden(ops, golden):
+    g = golden("gen_video_D32")
+    B, R = 8, 9
+    sd = GU.seeded_state_dict(GU.shapes_generator(32, frames=R), int(g["weight_seed"]))
+    head = O.gen_trunk(g["z"], sd).reshape(B * R, 35)
+    scaler = g["scaler"].reshape(B, 1, 8).repeat(1, R, 1).reshape(B * R, 8)
+    fake, _ = ops.gen_tail_forward(dev(head), dev(g["bone_len"]), dev(scaler))
+    assert maxabs(fake.reshape(B, R, 48), g["fake"]) <= 1e-5
+
+
+def test_gen_tail_backward(ops, golden):
+    s = golden("gen_D32")
+    head, bl, sc = s["head"], s["bone_len"], s["scaler"]
+    g = torch.randn(head.shape[0], 16, 3, generator=torch.Generator().manual_seed(3))
+    hd = head.double().requires_grad_(True)
+    fake, _ = O.gen_tail(hd, bl.double(), sc.double())
+    (fake.reshape(-1, 16, 3) * g.double()).sum().backward()
+    gh = ops.gen_tail_backward(dev(head), dev(bl), dev(sc), dev(g))
+    assert maxabs(gh, hd.grad) <= 1e-4 * hd.grad.abs().max().item()
+    assert gh[:, 31].abs().max().item() == 0.0
+    # no jitter (scaler = NULL) path
+    f0, _ = ops.gen_tail_forward(dev(head), dev(bl), None)
+    r0, _ = O.gen_tail(head, bl, torch.zeros(head.shape[0], 8))
+    assert maxabs(f0.reshape(-1, 48), r0) <= 1e-5
+
+
+# -------------------------------------------------------------------------------------- pose features
+def test_kcs_golden(ops, golden):
+    g = golden("kcs_256")
+    x = dev(g["pose16"])
+    assert maxabs(ops.bone_length(x), O.bone_lengths(g["pose16"])) <= 1e-6
+    f, b = ops.kcs_forward(x, with_lengths=True, f32=True, bf16_ld=32)
+    assert maxabs(f, g["kcs30"]) <= 5e-6
+    assert maxabs(b[:, :30].float(), g["kcs30"].to(torch.bfloat16).float()) <= 1e-2 and b[:, 30:].abs().max() == 0
+    assert maxabs(b[:, :30].float(), f.to(torch.bfloat16).float()) == 0.0
+    f15, _ = ops.kcs_forward(x, with_lengths=False)
+    assert maxabs(f15, g["kcs15"]) <= 5e-6
+
+
+@pytest.mark.parametrize("wl", [True, False])
+def test_kcs_vjp_jvp(ops, wl):
+    N = 300
+    x = GU.synth_pose16(N, seed=17)
+    W = 30 if wl else 15
+    gf = torch.randn(N, W, generator=torch.Generator().manual_seed(1))
+    tan = torch.randn(N, 16, 3, generator=torch.Generator().manual_seed(2))
+    xd = x.double().requires_grad_(True)
+    f = O.kcs_features(xd, with_lengths=wl)
+    (f * gf.double()).sum().backward()
+    got = ops.kcs_backward(dev(x), dev(gf), with_lengths=wl)
+    assert maxabs(got.reshape(N, 16, 3), xd.grad) <= 1e-4 * xd.grad.abs().max().item()
+    _, jv = torch.autograd.functional.jvp(lambda t: O.kcs_features(t, with_lengths=wl), x.double(), tan.double())
+    gj = ops.kcs_jvp(dev(x), dev(tan), with_lengths=wl)
+    assert maxabs(gj, jv) <= 1e-4 * jv.abs().max().item()
+
+
+def test_camera_golden_and_backward(ops, golden):
+    g = golden("camera_128")
+    q, t, cam = g["R"][0], g["t"][0], g["cam"][0]
+    c3, p2 = ops.world_to_camera_project(dev(g["X"]), q, t, cam)
+    assert maxabs(c3, g["Xc"]) <= 2e-6 and maxabs(p2, g["x2d"]) <= 2e-6
+    w = ops.camera_to_world(dev(g["Xc"]), dev(g["R"].repeat(128, 1)), dev(g["t"].repeat(128, 1)))
+    assert maxabs(w, g["Xw"]) <= 2e-6
+    assert maxabs(ops.center_flip(dev(g["X"]), False, True), g["flip"]) == 0.0
+    cen = g["X"] - g["X"][:, :1]
+    assert maxabs(ops.center_flip(dev(g["X"]), True, False), cen) <= 1e-7
+    assert maxabs(ops.center_flip(dev(g["X"]), True, True), O.flip_lr(cen)) <= 1e-7
+    # backward of w2c+project and of centre/flip (adjoint) against autograd on the oracle
+    g3 = torch.randn(128, 16, 3, generator=torch.Generator().manual_seed(5))
+    g2 = torch.randn(128, 16, 2, generator=torch.Generator().manual_seed(6))
+    X = g["X"].double().requires_grad_(True)
+    Xc = O.world_to_camera(X, g["R"].double(), g["t"].double())
+    x2 = O.project_to_2d(Xc, g["cam"].double())
+    ((Xc * g3.double()).sum() + (x2 * g2.double()).sum()).backward()
+    gx = ops.world_to_camera_project_backward(dev(g["X"]), q, t, cam, dev(g3), dev(g2))
+    assert maxabs(gx, X.grad) <= 1e-4 * X.grad.abs().max().item()
+    Y = g["X"].double().requires_grad_(True)
+    yc = Y - Y[:, :1]
+    yf = yc.clone(); yf[:, :, 0] = -yf[:, :, 0]
+    yf = yf[:, [0, 4, 5, 6, 1, 2, 3, 7, 8, 9, 13, 14, 15, 10, 11, 12]]
+    (yf * g3.double()).sum().backward()
+    assert maxabs(ops.center_flip(dev(g3), True, True, adjoint=True), Y.grad) <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (1000, 256, 128), (129, 100, 512), (4096, 35, 256), (777, 1, 112),
+                                   (64, 256, 48), (300, 256, 32), (2048, 112, 112), (515, 315, 1008)])
+def test_gemm_nt_plain(ops, M, N, K):
+    gen = torch.Generator().manual_seed(M + N + K)
+    A = _bf(torch.randn(M, K, generator=gen)).cuda()
+    B = _bf(torch.randn(N, K, generator=gen) / K ** 0.5).cuda()
+    ref = (A.float().cpu().double() @ B.float().cpu().double().t()).float()
+    _, cf = ops.gemm_nt(A, B, N, K, out_f32=True)
+    assert maxabs(cf, ref) <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("act,slope", [(0, 0.0), (1, 0.0), (2, 0.01)])
+def test_gemm_nt_epilogues(ops, act, slope):
+    M, N, K = 1111, 100, 256
+    gen = torch.Generator().manual_seed(act)
+    A = _bf(torch.randn(M, K, generator=gen)).cuda()
+    B = _bf(torch.randn(N, K, generator=gen) / 16).cuda()
+    bias = torch.randn(N, generator=gen).cuda()
+    res = _bf(torch.randn(M, 104, generator=gen)).cuda()
+    z = A.float().cpu().double() @ B.float().cpu().double().t() + bias.cpu().double() + res[:, :N].float().cpu().double()
+    ref = z if act == 0 else (torch.relu(z) if act == 1 else torch.nn.functional.leaky_relu(z, slope))
+    cb, cf = ops.gemm_nt(A, B, N, K, bias=bias, res_bf16=res, act=act, slope=slope, out_bf16=True, n_pad=112, out_f32=True)
+    assert maxabs(cf, ref) <= 3e-5 * ref.abs().max().item()
+    assert cb.shape == (M, 112) and cb[:, N:].abs().max().item() == 0.0
+    assert maxabs(cb[:, :N].float(), cf.to(torch.bfloat16).float()) == 0.0
+    # fp32 residual variant
+    resf = torch.randn(M, N, generator=gen).cuda()
+    _, cf2 = ops.gemm_nt(A, B, N, K, bias=bias, res_f32=resf, act=0, out_f32=True)
+    ref2 = A.float().cpu().double() @ B.float().cpu().double().t() + bias.cpu().double() + resf.cpu().double()
+    assert maxabs(cf2, ref2) <= 3e-5 * ref2.abs().max().item()
+
+
+def test_gemm_bf16x3_is_fp32_grade(ops):
+    """x = hi + lo split: three bf16 MFMA passes reproduce an fp32 product to ~1e-6 relative."""
+    M, N, K = 1024, 256, 256
+    gen = torch.Generator().manual_seed(9)
+    X = torch.randn(M, K, generator=gen)
+    W = torch.randn(N, K, generator=gen) / 16
+    A3 = ops.split3_bf16(X.cuda(), 0)
+    B3 = ops.split3_bf16(W.cuda(), 1)
+    _, cf = ops.gemm_nt(A3, B3, N, 3 * K, out_f32=True)
+    ref = X.double() @ W.double().t()
+    assert maxabs(cf, ref) <= 2e-5 * ref.abs().max().item()
+    one = ops.gemm_nt(ops.cast_pad_bf16(X.cuda()), ops.cast_pad_bf16(W.cuda()), N, K, out_f32=True)[1]
+    assert maxabs(one, ref) > 10 * maxabs(cf, ref)                 # single-pass bf16 is visibly coarser
+
+
+@pytest.mark.parametrize("M,N1,N2", [(4096, 256, 256), (1000, 100, 512), (777, 32, 256), (65536, 256, 48), (130, 1, 100)])
+def test_gemm_tn(ops, M, N1, N2):
+    gen = torch.Generator().manual_seed(M + N1)
+    p1, p2 = (N1 + 7) // 8 * 8, (N2 + 7) // 8 * 8
+    A = torch.zeros(M, p1); A[:, :N1] = torch.randn(M, N1, generator=gen)
+    B = torch.zeros(M, p2); B[:, :N2] = torch.randn(M, N2, generator=gen)
+    A, B = _bf(A).cuda(), _bf(B).cuda()
+    ref = A[:, :N1].float().cpu().double().t() @ B[:, :N2].float().cpu().double()
+    C = ops.gemm_tn(A, B, N1, N2)
+    tol = 1e-4 * max(1.0, ref.abs().max().item())                 # fp32 atomics: order-dependent rounding
+    assert maxabs(C, ref) <= tol
+    C2 = ops.gemm_tn(A, B, N1, N2, out=C.clone(), accumulate=True)
+    assert maxabs(C2, 2 * ref) <= 2 * tol
+
+
+def test_pack_kernels(ops):
+    gen = torch.Generator().manual_seed(4)
+    W = torch.randn(100, 30, generator=gen)
+    p = ops.cast_pad_bf16(W.cuda())
+    assert p.shape == (100, 32) and maxabs(p[:, :30].float(), W.to(torch.bfloat16).float()) == 0 and p[:, 30:].abs().max() == 0
+    t = ops.cast_transpose_bf16(W.cuda())
+    assert t.shape == (30, 112) and maxabs(t[:, :100].float(), W.t().to(torch.bfloat16).float()) == 0
+    assert t[:, 100:].abs().max() == 0
+    s = ops.split3_bf16(W.cuda(), 1)
+    hi, lo = s[:, :30].float(), s[:, 32:62].float()
+    assert maxabs(hi + lo, W) <= 2e-5 * W.abs().max().item() and maxabs(s[:, 64:94].float(), hi) == 0
+
+
+def test_colsum_actbwd_adam(ops):
+    gen = torch.Generator().manual_seed(8)
+    X = torch.randn(5000, 100, generator=gen)
+    assert maxabs(ops.colsum(X.cuda()), X.double().sum(0)) <= 1e-3
+    Xb = _bf(torch.cat([X, torch.zeros(5000, 4)], 1)).cuda()
+    assert maxabs(ops.colsum(Xb, N=100), Xb[:, :100].float().cpu().double().sum(0)) <= 1e-3
+    g = _bf(torch.randn(333, 256, generator=gen)).cuda()
+    y = _bf(torch.randn(333, 256, generator=gen)).cuda()
+    for act, neg in ((1, 0.0), (2, 0.01), (0, 1.0)):
+        ref = torch.where(y.float() > 0, g.float(), g.float() * neg).to(torch.bfloat16)
+        assert maxabs(ops.act_backward(g, y, act, 0.01).float(), ref.float()) == 0.0
+        reff = torch.where(y.float() > 0, g.float(), g.float() * neg)
+        assert maxabs(ops.act_backward(g.float(), y.float(), act, 0.01), reff) == 0.0
+    p = torch.randn(10007, generator=gen)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-4, betas=(0.5, 0.9))
+    pg = p.clone().cuda()
+    m, v = torch.zeros_like(pg), torch.zeros_like(pg)
+    for step in (1, 2, 3):
+        gr = torch.randn(10007, generator=gen)
+        pr.grad = gr.clone()
+        opt.step()
+        ops.adam_step(pg, gr.cuda(), m, v, step)
+    assert maxabs(pg, pr.detach()) <= 2e-7
