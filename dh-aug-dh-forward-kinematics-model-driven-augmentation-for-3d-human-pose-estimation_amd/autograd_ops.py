@@ -1,0 +1,396 @@
+"""torch.autograd plumbing over the HIP kernels.
+
+Every Function's backward is itself written with Functions of this file, so gradients of any order exist -- the
+WGAN-GP penalty (R/models_Fk_GAN/Fk_discriminator.py:205-231) differentiates the critic's input-gradient with
+create_graph=True, and the drop-in critics support exactly that through:
+
+    Linear(x, W)  = x W^T (+ bias + residual, activation)        d/dx -> LinearT,  d/dW -> Outer
+    LinearT(g, W) = g W                                          d/dg -> Linear,   d/dW -> Outer
+    Outer(g, x)   = g^T x                                        d/dg -> Linear,   d/dx -> LinearT
+    ActBwd(g, y)  = g * act'(y)      (ReLU / LeakyReLU: piecewise linear, act'' = 0 a.e.)
+    KCS, KCS-VJP, KCS-JVP close the same way (VJP and JVP are each other's adjoint in the cotangent argument).
+
+Precision ("prec"):
+    'bf16'   : operands rounded to bf16, fp32 accumulate on MFMA, hidden activations stored as bf16 (zero-padded to a
+               multiple of 16 columns so they are directly the next GEMM's operand).  The build's default.
+    'bf16x3' : x = hi + lo on the same bf16 MFMA kernel: A' = [hi|hi|lo], B' = [hi|lo|hi], K' = 3K (product terms
+               down to 2^-16 relative); activations stay fp32.
+    'bf16x6' : x = hi + mid + lo, six product terms, K' = 6K: fp32-grade (2^-24).  Used for the 1e-4 logit parity
+               tests against the fp32 reference.
+"""
+import torch
+
+from . import ops
+
+BF16 = torch.bfloat16
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+TERMS = {"bf16x3": 3, "bf16x6": 6}
+# (activation-side segment, weight-side segment) holding (hi, mid|lo ...) for the TN products
+_SEG = {3: dict(hi=0, lo=2), 6: dict(hi=0, mid=2, lo=5)}
+_PAIRS = {3: (("hi", "hi"), ("hi", "lo"), ("lo", "hi")),
+          6: (("hi", "hi"), ("hi", "mid"), ("mid", "hi"), ("mid", "mid"), ("hi", "lo"), ("lo", "hi"))}
+
+
+def ceil16(v):
+    return (v + 15) // 16 * 16
+
+
+# ---------------------------------------------------------------------------------------------------
+# packed-weight cache: bf16 copies in the two orientations the GEMMs need, rebuilt when the fp32 master changes
+# ---------------------------------------------------------------------------------------------------
+class _Packed:
+    __slots__ = ("key", "nt", "nn", "nt3", "nn3")
+
+    def __init__(self):
+        self.key = None
+        self.nt = {}
+        self.nn = None
+        self.nt3 = {}
+        self.nn3 = None
+
+
+_CACHE = {}
+
+
+def _pack(W):
+    """cache entry for a weight-like fp32 (N,K) tensor; cached only for leaf parameters."""
+    cacheable = isinstance(W, torch.nn.Parameter)
+    key = (W.data_ptr(), W._version, tuple(W.shape))
+    if cacheable:
+        ent = _CACHE.get(id(W))
+        if ent is not None and ent.key == key:
+            return ent
+    ent = _Packed()
+    ent.key = key
+    if cacheable:
+        _CACHE[id(W)] = ent
+    return ent
+
+
+def _w_nt(W, Kp, prec):
+    """B operand of x W^T: (N, Kp) bf16, or (N, 3Kp) for bf16x3."""
+    ent = _pack(W)
+    d = ent.nt if prec == "bf16" else ent.nt3
+    key = (Kp, prec)
+    if key not in d:
+        Wd = W.detach()
+        d[key] = ops.cast_pad_bf16(Wd, Kp) if prec == "bf16" else ops.split_bf16(Wd, 1, TERMS[prec], Kp)
+    return d[key]
+
+
+def _w_nn(W, prec):
+    """B operand of g W (= g (W^T)^T): (K, Np) bf16, or (K, 3Np)."""
+    ent = _pack(W)
+    if prec == "bf16":
+        if ent.nn is None:
+            ent.nn = ops.cast_transpose_bf16(W.detach())
+        return ent.nn
+    if ent.nn3 is None:
+        ent.nn3 = {}
+    if prec not in ent.nn3:
+        ent.nn3[prec] = ops.split_bf16(W.detach().t().contiguous(), 1, TERMS[prec])
+    return ent.nn3[prec]
+
+
+def clear_weight_cache():
+    _CACHE.clear()
+
+
+# ---------------------------------------------------------------------------------------------------
+# raw (non-autograd) products
+# ---------------------------------------------------------------------------------------------------
+def _operand(x, width):
+    """activation-side bf16 operand (M, width) of an fp32 (M, <=width) or bf16 (M, width) tensor"""
+    if x.dtype == BF16:
+        assert x.shape[1] == width, (x.shape, width)
+        return x
+    return ops.cast_pad_bf16(x, width)
+
+
+def _raw_linear(x, W, bias, res, act, slope, prec, out_f32):
+    N, K = W.shape
+    Kp = ceil16(K)
+    if prec == "bf16":
+        xb = _operand(x, Kp)
+        rb = res if (res is not None and res.dtype == BF16) else None
+        rf = res if (res is not None and res.dtype != BF16) else None
+        cb, cf = ops.gemm_nt(xb, _w_nt(W, Kp, prec), N, Kp, bias=bias, res_bf16=rb, res_f32=rf, act=act, slope=slope,
+                             out_bf16=not out_f32, n_pad=ceil16(N), out_f32=out_f32)
+        return cf if out_f32 else cb
+    T = TERMS[prec]
+    x3 = ops.split_bf16(x.float() if x.dtype == BF16 else x, 0, T, Kp)
+    _, cf = ops.gemm_nt(x3, _w_nt(W, Kp, prec), N, T * Kp, bias=bias, res_f32=res, act=act, slope=slope, out_f32=True)
+    return cf
+
+
+def _raw_linear_t(g, W, prec, out_f32):
+    N, K = W.shape
+    Np = ceil16(N)
+    if prec == "bf16":
+        gb = _operand(g, Np)
+        cb, cf = ops.gemm_nt(gb, _w_nn(W, prec), K, Np, out_bf16=not out_f32, n_pad=ceil16(K), out_f32=out_f32)
+        return cf if out_f32 else cb
+    T = TERMS[prec]
+    g3 = ops.split_bf16(g, 0, T, Np)
+    _, cf = ops.gemm_nt(g3, _w_nn(W, prec), K, T * Np, out_f32=True)
+    return cf
+
+
+def _raw_outer(g, x, N, K, prec):
+    if prec == "bf16":
+        gb = _operand(g, ceil16(N)) if g.dtype != BF16 else g
+        xb = _operand(x, ceil16(K)) if x.dtype != BF16 else x
+        return ops.gemm_tn(gb, xb, N, K)
+    Np, Kp, T = ceil16(N), ceil16(K), TERMS[prec]
+    g3 = ops.split_bf16(g, 0, T, Np)          # activation-side layout: hi / mid / lo live in fixed segments
+    x3 = ops.split_bf16(x, 0, T, Kp)
+    M = g.shape[0]
+    out = None
+    for a, b in _PAIRS[T]:
+        ga = g3[:, _SEG[T][a] * Np:]
+        xb = x3[:, _SEG[T][b] * Kp:]
+        out = ops.gemm_tn(ga, xb, N, K, out=out, accumulate=out is not None, M=M, lda=T * Np, ldb=T * Kp)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# dense-layer Functions
+# ---------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + bias + res).  x: fp32 (M,K) network input or bf16 (M,ceil16 K) hidden activation."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, res, act, slope, prec, out_f32):
+        y = _raw_linear(x, W, bias, res, act, slope, prec, out_f32)
+        ctx.save_for_backward(x, W, y if act != ACT_NONE else None)
+        ctx.cfg = (act, slope, prec, bias is not None, None if res is None else (res.dtype, res.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, W, y = ctx.saved_tensors
+        act, slope, prec, has_bias, res_info = ctx.cfg
+        N, K = W.shape
+        gz = ActBwdFn.apply(gy.contiguous(), y, act, slope) if act != ACT_NONE else gy.contiguous()
+        gx = gW = gb = gres = None
+        if ctx.needs_input_grad[0]:
+            gx = LinearTFn.apply(gz, W, prec, x.dtype != BF16)
+        if ctx.needs_input_grad[1]:
+            gW = OuterFn.apply(gz, x, N, K, prec)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = ColSumFn.apply(gz, N)
+        if res_info is not None and ctx.needs_input_grad[3]:
+            gres = gz if (gz.dtype == res_info[0] and gz.shape == res_info[1]) else ReshapeGradFn.apply(gz, res_info)
+        return gx, gW, gb, gres, None, None, None, None
+
+
+class LinearTFn(torch.autograd.Function):
+    """out = g W  (input gradient of Linear).  g: bf16 (M, ceil16 N) or fp32 (M,N)."""
+
+    @staticmethod
+    def forward(ctx, g, W, prec, out_f32):
+        ctx.save_for_backward(g, W)
+        ctx.cfg = (prec, g.dtype != BF16)
+        return _raw_linear_t(g, W, prec, out_f32 or prec != "bf16")
+
+    @staticmethod
+    def backward(ctx, go):
+        g, W = ctx.saved_tensors
+        prec, g_f32 = ctx.cfg
+        N, K = W.shape
+        gg = gW = None
+        if ctx.needs_input_grad[0]:
+            gg = LinearFn.apply(go.contiguous(), W, None, None, ACT_NONE, 0.0, prec, g_f32 or prec != "bf16")
+        if ctx.needs_input_grad[1]:
+            gW = OuterFn.apply(g, go.contiguous(), N, K, prec)
+        return gg, gW, None, None
+
+
+class OuterFn(torch.autograd.Function):
+    """out (N,K) fp32 = g^T x  (weight gradient of Linear)."""
+
+    @staticmethod
+    def forward(ctx, g, x, N, K, prec):
+        ctx.save_for_backward(g, x)
+        ctx.cfg = (N, K, prec)
+        return _raw_outer(g, x, N, K, prec)
+
+    @staticmethod
+    def backward(ctx, G):
+        g, x = ctx.saved_tensors
+        N, K, prec = ctx.cfg
+        gg = gx = None
+        G = G.contiguous()
+        if ctx.needs_input_grad[0]:
+            gg = LinearFn.apply(x, G, None, None, ACT_NONE, 0.0, prec, g.dtype != BF16 or prec != "bf16")
+        if ctx.needs_input_grad[1]:
+            gx = LinearTFn.apply(g, G, prec, x.dtype != BF16)
+        return gg, gx, None, None, None
+
+
+class ActBwdFn(torch.autograd.Function):
+    """g * act'(y); linear in g, y enters only through its sign."""
+
+    @staticmethod
+    def forward(ctx, g, y, act, slope):
+        if g.dtype != y.dtype or g.shape != y.shape:         # fp32 upstream gradient of a bf16 activation
+            g = ops.cast_pad_bf16(g, y.shape[1]) if y.dtype == BF16 else g.float()
+        ctx.save_for_backward(y)
+        ctx.cfg = (act, slope)
+        return ops.act_backward(g, y, act, slope)
+
+    @staticmethod
+    def backward(ctx, gg):
+        (y,) = ctx.saved_tensors
+        return ActBwdFn.apply(gg.contiguous(), y, ctx.cfg[0], ctx.cfg[1]), None, None, None
+
+
+class ColSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, N):
+        ctx.shape = (g.shape, g.dtype)
+        return ops.colsum(g, N=N)
+
+    @staticmethod
+    def backward(ctx, gb):
+        shape, dtype = ctx.shape
+        out = torch.zeros(shape, dtype=dtype, device=gb.device)
+        out[:, :gb.shape[0]] = gb.to(dtype)
+        return out, None
+
+
+class ReshapeGradFn(torch.autograd.Function):
+    """dtype / padding adapter between a gradient and the tensor it belongs to (fp32 (M,N) <-> bf16 (M,ceil16 N))."""
+
+    @staticmethod
+    def forward(ctx, g, info):
+        dtype, shape = info
+        ctx.info = (g.dtype, g.shape)
+        if dtype == BF16:
+            return ops.cast_pad_bf16(g.float()[:, :shape[1]].contiguous(), shape[1]) if g.dtype != BF16 else g[:, :shape[1]].contiguous()
+        return g.float()[:, :shape[1]].contiguous()
+
+    @staticmethod
+    def backward(ctx, gg):
+        return ReshapeGradFn.apply(gg, ctx.info), None
+
+
+def linear(x, W, bias=None, res=None, act=ACT_NONE, slope=0.0, prec="bf16", out_f32=False):
+    return LinearFn.apply(x, W, bias, res, act, slope, prec, out_f32 or prec != "bf16")
+
+
+# ---------------------------------------------------------------------------------------------------
+# pose features / FK / camera
+# ---------------------------------------------------------------------------------------------------
+class KcsFn(torch.autograd.Function):
+    """special_KCS_Input_transform: (M,48) fp32 -> (M,30|15) fp32."""
+
+    @staticmethod
+    def forward(ctx, x, with_lengths):
+        x = x.reshape(-1, 48)
+        ctx.save_for_backward(x)
+        ctx.wl = with_lengths
+        return ops.kcs_forward(x, with_lengths, f32=True)[0]
+
+    @staticmethod
+    def backward(ctx, gf):
+        (x,) = ctx.saved_tensors
+        return KcsVjpFn.apply(x, gf.contiguous(), ctx.wl), None
+
+
+class KcsVjpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gf, with_lengths):
+        ctx.save_for_backward(x)
+        ctx.wl = with_lengths
+        return ops.kcs_backward(x, gf, with_lengths)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        # adjoint in the cotangent argument; the second derivative w.r.t. the pose itself is not provided
+        # (no caller differentiates the penalty w.r.t. its interpolation points)
+        return None, KcsJvpFn.apply(x, g.contiguous(), ctx.wl), None
+
+
+class KcsJvpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, t, with_lengths):
+        ctx.save_for_backward(x)
+        ctx.wl = with_lengths
+        return ops.kcs_jvp(x, t, with_lengths)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return None, KcsVjpFn.apply(x, g.contiguous(), ctx.wl), None
+
+
+class FkFn(torch.autograd.Function):
+    """change_3d_joint_angle + 32->16 gather: angles (N,37), bone_len (N,15), root (N,3) -> (N,16,3)."""
+
+    @staticmethod
+    def forward(ctx, angles, bone_len, root):
+        ctx.save_for_backward(angles, bone_len)
+        return ops.fk_forward(angles, bone_len, root, 16)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        angles, bone_len = ctx.saved_tensors
+        ga, gb, gr = ops.fk_backward(angles, bone_len, g.contiguous())
+        return ga, gb, gr
+
+
+class GenTailFn(torch.autograd.Function):
+    """Fk_Generator tail: head (N,35), bone_len (N,15), scaler (N,8)|None -> fake (N,16,3)."""
+
+    @staticmethod
+    def forward(ctx, head, bone_len, scaler, use_preangle):
+        ctx.save_for_backward(head, bone_len, scaler)
+        ctx.pre = use_preangle
+        return ops.gen_tail_forward(head, bone_len, scaler, use_preangle)[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        head, bone_len, scaler = ctx.saved_tensors
+        return ops.gen_tail_backward(head, bone_len, scaler, g.contiguous(), ctx.pre), None, None, None
+
+
+class CenterFlipFn(torch.autograd.Function):
+    """x - x[:, :1] and/or L/R flip of (N,16,C); linear, so its backward is the transposed kernel."""
+
+    @staticmethod
+    def forward(ctx, x, center, flip, adjoint):
+        ctx.cfg = (center, flip, adjoint)
+        return ops.center_flip(x, center, flip, adjoint)
+
+    @staticmethod
+    def backward(ctx, g):
+        center, flip, adjoint = ctx.cfg
+        return CenterFlipFn.apply(g.contiguous(), center, flip, not adjoint), None, None, None
+
+
+class W2CProjectFn(torch.autograd.Function):
+    """GAN_torch_world_to_camera + project_to_2d with one shared camera -> (cam3d (N,16,3), proj2d (N,16,2))."""
+
+    @staticmethod
+    def forward(ctx, x, quat, trans, cam9):
+        ctx.save_for_backward(x)
+        ctx.cam = (quat, trans, cam9)
+        c3, p2 = ops.world_to_camera_project(x, quat, trans, cam9)
+        return c3, p2
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g3, g2):
+        (x,) = ctx.saved_tensors
+        quat, trans, cam9 = ctx.cam
+        gx = ops.world_to_camera_project_backward(x, quat, trans, cam9, None if g3 is None else g3.contiguous(),
+                                                  None if g2 is None else g2.contiguous())
+        return gx.reshape(x.shape), None, None, None
+
+
+def center_flip(x, center=False, flip=False):
+    return CenterFlipFn.apply(x, center, flip, False)

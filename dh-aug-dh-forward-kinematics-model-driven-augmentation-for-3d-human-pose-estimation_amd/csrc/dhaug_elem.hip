@@ -48,20 +48,32 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     }
 }
 
-// bf16x3: x = hi + lo; activation side [hi|hi|lo], weight side [hi|lo|hi]
-__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, long long ld_src,
-                                                     uint16_t* __restrict__ dst, long long rows, long long cols,
-                                                     long long pad_cols, int mode) {
+// Split of fp32 values into bf16 terms for fp32-grade products on the bf16 MFMA path.
+//   terms 3 ("bf16x3", x = hi + lo):           activation side [hi|hi|lo],           weight side [hi|lo|hi]
+//   terms 6 ("bf16x6", x = hi + mid + lo):     activation side [hi|hi|mid|mid|hi|lo], weight side [hi|mid|hi|mid|lo|hi]
+// so that A' B'^T = hi*hi + hi*mid + mid*hi (+ mid*mid + hi*lo + lo*hi): every product term down to 2^-16 (2^-24)
+// relative.  Each segment is pad_cols wide, zero padded.
+__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ src, long long ld_src,
+                                                    uint16_t* __restrict__ dst, long long rows, long long cols,
+                                                    long long pad_cols, int mode, int terms) {
     const long long total = rows * pad_cols;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long r = i / pad_cols, c = i - r * pad_cols;
         const float x = c < cols ? src[r * ld_src + c] : 0.0f;
         const uint16_t hi = dhaug_f32_to_bf16(x);
-        const uint16_t lo = dhaug_f32_to_bf16(x - dhaug_bf16_to_f32(hi));
-        uint16_t* row = dst + r * 3 * pad_cols;
-        row[c] = hi;
-        row[pad_cols + c] = mode == 0 ? hi : lo;
-        row[2 * pad_cols + c] = mode == 0 ? lo : hi;
+        const float r1 = x - dhaug_bf16_to_f32(hi);
+        const uint16_t mid = dhaug_f32_to_bf16(r1);
+        const uint16_t lo = dhaug_f32_to_bf16(r1 - dhaug_bf16_to_f32(mid));
+        uint16_t* row = dst + r * terms * pad_cols + c;
+        if (terms == 3) {
+            row[0] = hi;
+            row[pad_cols] = mode == 0 ? hi : mid;
+            row[2 * pad_cols] = mode == 0 ? mid : hi;
+        } else {
+            const uint16_t a[6] = {hi, hi, mid, mid, hi, lo}, b[6] = {hi, mid, hi, mid, lo, hi};
+#pragma unroll
+            for (int t = 0; t < 6; ++t) row[t * pad_cols] = mode == 0 ? a[t] : b[t];
+        }
     }
 }
 
@@ -185,13 +197,14 @@ int dhaug_cast_transpose_bf16(const float* src, int64_t ld_src, uint16_t* dst, i
     return dhaug_launch_status();
 }
 
-int dhaug_split3_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t rows, int64_t cols, int64_t pad_cols,
-                      int mode, void* stream) {
+int dhaug_split_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t rows, int64_t cols, int64_t pad_cols,
+                     int mode, int terms, void* stream) {
     DHAUG_CHECK(rows >= 0 && cols >= 1 && pad_cols >= cols && ld_src >= cols && (mode == 0 || mode == 1), DHAUG_EINVAL);
+    DHAUG_CHECK(terms == 3 || terms == 6, DHAUG_EINVAL);
     if (rows == 0) return DHAUG_OK;
     DHAUG_CHECK_PTR(src); DHAUG_CHECK_PTR(dst);
-    hipLaunchKernelGGL(split3_kernel, dim3(grid1d(rows * pad_cols, 256)), dim3(256), 0, (hipStream_t)stream, src,
-                       (long long)ld_src, dst, (long long)rows, (long long)cols, (long long)pad_cols, mode);
+    hipLaunchKernelGGL(split_kernel, dim3(grid1d(rows * pad_cols, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (long long)ld_src, dst, (long long)rows, (long long)cols, (long long)pad_cols, mode, terms);
     return dhaug_launch_status();
 }
 

@@ -1,0 +1,169 @@
+"""Drop-in for R/models_Fk_GAN/Fk_discriminator.py: KCS transforms, Fk_3D_Discriminator (:149-201),
+calc_gradient_penalty (:205-231), Fk_2D_Discriminator (:236-266) and the two video motion critics (:381-587).
+
+All Linear layers are bf16 MFMA GEMMs with fused bias / ReLU|LeakyReLU / residual; KCS features are one HIP kernel
+(value, VJP and JVP) -- the critics are differentiable to second order so that calc_gradient_penalty works exactly
+as in the reference (autograd.grad(..., create_graph=True))."""
+import torch
+import torch.autograd as autograd
+import torch.nn as nn
+
+from .. import autograd_ops as A
+from .Fk_generator import default_precision
+from .special_operate import myResNet
+
+
+def special_KCS_Input_transform(pos_16_3d, device=None):
+    """(N,16,3)|(N,48) -> (N,30): 15 adjacent-bone cosines + 15 bone lengths."""
+    return A.KcsFn.apply(pos_16_3d.reshape(-1, 48), True)
+
+
+def video_mode_special_KCS_Input_transform(pos_16_3d, device=None):
+    """(N,16,3)|(N,48) -> (N,15): cosines only."""
+    return A.KcsFn.apply(pos_16_3d.reshape(-1, 48), False)
+
+
+def _branch(x, first, blocks, prec):
+    h = A.linear(x, first.weight, first.bias, None, A.ACT_RELU, 0.0, prec)
+    for b in blocks:
+        h = b(h, prec)
+    return h
+
+
+def _frame_diff(x, frames, width):
+    x = x.reshape(-1, frames, width)
+    return (x[:, 1:] - x[:, :-1]).reshape(-1, (frames - 1) * width)
+
+
+class Fk_3D_Discriminator(nn.Module):
+    def __init__(self, device, args):
+        super().__init__()
+        self.device, self.args = device, args
+        self.precision = default_precision()
+        D = args.Dis_DenseDim_3D
+        self.previous = nn.Sequential(nn.Linear(16 * 3, D), nn.ReLU(True))
+        self.block1, self.block2, self.block3 = myResNet(D), myResNet(D), myResNet(D)
+        self.special_KCS_previous = nn.Sequential(nn.Linear(30, D), nn.ReLU(True))
+        self.special_KCS_block1, self.special_KCS_block2, self.special_KCS_block3 = myResNet(D), myResNet(D), myResNet(D)
+        self.merge_previous = nn.Sequential(nn.Linear(D + D, 100), nn.ReLU(True))
+        self.merge_block1 = myResNet(100)
+        self.output = nn.Linear(100, 1)
+
+    def forward(self, input):
+        p = self.precision
+        x = input.reshape(-1, 48)
+        k = _branch(A.KcsFn.apply(x, True), self.special_KCS_previous[0],
+                    (self.special_KCS_block1, self.special_KCS_block2, self.special_KCS_block3), p)
+        q = _branch(x, self.previous[0], (self.block1, self.block2, self.block3), p)
+        m = torch.cat((k, q), dim=-1)
+        m = A.linear(m, self.merge_previous[0].weight, self.merge_previous[0].bias, None, A.ACT_RELU, 0.0, p)
+        m = self.merge_block1(m, p)
+        return A.linear(m, self.output.weight, self.output.bias, None, A.ACT_NONE, 0.0, p, out_f32=True)
+
+
+def calc_gradient_penalty(netD, real_data, fake_data, BATCH_SIZE, LAMBDA, device, alpha=None):
+    """LAMBDA * mean((||dD/dx_hat||_2 - 1)^2).  `alpha` (B,1) may be injected (parity tests); otherwise it is drawn
+    on the device (the reference draws it from the global CPU generator, :210)."""
+    real_data = real_data.reshape(BATCH_SIZE, -1)
+    fake_data = fake_data.reshape(BATCH_SIZE, -1)
+    if alpha is None:
+        alpha = torch.rand(BATCH_SIZE, 1, device=real_data.device)
+    alpha = alpha.to(real_data.device).reshape(BATCH_SIZE, 1)
+    interpolates = (alpha * real_data + ((1 - alpha) * fake_data)).detach().requires_grad_(True)
+    disc_interpolates = netD(interpolates)
+    gradients = autograd.grad(outputs=disc_interpolates, inputs=interpolates,
+                              grad_outputs=torch.ones_like(disc_interpolates),
+                              create_graph=True, retain_graph=True, only_inputs=True)[0]
+    return ((gradients.norm(2, dim=1) - 1) ** 2).mean() * LAMBDA
+
+
+class Fk_2D_Discriminator(nn.Module):
+    def __init__(self, args, num_joints=16):
+        super().__init__()
+        self.args = args
+        self.precision = default_precision()
+        D = args.Dis_DenseDim_2D
+        self.pose_layer_1 = nn.Linear(num_joints * 2, D)
+        self.pose_layer_2 = nn.Linear(D, D)
+        self.pose_layer_3 = nn.Linear(D, D)
+        self.pose_layer_4 = nn.Linear(D, D)
+        self.layer_last = nn.Linear(D, D)
+        self.layer_pred = nn.Linear(D, 1)
+        self.relu = nn.LeakyReLU()
+        self.slope = 0.01
+
+    def forward(self, x):
+        p, s, L = self.precision, self.slope, A.ACT_LRELU
+        x = x.reshape(-1, 32)
+        d1 = A.linear(x, self.pose_layer_1.weight, self.pose_layer_1.bias, None, L, s, p)
+        d2 = A.linear(d1, self.pose_layer_2.weight, self.pose_layer_2.bias, None, L, s, p)
+        d3 = A.linear(d2, self.pose_layer_3.weight, self.pose_layer_3.bias, d1, L, s, p)
+        d4 = A.linear(d3, self.pose_layer_4.weight, self.pose_layer_4.bias, None, A.ACT_NONE, 0.0, p)
+        dl = A.linear(d4, self.layer_last.weight, self.layer_last.bias, None, L, s, p)
+        return A.linear(dl, self.layer_pred.weight, self.layer_pred.bias, None, A.ACT_NONE, 0.0, p, out_f32=True)
+
+
+class Video_motion_Fk_3D_Discriminator(nn.Module):
+    def __init__(self, device, args, video_frame_num):
+        super().__init__()
+        self.video_frame_num, self.device, self.args = video_frame_num, device, args
+        self.precision = default_precision()
+        D, R = args.video_Dis_DenseDim_3D, video_frame_num
+        for name, width in (("special_KCS", R * 15), ("diff_special_KCS", (R - 1) * 15), ("pos_3d", R * 48),
+                            ("diff_pos_3d", (R - 1) * 48)):
+            setattr(self, name + "_previous", nn.Sequential(nn.Linear(width, D), nn.ReLU(True)))
+            for i in (1, 2, 3):
+                setattr(self, "%s_block%d" % (name, i), myResNet(D))
+        self.use_pos = bool(args.motion_Dis_whether_use_3dPos_branch)
+        self.use_diff = bool(args.motion_Dis_whether_use_3dDiff_branch)
+        self.branch_num = 2 + int(self.use_pos) + int(self.use_diff)
+        self.kcs_merge_previous = nn.Sequential(nn.Linear(D * self.branch_num, 100), nn.ReLU(True))
+        self.kcs_merge_block1 = myResNet(100)
+        self.kcs_output = nn.Linear(100, 1)
+
+    def _b(self, x, name):
+        return _branch(x.contiguous(), getattr(self, name + "_previous")[0],
+                       [getattr(self, "%s_block%d" % (name, i)) for i in (1, 2, 3)], self.precision)
+
+    def forward(self, input):
+        R, p = self.video_frame_num, self.precision
+        x = input.reshape(-1, 48)
+        kc = A.KcsFn.apply(x, False).reshape(-1, R * 15)
+        outs = [self._b(kc, "special_KCS"), self._b(_frame_diff(kc, R, 15), "diff_special_KCS")]
+        if self.use_pos:
+            outs.append(self._b(x.reshape(-1, R * 48), "pos_3d"))
+        if self.use_diff:
+            outs.append(self._b(_frame_diff(x, R, 48), "diff_pos_3d"))
+        m = torch.cat(outs, dim=-1)
+        m = A.linear(m, self.kcs_merge_previous[0].weight, self.kcs_merge_previous[0].bias, None, A.ACT_RELU, 0.0, p)
+        m = self.kcs_merge_block1(m, p)
+        return A.linear(m, self.kcs_output.weight, self.kcs_output.bias, None, A.ACT_NONE, 0.0, p, out_f32=True)
+
+
+class Video_motion_Fk_2D_Discriminator(nn.Module):
+    def __init__(self, device, args, video_frame_num):
+        super().__init__()
+        self.video_frame_num, self.device, self.args = video_frame_num, device, args
+        self.precision = default_precision()
+        D, R = args.video_Dis_DenseDim_2D, video_frame_num
+        for name, width in (("pos_2d", R * 32), ("root_diff_2d", (R - 1) * 2)):
+            setattr(self, name + "_previous", nn.Sequential(nn.Linear(width, D), nn.ReLU(True)))
+            for i in (1, 2, 3):
+                setattr(self, "%s_block%d" % (name, i), myResNet(D))
+        self.merge_previous = nn.Sequential(nn.Linear(D + D, 100), nn.ReLU(True))
+        self.merge_block1 = myResNet(100)
+        self.merge_output = nn.Linear(100, 1)
+
+    def _b(self, x, name):
+        return _branch(x.contiguous(), getattr(self, name + "_previous")[0],
+                       [getattr(self, "%s_block%d" % (name, i)) for i in (1, 2, 3)], self.precision)
+
+    def forward(self, input):
+        R, p = self.video_frame_num, self.precision
+        x = input.reshape(-1, 32)
+        a = self._b(x.reshape(-1, R * 32), "pos_2d")
+        b = self._b(_frame_diff(x.reshape(-1, 16, 2)[:, 0, :], R, 2), "root_diff_2d")
+        m = torch.cat((a, b), dim=-1)
+        m = A.linear(m, self.merge_previous[0].weight, self.merge_previous[0].bias, None, A.ACT_RELU, 0.0, p)
+        m = self.merge_block1(m, p)
+        return A.linear(m, self.merge_output.weight, self.merge_output.bias, None, A.ACT_NONE, 0.0, p, out_f32=True)

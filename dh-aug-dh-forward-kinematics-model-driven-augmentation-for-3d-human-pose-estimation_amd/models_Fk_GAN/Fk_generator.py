@@ -1,0 +1,110 @@
+"""Drop-in for R/models_Fk_GAN/Fk_generator.py: Fk_Generator (:79-261), Video_Fk_Generator (:264-458).
+
+Trunk (Linear+ReLU, 3 x myResNet, Linear head) = bf16 MFMA GEMMs with fused epilogues; everything after the
+head (tanh, 31->37 slot scatter, joint-limit map, bone-length jitter, FK, 32->16 gather) is ONE HIP kernel
+(dhaug_gen_tail_forward) instead of ~7 100 ATen ops.  state_dict keys are the reference's
+(preprocess.0, block{1,2,3}.fc{1,2}, deconv_out).
+
+RNG: the reference draws bone_len_scaler from the global CPU generator inside forward (:197) / numpy (:383).  Here
+it is drawn on the device, or injected through `bone_len_scaler=` (parity tests)."""
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import autograd_ops as A
+from .. import ops
+from .special_operate import myResNet
+
+GAN_global_rotation_table = {k: {"range": (-180, 180), "changeRate": (-5, 5)} for k in ("angle_x", "angle_y", "angle_z")}
+_LO = [-110, -110, -110, -180, 0, -65, -65, -110, -180, 0] + [-180] * 12 + [0, 0] + [-155, -155, -100, 0, 0, -65, -65, -100, 0, 0]
+_HI = [65, 65, 180, 0, 0, 110, 110, 180, 0, 0] + [180] * 12 + [0, 0] + [65, 65, 180, 180, 0, 155, 155, 180, 180, 0]
+GAN_angle_range_table = {"joint%d" % (i + 1): {"range": (_LO[i], _HI[i])} for i in range(34)}
+
+
+def default_precision():
+    return os.environ.get("DHAUG_PRECISION", "bf16")
+
+
+class _GeneratorBase(nn.Module):
+    def __init__(self, frames, FK_DH_Class, args, device, INPUT_VEC_DIM):
+        super().__init__()
+        self.video_frame_num = frames
+        self.OUTPUT_DIM = args.GAN_OUTPUT_DIM
+        assert self.OUTPUT_DIM == 35, "the FK tail consumes 32 + 3 head columns (R/function_aug/config.py:85)"
+        self.BATCH_SIZE = args.batch_size
+        self.FK_DH_Class = FK_DH_Class
+        self.train_num = 0
+        self.args = args
+        self.INPUT_VEC_DIM = INPUT_VEC_DIM
+        self.device = device
+        self.precision = default_precision()
+        self.boneLength = torch.zeros((self.BATCH_SIZE, 15), dtype=torch.float32)
+        self.distribute_angle = []            # last generator_angle only (the reference leaks one per call, :170)
+        self.record_angles = False
+        D = args.Gen_DenseDim
+        self.preprocess = nn.Sequential(nn.Linear(INPUT_VEC_DIM, D), nn.ReLU(True))
+        self.block1 = myResNet(D)
+        self.block2 = myResNet(D)
+        self.block3 = myResNet(D)
+        self.deconv_out = nn.Linear(D, frames * self.OUTPUT_DIM)
+
+    def GAN_generator_get_bone_length(self, input):
+        """bone lengths of the real batch -> self.boneLength (N,15)   (:107-111 / :294-300)."""
+        self.boneLength = ops.bone_length(input.reshape(-1, 16, 3))
+
+    def trunk(self, z):
+        p = self.precision
+        lin = self.preprocess[0]
+        x = A.linear(z, lin.weight, lin.bias, None, A.ACT_RELU, 0.0, p)
+        x = self.block3(self.block2(self.block1(x, p), p), p)
+        return A.linear(x, self.deconv_out.weight, self.deconv_out.bias, None, A.ACT_NONE, 0.0, p, out_f32=True)
+
+    def _scaler(self, B, bone_len_scaler):
+        mode = self.args.bone_len_scaler
+        if bone_len_scaler is not None:
+            s = bone_len_scaler.to(device=self.boneLength.device, dtype=torch.float32)
+        elif mode == "different":
+            s = torch.randint(-200, 200, (B, 8), device=self.boneLength.device).float() / 1000.0
+        elif mode == "same":            # crashes in the reference; implemented as documented
+            s = (torch.randint(-200, 200, (B, 1), device=self.boneLength.device).float() / 1000.0).repeat(1, 8)
+        elif mode == "":
+            return None
+        else:
+            raise ValueError("args.bone_len_scaler")
+        if self.video_frame_num > 1:    # one draw per sample, shared by its frames (:389-390)
+            s = s.reshape(B, 1, 8).repeat(1, self.video_frame_num, 1).reshape(-1, 8)
+        return s.contiguous()
+
+    def forward(self, input, bone_len_scaler=None):
+        B, R = input.shape[0], self.video_frame_num
+        head = self.trunk(input).reshape(B * R, 35)
+        use_rt = getattr(self.args, "whether_use_RT", True)
+        if not use_rt:                   # global rotation off: tanh^-1(0) = 0 on the three rotation columns
+            head = head.clone()
+            head[:, 28:31] = 0.0
+            if not self.args.GAN_whether_use_preAngle:
+                pass
+        scaler = self._scaler(B, bone_len_scaler)
+        bl = self.boneLength
+        if bl.shape[0] != B * R:
+            raise RuntimeError("boneLength has %d rows, the batch needs %d (call GAN_generator_get_bone_length)"
+                               % (bl.shape[0], B * R))
+        fake = A.GenTailFn.apply(head.contiguous(), bl, scaler, bool(self.args.GAN_whether_use_preAngle))
+        self.train_num += 1
+        if self.record_angles:
+            with torch.no_grad():
+                self.distribute_angle = [ops.gen_tail_forward(head.detach(), bl, scaler,
+                                                              bool(self.args.GAN_whether_use_preAngle), True)[1]]
+        fake = fake.reshape(B * R, 48)
+        return fake.reshape(B, R, 48) if R > 1 else fake
+
+
+class Fk_Generator(_GeneratorBase):
+    def __init__(self, FK_DH_Class, args, device, INPUT_VEC_DIM=128):
+        super().__init__(1, FK_DH_Class, args, device, INPUT_VEC_DIM)
+
+
+class Video_Fk_Generator(_GeneratorBase):
+    def __init__(self, video_frame_num, FK_DH_Class, args, device, INPUT_VEC_DIM=128):
+        super().__init__(video_frame_num, FK_DH_Class, args, device, INPUT_VEC_DIM)

@@ -1,0 +1,233 @@
+"""Drop-in for R/models_Fk_GAN/model_fk_gan_train.py: model/optimizer factory (:97-173), the WGAN-GP critic step
+train_Fk_discriminator (:177-230) and the single-frame GAN epoch GAN_solutions_FK_generator (:236-511).
+
+Differences that are deliberate (documented in DESIGN.md):
+  * device work only: no per-iteration .cpu().numpy() of the generated pairs (reference :487-489); the epoch's
+    fake pairs stay on the device and are handed over as one tensor-backed loader ("next" row N2).
+  * RNG draws (noise, GP alpha, bone jitter, camera choice) happen on the device / are injectable.
+  * the three backward calls of the critic step are one backward of -D(real).mean() + D(fake).mean() + GP
+    (same gradients; fewer passes over the weights)."""
+import numpy as np
+import torch
+
+from .. import autograd_ops as A
+from .. import ops
+from ..common import camera as cam
+from ..common.h36m_dataset import h36m_cameras_extrinsic_params, h36m_cameras_intrinsic_params
+from ..optim import FusedAdam
+from .Fk_discriminator import (Fk_2D_Discriminator, Fk_3D_Discriminator, Video_motion_Fk_2D_Discriminator,
+                               Video_motion_Fk_3D_Discriminator, calc_gradient_penalty)
+from .Fk_generator import Fk_Generator, Video_Fk_Generator
+from .video_mode_operate import frames_from_args
+
+
+def set_grad(nets, requires_grad=False):
+    """R/utils/utils.py:123-127."""
+    for net in nets:
+        if net is not None:
+            for p in net.parameters():
+                p.requires_grad = requires_grad
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("the DH-AUG hot path needs a GPU (no CPU fallback exists)")
+    return torch.device("cuda")
+
+
+def my_get_poseFk_model(args, dataset, FK_DH_Class):
+    device = _device()
+    num_joints = dataset.skeleton().num_joints() if dataset is not None else 16
+    model_G = Fk_Generator(FK_DH_Class, args, device, INPUT_VEC_DIM=128).to(device)
+    model_d3d = Fk_3D_Discriminator(device, args).to(device)
+    model_d2d = Fk_2D_Discriminator(args, num_joints).to(device)
+    lr = 1e-4                                    # lr_g / lr_d are parsed but ignored by the reference (:112)
+    return {
+        'model_G': model_G, 'model_d3d': model_d3d, 'model_d2d': model_d2d,
+        'optimizer_G': FusedAdam(model_G.parameters(), lr=lr, betas=(0.5, 0.9)),
+        'optimizer_d3d': FusedAdam(model_d3d.parameters(), lr=lr, betas=(0.5, 0.9)),
+        'optimizer_d2d': FusedAdam(model_d2d.parameters(), lr=lr, betas=(0.5, 0.9)),
+    }
+
+
+def video_mode_my_get_poseFk_model(args, dataset, FK_DH_Class, video_frame_num):
+    device = _device()
+    model_G = Video_Fk_Generator(video_frame_num, FK_DH_Class, args, device, INPUT_VEC_DIM=128).to(device)
+    model_d3d = Fk_3D_Discriminator(device, args).to(device)
+    model_d2d = Fk_2D_Discriminator(args).to(device)
+    model_motion_d3d = Video_motion_Fk_3D_Discriminator(device, args, video_frame_num).to(device)
+    model_motion_d2d = Video_motion_Fk_2D_Discriminator(device, args, video_frame_num).to(device)
+    mk = lambda m: FusedAdam(m.parameters(), lr=1e-4, betas=(0.5, 0.9))
+    return {
+        'model_G': model_G, 'model_d3d': model_d3d, 'model_d2d': model_d2d,
+        'model_motion_d3d': model_motion_d3d, 'model_motion_d2d': model_motion_d2d,
+        'optimizer_G': mk(model_G), 'optimizer_d3d': mk(model_d3d), 'optimizer_d2d': mk(model_d2d),
+        'optimizer_motion_d3d': mk(model_motion_d3d), 'optimizer_motion_d2d': mk(model_motion_d2d),
+    }
+
+
+class MeanFn(torch.autograd.Function):
+    """mean of the (M,1) logits through the column-sum kernel."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return (ops.colsum(x.reshape(-1, 1).contiguous(), N=1) / x.numel()).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        n = 1
+        for s in ctx.shape:
+            n *= s
+        return (g / n).expand(ctx.shape).contiguous()
+
+
+def train_Fk_discriminator(model_dis, data_real, data_fake, summary, writer, writer_name, optimizerD, args,
+                           one=None, mone=None, dis_mode='single', alpha=None):
+    """One WGAN-GP critic step; returns (Wasserstein_D, D_cost) as 0-dim device tensors."""
+    device = _device()
+    model_dis.zero_grad()
+    optimizerD.zero_grad()
+    data_real = data_real.to(device)
+    data_fake = data_fake.to(device)
+    D_real = MeanFn.apply(model_dis(data_real))
+    D_fake = MeanFn.apply(model_dis(data_fake))
+    real_used_num = frames_from_args(args) if dis_mode != 'motion' else 1
+    gradient_penalty = calc_gradient_penalty(model_dis, data_real.detach(), data_fake.detach(),
+                                             args.batch_size * real_used_num, args.GAN_LAMBDA, device, alpha=alpha)
+    (D_fake - D_real + gradient_penalty).backward()      # == backward(mone) + backward(one) + GP.backward()
+    D_cost = (D_fake - D_real + gradient_penalty).detach()
+    Wasserstein_D = (D_real - D_fake).detach()
+    optimizerD.step()
+    if writer is not None:
+        it = getattr(summary, "train_iter_num", 0)
+        writer.add_scalar('train_G_iter_PoseFk/{}_D_real'.format(writer_name), D_real.detach(), it)
+        writer.add_scalar('train_G_iter_PoseFk/{}_D_fake'.format(writer_name), D_fake.detach(), it)
+        writer.add_scalar('train_G_iter_PoseFk/{}_Wasserstein_D'.format(writer_name), Wasserstein_D, it)
+    return Wasserstein_D, D_cost
+
+
+def pick_camera(train_subjects, rng=np.random):
+    """random subject + camera (R/models_Fk_GAN/model_fk_gan_train.py:344-364) -> (quat4, trans3 [m], cam9)."""
+    subject = train_subjects[rng.randint(0, len(train_subjects))]
+    cam_id = rng.randint(0, 4)
+    ext = h36m_cameras_extrinsic_params[subject][cam_id]
+    quat = [float(v) for v in ext['orientation']]
+    trans = [float(v) / 1000.0 for v in ext['translation']]
+    return quat, trans, cam.camera_params9(h36m_cameras_intrinsic_params[cam_id])
+
+
+class FakePairBuffer:
+    """The product of the augmentation epoch ("next" row N2): (pos_3d_cam (M,16,3), 2D (M,16,2), cam (M,9)) kept on
+    the device; iterating yields shuffled batches like the reference's DataLoader(PoseDataSet(...)) (:504-510)."""
+
+    def __init__(self, batch_size):
+        self.batch_size = batch_size
+        self.p3, self.p2, self.cam = [], [], []
+
+    def append(self, pos_3d_cam, pos_2d, cam9):
+        self.p3.append(pos_3d_cam.detach())
+        self.p2.append(pos_2d.detach())
+        self.cam.append(torch.as_tensor(cam9, dtype=torch.float32, device=pos_2d.device).reshape(1, 9).expand(pos_2d.shape[0], 9))
+
+    def tensors(self):
+        return torch.cat(self.p3), torch.cat(self.p2), torch.cat(self.cam)
+
+    def __len__(self):
+        n = sum(t.shape[0] for t in self.p3)
+        return (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        p3, p2, c = self.tensors()
+        perm = torch.randperm(p3.shape[0], device=p3.device)
+        for i in range(0, p3.shape[0], self.batch_size):
+            j = perm[i:i + self.batch_size]
+            yield p3[j], p2[j], ['none'] * j.shape[0], c[j]
+
+
+def gan_iteration(args, poseFk_dict, inputs_3d, cam_param, target_d2d, train_subjects, summary=None, writer=None,
+                  do_g_step=False, camera=None, rng=np.random):
+    """One pass of R/models_Fk_GAN/model_fk_gan_train.py:281-489 on one real batch.
+    inputs_3d (B,16,3) camera-space real poses, cam_param (B,>=16) with quaternion at [9:13] and translation at
+    [13:16], target_d2d (B,16,2).  Returns dict(pos_3d_cam, pos_2d, cam9, Wasserstein_D_3D, ..., G_cost)."""
+    device = _device()
+    G, D3, D2 = poseFk_dict['model_G'], poseFk_dict['model_d3d'], poseFk_dict['model_d2d']
+    oG, o3, o2 = poseFk_dict['optimizer_G'], poseFk_dict['optimizer_d3d'], poseFk_dict['optimizer_d2d']
+    B = args.batch_size
+    inputs_3d, cam_param, target_d2d = inputs_3d.to(device), cam_param.to(device), target_d2d.to(device)
+    G.GAN_generator_get_bone_length(inputs_3d)
+    real_world = cam.GAN_torch_camera_to_world_batch(inputs_3d.reshape(-1, 16, 3), cam_param[:, 9:13].contiguous(),
+                                                     cam_param[:, 13:16].contiguous())
+    real_c = ops.center_flip(real_world, True, False)                       # :295
+    set_grad([D3, D2], True)
+    set_grad([G], False)
+    with torch.no_grad():
+        noise = torch.randn(B, 128, device=device)
+        fake_world = G(noise).reshape(-1, 16, 3)                            # :305-310 (.data: no graph)
+    fake_c = ops.center_flip(fake_world, True, False)                        # :312
+    out = {}
+    W3, C3 = train_Fk_discriminator(D3, real_c, fake_c, summary, writer, 'Fk_d3d', o3, args)
+    flip = bool(args.flip_GAN_model_input)
+    if flip:                                                                 # :319-341
+        W3f, C3f = train_Fk_discriminator(D3, ops.center_flip(real_c, False, True), ops.center_flip(fake_c, False, True),
+                                          summary, writer, 'Fk_d3d', o3, args)
+        W3, C3 = (W3 + W3f) / 2, (C3 + C3f) / 2
+    quat, trans, cam9 = camera if camera is not None else pick_camera(train_subjects, rng)
+    pos_3d_cam, pos_2d = ops.world_to_camera_project(fake_world, quat, trans, cam9)      # :374-376
+    W2, C2 = train_Fk_discriminator(D2, target_d2d, pos_2d, summary, writer, 'd2d', o2, args)
+    if flip:                                                                 # :387-409
+        W2f, C2f = train_Fk_discriminator(D2, ops.center_flip(target_d2d, False, True),
+                                          ops.center_flip(pos_2d, False, True), summary, writer, 'd2d', o2, args)
+        W2, C2 = (W2 + W2f) / 2, (C2 + C2f) / 2
+    G_cost = None
+    if do_g_step:                                                            # :415-484
+        set_grad([D3, D2], False)
+        set_grad([G], True)
+        G.zero_grad()
+        oG.zero_grad()
+        noise = torch.randn(B, 128, device=device)
+        fw = G(noise).reshape(-1, 16, 3)
+        _, f2d = A.W2CProjectFn.apply(fw, tuple(quat), tuple(trans), tuple(cam9))
+        fc = A.center_flip(fw, True, False)
+        adv3 = MeanFn.apply(D3(fc))
+        adv2 = MeanFn.apply(D2(f2d))
+        if flip:                        # flipped copies contribute value but no gradient (detach, :455,:459)
+            with torch.no_grad():
+                adv3f = MeanFn.apply(D3(ops.center_flip(fc.detach(), False, True)))
+                adv2f = MeanFn.apply(D2(ops.center_flip(f2d.detach(), False, True)))
+            adv3, adv2 = (adv3 + adv3f) / 2, (adv2 + adv2f) / 2
+        gen_loss = adv3 * args.GAN_3d_loss_weight + adv2 * args.GAN_2d_loss_weight
+        (-gen_loss).backward()                                               # gen_loss.backward(mone)
+        G_cost = (-gen_loss).detach()
+        oG.step()
+        set_grad([D3, D2], True)
+    out.update(pos_3d_cam=pos_3d_cam, pos_2d=pos_2d, cam9=cam9, Wasserstein_D_3D=W3, D_cost_3D=C3,
+               Wasserstein_D_2D=W2, D_cost_2D=C2, G_cost=G_cost)
+    return out
+
+
+def GAN_solutions_FK_generator(args, poseFk_dict, data_dict, model_pos, summary, writer, train_subjects):
+    """The per-epoch loop; side effect data_dict['train_fake2d3d_loader'] (a FakePairBuffer)."""
+    for k in ('model_G', 'model_d3d', 'model_d2d'):
+        poseFk_dict[k].train()
+    if model_pos is not None:
+        model_pos.train()
+        set_grad([model_pos], False)
+    buf = FakePairBuffer(args.batch_size)
+    for (inputs_3d, _, _, cam_param), target_d2d, _target_d3d in zip(
+            data_dict['train_gt2d3d_loader'], data_dict['target_2d_loader'], data_dict['target_3d_loader']):
+        if inputs_3d.shape[0] < args.batch_size:        # ragged last batch is dropped, as in the reference (:276)
+            continue
+        r = gan_iteration(args, poseFk_dict, inputs_3d, cam_param, target_d2d, train_subjects, summary, writer,
+                          do_g_step=(summary.train_iter_num % 5 == 4))
+        if hasattr(summary, "summary_train_discrim_update"):
+            summary.summary_train_discrim_update()
+        if r['G_cost'] is not None and hasattr(summary, "summary_train_fakepose_iter_num_update"):
+            summary.summary_train_fakepose_iter_num_update()
+        buf.append(r['pos_3d_cam'], r['pos_2d'], r['cam9'])
+        if hasattr(summary, "summary_train_iter_num_update"):
+            summary.summary_train_iter_num_update()
+        else:
+            summary.train_iter_num += 1
+    data_dict['train_fake2d3d_loader'] = buf
+    return

@@ -183,14 +183,14 @@ def cast_transpose_bf16(src, pad_cols=None):
     return dst
 
 
-def split3_bf16(src, mode, pad_cols=None):
-    """fp32 (rows, cols) -> bf16 (rows, 3*pad): mode 0 [hi|hi|lo] (activation side), mode 1 [hi|lo|hi] (weight side)."""
-    s = _dev(src, torch.float32, "split3_bf16")
+def split_bf16(src, mode, terms, pad_cols=None):
+    """fp32 (rows, cols) -> bf16 (rows, terms*pad): see dhaug_split_bf16 (mode 0 activation side, 1 weight side)."""
+    s = _dev(src, torch.float32, "split_bf16")
     s = s.reshape(-1, s.shape[-1])
     rows, cols = s.shape
     pad_cols = ceil_to(cols, 16) if pad_cols is None else pad_cols
-    dst = torch.empty((rows, 3 * pad_cols), dtype=BF16, device=s.device)
-    _lib.call("dhaug_split3_bf16", _p(s), cols, _p(dst), rows, cols, pad_cols, mode, _stream())
+    dst = torch.empty((rows, terms * pad_cols), dtype=BF16, device=s.device)
+    _lib.call("dhaug_split_bf16", _p(s), cols, _p(dst), rows, cols, pad_cols, mode, terms, _stream())
     return dst
 
 

@@ -1,0 +1,77 @@
+"""Fused Adam on flat fp32 buffers + the data-parallel gradient exchange.
+
+One optimizer owns ONE contiguous parameter buffer and ONE contiguous gradient buffer (the module's parameters
+and .grad tensors are views into them), so that an optimizer step is
+    [one RCCL all-reduce of the flat gradient bucket]  ->  one dhaug_adam_step launch.
+With world_size > 1 (torch.distributed initialised, backend "nccl" = RCCL on ROCm, or "gloo" in the CPU tests)
+the all-reduce sums the replicas' gradients and the kernel scales by 1/world_size.  No activation, parameter or
+optimizer state crosses the fabric."""
+import torch
+import torch.distributed as dist
+
+from . import autograd_ops as A
+from . import ops
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (lr 1e-4, betas (0.5, 0.9) at R/models_Fk_GAN/model_fk_gan_train.py:112-118)."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.5, 0.9), eps=1e-8, process_group=None, data_parallel=None):
+        params = [p for p in params]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._params = params
+        n = sum(p.numel() for p in params)
+        dev = params[0].device
+        self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._views = []
+        off = 0
+        for p in params:
+            k = p.numel()
+            self.flat_param[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[off:off + k].view(p.shape)
+            gv = self.flat_grad[off:off + k].view(p.shape)
+            p.grad = gv
+            self._views.append(gv)
+            off += k
+        self.step_count = 0
+        self.process_group = process_group
+        self.data_parallel = data_parallel      # None: follow torch.distributed state
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grad.zero_()
+        for p, gv in zip(self._params, self._views):
+            p.grad = gv
+
+    def _gather_grads(self):
+        for p, gv in zip(self._params, self._views):
+            if p.grad is None:
+                gv.zero_()
+            elif p.grad.data_ptr() != gv.data_ptr():     # a module.zero_grad(set_to_none=True) replaced the view
+                gv.copy_(p.grad)
+            p.grad = gv
+
+    def world_size(self):
+        use = self.data_parallel
+        if use is None:
+            use = dist.is_available() and dist.is_initialized()
+        return dist.get_world_size(self.process_group) if use else 1
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self._gather_grads()
+        ws = self.world_size()
+        if ws > 1:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.process_group)
+        self.step_count += 1
+        g = self.param_groups[0]
+        if self.flat_param.is_cuda:
+            ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, g["lr"],
+                          tuple(g["betas"]), g["eps"], 1.0 / ws)
+        else:
+            raise RuntimeError("FusedAdam needs GPU parameters (no CPU fallback exists)")
+        for p in self._params:                 # the bf16 operand copies of these weights are now stale
+            A._CACHE.pop(id(p), None)
+        return None

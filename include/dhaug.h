@@ -179,12 +179,13 @@ int dhaug_cast_pad_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t
 int dhaug_cast_transpose_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst,
                               int64_t rows, int64_t cols, int64_t pad_cols, void* stream);
 
-/* "bf16x3" operand split for fp32-grade products on the bf16 MFMA path: x = hi + lo (both bf16).
- * mode 0 (activation side): dst row = [hi | hi | lo]; mode 1 (weight side): dst row = [hi | lo | hi],
- * each segment pad_cols wide (zero padded), so that A3 * B3^T = hi*hi + hi*lo + lo*hi.
- * dst is (rows, 3*pad_cols) contiguous. */
-int dhaug_split3_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t rows, int64_t cols,
-                      int64_t pad_cols, int mode, void* stream);
+/* Operand split for fp32-grade products on the bf16 MFMA path (the parity modes "bf16x3" / "bf16x6").
+ *   terms 3: x = hi + lo.         mode 0 (activation side) row = [hi|hi|lo],            mode 1 (weight side) [hi|lo|hi]
+ *   terms 6: x = hi + mid + lo.   mode 0 row = [hi|hi|mid|mid|hi|lo],                   mode 1 [hi|mid|hi|mid|lo|hi]
+ * each segment pad_cols wide (zero padded), so that A' * B'^T sums every product term down to 2^-16 (terms 3) or
+ * 2^-24 (terms 6) relative.  dst is (rows, terms*pad_cols) contiguous. */
+int dhaug_split_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t rows, int64_t cols,
+                     int64_t pad_cols, int mode, int terms, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Elementwise / reductions used by the training step

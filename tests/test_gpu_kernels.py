@@ -220,17 +220,18 @@ def test_gemm_nt_epilogues(ops, act, slope):
     assert maxabs(cf2, ref2) <= 3e-5 * ref2.abs().max().item()
 
 
-def test_gemm_bf16x3_is_fp32_grade(ops):
-    """x = hi + lo split: three bf16 MFMA passes reproduce an fp32 product to ~1e-6 relative."""
+@pytest.mark.parametrize("terms,tol", [(3, 3e-5), (6, 2e-6)])
+def test_gemm_split_terms(ops, terms, tol):
+    """x = hi + lo (3 products) / hi + mid + lo (6 products): bf16 MFMA passes that reproduce an fp32 product."""
     M, N, K = 1024, 256, 256
     gen = torch.Generator().manual_seed(9)
     X = torch.randn(M, K, generator=gen)
     W = torch.randn(N, K, generator=gen) / 16
-    A3 = ops.split3_bf16(X.cuda(), 0)
-    B3 = ops.split3_bf16(W.cuda(), 1)
-    _, cf = ops.gemm_nt(A3, B3, N, 3 * K, out_f32=True)
+    A3 = ops.split_bf16(X.cuda(), 0, terms)
+    B3 = ops.split_bf16(W.cuda(), 1, terms)
+    _, cf = ops.gemm_nt(A3, B3, N, terms * K, out_f32=True)
     ref = X.double() @ W.double().t()
-    assert maxabs(cf, ref) <= 2e-5 * ref.abs().max().item()
+    assert maxabs(cf, ref) <= tol * ref.abs().max().item()
     one = ops.gemm_nt(ops.cast_pad_bf16(X.cuda()), ops.cast_pad_bf16(W.cuda()), N, K, out_f32=True)[1]
     assert maxabs(one, ref) > 10 * maxabs(cf, ref)                 # single-pass bf16 is visibly coarser
 
@@ -258,9 +259,13 @@ def test_pack_kernels(ops):
     t = ops.cast_transpose_bf16(W.cuda())
     assert t.shape == (30, 112) and maxabs(t[:, :100].float(), W.t().to(torch.bfloat16).float()) == 0
     assert t[:, 100:].abs().max() == 0
-    s = ops.split3_bf16(W.cuda(), 1)
+    s = ops.split_bf16(W.cuda(), 1, 3)
     hi, lo = s[:, :30].float(), s[:, 32:62].float()
     assert maxabs(hi + lo, W) <= 2e-5 * W.abs().max().item() and maxabs(s[:, 64:94].float(), hi) == 0
+    s6 = ops.split_bf16(W.cuda(), 0, 6)                       # [hi|hi|mid|mid|hi|lo]
+    seg = [s6[:, 32 * t:32 * t + 30].float() for t in range(6)]
+    assert maxabs(seg[0] + seg[2] + seg[5], W) <= 2e-7 * W.abs().max().item()
+    assert maxabs(seg[1], seg[0]) == 0 and maxabs(seg[3], seg[2]) == 0 and maxabs(seg[4], seg[0]) == 0
 
 
 def test_colsum_actbwd_adam(ops):

@@ -1,0 +1,264 @@
+"""GPU parity tests, module level: the drop-in classes (same names / state_dict keys as the reference) against the
+golden vectors captured from the reference and against the oracle.
+
+Tolerances
+  * FK joints / generated poses: <= 1e-5 abs given the same head pre-activation; through the dense trunk the
+    fp32-grade path ('bf16x6': x = hi + mid + lo, six bf16 MFMA passes) is held to 1e-4 on the logits / 2e-5 m on the poses, the single-pass bf16 path
+    (the build's default arithmetic for the dense layers) is compared with the oracle's bf16 emulation
+    (same rounding points) and, loosely, with the fp32 golden.
+  * relative logit error = |a-b| / max(|b|, 0.1 * mean|b|)."""
+import argparse
+
+import pytest
+import torch
+
+import golden_util as GU
+from oracle import dhaug_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import dhaug_amd
+    dhaug_amd._lib.lib()
+    from dhaug_amd.models_Fk_GAN import (Fk_discriminator, Fk_generator, forward_kinematics_DH_model,
+                                         model_fk_gan_train)
+    return argparse.Namespace(gen=Fk_generator, dis=Fk_discriminator, fkm=forward_kinematics_DH_model,
+                              train=model_fk_gan_train)
+
+
+def make_args(**over):
+    d = dict(batch_size=64, random_seed=0, GAN_OUTPUT_DIM=35, GAN_LAMBDA=10, GAN_whether_use_preAngle=True,
+             Gen_DenseDim=32, Dis_DenseDim_3D=32, Dis_DenseDim_2D=32, video_Dis_DenseDim_3D=32,
+             video_Dis_DenseDim_2D=32, GAN_3d_loss_weight=1.0, GAN_2d_loss_weight=0.2, bone_len_scaler="different",
+             whether_use_RT=True, flip_GAN_model_input=True, single_or_multi_train_mode="single", architecture="3,3,3",
+             motion_Dis_whether_use_3dPos_branch=True, motion_Dis_whether_use_3dDiff_branch=True)
+    d.update(over)
+    return argparse.Namespace(**d)
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return ((a - b).abs() / b.abs().clamp_min(0.1 * b.abs().mean())).max().item()
+
+
+def maxabs(a, b):
+    return (a.detach().double().cpu() - b.detach().double().cpu()).abs().max().item()
+
+
+def load(mod, sd, prec):
+    mod.load_state_dict(sd)
+    mod.precision = prec
+    return mod.cuda()
+
+
+# ------------------------------------------------------------------------------------------ FK drop-in
+def test_fk_class_api(M, golden):
+    g = golden("fk_N8")
+    fk = M.fkm.Forward_Kinematics_DH_Model(make_args(batch_size=3), ["S1"], None)     # batch-size independent
+    a, bl, rt = g["angles"].cuda(), g["bone_len"].cuda(), g["root"].cuda()
+    kw = dict(right_leg_joints_angle=a[:, 0:5], left_leg_joints_angle=a[:, 5:10], body_joints_angle=a[:, 10:23],
+              right_hand_joints_angle=a[:, 23:28], left_hand_joints_angle=a[:, 28:33],
+              generator_global_rot_3d_pos_angle=a[:, 34:37], root_3d_pos=rt)
+    names = ["left_small_leg_len", "right_small_leg_len", "left_big_leg_len", "right_big_leg_len", "left_hip_len",
+             "right_hip_len", "waist_len", "thorax_len", "left_shoulder_len", "right_shoulder_len", "left_big_arm_len",
+             "right_big_arm_len", "left_small_arm_len", "right_small_arm_len", "neck_len"]
+    kw.update({n: bl[:, i] for i, n in enumerate(names)})
+    out = fk.change_3d_joint_angle(**kw)
+    assert out.shape == (8, 32, 3) and maxabs(out, g["out32"]) <= 1e-5
+    # differentiable variant returns the same tensor
+    kw["root_3d_pos"] = rt.clone().requires_grad_(True)
+    out_g = fk.change_3d_joint_angle(**kw)
+    assert maxabs(out_g, g["out32"]) <= 1e-5
+    out_g.sum().backward()
+    assert maxabs(kw["root_3d_pos"].grad, torch.full((8, 3), 32.0)) <= 1e-4
+    # scalar branch + T-pose known answer
+    t = fk.init_Fk_DH_angle()
+    gt = golden("fk_numpy_branch")
+    assert t.shape == (32, 3) and abs(t - gt["tpose32"].numpy()).max() <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------ generator
+@pytest.mark.parametrize("D", [32, 256])
+def test_generator_forward(M, golden, D):
+    g = golden("gen_D%d" % D)
+    B = g["z"].shape[0]
+    args = make_args(batch_size=B, Gen_DenseDim=D)
+    sd = GU.seeded_state_dict(GU.shapes_generator(D), int(g["weight_seed"]))
+    fk = M.fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+    G = load(M.gen.Fk_Generator(fk, args, "cuda"), sd, "bf16x6")
+    assert list(G.state_dict().keys()) == list(sd.keys())
+    G.GAN_generator_get_bone_length(g["real16"].cuda())
+    assert maxabs(G.boneLength, g["bone_len"]) <= 1e-6
+    head = G.trunk(g["z"].cuda())
+    assert maxabs(head, g["head"]) <= 2e-5
+    G.record_angles = True
+    fake = G(g["z"].cuda(), bone_len_scaler=g["scaler"])
+    assert fake.shape == g["fake"].shape
+    assert maxabs(G.distribute_angle[-1], g["angle37"]) <= 5e-3       # degrees, through tanh of a 2e-5 head error
+    assert maxabs(fake, g["fake"]) <= 2e-5
+    # single-pass bf16: same rounding points as the oracle's bf16 emulation
+    G.precision = "bf16"
+    head_b = G.trunk(g["z"].cuda())
+    ref_b = O.gen_trunk(g["z"], sd, precision="bf16")
+    assert maxabs(head_b, ref_b) <= 2e-2 * ref_b.abs().max().item()
+    assert maxabs(head_b, g["head"]) <= 5e-2 * g["head"].abs().max().item()
+    fake_b = G(g["z"].cuda(), bone_len_scaler=g["scaler"])
+    tail_of_own_head, _ = O.gen_tail(head_b.cpu(), g["bone_len"], g["scaler"])
+    assert maxabs(fake_b, tail_of_own_head) <= 1e-5                  # FK tail exact given the head it was fed
+
+
+def test_video_generator_forward(M, golden):
+    g = golden("gen_video_D32")
+    args = make_args(batch_size=8, Gen_DenseDim=32, single_or_multi_train_mode="multi", architecture="3,3")
+    sd = GU.seeded_state_dict(GU.shapes_generator(32, frames=9), int(g["weight_seed"]))
+    fk = M.fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+    G = load(M.gen.Video_Fk_Generator(9, fk, args, "cuda"), sd, "bf16x6")
+    G.GAN_generator_get_bone_length(g["real16"].cuda())
+    fake = G(g["z"].cuda(), bone_len_scaler=g["scaler"])
+    assert fake.shape == (8, 9, 48) and maxabs(fake, g["fake"]) <= 2e-5
+
+
+# -------------------------------------------------------------------------------------------- critics
+@pytest.mark.parametrize("D", [32, 256])
+def test_critic_logits(M, golden, D):
+    g = golden("critics_D%d" % D)
+    B = g["x3"].shape[0]
+    args = make_args(batch_size=B, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D)
+    sd3 = GU.seeded_state_dict(GU.shapes_d3(D), int(g["weight_seed3"]))
+    sd2 = GU.seeded_state_dict(GU.shapes_d2(D), int(g["weight_seed2"]))
+    D3 = load(M.dis.Fk_3D_Discriminator("cuda", args), sd3, "bf16x6")
+    D2 = load(M.dis.Fk_2D_Discriminator(args, 16), sd2, "bf16x6")
+    assert list(D3.state_dict().keys()) == list(sd3.keys()) and list(D2.state_dict().keys()) == list(sd2.keys())
+    l3, l2 = D3(g["x3"].cuda()), D2(g["x2"].cuda())
+    assert l3.shape == (B, 1) and l2.shape == (B, 1)
+    assert relerr(l3, g["logit3"]) <= 1e-4 and relerr(l2, g["logit2"]) <= 1e-4      # north_star: 1e-4 rel
+    D3.precision = D2.precision = "bf16"
+    b3, b2 = D3(g["x3"].cuda()), D2(g["x2"].cuda())
+    e3, e2 = O.d3_forward(g["x3"], sd3, precision="bf16"), O.d2_forward(g["x2"], sd2, precision="bf16")
+    assert relerr(b3, e3) <= 2e-2 and relerr(b2, e2) <= 2e-2        # vs bf16 emulation (accumulation order differs)
+    # vs the fp32 reference: bf16 rounding noise, measured against the logit scale
+    n3 = maxabs(b3, g["logit3"]) / g["logit3"].abs().max().item()
+    n2 = maxabs(b2, g["logit2"]) / g["logit2"].abs().max().item()
+    print("bf16 logit error / logit scale: D3 %.3e  D2 %.3e" % (n3, n2))
+    assert n3 <= 5e-2 and n2 <= 5e-2
+
+
+def _motion_shapes(D, R):
+    s3 = {}
+    for name, width in (("special_KCS", R * 15), ("diff_special_KCS", (R - 1) * 15), ("pos_3d", R * 48),
+                        ("diff_pos_3d", (R - 1) * 48)):
+        s3[name + "_previous.0.weight"] = (D, width); s3[name + "_previous.0.bias"] = (D,)
+        for i in (1, 2, 3):
+            GU._res(s3, "%s_block%d" % (name, i), D)
+    s3["kcs_merge_previous.0.weight"] = (100, 4 * D); s3["kcs_merge_previous.0.bias"] = (100,)
+    GU._res(s3, "kcs_merge_block1", 100)
+    s3["kcs_output.weight"] = (1, 100); s3["kcs_output.bias"] = (1,)
+    s2 = {}
+    for name, width in (("pos_2d", R * 32), ("root_diff_2d", (R - 1) * 2)):
+        s2[name + "_previous.0.weight"] = (D, width); s2[name + "_previous.0.bias"] = (D,)
+        for i in (1, 2, 3):
+            GU._res(s2, "%s_block%d" % (name, i), D)
+    s2["merge_previous.0.weight"] = (100, 2 * D); s2["merge_previous.0.bias"] = (100,)
+    GU._res(s2, "merge_block1", 100)
+    s2["merge_output.weight"] = (1, 100); s2["merge_output.bias"] = (1,)
+    return s3, s2
+
+
+def test_motion_critic_logits(M, golden):
+    g = golden("motion_critics_D32")
+    args = make_args(batch_size=8, single_or_multi_train_mode="multi", architecture="3,3")
+    s3, s2 = _motion_shapes(32, 9)
+    sd3 = GU.seeded_state_dict(s3, int(g["weight_seed3"]))
+    sd2 = GU.seeded_state_dict(s2, int(g["weight_seed2"]))
+    M3 = load(M.dis.Video_motion_Fk_3D_Discriminator("cuda", args, 9), sd3, "bf16x6")
+    M2 = load(M.dis.Video_motion_Fk_2D_Discriminator("cuda", args, 9), sd2, "bf16x6")
+    assert set(M3.state_dict().keys()) == set(sd3.keys()) and set(M2.state_dict().keys()) == set(sd2.keys())
+    l3, l2 = M3(g["x3"].cuda()), M2(g["x2"].cuda())
+    assert l3.shape == (8, 1) and l2.shape == (8, 1)
+    assert relerr(l3, g["logit3"]) <= 1e-4 and relerr(l2, g["logit2"]) <= 1e-4
+
+
+# ----------------------------------------------------------------------- gradient penalty, critic step
+@pytest.mark.parametrize("tag", ["d3", "d2"])
+def test_gradient_penalty_and_critic_step(M, golden, tag):
+    g = golden("critic_step_%s_D32" % tag)
+    args = make_args(batch_size=64)
+    shapes = GU.shapes_d3(32) if tag == "d3" else GU.shapes_d2(32)
+    sd = GU.seeded_state_dict(shapes, int(g["weight_seed"]))
+    mk = (lambda: M.dis.Fk_3D_Discriminator("cuda", args)) if tag == "d3" else (lambda: M.dis.Fk_2D_Discriminator(args, 16))
+    net = load(mk(), sd, "bf16x6")
+    real, fake, alpha = g["real"].cuda(), g["fake"].cuda(), g["alpha"].cuda()
+    gp = M.dis.calc_gradient_penalty(net, real, fake, 64, 10, "cuda", alpha=alpha)
+    assert abs(gp.item() - g["gp"].item()) <= 1e-4 * max(1.0, abs(g["gp"].item()))
+    gp.backward()
+    for k, p in net.named_parameters():
+        ref = g["gpgrad__" + k]
+        got = torch.zeros_like(ref) if p.grad is None else p.grad.cpu()
+        assert maxabs(got, ref) <= 2e-5 + 2e-4 * ref.abs().max().item(), k
+    # one full critic step: returned scalars, gradients before the step, parameters after it
+    net = load(mk(), sd, "bf16x6")
+    opt = M.train.FusedAdam(net.parameters(), lr=1e-4, betas=(0.5, 0.9))
+    W, C = M.train.train_Fk_discriminator(net, real.clone(), fake.clone(), argparse.Namespace(train_iter_num=1), None,
+                                          "Fk_" + tag, opt, args, alpha=alpha)
+    assert abs(W.item() - g["Wasserstein_D"].item()) <= 1e-5
+    assert abs(C.item() - g["D_cost"].item()) <= 1e-4 * max(1.0, abs(g["D_cost"].item()))
+    for k, p in net.named_parameters():
+        gref = g["grad__" + k]
+        assert maxabs(p.grad, gref) <= 2e-5 + 2e-4 * gref.abs().max().item(), k
+        # Adam's first step is lr * g / (|g| + eps): well-conditioned wherever |g| is not tiny
+        well = gref.abs() > max(1e-3 * gref.abs().max().item(), 1e-7)
+        if well.any():
+            assert maxabs(p.cpu()[well], g["new__" + k][well]) <= 2e-6, k
+        assert maxabs(p, g["new__" + k]) <= 1.01e-4, k
+    # the build's default arithmetic (bf16) takes the same step up to bf16 noise in the gradient
+    netb = load(mk(), sd, "bf16")
+    optb = M.train.FusedAdam(netb.parameters(), lr=1e-4, betas=(0.5, 0.9))
+    Wb, _ = M.train.train_Fk_discriminator(netb, real.clone(), fake.clone(), argparse.Namespace(train_iter_num=1), None,
+                                           "Fk_" + tag, optb, args, alpha=alpha)
+    assert abs(Wb.item() - g["Wasserstein_D"].item()) <= 5e-2 * max(1.0, abs(g["Wasserstein_D"].item()))
+    cos = []
+    for k, p in netb.named_parameters():
+        gref = g["grad__" + k].reshape(-1).double()
+        if gref.abs().max() > 0:
+            cos.append(torch.nn.functional.cosine_similarity(p.grad.cpu().reshape(-1).double(), gref, dim=0).item())
+    assert min(cos) > 0.98, cos
+
+
+# ------------------------------------------------------------------------------------------- G step
+def test_generator_step_gradients(M, golden):
+    """gen_loss = 1*D3(centre(G(z))).mean() + 0.2*D2(project(G(z))).mean(): gradients w.r.t. G's weights against
+    torch autograd on the oracle (restated from R/models_Fk_GAN/model_fk_gan_train.py:415-482, fixed camera)."""
+    B, D = 64, 32
+    args = make_args(batch_size=B)
+    gg, gc, cam = golden("gen_D32"), golden("critics_D32"), golden("camera_128")
+    sdG = GU.seeded_state_dict(GU.shapes_generator(D), int(gg["weight_seed"]))
+    sd3 = GU.seeded_state_dict(GU.shapes_d3(D), int(gc["weight_seed3"]))
+    sd2 = GU.seeded_state_dict(GU.shapes_d2(D), int(gc["weight_seed2"]))
+    z, bl, sc = gg["z"], gg["bone_len"], gg["scaler"]
+    q, t, c9 = cam["R"], cam["t"], cam["cam"][:B]
+    # oracle (fp64)
+    pG = {k: v.double().requires_grad_(True) for k, v in sdG.items()}
+    d = lambda s: {k: v.double() for k, v in s.items()}
+    fake, _, _ = O.generator_forward(z.double(), pG, bl.double(), sc.double())
+    fw = fake.reshape(-1, 16, 3)
+    x2 = O.project_to_2d(O.world_to_camera(fw, q.double(), t.double()), c9.double())
+    loss = O.d3_forward(fw - fw[:, :1], d(sd3)).mean() * 1.0 + O.d2_forward(x2, d(sd2)).mean() * 0.2
+    ref = torch.autograd.grad(loss, list(pG.values()))
+    # build
+    fk = M.fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+    G = load(M.gen.Fk_Generator(fk, args, "cuda"), sdG, "bf16x6")
+    D3 = load(M.dis.Fk_3D_Discriminator("cuda", args), sd3, "bf16x6")
+    D2 = load(M.dis.Fk_2D_Discriminator(args, 16), sd2, "bf16x6")
+    G.boneLength = bl.cuda()
+    from dhaug_amd import autograd_ops as A
+    fwg = G(z.cuda(), bone_len_scaler=sc).reshape(-1, 16, 3)
+    _, f2d = A.W2CProjectFn.apply(fwg, tuple(q[0].tolist()), tuple(t[0].tolist()), tuple(c9[0].tolist()))
+    lossg = M.train.MeanFn.apply(D3(A.center_flip(fwg, True, False))) * 1.0 + M.train.MeanFn.apply(D2(f2d)) * 0.2
+    assert abs(lossg.item() - loss.item()) <= 1e-4 * max(1.0, abs(loss.item()))
+    lossg.backward()
+    for (k, p), r in zip(G.named_parameters(), ref):
+        assert maxabs(p.grad, r) <= 1e-6 + 5e-4 * r.abs().max().item(), k
