@@ -1,0 +1,74 @@
+"""smoke(): one small invocation of the hot path on cuda:0, checked against the oracle (test infrastructure)."""
+import argparse
+import os
+import sys
+
+import torch
+
+
+def synth_args(batch_size, D=256, **over):
+    d = dict(batch_size=batch_size, random_seed=0, GAN_OUTPUT_DIM=35, GAN_LAMBDA=10, GAN_whether_use_preAngle=True,
+             Gen_DenseDim=D, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D, video_Dis_DenseDim_3D=1000, video_Dis_DenseDim_2D=1000,
+             GAN_3d_loss_weight=1.0, GAN_2d_loss_weight=0.2, GAN_3d_motion_loss_weight=1.0, GAN_2d_motion_loss_weight=1.0,
+             bone_len_scaler="different", whether_use_RT=True, flip_GAN_model_input=True, GAN_video_playback_input=True,
+             single_or_multi_train_mode="single", architecture="3,3,3", motion_Dis_whether_use_3dPos_branch=True,
+             motion_Dis_whether_use_3dDiff_branch=True, warmup=2, num_workers=0)
+    d.update(over)
+    return argparse.Namespace(**d)
+
+
+def smoke():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from oracle import dhaug_oracle as O           # checker only
+    from . import _lib, ops
+    from .models_Fk_GAN import model_fk_gan_train as T
+    from .models_Fk_GAN.forward_kinematics_DH_model import Forward_Kinematics_DH_Model
+
+    _lib.lib()
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    g = torch.Generator().manual_seed(0)
+    N = 1000
+    ang = (torch.rand(N, 37, generator=g) * 2 - 1) * 180
+    bl = torch.rand(N, 15, generator=g) * 0.4 + 0.1
+    rt = torch.randn(N, 3, generator=g)
+    out = ops.fk_forward(ang.to(dev), bl.to(dev), rt.to(dev))
+    err = (out.cpu() - O.fk_forward16(ang, bl, rt)).abs().max().item()
+    assert err <= 1e-5, "FK parity %g" % err
+    # generator + critics, fp32-grade mode, against the oracle on the same weights
+    B, D = 256, 64
+    args = synth_args(B, D)
+    fk = Forward_Kinematics_DH_Model(args, ["S1"], None)
+    d = T.my_get_poseFk_model(args, None, fk)
+    G, D3, D2 = d["model_G"], d["model_d3d"], d["model_d2d"]
+    for m in (G, D3, D2):
+        m.precision = "bf16x6"
+    z = torch.randn(B, 128, generator=g)
+    real = torch.randn(B, 16, 3, generator=g) * 0.3
+    sc = torch.randint(-200, 200, (B, 8), generator=g) / 1000.0
+    G.GAN_generator_get_bone_length(real.to(dev))
+    fake = G(z.to(dev), bone_len_scaler=sc)
+    sdG = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    ref, _, _ = O.generator_forward(z, sdG, O.bone_lengths(real), sc)
+    e = (fake.detach().cpu() - ref).abs().max().item()
+    assert e <= 5e-5, "generator parity %g" % e
+    fw = fake.detach().reshape(-1, 16, 3)
+    x3 = ops.center_flip(fw, True, False)
+    l3 = D3(x3)
+    r3 = O.d3_forward(x3.cpu(), {k: v.detach().cpu() for k, v in D3.state_dict().items()})
+    rel = ((l3.detach().cpu() - r3).abs() / r3.abs().clamp_min(0.1 * r3.abs().mean())).max().item()
+    assert rel <= 1e-3, "D3 parity %g" % rel
+    # one full GAN iteration in the default (bf16) arithmetic: runs, finite, parameters move
+    for m in (G, D3, D2):
+        m.precision = "bf16"
+    before = D3.output.weight.detach().clone()
+    cam_param = torch.zeros(B, 16)
+    cam_param[:, 9] = 1.0
+    r = T.gan_iteration(args, d, real, cam_param, torch.rand(B, 16, 2) - 0.5, ["S1"], summary=None, writer=None,
+                        do_g_step=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(r["Wasserstein_D_3D"]).item() and torch.isfinite(r["G_cost"]).item()
+    assert (D3.output.weight.detach() - before).abs().max().item() > 0
+    print("smoke: FK err %.2e, generator err %.2e, D3 rel %.2e, W3 %.4f" % (err, e, rel, r["Wasserstein_D_3D"].item()))

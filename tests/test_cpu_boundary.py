@@ -1,0 +1,126 @@
+"""CPU-only checks of the boundary and the host logic (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    ge.build_lib(verbose=False)
+    ge.build_hostcheck(verbose=False)
+    ge.build_oracle(verbose=False)
+    return ge
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "dhaug.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(dhaug_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    import dhaug_amd
+    lib = ctypes.CDLL(dhaug_amd._lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "libdhaug.so does not export %s" % n
+    lib.dhaug_version.restype = ctypes.c_int
+    lib.dhaug_arch.restype = ctypes.c_char_p
+    assert lib.dhaug_version() == 100 and lib.dhaug_arch() == b"gfx950"
+    # every declared compute entry point has a ctypes signature in the binding (and nothing else is bound)
+    bound = set(dhaug_amd._lib.SIGNATURES)
+    assert bound == set(names) - {"dhaug_version", "dhaug_arch"}
+
+
+def test_argument_errors_are_returned_not_thrown(built):
+    """host-side validation happens before any launch, so it can be exercised without a GPU"""
+    import dhaug_amd
+    L = dhaug_amd._lib.lib()
+    assert L.dhaug_fk_forward(None, None, None, None, 4, 16, None) == -1             # null pointers
+    assert L.dhaug_fk_forward(None, None, None, None, 0, 16, None) == 0              # empty batch is a no-op
+    assert L.dhaug_fk_forward(None, None, None, None, 4, 17, None) == -1             # bad out_joints
+    buf = (ctypes.c_float * 64)()
+    mis = ctypes.c_void_p(ctypes.addressof(buf) + 4)
+    assert L.dhaug_fk_forward(mis, mis, mis, mis, 1, 16, None) == -2                 # misaligned
+    assert L.dhaug_gemm_bf16(mis, 8, mis, 8, None, None, 0, None, 0, None, 0, 0, None, 0, 4, 4, 24, 0, 0.0, None) in (-1, -3)
+    with pytest.raises(RuntimeError):
+        dhaug_amd._lib.check(-2, "x")
+
+
+def test_ops_refuse_cpu_tensors(built):
+    from dhaug_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.fk_forward(torch.zeros(2, 37), torch.zeros(2, 15), torch.zeros(2, 3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.kcs_forward(torch.zeros(2, 16, 3))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "dh-aug-dh-forward-kinematics-model-driven-augmentation-for-3d-human-pose-estimation_amd")
+    allowed = {"selfcheck.py"}          # smoke() is the one sanctioned checker inside the package
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py") and f not in allowed:
+                src = open(os.path.join(d, f)).read()
+                assert "oracle" not in src, os.path.join(d, f)
+
+
+def test_module_state_dict_keys_and_host_logic(built):
+    """module construction, state_dict key parity with the reference, config defaults: all host-side"""
+    import golden_util as GU
+    from dhaug_amd.function_aug.config import get_parse_args
+    from dhaug_amd.models_Fk_GAN import Fk_discriminator as dis, Fk_generator as gen, forward_kinematics_DH_model as fkm
+    from dhaug_amd.models_Fk_GAN.video_mode_operate import video_receptive_field
+    args = get_parse_args([])
+    assert args.batch_size == 1024 and args.GAN_OUTPUT_DIM == 35 and args.GAN_LAMBDA == 10 and args.Gen_DenseDim == 1000
+    assert args.bone_len_scaler == "different" and args.flip_GAN_model_input is True and args.architecture == "3,3,3"
+    a2 = get_parse_args(["--batch_size", "512", "--GAN_whether_use_preAngle", "False", "--architecture", "3,3",
+                         "--single_or_multi_train_mode", "multi"])
+    assert a2.batch_size == 512 and a2.GAN_whether_use_preAngle is False
+    assert video_receptive_field([3, 3]) == 9 and video_receptive_field([3, 3, 3]) == 27
+    args.Gen_DenseDim = args.Dis_DenseDim_3D = args.Dis_DenseDim_2D = 32
+    fk = fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+    G = gen.Fk_Generator(fk, args, "cpu")
+    assert list(G.state_dict().keys()) == list(GU.shapes_generator(32).keys())
+    assert {k: tuple(v.shape) for k, v in G.state_dict().items()} == GU.shapes_generator(32)
+    D3 = dis.Fk_3D_Discriminator("cpu", args)
+    assert {k: tuple(v.shape) for k, v in D3.state_dict().items()} == GU.shapes_d3(32)
+    D2 = dis.Fk_2D_Discriminator(args, 16)
+    assert {k: tuple(v.shape) for k, v in D2.state_dict().items()} == GU.shapes_d2(32)
+    assert sum(p.numel() for p in gen.Fk_Generator(fk, get_parse_args(["--Gen_DenseDim", "256"]), "cpu").parameters()) == 436771
+    assert fkm.H36M_32_To_16_Table == [0, 1, 2, 3, 6, 7, 8, 12, 13, 15, 17, 18, 19, 25, 26, 27]
+
+
+def test_hostcheck_fk_math_matches_oracle(built):
+    """the per-pose arithmetic of csrc/dhaug_fk_math.h, compiled for the HOST by the test-only harness, against
+    the oracle: forward <= 1e-5 abs, reverse mode <= 1e-4 relative (the device runs the same source)."""
+    import numpy as np
+    import golden_util as GU
+    from oracle import dhaug_oracle as O
+    lib = ctypes.CDLL(os.path.join(ROOT, "tests", "hostcheck", "_build", "libhostcheck.so"))
+    P = ctypes.POINTER(ctypes.c_float)
+    ptr = lambda a: a.ctypes.data_as(P)
+    N = 2048
+    a, bl, rt = GU.synth_fk_inputs(N, 3)
+    an, bn, rn = a.numpy().copy(), bl.numpy().copy(), rt.numpy().copy()
+    out = np.zeros((N, 48), np.float32)
+    lib.hostcheck_fk_forward(ptr(an), ptr(bn), ptr(rn), ptr(out), ctypes.c_long(N))
+    assert np.abs(out - O.fk_forward16(a, bl, rt).reshape(N, 48).numpy()).max() <= 1e-5
+    g = torch.randn(N, 16, 3, generator=torch.Generator().manual_seed(1))
+    ad, bd, rd = (t.double().requires_grad_(True) for t in (a, bl, rt))
+    (O.fk_forward16(ad, bd, rd) * g.double()).sum().backward()
+    ga, gb, gr = np.zeros((N, 37), np.float32), np.zeros((N, 15), np.float32), np.zeros((N, 3), np.float32)
+    gn = g.numpy().reshape(N, 48).copy()
+    lib.hostcheck_fk_backward(ptr(an), ptr(bn), ptr(gn), ptr(ga), ptr(gb), ptr(gr), ctypes.c_long(N))
+    for got, ref in ((ga, ad.grad), (gb, bd.grad), (gr, rd.grad)):
+        assert np.abs(got - ref.numpy()).max() <= 1e-4 * ref.abs().max().item()
