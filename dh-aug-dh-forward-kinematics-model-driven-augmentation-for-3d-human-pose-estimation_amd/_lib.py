@@ -35,6 +35,16 @@ SIGNATURES = {
     "dhaug_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp],
 }
 
+class MlpUnit(ctypes.Structure):
+    """struct dhaug_mlp_unit (include/dhaug.h)"""
+    _fields_ = [("kind", _i32), ("flags", _i32), ("src", _i32), ("dst", _i32), ("res", _i32), ("src2", _i32),
+                ("ksteps2", _i32), ("ksteps", _i32), ("n", _i32), ("act", _i32), ("slope", _f32), ("cols", _i32),
+                ("ld", _i64), ("g", _vp), ("w", _vp), ("w2", _vp), ("bias", _vp)]
+
+
+SIGNATURES["dhaug_pack_wfrag"] = [_vp, _i64, _vp, _i64, _i64, _i64, _vp]
+SIGNATURES["dhaug_mlp_forward"] = [ctypes.POINTER(MlpUnit), _i32, _i64, _vp]
+
 ERRORS = {-1: "DHAUG_EINVAL (bad argument)", -2: "DHAUG_EALIGN (alignment contract violated)",
           -3: "DHAUG_EUNSUPPORTED (shape not implemented)"}
 

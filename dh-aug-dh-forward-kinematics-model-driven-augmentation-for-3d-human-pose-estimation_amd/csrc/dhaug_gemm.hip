@@ -16,6 +16,7 @@
 // [64 m][160] (320-B rows: consecutive rows shift by 16 banks) and are read with ds_read_b64_tr_b16, the
 // hardware transpose read, because the contraction index m is the slow axis in memory.
 #include "dhaug_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -36,10 +37,10 @@ struct GemmArgs {
     int act; float slope;
 };
 
+// branch-free activation: v > 0 ? v : v * neg, neg = 0 (ReLU) / slope (LeakyReLU) / 1 (identity)
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
-    if (act == DHAUG_ACT_RELU) return v > 0.0f ? v : 0.0f;
-    if (act == DHAUG_ACT_LRELU) return v > 0.0f ? v : v * slope;
-    return v;
+    const float neg = act == DHAUG_ACT_RELU ? 0.0f : (act == DHAUG_ACT_LRELU ? slope : 1.0f);
+    return v > 0.0f ? v : v * neg;
 }
 
 constexpr int BK = 64;
@@ -320,6 +321,218 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Weight-stationary NT kernel for the layer shapes of this path (M = batch, huge; N <= a few hundred; K <= 256).
+//
+// The first version above is bound by exposed global-load latency (its time is flat in K).  Here a workgroup
+// owns 128 output features for the whole launch: each wave keeps ITS 32 weight rows as MFMA A-operand fragments in
+// registers (K/16 x 4 VGPRs, loaded once), and the workgroup walks over 64-row batch tiles persistently:
+//     top of iteration t : issue global loads of X(t+1) (and of the residual rows of tile t) into registers
+//     compute tile t     : ds_read_b128 X fragments (swizzled image) -> 2 x K/16 MFMAs per wave
+//     barrier            : tile t's image is dead -> reused as the fp32 C staging tile
+//     stage C, write X(t+1) registers into the other buffer, barrier
+//     coalesced epilogue : bias + residual + activation, 16-byte bf16 / fp32 stores
+// so HBM requests stay in flight across the compute and epilogue phases; two workgroups per CU cover each
+// other's waits.  LDS: 2 x 33 792 B.
+// ---------------------------------------------------------------------------------------------------
+constexpr int WS_BM = 64, WS_BN = 128, WS_CS = WS_BN + 4;
+constexpr int WS_BUF_BYTES = WS_BM * WS_CS * 4;          // 33 792 >= 64 rows x 512 B
+
+constexpr int ws_pow2_chunks(int s) { int p = 2; while (p < s) p <<= 1; return p; }
+
+template <int SP> __device__ __forceinline__ int ws_swz(int row) {
+    if (SP >= 16) return row & 15;
+    if (SP == 8) return (row >> 1) & 7;
+    if (SP == 4) return (row >> 2) & 3;
+    return (row >> 3) & 1;
+}
+
+template <int KSTEPS>
+__global__ __launch_bounds__(256, 2) void gemm_nt_ws_kernel(GemmArgs p) {
+    constexpr int S = 2 * KSTEPS;                       // 16-byte chunks per operand row
+    constexpr int SP = ws_pow2_chunks(S);               // LDS row pitch in chunks
+    constexpr int XCH = (WS_BM * S + 255) / 256;        // X chunks per thread
+    static_assert(WS_BM * SP * 16 <= WS_BUF_BYTES, "X tile must fit the staging buffer");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r31 = lane & 31, h = lane >> 5;
+    const long long n0 = (long long)blockIdx.y * WS_BN;
+    const long long mtiles = (p.M + WS_BM - 1) / WS_BM;
+
+    // this wave's 32 weight rows, resident for the whole launch
+    bf16x8 wf[KSTEPS];
+    {
+        const long long gn = n0 + 32 * wave + r31;
+        const uint16_t* wrow = p.B + gn * p.ldb + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            if (gn < p.N) wf[ks] = *reinterpret_cast<const bf16x8*>(wrow + 16 * ks);
+            else { bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0}; wf[ks] = z; }
+        }
+    }
+
+    uint4 rx[XCH];
+    auto load_x = [&](long long mt) {
+        const long long m0 = mt * WS_BM;
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int q = tid + 256 * i, row = q / S, c = q - row * S;
+            const long long gm = m0 + row;
+            rx[i] = (q < WS_BM * S && gm < p.M) ? *reinterpret_cast<const uint4*>(p.A + gm * p.lda + c * 8)
+                                                : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_x = [&](int buf) {
+        uint16_t* img = reinterpret_cast<uint16_t*>(smem_raw + buf * WS_BUF_BYTES);
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int q = tid + 256 * i, row = q / S, c = q - row * S;
+            if (q < WS_BM * S) *reinterpret_cast<uint4*>(img + row * (SP * 8) + ((c ^ ws_swz<SP>(row)) << 3)) = rx[i];
+        }
+    };
+
+    long long mt = blockIdx.x;
+    if (mt >= mtiles) return;
+    load_x(mt);
+    store_x(0);
+    __syncthreads();
+    int buf = 0;
+    for (; mt < mtiles; mt += gridDim.x, buf ^= 1) {
+        const long long m0 = mt * WS_BM;
+        const long long mt_next = mt + gridDim.x;
+        const bool has_next = mt_next < mtiles;
+        if (has_next) load_x(mt_next);
+        // residual rows of this tile, 16 bytes per epilogue piece
+        uint4 rres[4];
+        const bool res_vec = p.res != nullptr;
+        if (res_vec) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = tid + 256 * i, row = q >> 4, pc = q & 15;
+                const long long gm = m0 + row, n = n0 + pc * 8;
+                rres[i] = (gm < p.M && n + 8 <= p.N) ? *reinterpret_cast<const uint4*>(p.res + gm * p.ld_res + n)
+                                                     : make_uint4(0, 0, 0, 0);
+            }
+        }
+        // compute
+        const uint16_t* img = reinterpret_cast<const uint16_t*>(smem_raw + buf * WS_BUF_BYTES);
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = 32 * j + r31;
+                const bf16x8 fx = *reinterpret_cast<const bf16x8*>(img + row * (SP * 8) + (((2 * ks + h) ^ ws_swz<SP>(row)) << 3));
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], fx, acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                   // every wave is done reading this image
+        float* sC = reinterpret_cast<float*>(smem_raw + buf * WS_BUF_BYTES);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = 32 * j + r31;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(sC + m * WS_CS + 32 * wave + 8 * g + 4 * h) = v;
+            }
+        }
+        if (has_next) store_x(buf ^ 1);
+        __syncthreads();
+        // epilogue: 1024 pieces of 8 features
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + 256 * i, row = q >> 4, pc = q & 15;
+            const long long gm = m0 + row, n = n0 + pc * 8;
+            if (gm >= p.M) continue;
+            if (!(n < p.N || (p.cb != nullptr && n < p.npad))) continue;
+            float v[8];
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(sC + row * WS_CS + pc * 8);
+            const f32x4 c1 = *reinterpret_cast<const f32x4*>(sC + row * WS_CS + pc * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = c0[e]; v[4 + e] = c1[e]; }
+            const bool full = n + 8 <= p.N;
+            if (p.bias != nullptr) {
+                if (full) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] += p.bias[n + e];
+                }
+            }
+            if (p.resf != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (full || n + e < p.N) v[e] += p.resf[gm * p.ld_resf + n + e];
+            }
+            if (res_vec) {
+                if (full) {
+                    const uint32_t w[4] = {rres[i].x, rres[i].y, rres[i].z, rres[i].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] += __builtin_bit_cast(float, w[e] << 16);
+                        v[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] += dhaug_bf16_to_f32(p.res[gm * p.ld_res + n + e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (full || n + e < p.N) ? apply_act(v[e], p.act, p.slope) : 0.0f;
+            if (p.cb != nullptr) {
+                if (n + 8 <= p.npad || full) {
+                    uint4 o;
+                    o.x = (uint32_t)dhaug_f32_to_bf16(v[0]) | ((uint32_t)dhaug_f32_to_bf16(v[1]) << 16);
+                    o.y = (uint32_t)dhaug_f32_to_bf16(v[2]) | ((uint32_t)dhaug_f32_to_bf16(v[3]) << 16);
+                    o.z = (uint32_t)dhaug_f32_to_bf16(v[4]) | ((uint32_t)dhaug_f32_to_bf16(v[5]) << 16);
+                    o.w = (uint32_t)dhaug_f32_to_bf16(v[6]) | ((uint32_t)dhaug_f32_to_bf16(v[7]) << 16);
+                    *reinterpret_cast<uint4*>(p.cb + gm * p.ldcb + n) = o;
+                } else {
+                    const long long lim = p.npad > p.N ? p.npad : p.N;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (n + e < lim) p.cb[gm * p.ldcb + n + e] = dhaug_f32_to_bf16(v[e]);
+                }
+            }
+            if (p.cf != nullptr) {
+                if (full && (p.ldcf & 3) == 0) {
+                    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                    *reinterpret_cast<f32x4*>(p.cf + gm * p.ldcf + n) = o0;
+                    *reinterpret_cast<f32x4*>(p.cf + gm * p.ldcf + n + 4) = o1;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (n + e < p.N) p.cf[gm * p.ldcf + n + e] = v[e];
+                }
+            }
+        }
+        // no barrier here: the next iteration's first LDS write (C staging) is behind its own barrier, and the
+        // image it reads (buf^1) was completed before the second barrier above
+    }
+}
+
+template <int KSTEPS>
+int launch_ws(hipStream_t s, const GemmArgs& p) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ws_kernel<KSTEPS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WS_BUF_BYTES);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    const long long ntiles = (p.W + WS_BN - 1) / WS_BN, mtiles = (p.M + WS_BM - 1) / WS_BM;
+    long long gx = 512 / ntiles;
+    if (gx < 1) gx = 1;
+    if (gx > mtiles) gx = mtiles;
+    hipLaunchKernelGGL(gemm_nt_ws_kernel<KSTEPS>, dim3((unsigned)gx, (unsigned)ntiles), dim3(256), 2 * WS_BUF_BYTES, s, p);
+    return dhaug_launch_status();
+}
+
 template <typename Kern>
 int launch_nt(Kern kern, long long grid, size_t lds, hipStream_t s, const GemmArgs& p) {
     static bool configured = false;          // one attribute call per kernel instantiation
@@ -357,6 +570,18 @@ int dhaug_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t l
     hipStream_t s = (hipStream_t)stream;
     const long long width = (c_bf16 && p.npad > N) ? p.npad : N;
     p.W = width;
+    if (width > 64 && K <= 256 && getenv("DHAUG_GEMM_GENERIC") == nullptr) {
+        switch (K / 16) {
+            case 1: return launch_ws<1>(s, p);
+            case 2: return launch_ws<2>(s, p);
+            case 3: return launch_ws<3>(s, p);
+            case 4: return launch_ws<4>(s, p);
+            case 7: return launch_ws<7>(s, p);
+            case 8: return launch_ws<8>(s, p);
+            case 16: return launch_ws<16>(s, p);
+            default: break;
+        }
+    }
     if (width > 64) {
         constexpr int BM = 128, BN = 128;
         const long long grid = ((M + BM - 1) / BM) * ((width + BN - 1) / BN);

@@ -1,0 +1,194 @@
+"""Fused one-launch forward of the generator trunk and the critics (dhaug_mlp_forward).
+
+A network is compiled into a short program of units (include/dhaug.h, struct dhaug_mlp_unit) over three LDS
+activation buffers; its weights are re-packed into MFMA fragment order (dhaug_pack_wfrag) whenever a parameter
+changes (the optimizer step invalidates the cache).  Used for the no-grad passes of the hot path: sampling fakes
+(model_fk_gan_train.py:305-308 `.data`), the flipped critic evaluations of the G step (:463-468) and inference.
+Same arithmetic as the layer-by-layer bf16 path (bf16 operands, fp32 accumulate, bf16 activations)."""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+from .autograd_ops import ACT_LRELU, ACT_NONE, ACT_RELU
+
+LOAD_F32, LOAD_BF16, STORE_BF16, GEMM = 0, 1, 2, 3
+F_OUT_F32 = 4
+_vp = ctypes.c_void_p
+
+
+def supported(*dims):
+    """hidden widths the fused kernel handles: whole 64-column chunks, at most 256 (three LDS buffers)"""
+    return all(d <= 256 and d % 64 == 0 for d in dims)
+
+
+class _Layer:
+    """packed fragments + padded bias of one nn.Linear (optionally split over two input column ranges)"""
+
+    def __init__(self, lin, splits=None):
+        W, b = lin.weight.detach(), lin.bias.detach()
+        N, K = W.shape
+        self.N = N
+        splits = splits or [(0, K)]
+        self.w, self.ksteps = [], []
+        for k0, k in splits:
+            ks = (k + 15) // 16
+            kpad = (k + 63) // 64 * 4                         # k-steps padded to whole 64-wide chunks
+            blob = torch.empty(8 * kpad * 512, dtype=torch.bfloat16, device=W.device)      # always 8 slices
+            _lib.call("dhaug_pack_wfrag", _vp(W.data_ptr()), K, _vp(blob.data_ptr()), N, k, k0, ops._stream())
+            self.w.append(blob)
+            self.ksteps.append(ks)
+        self.bias = torch.zeros(256, dtype=torch.float32, device=W.device)
+        self.bias[:N] = b
+
+
+def _unit(kind, flags=0, src=-1, dst=-1, res=-1, src2=-1, ksteps2=0, ksteps=0, n=0, act=0, slope=0.0, cols=0, ld=0,
+          g=None, w=None, w2=None, bias=None):
+    u = _lib.MlpUnit()
+    u.kind, u.flags, u.src, u.dst, u.res, u.src2, u.ksteps2 = kind, flags, src, dst, res, src2, ksteps2
+    u.ksteps, u.n, u.act, u.slope, u.cols, u.ld = ksteps, n, act, float(slope), cols, ld
+    u.g = None if g is None else g.data_ptr()
+    u.w = None if w is None else w.data_ptr()
+    u.w2 = None if w2 is None else w2.data_ptr()
+    u.bias = None if bias is None else bias.data_ptr()
+    return u
+
+
+def _gemm(layer, src, dst, act, slope=0.0, res=-1, out=None, src2=-1):
+    kw = dict(src=src, ksteps=layer.ksteps[0], n=layer.N, act=act, slope=slope, w=layer.w[0], bias=layer.bias, res=res)
+    if len(layer.w) == 2:
+        kw.update(src2=src2, ksteps2=layer.ksteps[1], w2=layer.w[1])
+    if out is not None:
+        return _unit(GEMM, flags=F_OUT_F32, g=out, ld=out.stride(0), dst=dst, **kw)
+    return _unit(GEMM, dst=dst, **kw)
+
+
+class FusedNet:
+    """compiled program + packed weights of one module; rebuilt when any parameter changes"""
+
+    def __init__(self, module, build):
+        self.module, self.build, self.key, self.layers = module, build, None, None
+
+    def _fresh(self):
+        key = tuple((p.data_ptr(), p._version) for p in self.module.parameters())
+        if key != self.key:
+            self.layers = {name: _Layer(lin, splits) for name, lin, splits in self.build["layers"](self.module)}
+            self.key = key
+        return self.layers
+
+    def invalidate(self):
+        self.key = None
+
+    def run(self, inputs, M):
+        L = self._fresh()
+        units, keep = self.build["program"](self.module, L, inputs, M)
+        arr = (_lib.MlpUnit * len(units))(*units)
+        _lib.call("dhaug_mlp_forward", arr, len(units), M, ops._stream())
+        return keep
+
+
+def _res_blocks(L, units, names, a=0, b=1, act=ACT_RELU):
+    """three myResNet blocks: x in buffer a -> result in buffer a (h in b, in-place residual)"""
+    for n in names:
+        units.append(_gemm(L[n + ".fc1"], a, b, act))
+        units.append(_gemm(L[n + ".fc2"], b, a, act, res=a))
+
+
+# ---- generator trunk: z (B,128) fp32 -> head (B,35*R) fp32 ------------------------------------------------------
+def _gen_layers(G):
+    out = [("preprocess.0", G.preprocess[0], None)]
+    for b in ("block1", "block2", "block3"):
+        blk = getattr(G, b)
+        out += [(b + ".fc1", blk.fc1, None), (b + ".fc2", blk.fc2, None)]
+    out.append(("deconv_out", G.deconv_out, None))
+    return out
+
+
+def _gen_program(G, L, inputs, M):
+    z = inputs["z"]
+    head = torch.empty((M, G.deconv_out.weight.shape[0]), dtype=torch.float32, device=z.device)
+    u = [_unit(LOAD_F32, dst=1, cols=z.shape[1], ld=z.stride(0), g=z), _gemm(L["preprocess.0"], 1, 0, ACT_RELU)]
+    _res_blocks(L, u, ("block1", "block2", "block3"))
+    u.append(_gemm(L["deconv_out"], 0, 1, ACT_NONE, out=head))
+    return u, head
+
+
+GEN = dict(layers=_gen_layers, program=_gen_program)
+
+
+# ---- 2D critic: x (B,32) fp32 -> logit (B,1) ----------------------------------------------------------------------
+def _d2_layers(D):
+    return [(n, getattr(D, n), None) for n in ("pose_layer_1", "pose_layer_2", "pose_layer_3", "pose_layer_4",
+                                                "layer_last", "layer_pred")]
+
+
+def _d2_program(D, L, inputs, M):
+    x = inputs["x"]
+    out = torch.empty((M, 1), dtype=torch.float32, device=x.device)
+    s = D.slope
+    u = [_unit(LOAD_F32, dst=1, cols=32, ld=x.stride(0), g=x),
+         _gemm(L["pose_layer_1"], 1, 0, ACT_LRELU, s),                 # d1 -> 0
+         _gemm(L["pose_layer_2"], 0, 1, ACT_LRELU, s),                 # d2 -> 1
+         _gemm(L["pose_layer_3"], 1, 0, ACT_LRELU, s, res=0),          # d3 = lrelu(L3 d2 + d1) -> 0 (in place)
+         _gemm(L["pose_layer_4"], 0, 1, ACT_NONE),                     # d4 -> 1
+         _gemm(L["layer_last"], 1, 0, ACT_LRELU, s),
+         _gemm(L["layer_pred"], 0, 1, ACT_NONE, out=out)]
+    return u, out
+
+
+D2 = dict(layers=_d2_layers, program=_d2_program)
+
+
+# ---- 3D critic: pose (B,48) fp32 + KCS (B,32) bf16 -> logit (B,1) ------------------------------------------------
+def _d3_layers(D):
+    out = [("special_KCS_previous.0", D.special_KCS_previous[0], None), ("previous.0", D.previous[0], None)]
+    for b in ("special_KCS_block1", "special_KCS_block2", "special_KCS_block3", "block1", "block2", "block3",
+              "merge_block1"):
+        blk = getattr(D, b)
+        out += [(b + ".fc1", blk.fc1, None), (b + ".fc2", blk.fc2, None)]
+    Dd = D.previous[0].weight.shape[0]
+    out.append(("merge_previous.0", D.merge_previous[0], [(0, Dd), (Dd, Dd)]))
+    out.append(("output", D.output, None))
+    return out
+
+
+def _d3_program(D, L, inputs, M):
+    x, kcs = inputs["x"], inputs["kcs"]
+    Dd = D.previous[0].weight.shape[0]
+    out = torch.empty((M, 1), dtype=torch.float32, device=x.device)
+    scratch = torch.empty((M, 256), dtype=torch.bfloat16, device=x.device)     # KCS-branch output parked in L2/HBM
+    u = [_unit(LOAD_BF16, dst=1, cols=32, ld=kcs.stride(0), g=kcs), _gemm(L["special_KCS_previous.0"], 1, 0, ACT_RELU)]
+    _res_blocks(L, u, ("special_KCS_block1", "special_KCS_block2", "special_KCS_block3"))
+    u.append(_unit(STORE_BF16, src=0, cols=256, ld=256, g=scratch))
+    u += [_unit(LOAD_F32, dst=1, cols=48, ld=x.stride(0), g=x), _gemm(L["previous.0"], 1, 0, ACT_RELU)]
+    _res_blocks(L, u, ("block1", "block2", "block3"))
+    u.append(_unit(LOAD_BF16, dst=1, cols=256, ld=256, g=scratch))
+    u.append(_gemm(L["merge_previous.0"], 1, 2, ACT_RELU, src2=0))             # cat(kcs_out, pos_out) -> buffer 2
+    u.append(_gemm(L["merge_block1.fc1"], 2, 0, ACT_RELU))
+    u.append(_gemm(L["merge_block1.fc2"], 0, 2, ACT_RELU, res=2))
+    u.append(_gemm(L["output"], 2, 0, ACT_NONE, out=out))
+    return u, (out, scratch)
+
+
+D3 = dict(layers=_d3_layers, program=_d3_program)
+
+
+def generator_head(G, z):
+    if not hasattr(G, "_fused"):
+        G._fused = FusedNet(G, GEN)
+    return G._fused.run(dict(z=z.contiguous()), z.shape[0])
+
+
+def critic2d(D, x):
+    if not hasattr(D, "_fused"):
+        D._fused = FusedNet(D, D2)
+    x = x.reshape(-1, 32).contiguous()
+    return D._fused.run(dict(x=x), x.shape[0])
+
+
+def critic3d(D, x):
+    if not hasattr(D, "_fused"):
+        D._fused = FusedNet(D, D3)
+    x = x.reshape(-1, 48).contiguous()
+    _, kcs = ops.kcs_forward(x, True, f32=False, bf16_ld=32)
+    return D._fused.run(dict(x=x, kcs=kcs), x.shape[0])[0]

@@ -9,6 +9,7 @@ import torch.autograd as autograd
 import torch.nn as nn
 
 from .. import autograd_ops as A
+from .. import fused
 from .Fk_generator import default_precision
 from .special_operate import myResNet
 
@@ -21,6 +22,10 @@ def special_KCS_Input_transform(pos_16_3d, device=None):
 def video_mode_special_KCS_Input_transform(pos_16_3d, device=None):
     """(N,16,3)|(N,48) -> (N,15): cosines only."""
     return A.KcsFn.apply(pos_16_3d.reshape(-1, 48), False)
+
+
+def _no_graph(module, x):
+    return not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters())))
 
 
 def _branch(x, first, blocks, prec):
@@ -52,6 +57,8 @@ class Fk_3D_Discriminator(nn.Module):
     def forward(self, input):
         p = self.precision
         x = input.reshape(-1, 48)
+        if p == "bf16" and x.is_cuda and _no_graph(self, x) and fused.supported(self.args.Dis_DenseDim_3D):
+            return fused.critic3d(self, x.float())          # one launch, activations stay in LDS
         k = _branch(A.KcsFn.apply(x, True), self.special_KCS_previous[0],
                     (self.special_KCS_block1, self.special_KCS_block2, self.special_KCS_block3), p)
         q = _branch(x, self.previous[0], (self.block1, self.block2, self.block3), p)
@@ -95,6 +102,8 @@ class Fk_2D_Discriminator(nn.Module):
     def forward(self, x):
         p, s, L = self.precision, self.slope, A.ACT_LRELU
         x = x.reshape(-1, 32)
+        if p == "bf16" and x.is_cuda and _no_graph(self, x) and fused.supported(self.args.Dis_DenseDim_2D):
+            return fused.critic2d(self, x.float())
         d1 = A.linear(x, self.pose_layer_1.weight, self.pose_layer_1.bias, None, L, s, p)
         d2 = A.linear(d1, self.pose_layer_2.weight, self.pose_layer_2.bias, None, L, s, p)
         d3 = A.linear(d2, self.pose_layer_3.weight, self.pose_layer_3.bias, d1, L, s, p)

@@ -53,7 +53,18 @@ class _GeneratorBase(nn.Module):
         """bone lengths of the real batch -> self.boneLength (N,15)   (:107-111 / :294-300)."""
         self.boneLength = ops.bone_length(input.reshape(-1, 16, 3))
 
+    def _use_fused(self, x):
+        """one-launch fused forward (csrc/dhaug_mlp.hip) for passes that need no autograd graph"""
+        from .. import fused
+        return (self.precision == "bf16" and x.is_cuda and not (torch.is_grad_enabled() and (
+            x.requires_grad or any(p.requires_grad for p in self.parameters())))
+            and fused.supported(self.args.Gen_DenseDim) and self.INPUT_VEC_DIM % 64 == 0
+            and self.deconv_out.weight.shape[0] <= 64)
+
     def trunk(self, z):
+        if self._use_fused(z):
+            from .. import fused
+            return fused.generator_head(self, z.float())
         p = self.precision
         lin = self.preprocess[0]
         x = A.linear(z, lin.weight, lin.bias, None, A.ACT_RELU, 0.0, p)
@@ -83,8 +94,6 @@ class _GeneratorBase(nn.Module):
         if not use_rt:                   # global rotation off: tanh^-1(0) = 0 on the three rotation columns
             head = head.clone()
             head[:, 28:31] = 0.0
-            if not self.args.GAN_whether_use_preAngle:
-                pass
         scaler = self._scaler(B, bone_len_scaler)
         bl = self.boneLength
         if bl.shape[0] != B * R:

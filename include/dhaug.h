@@ -188,6 +188,46 @@ int dhaug_split_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ro
                      int64_t pad_cols, int mode, int terms, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Fused multi-layer forward (one launch per network; activations stay in LDS)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* Weight fragments in MFMA A-operand order for dhaug_mlp_forward:
+ *   dst[((slice*ksteps + ks)*64 + lane)*8 + j] = bf16( W[32*slice + (lane&31)][k0 + 16*ks + 8*(lane>>5) + j] )
+ * (0 outside N x K), ksteps = 4*ceil(K/64) <= 16 (whole 64-wide chunks), slice = 0..7 (always 8 slices = 256
+ * feature rows, zero beyond N): dst holds 8 * ksteps * 512 bf16.  W is the fp32 nn.Linear weight
+ * [N, ldw]; (k0, K) selects a column range (layers fed by a concatenation take one block per source). */
+int dhaug_pack_wfrag(const float* W, int64_t ldw, uint16_t* dst, int64_t N, int64_t K, int64_t k0, void* stream);
+
+/* One unit of a fused network program.  Three LDS activation buffers exist per 128-row batch tile:
+ * ids 0 and 1 hold up to 256 bf16 columns, id 2 up to 128. */
+#define DHAUG_MLP_LOAD_F32    0   /* global fp32 (M, ld) columns [0, cols) -> buffer dst (rounded to bf16)          */
+#define DHAUG_MLP_LOAD_BF16   1   /* global bf16 (M, ld) columns [0, cols) -> buffer dst                              */
+#define DHAUG_MLP_STORE_BF16  2   /* buffer src columns [0, cols) -> global bf16 (M, ld)                              */
+#define DHAUG_MLP_GEMM        3   /* one layer: dst = act(W * src [+ W2 * src2] + bias + res)                          */
+#define DHAUG_MLP_F_OUT_F32   4   /* network output (n <= 64): fp32 (M, ld) to g, staged through buffer dst (0 or 1)    */
+typedef struct dhaug_mlp_unit {
+    int kind, flags;
+    int src, dst, res;            /* buffer ids, -1 = none; dst may equal res (in-place residual), never src        */
+    int src2, ksteps2;            /* optional second source (input = concatenation of two buffers); ksteps2 = 0: none */
+    int ksteps;                   /* K/16 of the first source (K zero-padded to 16 by the producer)                  */
+    int n;                        /* output features of the layer (<= 256)                                          */
+    int act;                      /* DHAUG_ACT_*                                                                     */
+    float slope;
+    int cols;                     /* LOAD/STORE: columns moved (multiple of 8)                                       */
+    int64_t ld;
+    const void* g;                /* global tensor of LOAD / STORE / OUT_F32                                         */
+    const void* w;                /* GEMM: packed fragments of the first source's weight columns (dhaug_pack_wfrag)  */
+    const void* w2;               /* fragments of the second source's weight columns                                 */
+    const float* bias;            /* GEMM: fp32 [256], zero padded                                                   */
+} dhaug_mlp_unit;
+
+/* Runs the program on every 128-row tile of the batch: replaces the nn.Sequential / myResNet stacks of
+ * R/models_Fk_GAN/Fk_generator.py:115-119, Fk_discriminator.py:180-201 and :253-266 (inference / sampling passes).
+ * bf16 operands, fp32 accumulate, bf16 activations between layers -- the same arithmetic as a chain of
+ * dhaug_gemm_bf16 calls. */
+int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Elementwise / reductions used by the training step
  * ---------------------------------------------------------------------------------------------------- */
 

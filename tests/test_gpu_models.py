@@ -262,3 +262,37 @@ def test_generator_step_gradients(M, golden):
     lossg.backward()
     for (k, p), r in zip(G.named_parameters(), ref):
         assert maxabs(p.grad, r) <= 1e-6 + 5e-4 * r.abs().max().item(), k
+
+
+# ------------------------------------------------------------------------------------- fused one-launch forward
+@pytest.mark.parametrize("D,B", [(256, 256), (256, 1000), (64, 333)])
+def test_fused_forward_matches_layerwise(M, D, B):
+    """dhaug_mlp_forward (activations in LDS, one launch per network) against the layer-by-layer bf16 path and the
+    oracle's bf16 emulation; ragged batch sizes exercise the tail tile."""
+    from dhaug_amd import fused, ops
+    args = make_args(batch_size=B, Gen_DenseDim=D, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D)
+    fk = M.fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+    torch.manual_seed(5)
+    G = M.gen.Fk_Generator(fk, args, "cuda").cuda()
+    D3 = M.dis.Fk_3D_Discriminator("cuda", args).cuda()
+    D2 = M.dis.Fk_2D_Discriminator(args, 16).cuda()
+    g = torch.Generator().manual_seed(6)
+    z = torch.randn(B, 128, generator=g).cuda()
+    x3 = GU.synth_pose16(B, seed=8); x3 = (x3 - x3[:, :1]).cuda()
+    x2 = ((torch.rand(B, 16, 2, generator=g) - 0.5) * 1.6).cuda()
+    with torch.no_grad():
+        head_l, l3_l, l2_l = G.trunk(z), D3(x3), D2(x2)
+        head_f, l3_f, l2_f = fused.generator_head(G, z), fused.critic3d(D3, x3), fused.critic2d(D2, x2)
+    for f, l in ((head_f, head_l), (l3_f, l3_l), (l2_f, l2_l)):
+        assert f.shape == l.shape
+        assert maxabs(f, l) <= 2e-2 * l.abs().max().item() + 1e-6      # same arithmetic, different summation order
+    sdG = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    ref = O.gen_trunk(z.cpu(), sdG, precision="bf16")
+    assert maxabs(head_f, ref) <= 2e-2 * ref.abs().max().item()
+    sd3 = {k: v.detach().cpu() for k, v in D3.state_dict().items()}
+    r3 = O.d3_forward(x3.cpu(), sd3, precision="bf16")
+    assert relerr(l3_f, r3) <= 3e-2
+    # weights change -> the packed fragments are rebuilt
+    with torch.no_grad():
+        D2.layer_pred.bias.add_(1.0)
+        assert maxabs(fused.critic2d(D2, x2), l2_l + 1.0) <= 2e-2 * l2_l.abs().max().item() + 1e-6
