@@ -169,7 +169,8 @@ def main():
         tg = max(tg - kcs_t, 1e-9)                       # critic3d() = KCS kernel + fused kernel
         roofline = {"kernel": "fused_mlp_kernel (Fk_3D_Discriminator forward, M=%d, D=%d, 17 layers in one launch)" % (B, D),
                     "bound": "mfma", "achieved": 2.0 * d3_mac * B / tg / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": 2.0 * d3_mac * B / tg / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": 2.0 * d3_mac * B / tg / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                    "traffic": pmc_traffic("fused_mlp_kernel") if (B, D) == (65536, 256) else None,
                     "avg_us": tg * 1e6, "algorithmic_flop_per_pose": 2 * d3_mac}
         xb = torch.randn(B, D, device=dev).to(torch.bfloat16)
         wb = (torch.randn(D, D, device=dev) / D ** 0.5).to(torch.bfloat16)
@@ -187,7 +188,7 @@ def main():
         tf_b = event_time(step_fk, 50, 10)
         roofline_fk = {"kernel": "fk_forward_kernel<0,16,true>", "bound": "hbm", "achieved": FK_BYTES_PER_POSE * nfk / tf / 1e9,
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": FK_BYTES_PER_POSE * nfk / tf / 1e9 / HBM_PEAK_GBS,
-                       "traffic": None, "poses_per_launch": nfk, "avg_us": tf * 1e6,
+                       "traffic": pmc_traffic("fk_forward_kernel<0; 16; true>"), "algorithmic_bytes": FK_BYTES_PER_POSE * nfk, "poses_per_launch": nfk, "avg_us": tf * 1e6,
                        "at_batch": {"poses": B, "avg_us": tf_b * 1e6, "achieved": FK_BYTES_PER_POSE * B / tf_b / 1e9}}
         del a4, b4, r4
 
@@ -211,6 +212,24 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summaries (profiles/r01_pmc_*_summary.csv,
+    collected with separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).  The largest dispatch of the
+    kernel is the one bench.py times.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts half of the
+    bytes of wide coalesced reads -> doubled; both counters are in KiB."""
+    import csv
+    tot = 0.0
+    for tag, mult in (("fetch", 2.0), ("write", 1.0)):
+        path = os.path.join(ROOT, "profiles", "r01_pmc_%s_summary.csv" % tag)
+        if not os.path.exists(path):
+            return None
+        hit = [float(r["max"]) for r in csv.DictReader(open(path)) if kernel_substr in r["kernel"]]
+        if not hit:
+            return None
+        tot += mult * max(hit) * 1024.0
+    return tot
 
 
 def usable_cores():

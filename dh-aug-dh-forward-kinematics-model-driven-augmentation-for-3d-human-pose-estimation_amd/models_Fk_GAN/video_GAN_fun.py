@@ -1,0 +1,144 @@
+"""Drop-in for R/models_Fk_GAN/video_GAN_fun.py:79-601 (multi-frame GAN epoch, R = prod(filter widths) frames per
+sample folded into the batch axis for FK / single-frame critics and into the feature axis for the motion critics).
+
+Per iteration (reference lines in brackets): sample fakes [:193-200]; D3 step [:208]; motion-D3 step on the clip and on
+its time reversal once epoch >= single_dis_warmup_epoch [:213-232]; the same on L/R-flipped copies [:237-289]; random
+camera, world->camera, projection [:291-330]; D2 / motion-D2 steps, reversed, flipped [:335-418]; every 5th iteration
+the G step with up to four adversarial terms [:421-566]; generated pairs appended to the device-resident buffer.
+Time reversal is a frame permutation (torch.flip, data movement only)."""
+import numpy as np
+import torch
+
+from .. import autograd_ops as A
+from .. import ops
+from ..common import camera as cam
+from .model_fk_gan_train import FakePairBuffer, MeanFn, pick_camera, set_grad, train_Fk_discriminator, _device
+from .video_mode_operate import frames_from_args
+
+
+def _rev(x, R, width):
+    """time reversal of (B*R, ...) clips -> same layout"""
+    return torch.flip(x.reshape(-1, R, width), dims=[1]).contiguous()
+
+
+def video_gan_iteration(args, poseFk_dict, inputs_3d, cam_param, inputs_2d, train_subjects, summary, writer=None,
+                        do_g_step=False, camera=None, rng=np.random):
+    """inputs_3d (B,R,16,3) camera-space real clips, cam_param (B,>=16), inputs_2d (B,R,16,2)."""
+    device = _device()
+    R, B = frames_from_args(args), args.batch_size
+    G, D3, D2 = poseFk_dict['model_G'], poseFk_dict['model_d3d'], poseFk_dict['model_d2d']
+    M3, M2 = poseFk_dict['model_motion_d3d'], poseFk_dict['model_motion_d2d']
+    oG, o3, o2 = poseFk_dict['optimizer_G'], poseFk_dict['optimizer_d3d'], poseFk_dict['optimizer_d2d']
+    om3, om2 = poseFk_dict['optimizer_motion_d3d'], poseFk_dict['optimizer_motion_d2d']
+    motion_on = summary.epoch >= args.single_dis_warmup_epoch
+    playback, flip = bool(args.GAN_video_playback_input), bool(args.flip_GAN_model_input)
+    inputs_3d, cam_param, inputs_2d = inputs_3d.to(device), cam_param.to(device), inputs_2d.to(device)
+    G.GAN_generator_get_bone_length(inputs_3d)
+    camR = cam_param[:, 9:13].unsqueeze(1).repeat(1, R, 1).reshape(-1, 4).contiguous()
+    camT = cam_param[:, 13:16].unsqueeze(1).repeat(1, R, 1).reshape(-1, 3).contiguous()
+    real = ops.center_flip(cam.GAN_torch_camera_to_world_batch(inputs_3d.reshape(-1, 16, 3), camR, camT), True, False)
+    set_grad([D3, D2, M3, M2], True)
+    set_grad([G], False)
+    with torch.no_grad():
+        fake_world = G(torch.randn(B, 128, device=device)).reshape(-1, 16, 3)
+    fake = ops.center_flip(fake_world, True, False)
+    avg = lambda a, b: tuple((x + y) / 2 for x, y in zip(a, b))
+
+    def critic_pair(net, opt, name, r, f, mode):
+        return train_Fk_discriminator(net, r, f, summary, writer, name, opt, args, dis_mode=mode)
+
+    def motion_steps(net, opt, name, r, f, width):
+        """clip + (optionally) time-reversed clip"""
+        res = critic_pair(net, opt, name, r, f, 'motion')
+        if playback:
+            res = avg(res, critic_pair(net, opt, 'back_' + name, _rev(r, R, width), _rev(f, R, width), 'motion'))
+        return res
+
+    out = {}
+    out['d3'] = critic_pair(D3, o3, 'Fk_d3d', real, fake, 'single')
+    if motion_on:
+        out['m3'] = motion_steps(M3, om3, 'motion_Fk_d3d', real.reshape(-1, 48), fake.reshape(-1, 48), 48)
+    if flip:
+        rf, ff = ops.center_flip(real, False, True), ops.center_flip(fake, False, True)
+        out['d3'] = avg(out['d3'], critic_pair(D3, o3, 'Fk_d3d', rf, ff, 'single'))
+        if motion_on:
+            out['m3'] = avg(out['m3'], motion_steps(M3, om3, 'motion_Fk_d3d', rf.reshape(-1, 48), ff.reshape(-1, 48), 48))
+    quat, trans, cam9 = camera if camera is not None else pick_camera(train_subjects, rng)
+    pos_3d_cam, pos_2d = ops.world_to_camera_project(fake_world, quat, trans, cam9)
+    real2d = inputs_2d.reshape(-1, 16, 2)
+    out['d2'] = critic_pair(D2, o2, 'd2d', real2d, pos_2d, 'single')
+    if motion_on:
+        out['m2'] = motion_steps(M2, om2, 'motion_d2d', real2d.reshape(-1, 32), pos_2d.reshape(-1, 32), 32)
+    if flip:
+        r2f, f2f = ops.center_flip(real2d, False, True), ops.center_flip(pos_2d, False, True)
+        out['d2'] = avg(out['d2'], critic_pair(D2, o2, 'd2d', r2f, f2f, 'single'))
+        if motion_on:
+            out['m2'] = avg(out['m2'], motion_steps(M2, om2, 'motion_d2d', r2f.reshape(-1, 32), f2f.reshape(-1, 32), 32))
+    out['G_cost'] = None
+    if do_g_step:
+        set_grad([D3, D2, M3, M2], False)
+        set_grad([G], True)
+        G.zero_grad()
+        oG.zero_grad()
+        fw = G(torch.randn(B, 128, device=device)).reshape(-1, 16, 3)
+        _, f2d = A.W2CProjectFn.apply(fw, tuple(quat), tuple(trans), tuple(cam9))
+        fc = A.center_flip(fw, True, False)
+        mean = lambda net, x: MeanFn.apply(net(x))
+        a3, a2 = mean(D3, fc), mean(D2, f2d)
+        am3 = am2 = 0.0
+        if motion_on:
+            am3, am2 = mean(M3, fc.reshape(-1, 48)), mean(M2, f2d.reshape(-1, 32))
+            if playback:
+                # reference quirk: the 3D clip is viewed as (-1, R, 32) before the frame flip (:467,:521)
+                am3 = (am3 + mean(M3, torch.flip(fc.reshape(-1, R, 32), dims=[1]).reshape(-1, 48))) / 2
+                am2 = (am2 + mean(M2, torch.flip(f2d.reshape(-1, R, 32), dims=[1]).reshape(-1, 32))) / 2
+        if flip:                                   # flipped copies: value only (detach), as in the reference
+            with torch.no_grad():
+                f3f, f2f = ops.center_flip(fc.detach(), False, True), ops.center_flip(f2d.detach(), False, True)
+                b3, b2 = mean(D3, f3f), mean(D2, f2f)
+                bm3 = bm2 = 0.0
+                if motion_on:
+                    bm3, bm2 = mean(M3, f3f.reshape(-1, 48)), mean(M2, f2f.reshape(-1, 32))
+                    if playback:
+                        bm3 = (bm3 + mean(M3, torch.flip(f3f.reshape(-1, R, 32), dims=[1]).reshape(-1, 48))) / 2
+                        bm2 = (bm2 + mean(M2, torch.flip(f2f.reshape(-1, R, 32), dims=[1]).reshape(-1, 32))) / 2
+            a3, a2 = (a3 + b3) / 2, (a2 + b2) / 2
+            if motion_on:
+                am3, am2 = (am3 + bm3) / 2, (am2 + bm2) / 2
+        gen_loss = a3 * args.GAN_3d_loss_weight + a2 * args.GAN_2d_loss_weight
+        if motion_on:
+            gen_loss = gen_loss + am3 * args.GAN_3d_motion_loss_weight + am2 * args.GAN_2d_motion_loss_weight
+        (-gen_loss).backward()
+        out['G_cost'] = (-gen_loss).detach()
+        oG.step()
+        set_grad([D3, D2, M3, M2], True)
+    out.update(pos_3d_cam=pos_3d_cam.reshape(B, R, 16, 3), pos_2d=pos_2d.reshape(B, R, 16, 2), cam9=cam9)
+    return out
+
+
+def video_mode_GAN_solutions_FK_generator(args, poseFk_dict, data_dict, model_pos, summary, writer, train_subjects):
+    """epoch loop over data_dict['target_GAN_loader'].next_epoch() -> (cam_param, inputs_3d, inputs_2d) numpy batches;
+    side effect data_dict['train_fake2d3d_loader'] (device-resident FakePairBuffer of clips)."""
+    for k in ('model_G', 'model_d3d', 'model_d2d', 'model_motion_d3d', 'model_motion_d2d'):
+        poseFk_dict[k].train()
+    if model_pos is not None:
+        model_pos.train()
+        set_grad([model_pos], False)
+    buf = FakePairBuffer(args.batch_size)
+    for cam_param, inputs_3d, inputs_2d in data_dict['target_GAN_loader'].next_epoch():
+        if inputs_3d.shape[0] < args.batch_size:
+            continue
+        t = lambda x: x if torch.is_tensor(x) else torch.from_numpy(np.asarray(x).astype('float32'))
+        r = video_gan_iteration(args, poseFk_dict, t(inputs_3d), t(cam_param), t(inputs_2d), train_subjects, summary,
+                                writer, do_g_step=(summary.train_iter_num % 5 == 4))
+        if hasattr(summary, "summary_train_discrim_update"):
+            summary.summary_train_discrim_update()
+        if r['G_cost'] is not None and hasattr(summary, "summary_train_fakepose_iter_num_update"):
+            summary.summary_train_fakepose_iter_num_update()
+        buf.append(r['pos_3d_cam'], r['pos_2d'], r['cam9'])
+        if hasattr(summary, "summary_train_iter_num_update"):
+            summary.summary_train_iter_num_update()
+        else:
+            summary.train_iter_num += 1
+    data_dict['train_fake2d3d_loader'] = buf
+    return

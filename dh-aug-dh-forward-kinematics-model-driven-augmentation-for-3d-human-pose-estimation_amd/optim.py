@@ -60,11 +60,18 @@ class FusedAdam(torch.optim.Optimizer):
         return dist.get_world_size(self.process_group) if use else 1
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def exchange(self):
+        """the one exchange step of the data-parallel path: sum the flat gradient bucket over the replicas.
+        Returns the world size (the Adam kernel applies the 1/world scale)."""
         self._gather_grads()
         ws = self.world_size()
         if ws > 1:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.process_group)
+        return ws
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        ws = self.exchange()
         self.step_count += 1
         g = self.param_groups[0]
         if self.flat_param.is_cuda:

@@ -1,0 +1,42 @@
+"""Data-parallel helpers: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on ROCm, "gloo" in the
+CPU tests).  The augmentation batch shards across ranks; weights are replicated; the only exchange is the flat
+gradient bucket of the network being stepped (optim.FusedAdam.exchange)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run).
+    Returns (rank, world, local_rank); a no-op for single-process runs."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, world, local
+
+
+def shard_range(total, rank, world):
+    """[begin, end) of this rank's contiguous shard of `total` units (videos stay whole: shard B, not B*R)."""
+    base, rem = divmod(total, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def rank_seed(seed, rank):
+    """per-rank RNG stream for noise / jitter / GP alpha / camera draws"""
+    return int(seed) * 1000003 + int(rank)
+
+
+def broadcast_parameters(modules, src=0):
+    """replicas start from rank `src`'s weights"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    for m in modules:
+        for p in m.parameters():
+            dist.broadcast(p.data, src)

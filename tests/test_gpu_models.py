@@ -296,3 +296,90 @@ def test_fused_forward_matches_layerwise(M, D, B):
     with torch.no_grad():
         D2.layer_pred.bias.add_(1.0)
         assert maxabs(fused.critic2d(D2, x2), l2_l + 1.0) <= 2e-2 * l2_l.abs().max().item() + 1e-6
+
+
+# ------------------------------------------------------------------------------------------- epoch loops
+class _Summary:
+    def __init__(self, epoch=0):
+        self.epoch, self.train_iter_num, self.train_discrim_iter_num = epoch, 0, 0
+
+    def summary_train_iter_num_update(self):
+        self.train_iter_num += 1
+
+
+def _synthetic_real(ops_mod, B, seed):
+    a, bl, rt = GU.synth_fk_inputs(B, seed)
+    a = a * 0.25
+    world = ops_mod.fk_forward(a.cuda(), bl.cuda(), (rt * 0.2).cuda())
+    return world
+
+
+def test_single_frame_epoch_loop(M, golden):
+    """GAN_solutions_FK_generator over 6 synthetic batches (G step on the 5th): finite losses, every network's
+    parameters move, the fake-pair buffer has the reference's item format."""
+    from dhaug_amd import ops
+    B = 128
+    args = make_args(batch_size=B, Gen_DenseDim=64, Dis_DenseDim_3D=64, Dis_DenseDim_2D=64)
+    fk = M.fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+    torch.manual_seed(3)
+    d = M.train.my_get_poseFk_model(args, None, fk)
+    cam = golden("camera_128")
+    q, t, c9 = cam["R"][0].tolist(), cam["t"][0].tolist(), cam["cam"][0].tolist()
+    batches = []
+    for i in range(6):
+        world = _synthetic_real(ops, B, 40 + i)
+        c3, p2 = ops.world_to_camera_project(world, q, t, c9)
+        cp = torch.zeros(B, 16); cp[:, 9:13] = torch.tensor(q); cp[:, 13:16] = torch.tensor(t)
+        batches.append(((c3.cpu(), None, None, cp), p2.cpu(), None))
+    batches.append(((batches[0][0][0][:5], None, None, batches[0][0][3][:5]), batches[0][1][:5], None))   # ragged: dropped
+    data = dict(train_gt2d3d_loader=[b[0] for b in batches], target_2d_loader=[b[1] for b in batches],
+                target_3d_loader=[b[2] for b in batches])
+    before = {k: [p.detach().clone() for p in d[k].parameters()] for k in ("model_G", "model_d3d", "model_d2d")}
+    s = _Summary()
+    M.train.GAN_solutions_FK_generator(args, d, data, None, s, None, ["S1", "S5"])
+    assert s.train_iter_num == 6
+    for k, ps in before.items():
+        assert any((p.detach() - q0).abs().max().item() > 0 for p, q0 in zip(d[k].parameters(), ps)), k
+        assert all(torch.isfinite(p).all().item() for p in d[k].parameters()), k
+    buf = data["train_fake2d3d_loader"]
+    p3, p2, c = buf.tensors()
+    assert p3.shape == (6 * B, 16, 3) and p2.shape == (6 * B, 16, 2) and c.shape == (6 * B, 9)
+    item = next(iter(buf))
+    assert item[0].shape == (B, 16, 3) and item[1].shape == (B, 16, 2) and len(item[2]) == B and item[3].shape == (B, 9)
+
+
+def test_video_epoch_loop(M, golden):
+    """video_mode_GAN_solutions_FK_generator, R = 9 (architecture 3,3): motion critics active, time-reversed and
+    flipped copies, G step with the four adversarial terms."""
+    from dhaug_amd import ops
+    from dhaug_amd.models_Fk_GAN import video_GAN_fun as V
+    B, R = 16, 9
+    args = make_args(batch_size=B, Gen_DenseDim=64, Dis_DenseDim_3D=64, Dis_DenseDim_2D=64, video_Dis_DenseDim_3D=64,
+                     video_Dis_DenseDim_2D=64, single_or_multi_train_mode="multi", architecture="3,3",
+                     single_dis_warmup_epoch=0, GAN_video_playback_input=True, GAN_3d_motion_loss_weight=1.0,
+                     GAN_2d_motion_loss_weight=1.0)
+    fk = M.fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+    torch.manual_seed(4)
+    d = M.train.video_mode_my_get_poseFk_model(args, None, fk, R)
+    cam = golden("camera_128")
+    q, t, c9 = cam["R"][0].tolist(), cam["t"][0].tolist(), cam["cam"][0].tolist()
+
+    class Loader:
+        def next_epoch(self):
+            for i in range(5):
+                world = _synthetic_real(ops, B * R, 60 + i)
+                c3, p2 = ops.world_to_camera_project(world, q, t, c9)
+                cp = torch.zeros(B, 16); cp[:, 9:13] = torch.tensor(q); cp[:, 13:16] = torch.tensor(t)
+                yield cp.numpy(), c3.reshape(B, R, 16, 3).cpu().numpy(), p2.reshape(B, R, 16, 2).cpu().numpy()
+
+    data = dict(target_GAN_loader=Loader())
+    keys = ("model_G", "model_d3d", "model_d2d", "model_motion_d3d", "model_motion_d2d")
+    before = {k: [p.detach().clone() for p in d[k].parameters()] for k in keys}
+    s = _Summary(epoch=1)
+    V.video_mode_GAN_solutions_FK_generator(args, d, data, None, s, None, ["S1"])
+    assert s.train_iter_num == 5
+    for k, ps in before.items():
+        assert any((p.detach() - q0).abs().max().item() > 0 for p, q0 in zip(d[k].parameters(), ps)), k
+        assert all(torch.isfinite(p).all().item() for p in d[k].parameters()), k
+    p3, p2, c = data["train_fake2d3d_loader"].tensors()
+    assert p3.shape == (5 * B, R, 16, 3) and p2.shape == (5 * B, R, 16, 2)
