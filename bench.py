@@ -88,6 +88,9 @@ def main():
     fk = Forward_Kinematics_DH_Model(args, ["S1"], None)
     models = T.my_get_poseFk_model(args, None, fk)
     G, D3, D2 = models["model_G"], models["model_d3d"], models["model_d2d"]
+    if world > 1:                                # data-parallel replicas start from rank 0's weights
+        for k in ("optimizer_G", "optimizer_d3d", "optimizer_d2d"):
+            dist.broadcast(models[k].flat_param, 0)
 
     # synthetic inputs, resident in HBM
     ext = h36m_cameras_extrinsic_params["S1"][0]
@@ -155,8 +158,12 @@ def main():
         for name in ("fk_gen_fwd", "fwd", "gan_step"):
             if name != a.workload:
                 k = max(5, min(a.steps, 10))
-                te = timed(steps[name], k, 5 if name == "gan_step" else 3)
-                extra[name + "_poses_per_s"] = B * world * k / te
+                try:
+                    te = timed(steps[name], k, 5 if name == "gan_step" else 3)
+                    extra[name + "_poses_per_s"] = B * world * k / te
+                    extra[name + "_ms_per_step"] = te / k * 1e3
+                except Exception as ex:              # never lose the headline line to an optional measurement
+                    extra[name + "_error"] = repr(ex)[:200]
 
     if rank == 0:
         gen_mac, d3_mac, d2_mac = mac_per_pose(D)

@@ -24,7 +24,7 @@ SIGNATURES = {
     "dhaug_center_flip_backward": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "dhaug_gemm_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i32,
                         _f32, _vp],
-    "dhaug_gemm_tn_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
+    "dhaug_gemm_tn_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp],
     "dhaug_cast_pad_bf16": [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp],
     "dhaug_cast_transpose_bf16": [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp],
     "dhaug_split_bf16": [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp],

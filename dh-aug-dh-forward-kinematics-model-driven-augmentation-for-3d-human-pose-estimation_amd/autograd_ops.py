@@ -136,11 +136,11 @@ def _raw_linear_t(g, W, prec, out_f32):
     return cf
 
 
-def _raw_outer(g, x, N, K, prec):
+def _raw_outer(g, x, N, K, prec, colsum=None):
     if prec == "bf16":
         gb = _operand(g, ceil16(N)) if g.dtype != BF16 else g
         xb = _operand(x, ceil16(K)) if x.dtype != BF16 else x
-        return ops.gemm_tn(gb, xb, N, K)
+        return ops.gemm_tn(gb, xb, N, K, colsum=colsum)
     Np, Kp, T = ceil16(N), ceil16(K), TERMS[prec]
     g3 = ops.split_bf16(g, 0, T, Np)          # activation-side layout: hi / mid / lo live in fixed segments
     x3 = ops.split_bf16(x, 0, T, Kp)
@@ -175,9 +175,16 @@ class LinearFn(torch.autograd.Function):
         gx = gW = gb = gres = None
         if ctx.needs_input_grad[0]:
             gx = LinearTFn.apply(gz, W, prec, x.dtype != BF16)
+        want_b = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            gW = OuterFn.apply(gz, x, N, K, prec)
-        if has_bias and ctx.needs_input_grad[2]:
+            if want_b and prec == "bf16" and not torch.is_grad_enabled():
+                # first-order pass: the weight-gradient GEMM also emits the bias gradient (A^T * ones on the MFMA pipe)
+                gb = torch.empty((N,), dtype=torch.float32, device=gz.device)
+                gW = _raw_outer(gz, x, N, K, prec, colsum=gb)
+                want_b = False
+            else:
+                gW = OuterFn.apply(gz, x, N, K, prec)
+        if want_b:
             gb = ColSumFn.apply(gz, N)
         if res_info is not None and ctx.needs_input_grad[3]:
             gres = gz if (gz.dtype == res_info[0] and gz.shape == res_info[1]) else ReshapeGradFn.apply(gz, res_info)

@@ -221,12 +221,15 @@ struct TnArgs {
     const uint16_t* A; long long lda;
     const uint16_t* B; long long ldb;
     float* C; long long ldc;
+    float* colsum;                 // optional [N1]: column sums of A (bias gradient), accumulated by the n2-tile-0 blocks
     long long M, N1, N2;
-    long long rows_per_split;
+    long long rows_per_split, ntiles, nsplits;
 };
 
-constexpr int TN_BN = 128;          // tile edge in both output dimensions
-constexpr int TN_LD = 160;          // LDS row stride (elements): 320 B = 16 banks shift per row
+constexpr int TN_BN = 64;           // output tile edge: small tiles keep the split-K partial sums (fp32 atomics, the
+                                    // scarce resource: ~1.3 TB/s chip-wide) at splits x N1 x N2 x 4 B with few splits
+constexpr int TN_LD = 96;           // LDS row stride (elements): 192 B = 48 banks, so the 4 rows of a transpose-read
+                                    // block (64 B each) land on disjoint bank quarters
 
 // 8 consecutive contraction rows k = kbase..kbase+7 of column (col0 + lane&15) : two hardware transpose reads.
 __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* tile, int kbase, int col0, int lane) {
@@ -239,25 +242,35 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* tile, int kbase, int c
     return f;
 }
 
+// One workgroup = one 64 x 64 output tile over one slice of the batch.  The tiles of a slice are mapped to the same
+// XCD (equal blockIdx % 8) so that the slice's rows are fetched from HBM once and re-read from that XCD's L2 by the
+// other tiles (speed only; any placement is correct).
 __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint16_t* sA = reinterpret_cast<uint16_t*>(smem_raw);      // [2][64*TN_LD]
-    uint16_t* sB = sA + 2 * BK * TN_LD;
+    __shared__ __attribute__((aligned(16))) uint16_t sA[2][BK * TN_LD];
+    __shared__ __attribute__((aligned(16))) uint16_t sB[2][BK * TN_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int w1 = wave >> 1, w2 = wave & 1;                    // 2 x 2 waves, 64 x 64 each
+    const int w1 = wave >> 1, w2 = wave & 1;                    // 2 x 2 waves, one 32 x 32 MFMA tile each
     const long long nt2 = (p.N2 + TN_BN - 1) / TN_BN;
-    const long long tile = blockIdx.x;
+    long long tile, split;
+    if ((p.nsplits & 7) == 0) {
+        const long long xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        tile = local % p.ntiles;
+        split = xcd + 8 * (local / p.ntiles);
+    } else {
+        tile = blockIdx.x % p.ntiles;
+        split = blockIdx.x / p.ntiles;
+    }
     const long long n1_0 = (tile / nt2) * TN_BN, n2_0 = (tile % nt2) * TN_BN;
-    const long long ms = (long long)blockIdx.y * p.rows_per_split;
+    const long long ms = split * p.rows_per_split;
     long long me = ms + p.rows_per_split;
     if (me > p.M) me = p.M;
     if (ms >= me) return;
 
-    uint4 ra[4], rb[4];
+    uint4 ra[2], rb[2];
     auto gload = [&](long long mrow0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = tid + 256 * i, row = q >> 4, c = q & 15;
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + 256 * i, row = q >> 3, c = q & 7;
             const long long gm = mrow0 + row;
             const long long ca = n1_0 + c * 8, cb = n2_0 + c * 8;
             ra[i] = (gm < me && ca < p.N1) ? *reinterpret_cast<const uint4*>(p.A + gm * p.lda + ca) : make_uint4(0, 0, 0, 0);
@@ -266,20 +279,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = tid + 256 * i, row = q >> 4, c = q & 15;
-            *reinterpret_cast<uint4*>(sA + buf * BK * TN_LD + row * TN_LD + c * 8) = ra[i];
-            *reinterpret_cast<uint4*>(sB + buf * BK * TN_LD + row * TN_LD + c * 8) = rb[i];
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + 256 * i, row = q >> 3, c = q & 7;
+            *reinterpret_cast<uint4*>(&sA[buf][row * TN_LD + c * 8]) = ra[i];
+            *reinterpret_cast<uint4*>(&sB[buf][row * TN_LD + c * 8]) = rb[i];
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc, accs;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; accs[r] = 0.0f; }
+    // bias gradient for free: A^T * ones on the matrix pipe (only the tiles of output-column block 0)
+    const bool do_cs = p.colsum != nullptr && (tile % nt2) == 0 && w2 == 0;
+    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
     const int nkt = (int)((me - ms + BK - 1) / BK);
     gload(ms);
@@ -288,39 +300,28 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
     const int grp = lane >> 4;                                  // 16-lane group: columns 16*(grp&1), k half grp>>1
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) gload(ms + (long long)(kt + 1) * BK);
-        const uint16_t* bufA = sA + (kt & 1) * BK * TN_LD;
-        const uint16_t* bufB = sB + (kt & 1) * BK * TN_LD;
+        const uint16_t* bufA = sA[kt & 1];
+        const uint16_t* bufB = sB[kt & 1];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int kbase = 16 * ks + 8 * (grp >> 1);
-            bf16x8 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = tr_frag(bufA, kbase, w1 * 64 + 32 * i + 16 * (grp & 1), lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = tr_frag(bufB, kbase, w2 * 64 + 32 * j + 16 * (grp & 1), lane);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            const bf16x8 fa = tr_frag(bufA, kbase, w1 * 32 + 16 * (grp & 1), lane);
+            const bf16x8 fb = tr_frag(bufB, kbase, w2 * 32 + 16 * (grp & 1), lane);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+            if (do_cs) accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, ones, accs, 0, 0, 0);
         }
         if (kt + 1 < nkt) lstore((kt + 1) & 1);
         __syncthreads();
     }
     // D[n1][n2]: lane owns column n2 = lane&31, rows n1 = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const long long n2 = n2_0 + w2 * 32 + (lane & 31);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const long long n2 = n2_0 + w2 * 64 + 32 * j + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long n1 = n1_0 + w1 * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (n1 < p.N1 && n2 < p.N2) atomicAdd(p.C + n1 * p.ldc + n2, acc[i][j][r]);
-            }
-        }
+    for (int r = 0; r < 16; ++r) {
+        const long long n1 = n1_0 + w1 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (n1 < p.N1 && n2 < p.N2) atomicAdd(p.C + n1 * p.ldc + n2, acc[r]);
+        if (do_cs && (lane & 31) == 0 && n1 < p.N1) atomicAdd(p.colsum + n1, accs[r]);   // every column of A^T*ones
+    }
 }
-
 
 // ---------------------------------------------------------------------------------------------------
 // Weight-stationary NT kernel for the layer shapes of this path (M = batch, huge; N <= a few hundred; K <= 256).
@@ -600,8 +601,8 @@ int dhaug_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t l
     }
 }
 
-int dhaug_gemm_tn_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
-                       int64_t N1, int64_t N2, int accumulate, void* stream) {
+int dhaug_gemm_tn_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,
+                       float* colsum_a, int64_t M, int64_t N1, int64_t N2, int accumulate, void* stream) {
     DHAUG_CHECK(M >= 0 && N1 >= 1 && N2 >= 1, DHAUG_EINVAL);
     DHAUG_CHECK_PTR(C);
     DHAUG_CHECK(ldc >= N2, DHAUG_EINVAL);
@@ -609,6 +610,10 @@ int dhaug_gemm_tn_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
     if (!accumulate) {
         hipError_t e = hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N2 * 4, (size_t)N1, s);
         if (e != hipSuccess) return (int)e;
+        if (colsum_a != nullptr) {
+            e = hipMemsetAsync(colsum_a, 0, (size_t)N1 * 4, s);
+            if (e != hipSuccess) return (int)e;
+        }
     }
     if (M == 0) return DHAUG_OK;
     DHAUG_CHECK_PTR(A); DHAUG_CHECK_PTR(B);
@@ -616,23 +621,16 @@ int dhaug_gemm_tn_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
     DHAUG_CHECK(lda % 8 == 0 && ldb % 8 == 0 && lda >= ((N1 + 7) & ~7LL) && ldb >= ((N2 + 7) & ~7LL), DHAUG_EALIGN);
     DHAUG_CHECK(dhaug_aligned16(A) && dhaug_aligned16(B), DHAUG_EALIGN);
     const long long tiles = ((N1 + TN_BN - 1) / TN_BN) * ((N2 + TN_BN - 1) / TN_BN);
-    long long splits = 512 / tiles;
+    // about two resident workgroups per CU; few splits keep the atomic traffic (splits x N1 x N2 x 4 B) small
+    long long splits = 768 / tiles;                              // three resident workgroups per CU (LDS 49 KB each)
     if (splits < 1) splits = 1;
     long long rows = (M + splits - 1) / splits;
     rows = (rows + BK - 1) / BK * BK;
     if (rows < 4 * BK) rows = 4 * BK;
     splits = (M + rows - 1) / rows;
-    TnArgs p{A, lda, B, ldb, C, ldc, M, N1, N2, rows};
-    {
-        static bool configured = false;
-        if (!configured) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BK * TN_LD * 2);
-            if (e != hipSuccess) return (int)e;
-            configured = true;
-        }
-    }
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(256), (size_t)4 * BK * TN_LD * 2, s, p);
+    if (splits > 8) splits = (splits + 7) / 8 * 8;              // multiple of 8: XCD-local tile groups (empty slices exit)
+    TnArgs p{A, lda, B, ldb, C, ldc, colsum_a, M, N1, N2, rows, tiles, splits};
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, p);
     return dhaug_launch_status();
 }
 

@@ -218,15 +218,15 @@ def gemm_nt(A, B, N, K, bias=None, res_bf16=None, res_f32=None, act=0, slope=0.0
     return cb, cf
 
 
-def gemm_tn(A, B, N1, N2, out=None, accumulate=False, M=None, lda=None, ldb=None):
-    """C[N1,N2] (+)= A[M,N1]^T B[M,N2], bf16 operands, fp32 result."""
+def gemm_tn(A, B, N1, N2, out=None, accumulate=False, M=None, lda=None, ldb=None, colsum=None):
+    """C[N1,N2] (+)= A[M,N1]^T B[M,N2], bf16 operands, fp32 result; colsum (fp32 [N1], optional) (+)= column sums of A."""
     assert A.dtype == BF16 and B.dtype == BF16
     M = A.shape[0] if M is None else M
     if out is None:
         out = torch.empty((N1, N2), dtype=torch.float32, device=A.device)
         accumulate = False
     _lib.call("dhaug_gemm_tn_bf16", _p(A), A.stride(0) if lda is None else lda, _p(B), B.stride(0) if ldb is None else ldb,
-              _p(out), out.stride(0), M, N1, N2, int(accumulate), _stream())
+              _p(out), out.stride(0), _p(colsum), M, N1, N2, int(accumulate), _stream())
     return out
 
 

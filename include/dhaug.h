@@ -165,9 +165,11 @@ int dhaug_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t l
 
 /* Weight-gradient GEMM: C[N1,N2] (+)= A[M,N1]^T * B[M,N2], contraction over the batch dimension M
  * (split across workgroups, fp32 atomics into C).  bf16 operands, fp32 result.  `accumulate` != 0 adds
- * into C, otherwise C is overwritten (zeroed by the library on the stream first). */
+ * into C, otherwise C is overwritten (zeroed by the library on the stream first).  colsum_a (optional, fp32 [N1])
+ * receives the column sums of A over M -- the bias gradient of the same layer -- computed on the matrix pipe as
+ * A^T * ones by the workgroups that already hold the A tiles (same accumulate / overwrite rule as C). */
 int dhaug_gemm_tn_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
-                       float* C, int64_t ldc, int64_t M, int64_t N1, int64_t N2, int accumulate,
+                       float* C, int64_t ldc, float* colsum_a, int64_t M, int64_t N1, int64_t N2, int accumulate,
                        void* stream);
 
 /* fp32 -> bf16 (round-to-nearest-even) with zero padding: src (rows, cols) ld_src -> dst (rows, ld_dst),

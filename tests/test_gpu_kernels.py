@@ -249,6 +249,12 @@ def test_gemm_tn(ops, M, N1, N2):
     assert maxabs(C, ref) <= tol
     C2 = ops.gemm_tn(A, B, N1, N2, out=C.clone(), accumulate=True)
     assert maxabs(C2, 2 * ref) <= 2 * tol
+    # bias gradient from the same launch: column sums of A
+    cs = torch.empty(N1, device="cuda")
+    C3 = ops.gemm_tn(A, B, N1, N2, colsum=cs)
+    assert maxabs(C3, ref) <= tol
+    csref = A[:, :N1].float().cpu().double().sum(0)
+    assert maxabs(cs, csref) <= 1e-4 * max(1.0, csref.abs().max().item()) + 1e-3
 
 
 def test_pack_kernels(ops):
