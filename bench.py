@@ -69,7 +69,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")          # RCCL on ROCm
+        # "nccl" = RCCL over xGMI on ROCm.  DHAUG_DIST_BACKEND=gloo lets the multi-rank path be rehearsed with all
+        # ranks on one GPU (RCCL refuses duplicate devices).
+        dist.init_process_group(os.environ.get("DHAUG_DIST_BACKEND", "nccl"))
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

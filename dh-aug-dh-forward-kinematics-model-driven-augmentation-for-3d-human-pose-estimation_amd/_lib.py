@@ -20,6 +20,8 @@ SIGNATURES = {
     "dhaug_world_to_camera_project": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "dhaug_world_to_camera_project_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "dhaug_camera_to_world": [_vp, _vp, _vp, _vp, _i64, _vp],
+    "dhaug_bone_length_swap": [_vp, _vp, _vp, _i64, _vp],
+    "dhaug_project_to_2d": [_vp, _vp, _vp, _i64, _vp],
     "dhaug_center_flip": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "dhaug_center_flip_backward": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "dhaug_gemm_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i32,

@@ -49,21 +49,30 @@ class _Packed:
         self.nn3 = None
 
 
-_CACHE = {}
+# Bumped by every optimizer step (the fused Adam kernel writes the masters through raw pointers, which torch's
+# version counter does not see); every packed copy made under an older epoch is stale.
+WEIGHT_EPOCH = 0
+
+
+def bump_weight_epoch():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
 
 
 def _pack(W):
-    """cache entry for a weight-like fp32 (N,K) tensor; cached only for leaf parameters."""
-    cacheable = isinstance(W, torch.nn.Parameter)
-    key = (W.data_ptr(), W._version, tuple(W.shape))
-    if cacheable:
-        ent = _CACHE.get(id(W))
+    """cache entry for a weight-like fp32 (N,K) tensor.  The entry lives ON the parameter object (an id()-keyed dict
+    would alias a freed parameter whose id / address get reused), and is valid for one (storage, version, epoch)."""
+    key = (W.data_ptr(), W._version, tuple(W.shape), WEIGHT_EPOCH)
+    if isinstance(W, torch.nn.Parameter):
+        ent = getattr(W, "_dhaug_pack", None)
         if ent is not None and ent.key == key:
             return ent
+        ent = _Packed()
+        ent.key = key
+        W._dhaug_pack = ent
+        return ent
     ent = _Packed()
     ent.key = key
-    if cacheable:
-        _CACHE[id(W)] = ent
     return ent
 
 
@@ -93,7 +102,7 @@ def _w_nn(W, prec):
 
 
 def clear_weight_cache():
-    _CACHE.clear()
+    bump_weight_epoch()
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -297,6 +297,58 @@ __global__ __launch_bounds__(256) void center_flip_kernel(const float* __restric
     }
 }
 
+// PoseAug bone order (R/utils/gan_utils.py:90-120): bone k = joint[P] - joint[C]
+constexpr int kPaP[15] = {0, 1, 2, 0, 4, 5, 0, 7, 8, 8, 10, 11, 8, 13, 14};
+constexpr int kPaC[15] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+
+// random_bl_aug (R/function_aug/dataloader_update.py:18-40): keep every bone's direction, replace its length by
+// new_len[k], rebuild the pose from the root down (get_pose3dbyBoneVec), add the root back.
+__global__ __launch_bounds__(TILE) void bone_swap_kernel(const float* __restrict__ pose, const float* __restrict__ new_len,
+                                                         float* __restrict__ out, long long N) {
+    __shared__ float lp[TILE * PS];
+    __shared__ float ll[TILE * 15];
+    const int lane = threadIdx.x;
+    const long long ntiles = (N + TILE - 1) / TILE;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long base = tile * TILE;
+        const int rows = (int)((N - base) < TILE ? (N - base) : TILE);
+        rows_in<48, PS>(pose + base * 48, lp, rows, lane);
+        rows_in<15, 15>(new_len + base * 15, ll, rows, lane);
+        __syncthreads();
+        const int row = lane < rows ? lane : 0;
+        V3 p[16], o[16];
+        load_joints(lp, row, p);
+        o[0] = p[0];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) {                       // parents always precede children in this order
+            const V3 b = p[kPaP[k]] - p[kPaC[k]];
+            const float s = ll[row * 15 + k] / sqrtf(dot(b, b));
+            o[kPaC[k]] = o[kPaP[k]] - s * b;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { lp[lane * PS + 3 * j] = o[j].x; lp[lane * PS + 3 * j + 1] = o[j].y; lp[lane * PS + 3 * j + 2] = o[j].z; }
+        __syncthreads();
+        rows_out<48, PS>(lp, out + base * 48, rows, lane);
+        __syncthreads();
+    }
+}
+
+// project_to_2d with per-sample intrinsics (N,9) on camera-space poses (R/common/camera.py:62-94)
+__global__ __launch_bounds__(256) void project_batch_kernel(const float* __restrict__ cam3d, const float* __restrict__ cam9,
+                                                            float* __restrict__ proj2d, long long njoints) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < njoints; i += (long long)gridDim.x * 256) {
+        const float* c = cam9 + (i >> 4) * 9;
+        const float x = cam3d[3 * i], y = cam3d[3 * i + 1], z = cam3d[3 * i + 2];
+        const float u = fminf(fmaxf(x / z, -1.0f), 1.0f), v = fminf(fmaxf(y / z, -1.0f), 1.0f);
+        const float r2 = u * u + v * v;
+        const float radial = 1.0f + (c[4] * r2 + c[5] * (r2 * r2) + c[6] * (r2 * r2 * r2));
+        const float tan = c[7] * u + c[8] * v;
+        proj2d[2 * i] = c[0] * (u * (radial + tan) + c[7] * r2) + c[2];
+        proj2d[2 * i + 1] = c[1] * (v * (radial + tan) + c[8] * r2) + c[3];
+    }
+}
+
 Cam make_cam(const float* q, const float* t, const float* c9) {
     Cam c;
     for (int i = 0; i < 4; ++i) c.q[i] = q[i];
@@ -378,6 +430,24 @@ int dhaug_world_to_camera_project_backward(const float* pose16, const float* qua
     DHAUG_CHECK(grad_proj2d == nullptr || cam9 != nullptr, DHAUG_EINVAL);
     hipLaunchKernelGGL(w2c_project_bwd_kernel, dim3(grid1d(N * 16, 256)), dim3(256), 0, (hipStream_t)stream, pose16,
                        make_cam(quat, trans, cam9), grad_cam3d, grad_proj2d, grad_pose16, (long long)N * 16);
+    return dhaug_launch_status();
+}
+
+int dhaug_bone_length_swap(const float* pose16, const float* new_len, float* out, int64_t N, void* stream) {
+    DHAUG_CHECK(N >= 0, DHAUG_EINVAL);
+    if (N == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(pose16); DHAUG_CHECK_PTR(new_len); DHAUG_CHECK_PTR(out);
+    hipLaunchKernelGGL(bone_swap_kernel, dim3(grid1d((N + TILE - 1) / TILE, 1)), dim3(TILE), 0, (hipStream_t)stream, pose16,
+                       new_len, out, (long long)N);
+    return dhaug_launch_status();
+}
+
+int dhaug_project_to_2d(const float* cam3d, const float* cam9, float* proj2d, int64_t N, void* stream) {
+    DHAUG_CHECK(N >= 0, DHAUG_EINVAL);
+    if (N == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(cam3d); DHAUG_CHECK_PTR(cam9); DHAUG_CHECK_PTR(proj2d);
+    hipLaunchKernelGGL(project_batch_kernel, dim3(grid1d(N * 16, 256)), dim3(256), 0, (hipStream_t)stream, cam3d, cam9, proj2d,
+                       (long long)N * 16);
     return dhaug_launch_status();
 }
 

@@ -70,7 +70,8 @@ class FusedNet:
         self.module, self.build, self.key, self.layers = module, build, None, None
 
     def _fresh(self):
-        key = tuple((p.data_ptr(), p._version) for p in self.module.parameters())
+        from . import autograd_ops as A
+        key = (A.WEIGHT_EPOCH,) + tuple((p.data_ptr(), p._version) for p in self.module.parameters())
         if key != self.key:
             self.layers = {name: _Layer(lin, splits) for name, lin, splits in self.build["layers"](self.module)}
             self.key = key

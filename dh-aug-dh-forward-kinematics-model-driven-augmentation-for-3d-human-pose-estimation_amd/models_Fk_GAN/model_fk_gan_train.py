@@ -66,6 +66,27 @@ def video_mode_my_get_poseFk_model(args, dataset, FK_DH_Class, video_frame_num):
     }
 
 
+def traditional_solutions_FK_generator(args, FK_DH_Class, data_dict, train_subjects):
+    """'normal' (non-GAN) augmentation, R/models_Fk_GAN/model_fk_gan_train.py:37-93: sample
+    args.generator_whole_number poses with the FK model's handler_but_generater and view them through the 4 cameras
+    of every training subject; the pairs become data_dict['train_fake2d3d_loader'] (device-resident)."""
+    device = _device()
+    pos32, _, _, _, _ = FK_DH_Class.handler_but_generater()
+    from ..common.h36m_dataset import H36M_32_To_16_Table
+    world16 = torch.as_tensor(pos32[:, H36M_32_To_16_Table, :], device=device)
+    buf = FakePairBuffer(args.batch_size)
+    for subject in train_subjects:
+        for cam_id in range(4):
+            ext = h36m_cameras_extrinsic_params[subject][cam_id]
+            quat = [float(v) for v in ext['orientation']]
+            trans = [float(v) / 1000.0 for v in ext['translation']]
+            cam9 = cam.camera_params9(h36m_cameras_intrinsic_params[cam_id])
+            c3, p2 = ops.world_to_camera_project(world16, quat, trans, cam9)
+            buf.append(c3, p2, [0.0] * 9)            # the reference stores a dummy camera column here (:80-84)
+    data_dict['train_fake2d3d_loader'] = buf
+    return
+
+
 class MeanFn(torch.autograd.Function):
     """mean of the (M,1) logits through the column-sum kernel."""
 

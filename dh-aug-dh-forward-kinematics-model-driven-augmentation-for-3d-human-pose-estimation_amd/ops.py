@@ -154,6 +154,24 @@ def camera_to_world(cam3d, quat, trans):
     return out
 
 
+def bone_length_swap(pose16, new_len):
+    x = _dev(pose16, torch.float32, "bone_length_swap").reshape(-1, 48)
+    l = _dev(new_len, torch.float32, "bone_length_swap").reshape(-1, 15)
+    assert l.shape[0] == x.shape[0]
+    out = torch.empty((x.shape[0], 16, 3), dtype=torch.float32, device=x.device)
+    _lib.call("dhaug_bone_length_swap", _p(x), _p(l), _p(out), x.shape[0], _stream())
+    return out
+
+
+def project_to_2d(cam3d, cam9):
+    x = _dev(cam3d, torch.float32, "project_to_2d").reshape(-1, 48)
+    c = _dev(cam9, torch.float32, "project_to_2d")[:, :9].contiguous()
+    assert c.shape[0] == x.shape[0]
+    out = torch.empty((x.shape[0], 16, 2), dtype=torch.float32, device=x.device)
+    _lib.call("dhaug_project_to_2d", _p(x), _p(c), _p(out), x.shape[0], _stream())
+    return out
+
+
 def center_flip(x, center, flip, adjoint=False):
     C = x.shape[-1]
     v = _dev(x, torch.float32, "center_flip").reshape(-1, 16 * C)

@@ -79,6 +79,5 @@ class FusedAdam(torch.optim.Optimizer):
                           tuple(g["betas"]), g["eps"], 1.0 / ws)
         else:
             raise RuntimeError("FusedAdam needs GPU parameters (no CPU fallback exists)")
-        for p in self._params:                 # the bf16 operand copies of these weights are now stale
-            A._CACHE.pop(id(p), None)
+        A.bump_weight_epoch()                  # every packed bf16 copy of a weight is now stale
         return None

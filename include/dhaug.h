@@ -132,6 +132,15 @@ int dhaug_world_to_camera_project_backward(const float* pose16, const float* qua
 int dhaug_camera_to_world(const float* cam3d, const float* quat, const float* trans, float* world,
                           int64_t N, void* stream);
 
+/* Real-data side of the augmentation API ("next" row N3).
+ * dhaug_bone_length_swap: random_bl_aug of R/function_aug/dataloader_update.py:18-40 -- every bone keeps its direction
+ * and takes the length new_len[k] (N,15 in PoseAug bone order: (0,1)(1,2)(2,3)(0,4)(4,5)(5,6)(0,7)(7,8)(8,9)(8,10)
+ * (10,11)(11,12)(8,13)(13,14)(14,15), R/utils/gan_utils.py:90-138); the pose is rebuilt from the root down.
+ * dhaug_project_to_2d: project_to_2d (R/common/camera.py:62-94) of camera-space poses with per-sample intrinsics
+ * cam9 (N,9) on the device, as called at dataloader_update.py:69. */
+int dhaug_bone_length_swap(const float* pose16, const float* new_len, float* out, int64_t N, void* stream);
+int dhaug_project_to_2d(const float* cam3d, const float* cam9, float* proj2d, int64_t N, void* stream);
+
 /* Root-centre and/or left/right flip of (N,16,C) poses, C in {2,3}:
  * x - x[:, :1] (R/models_Fk_GAN/model_fk_gan_train.py:295,312) and the flip of :320-331
  * (negate coordinate 0, swap joints [4,5,6,10,11,12] <-> [1,2,3,13,14,15]). */

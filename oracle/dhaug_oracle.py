@@ -497,3 +497,24 @@ def flip_lr(x):
     y[:, :, 0] *= -1
     y[:, FLIP_LEFT + FLIP_RIGHT, :] = y[:, FLIP_RIGHT + FLIP_LEFT, :]
     return y
+
+
+# ----------------------------------------------------------------------------------------------
+# "next" row N3: bone-length swap of real poses (PoseAug bone algebra)
+# ----------------------------------------------------------------------------------------------
+PA_PARENT = [0, 1, 2, 0, 4, 5, 0, 7, 8, 8, 10, 11, 8, 13, 14]
+PA_CHILD = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]
+
+
+def random_bl_aug(x, new_len):
+    """x (N,16,3), new_len (N,15) PoseAug bone order -> (N,16,3).  R/function_aug/dataloader_update.py:18-40 with the
+    bone algebra of R/utils/gan_utils.py:56-138 (bone = parent - child, pose rebuilt as minus the path sums)."""
+    root = x[:, :1, :] * 1.0
+    x = x - x[:, :1, :]
+    b = x[:, PA_PARENT] - x[:, PA_CHILD]
+    unit = b / torch.norm(b, dim=2, keepdim=True)
+    nb = unit * new_len.unsqueeze(2)
+    out = [torch.zeros_like(x[:, 0])] * 16
+    for k in range(15):
+        out[PA_CHILD[k]] = out[PA_PARENT[k]] - nb[:, k]
+    return torch.stack(out, dim=1) + root

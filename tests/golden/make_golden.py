@@ -217,6 +217,35 @@ def main():
         save("critic_step_%s_D32" % tag, real=xr, fake=xf, alpha=alpha, gp=gp.detach(), Wasserstein_D=W.detach(),
              D_cost=C.detach(), weight_seed=np.array(600 + len(tag)), **gp_grads, **grads, **newp)
 
+    # ---- N4: 'normal'-mode sampler handler_but_generater on a synthetic two-subject data set -----------------
+    rs = np.random.RandomState(3)
+    ds_pos = {s: {a: {c: (rs.standard_normal((20 + 5 * i, 16, 3)) * 0.3 + np.array([0.1 * i, 0.2, 0.9])).astype(np.float32)
+                      for c in range(2)} for i, a in enumerate(("Walk", "Sit"))} for s in ("S1", "S5")}
+    args_n = RI.make_args(batch_size=4, generator_whole_number=48, generator_choose_BoneLen=True,
+                          generator_choose_root_pos=True, generator_global_rot=True, random_seed=11)
+    fkn = fkm.Forward_Kinematics_DH_Model(args_n, ["S1", "S5"], None)
+    fkn.dataSet_world_3d_pos = ds_pos
+    fkn.dataSet_2d_pos = {s: {a: {c: np.zeros((v.shape[0], 16, 2), np.float32) for c, v in cams.items()}
+                              for a, cams in acts.items()} for s, acts in ds_pos.items()}
+    pos, ang, grot, blen, roots = fkn.handler_but_generater()
+    flat = {"%s|%s|%d" % (s, a, c): v for s, acts in ds_pos.items() for a, cams in acts.items() for c, v in cams.items()}
+    save("normal_sampler_48", pos=pos, angles=np.asarray(ang), global_rot=np.asarray(grot), bone_len=np.asarray(blen),
+         root=np.asarray(roots), **{("ds__" + k): v for k, v in flat.items()})
+
+    # ---- N3: random_bl_aug (bone-length swap) + per-sample projection ------------------------------------------
+    import importlib
+    os.chdir(RI.REF_ROOT)                      # random_bl_aug loads ./data_extra/... relative to the reference root
+    du = importlib.import_module("function_aug.dataloader_update")
+    xs = synth_pose16(96, seed=41) + torch.tensor([0.2, -0.1, 4.0])
+    np.random.seed(77)
+    idx = np.random.choice(5, 96)
+    np.random.seed(77)
+    swapped = du.random_bl_aug(xs.clone())
+    os.chdir(HERE)
+    camp = torch.tensor(np.random.RandomState(5).uniform(-0.1, 0.1, (96, 9)), dtype=torch.float32)
+    camp[:, :2] += 2.2
+    save("bl_aug_96", x=xs, idx=idx, out=swapped, cam=camp, proj=M["camera"].project_to_2d(swapped, camp))
+
     # ---- N1: camera / projection / flip ("next" row, pinned with the same recipe) ----------------
     cam = M["camera"]
     h36m = M["h36m"]

@@ -298,3 +298,16 @@ def test_colsum_actbwd_adam(ops):
         opt.step()
         ops.adam_step(pg, gr.cuda(), m, v, step)
     assert maxabs(pg, pr.detach()) <= 2e-7
+
+
+def test_random_bl_aug_golden(ops, golden):
+    """next row N3: bone-length swap + per-sample projection against the reference's own output"""
+    from dhaug_amd.function_aug.dataloader_update import random_bl_aug, BL_TEMPLATES
+    g = golden("bl_aug_96")
+    out = random_bl_aug(dev(g["x"]), template_idx=g["idx"].numpy())
+    assert maxabs(out, g["out"]) <= 1e-5
+    assert maxabs(ops.project_to_2d(dev(g["out"]), dev(g["cam"])), g["proj"]) <= 2e-6
+    # the swapped pose has exactly the template's lengths (PoseAug bone order)
+    P, C = O.PA_PARENT, O.PA_CHILD
+    L = (out[:, P] - out[:, C]).norm(dim=2).cpu()
+    assert maxabs(L, torch.tensor(BL_TEMPLATES)[g["idx"].long()]) <= 2e-6

@@ -383,3 +383,26 @@ def test_video_epoch_loop(M, golden):
         assert all(torch.isfinite(p).all().item() for p in d[k].parameters()), k
     p3, p2, c = data["train_fake2d3d_loader"].tensors()
     assert p3.shape == (5 * B, R, 16, 3) and p2.shape == (5 * B, R, 16, 2)
+
+
+def test_normal_mode_sampler_golden(M, golden):
+    """handler_but_generater ('normal' augmentation mode, next row N4): same numpy RNG stream as the reference -> same
+    angles / lengths / roots, and the 48 poses from ONE FK launch match the reference's 48 numpy FK evaluations."""
+    import numpy as np
+    g = golden("normal_sampler_48")
+    ds = {}
+    for k, v in g.items():
+        if k.startswith("ds__"):
+            s, a, c = k[4:].split("|")
+            ds.setdefault(s, {}).setdefault(a, {})[int(c)] = v.numpy()
+    args = make_args(batch_size=4, generator_whole_number=48, generator_choose_BoneLen=True, generator_choose_root_pos=True,
+                     generator_global_rot=True, random_seed=11)
+    fk = M.fkm.Forward_Kinematics_DH_Model(args, ["S1", "S5"], None)
+    fk.dataSet_world_3d_pos = ds
+    fk.dataSet_2d_pos = None
+    pos, ang, grot, blen, roots = fk.handler_but_generater()
+    assert np.abs(np.asarray(ang) - g["angles"].numpy()).max() == 0.0
+    assert np.abs(np.asarray(grot) - g["global_rot"].numpy()).max() == 0.0
+    assert np.abs(np.asarray(blen) - g["bone_len"].numpy()).max() <= 1e-6
+    assert np.abs(np.asarray(roots) - g["root"].numpy()).max() == 0.0
+    assert pos.shape == (48, 32, 3) and np.abs(pos - g["pos"].numpy()).max() <= 1e-5
