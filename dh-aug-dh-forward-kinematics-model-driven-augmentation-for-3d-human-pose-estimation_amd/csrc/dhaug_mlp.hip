@@ -3,9 +3,9 @@
 // Layer-by-layer execution of these 256-wide stacks is HBM/latency bound (AI ~ 128 FLOP/B per layer); fused, the
 // compulsory traffic is the network input and its logits/head only and the stack becomes MFMA-bound.
 //
-// Structure (256 threads = 4 waves; TWO workgroups per CU, each persistent over its own 64-row batch tiles -- the two
-// run out of phase, so one's epilogue VALU work overlaps the other's MFMAs on the same SIMDs):
-//   * activations: bf16 tiles [64 rows][256] in LDS (two 32 KB buffers + one 16 KB [64][128] buffer), 16-byte
+// Structure (256 threads = 4 waves = one wave per SIMD with the 512-register budget; one persistent workgroup per CU
+// walking 128-row batch tiles):
+//   * activations: bf16 tiles [128 rows][256] in LDS (two 64 KB buffers + one 32 KB [128][128] buffer), 16-byte
 //     chunks XOR-swizzled by (row & 15) -> conflict-free ds_read_b128 of MFMA B-operand fragments;
 //   * weights: pre-packed on the host side in MFMA A-operand fragment order (dhaug_pack_wfrag): for every
 //     32-feature slice and 16-wide k-step one contiguous 1 KB block = 64 lanes x 16 B, so a wave's weight load is
@@ -19,6 +19,7 @@
 //     (dst == res) are safe: a lane reads and writes only its own elements.
 //   * the network is a short "program" of units (load / gemm / store) passed by value; all control flow is
 //     workgroup-uniform.
+#include <cstdlib>
 #include "dhaug_common.h"
 
 namespace {
@@ -28,16 +29,16 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int MLP_BM = 64;                                            // batch rows per tile
+constexpr int MLP_BM = 128;                                           // batch rows per tile
 constexpr int MLP_MT = MLP_BM / 32;                                   // 32-row MFMA tiles per batch tile
 constexpr int MLP_THREADS = 256;
 constexpr int MLP_NS = 2;                                             // feature slices (of 32) per wave: w and w + 4
 constexpr int MLP_MAX_UNITS = 32;
 constexpr int MLP_MAX_KSTEPS = 16;
 constexpr int BUF01_PITCH = 256, BUF2_PITCH = 128;                  // elements
-constexpr int BUF01_BYTES = MLP_BM * BUF01_PITCH * 2;               // 32 768
-constexpr int BUF2_BYTES = MLP_BM * BUF2_PITCH * 2;                 // 16 384
-constexpr int MLP_LDS_BYTES = 2 * BUF01_BYTES + BUF2_BYTES;         // 81 920: two workgroups per CU
+constexpr int BUF01_BYTES = MLP_BM * BUF01_PITCH * 2;               // 65 536
+constexpr int BUF2_BYTES = MLP_BM * BUF2_PITCH * 2;                 // 32 768
+constexpr int MLP_LDS_BYTES = 2 * BUF01_BYTES + BUF2_BYTES;         // 163 840: all of the CU's LDS
 
 enum { U_LOAD_F32 = 0, U_LOAD_BF16 = 1, U_STORE_BF16 = 2, U_GEMM = 3 };
 enum { F_OUT_F32 = 4 };
@@ -58,6 +59,7 @@ struct Unit {
 
 struct Program {
     int nunits;
+    int min_run;                                                             // shortest run of 256 -> 256 layers taken by gemm_stack
     Unit u[MLP_MAX_UNITS];
 };
 
@@ -83,7 +85,6 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {          // 
 
 constexpr int MLP_CH = 4;                                            // k-steps per ring slot (64 k)
 constexpr int OUT_PITCH = 68;                                        // floats per row of the fp32 output staging image
-typedef bf16x8 WRing[3][MLP_NS][MLP_CH];
 typedef const Unit __attribute__((address_space(4))) * UnitPtr;      // units are read from the kernarg segment (s_load)
 
 // K is processed in chunks of 64 (4 k-steps); sources narrower than a multiple of 64 are zero-filled by their
@@ -93,15 +94,15 @@ typedef const Unit __attribute__((address_space(4))) * UnitPtr;      // units ar
 __device__ __forceinline__ int chunks_of(int ksteps) { return (ksteps + MLP_CH - 1) / MLP_CH; }
 
 // issue the global loads of chunk C (of the concatenated sources; the first source has NCH1 chunks) into a ring slot
-template <int C, int NCH, int NCH1>
+template <int C, int NCH, int NCH1, int NS>
 __device__ __forceinline__ void load_chunk(const uint16_t* w1, const uint16_t* w2, int wave, int lane,
-                                           bf16x8 (&slot)[MLP_NS][MLP_CH]) {
+                                           bf16x8 (&slot)[NS][MLP_CH]) {
     constexpr bool second = C >= NCH1;
     constexpr int kpad = (second ? NCH - NCH1 : NCH1) * MLP_CH;              // padded k-steps of this source's blob
     constexpr int k0 = (second ? C - NCH1 : C) * MLP_CH;
     const uint16_t* w = second ? w2 : w1;
 #pragma unroll
-    for (int t = 0; t < MLP_NS; ++t) {
+    for (int t = 0; t < NS; ++t) {
         const uint16_t* base = w + ((long long)(wave + 4 * t) * kpad * 64 + lane) * 8 + (long long)k0 * 512;
 #pragma unroll
         for (int q = 0; q < MLP_CH; ++q) slot[t][q] = *reinterpret_cast<const bf16x8*>(base + q * 512);
@@ -115,15 +116,22 @@ __device__ __forceinline__ void load_chunk(const uint16_t* w1, const uint16_t* w
 // and then waits for the youngest load (vmcnt(0..2)) at every step:
 //   k-step k :  [4 ds_read_b128 of the activation fragments of k+1]  [8 global loads of chunk c+2, once per chunk]
 //               -- sched_barrier --   8 MFMAs (2 slices x 4 row tiles) on the fragments read during step k-1
-template <int NCH, int NCH1>
-__device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int wave, int lane) {
+// NS = feature slices this wave really owns in this layer (2: slices wave and wave+4; 1: only slice wave -- layers
+// narrower than 160 features); waves with no slice skip the layer.
+// `ring` belongs to the caller: with PRELOADED the first two chunks are already in flight in ring[0], ring[1];
+// `nxt` (may be null) is a following layer of the SAME shape whose first two chunks are requested right after the
+// last MFMA has issued, i.e. before this layer's epilogue and barrier (gemm_stack).
+template <int NCH, int NCH1, int NS, bool PRELOADED>
+__device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int wave, int lane, bf16x8 (&ring)[3][NS][MLP_CH],
+                                           UnitPtr nxt) {
     const int r31 = lane & 31, h = lane >> 5;
     const uint16_t* w1 = u->w;
     const uint16_t* w2 = NCH1 < NCH ? u->w2 : u->w;
-    WRing ring;
-    load_chunk<0, NCH, NCH1>(w1, w2, wave, lane, ring[0]);
-    if constexpr (NCH > 1) load_chunk<1, NCH, NCH1>(w1, w2, wave, lane, ring[1]);
-    f32x16 acc[MLP_NS][MLP_MT];
+    if constexpr (!PRELOADED) {
+        load_chunk<0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[0]);
+        if constexpr (NCH > 1) load_chunk<1, NCH, NCH1, NS>(w1, w2, wave, lane, ring[1]);
+    }
+    f32x16 acc[NS][MLP_MT];
     const unsigned char* src1 = buf_base(smem, u->src);
     const int pbs1 = buf_pitch_bytes(u->src);
     const unsigned char* src2 = NCH1 < NCH ? buf_base(smem, u->src2) : src1;
@@ -147,22 +155,28 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
         if (k + 1 < KT) read_frags(k + 1, fx[(k + 1) & 1]);
         if (q == 0) {
             if (c + 2 < NCH) {
-                if (c + 2 == 2) load_chunk<2 < NCH ? 2 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[2]);
-                if (c + 2 == 3) load_chunk<3 < NCH ? 3 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[0]);
-                if (c + 2 == 4) load_chunk<4 < NCH ? 4 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[1]);
-                if (c + 2 == 5) load_chunk<5 < NCH ? 5 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[2]);
-                if (c + 2 == 6) load_chunk<6 < NCH ? 6 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[0]);
-                if (c + 2 == 7) load_chunk<7 < NCH ? 7 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[1]);
+                if (c + 2 == 2) load_chunk<2 < NCH ? 2 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[2]);
+                if (c + 2 == 3) load_chunk<3 < NCH ? 3 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[0]);
+                if (c + 2 == 4) load_chunk<4 < NCH ? 4 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[1]);
+                if (c + 2 == 5) load_chunk<5 < NCH ? 5 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[2]);
+                if (c + 2 == 6) load_chunk<6 < NCH ? 6 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[0]);
+                if (c + 2 == 7) load_chunk<7 < NCH ? 7 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[1]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < MLP_MT; ++mt)
 #pragma unroll
-            for (int t = 0; t < MLP_NS; ++t)
+            for (int t = 0; t < NS; ++t)
                 acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[c % 3][t][q], fx[k & 1][mt], k == 0 ? zero : acc[t][mt],
                                                                     0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nxt != nullptr) {                                       // the ring is dead: every MFMA of this layer has issued
+        const uint16_t* n1 = nxt->w;
+        const uint16_t* n2 = NCH1 < NCH ? nxt->w2 : nxt->w;
+        load_chunk<0, NCH, NCH1, NS>(n1, n2, wave, lane, ring[0]);
+        if constexpr (NCH > 1) load_chunk<1, NCH, NCH1, NS>(n1, n2, wave, lane, ring[1]);
     }
 
     const int nslices = (u->N + 31) >> 5;
@@ -175,7 +189,7 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
     const float neg = act_neg(u->act, u->slope);
     // epilogue: this lane owns row (32 mt + r31), features 32*slice + 8g + 4h .. +3
 #pragma unroll
-    for (int t = 0; t < MLP_NS; ++t) {
+    for (int t = 0; t < NS; ++t) {
         const int slice = wave + 4 * t;
         if (slice >= nslices) continue;                        // wave-uniform: slices beyond N are never stored
         f32x4 bias[4];
@@ -233,35 +247,256 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
     }
 }
 
-// fp32 staging image of the last layer -> global (M, ld), columns [0, N)
-__device__ __forceinline__ void store_output(UnitPtr u, unsigned char* smem, long long m0, long long M, int tid) {
-    const float* st = reinterpret_cast<const float*>(buf_base(smem, u->dst));
-    float* out = static_cast<float*>(const_cast<void*>(u->g));
-    const int N = u->N, total = MLP_BM * N;
-    const long long ld = u->ld;
-    for (int e = tid; e < total; e += MLP_THREADS) {
-        const int row = e / N, n = e - row * N;
-        if (m0 + row < M) out[(m0 + row) * ld + n] = st[row * OUT_PITCH + n];
+template <int NCH, int NCH1, int NS>
+__device__ __forceinline__ void gemm_single(UnitPtr u, unsigned char* smem, int wave, int lane) {
+    bf16x8 ring[3][NS][MLP_CH];
+    gemm_layer<NCH, NCH1, NS, false>(u, smem, wave, lane, ring, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Runs of consecutive full-width 256 -> 256 layers (the residual stacks: 6 of the generator's 8 layers, 12 of the 3D
+// critic's 17).  At K = 256 the epilogue (bias, residual, activation, bf16 pack: ~5 VALU per element) costs about as
+// many issue cycles as the layer's MFMAs, so it has to run BESIDE them:
+//   * a wave holds the layer's complete weight fragments for its two feature slices in registers (128 VGPRs) and the
+//     NEXT layer's are loaded into a second set while this layer computes (512-register budget, one wave per SIMD);
+//   * the four 32-row tiles are processed one after the other; the epilogue of tile mt-1 sits in the same basic block
+//     as the 32 MFMAs of tile mt, so the scheduler interleaves ~5 VALU per MFMA gap (separate pipes); only the last
+//     tile's epilogue is exposed.
+// ---------------------------------------------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, which would expose the latency
+// of the weight fragments a wave has in flight for the next layer.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+#ifdef DHAUG_MLP_TIMING
+#ifndef DHAUG_STAMP_TID
+#define DHAUG_STAMP_TID 0
+#endif
+// development aid (not built by default): shader-clock stamps of workgroup 0 at every unit boundary of its first tile
+__device__ long long g_mlp_stamps[MLP_MAX_UNITS + 64];
+#define DHAUG_STAMP(idx)                                                      \
+    if (blockIdx.x == 0 && tid == 0 && tile == 0) g_mlp_stamps[idx] = (long long)__builtin_readcyclecounter();
+#define DHAUG_LSTAMP(idx) \
+    if (blockIdx.x == 0 && threadIdx.x == DHAUG_STAMP_TID) g_mlp_stamps[idx] = (long long)__builtin_readcyclecounter();
+#else
+#define DHAUG_STAMP(idx)
+#define DHAUG_LSTAMP(idx)
+#endif
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef bf16x8 WFull[MLP_NS][MLP_MAX_KSTEPS];
+
+// what a stack layer needs from its unit, fetched (scalar loads) one layer ahead so that no layer starts by waiting
+// on the constant cache
+struct StackDesc {
+    int src, dst, res, act;
+    float slope;
+    const float* bias;
+    const uint16_t* w;
+};
+__device__ __forceinline__ StackDesc stack_desc(UnitPtr u) {
+    StackDesc d;
+    d.src = u->src; d.dst = u->dst; d.res = u->res; d.act = u->act; d.slope = u->slope; d.bias = u->bias; d.w = u->w;
+    return d;
+}
+
+// per-lane base pointers of a layer's fragments: [t][half] points at k-step 4 / 12 of slice wave + 4t, so that every
+// fragment is base + a 13-bit signed immediate ((k - 4) * 1024 bytes)
+struct WBase {
+    const uint16_t* p[MLP_NS][2];
+    __device__ __forceinline__ WBase(const uint16_t* w, int wave, int lane) {
+#pragma unroll
+        for (int t = 0; t < MLP_NS; ++t)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) p[t][hh] = w + ((long long)((wave + 4 * t) * MLP_MAX_KSTEPS + 4 + 8 * hh) * 64 + lane) * 8;
+    }
+    __device__ __forceinline__ bf16x8 frag(int t, int k) const {
+        return *reinterpret_cast<const bf16x8*>(p[t][k >> 3] + ((k & 7) - 4) * 512);
+    }
+};
+
+__device__ __forceinline__ void load_seed(const float* bias, int wave, int lane, f32x16 (&seed)[MLP_NS]) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < MLP_NS; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 32 * (wave + 4 * t) + 4 * h + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) seed[t][4 * g + e] = b4[e];
+        }
+}
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// One layer of a stack.  On entry `w`/`seed` hold this layer's weight fragments and bias; on exit those of layer
+// `nd` (the layer itself again for the last one): each fragment is re-requested right behind its last use in the
+// layer's last tile, so the next layer's weights arrive during that tile and the drain, with no second register set.
+// All images of a stack are the 512-byte-pitch buffers 0/1, so every LDS address is (per-lane constant) ^ (compile-
+// time constant) + immediate.
+// The wave has ONE issue port and a 32-cycle MFMA gap holds only ~6 VALU slots, fewer beside LDS instructions
+// (tools/ubench/mfma_gap.hip), so everything that can ride the matrix pipe does: the bias seeds the accumulators and
+// the residual is added by two extra k-steps against identity fragments (exact: 1.0 * bf16 in fp32).  What is left of
+// the epilogue -- bf16 pack, ReLU on the packed pair (v_pk_max_i16 against 0: a negative bf16 is a negative int16;
+// against INT16_MIN it is the identity), one ds_write_b64 per 4 elements -- is dealt out behind the MFMAs of the NEXT
+// tile and pinned there (sched_barrier).  LEAKY stacks (the 2D critic) pay mul + max per element instead.
+// One body per stack: a second instantiation inside the layer loop would make the register allocator shuffle the
+// 128 weight registers between the bodies' assignments at every layer boundary.
+template <bool LEAKY>
+__device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc& nd, unsigned char* smem, int wave, int lane,
+                                            WFull& w, f32x16 (&seed)[MLP_NS], const bf16x8 (&idf)[2], int dbg) {
+    DHAUG_LSTAMP(dbg)
+    constexpr int STEPS = MLP_NS * MLP_MAX_KSTEPS;                          // 32 weight MFMAs and 32 accumulator elements per tile
+    constexpr int TILE_BYTES = 32 * BUF01_PITCH * 2;                         // 16 384
+    const int r31 = lane & 31, h = lane >> 5, x = lane & 15;
+    f32x16 nseed[MLP_NS];
+    load_seed(nd.bias, wave, lane, nseed);
+    const WBase nb(nd.w, wave, lane);
+    const unsigned char* src = buf_base(smem, d.src);
+    unsigned char* dst = buf_base(smem, d.dst);
+    const bool has_res = d.res >= 0;
+    const unsigned char* res = buf_base(smem, has_res ? d.res : 0);
+    const float neg = act_neg(d.act, d.slope);
+    const uint32_t lb = d.act == DHAUG_ACT_RELU ? 0u : 0x80008000u;        // packed int16 lower bound
+    const int lfx = r31 * (BUF01_PITCH * 2) | ((x >> 1) << 5) | ((h ^ (x & 1)) << 4);      // ^ (k << 5): chunk 2k+h of row
+    const int lrx = lfx ^ (wave << 6);                                                      // ^ (t << 8 | ks2 << 5): k-step 2(wave+4t)+ks2
+    const int lep = r31 * (BUF01_PITCH * 2) | (((4 * wave) ^ x) << 4) | (h << 3);          // ^ ((16t+g) << 4): chunk 4(wave+4t)+g
+    constexpr int FXD = 3;                                                   // fx prefetch distance in k-steps
+    f32x16 acc[2][MLP_NS];                                                   // tile mt accumulates while tile mt-1 drains
+    bf16x8 fx[4], rx[4];
+    uint32_t ov = 0;
+    auto fx_load = [&](int s) {                                              // s = 16 * tile + k-step
+        fx[s & 3] = *reinterpret_cast<const bf16x8*>(src + (lfx ^ ((s % MLP_MAX_KSTEPS) << 5)) + (s / MLP_MAX_KSTEPS) * TILE_BYTES);
+    };
+#pragma unroll
+    for (int s = 0; s < FXD; ++s) fx_load(s);
+    // elements j, j+1 (j even) of tile `mt` (held in `a`): j = 16t + 4g + e
+    auto element_pair = [&](const f32x16 (&a)[MLP_NS], int mt, int j) {
+        const int t = j >> 4, g = (j >> 2) & 3, e = j & 3;
+        const float v0 = a[t][4 * g + e], v1 = a[t][4 * g + e + 1];
+        uint32_t o;
+        if (!LEAKY) {
+            o = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16x2(v0, v1)),
+                                                                       __builtin_bit_cast(s16x2, lb)));
+        } else {
+            o = pack_bf16x2(act_fn(v0, neg), act_fn(v1, neg));
+        }
+        if (e == 0) {
+            ov = o;
+        } else {
+            uint2 oo;
+            oo.x = ov; oo.y = o;
+            *reinterpret_cast<uint2*>(dst + (lep ^ ((16 * t + g) << 4)) + mt * TILE_BYTES) = oo;
+        }
+    };
+#pragma unroll
+    for (int mt = 0; mt < MLP_MT; ++mt) {
+#pragma unroll
+        for (int k = 0; k < MLP_MAX_KSTEPS; ++k) {
+            const int s = mt * MLP_MAX_KSTEPS + k;
+            if (s + FXD < MLP_MT * MLP_MAX_KSTEPS) fx_load(s + FXD);
+            if (k < 4)                                                       // this tile's residual fragments, used after k = 15
+                rx[k] = *reinterpret_cast<const bf16x8*>(res + (lrx ^ ((k >> 1) << 8 | (k & 1) << 5)) + mt * TILE_BYTES);
+#pragma unroll
+            for (int t = 0; t < MLP_NS; ++t) {
+                acc[mt & 1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t][k], fx[s & 3], k == 0 ? seed[t] : acc[mt & 1][t], 0, 0, 0);
+                if (mt == MLP_MT - 1) w[t][k] = nb.frag(t, k);
+                if (mt > 0 && t == 1) element_pair(acc[(mt - 1) & 1], mt - 1, MLP_NS * k);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (has_res) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)                                      // i = 2t + ks2
+                acc[mt & 1][i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(idf[i & 1], rx[i], acc[mt & 1][i >> 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        DHAUG_LSTAMP(dbg + 1 + mt)
+    }
+#pragma unroll
+    for (int j = 0; j < STEPS; j += 2) element_pair(acc[(MLP_MT - 1) & 1], MLP_MT - 1, j);
+    DHAUG_LSTAMP(dbg + 5)
+#pragma unroll
+    for (int t = 0; t < MLP_NS; ++t) seed[t] = nseed[t];
+}
+
+template <bool LEAKY>
+__device__ __forceinline__ void gemm_stack(UnitPtr first, int n, unsigned char* smem, int wave, int lane) {
+    StackDesc cur = stack_desc(first), nxt = stack_desc(first + (n > 1 ? 1 : 0));
+    WFull w;
+    f32x16 seed[MLP_NS];
+    load_seed(cur.bias, wave, lane, seed);
+    {
+        const WBase b0(cur.w, wave, lane);
+#pragma unroll
+        for (int t = 0; t < MLP_NS; ++t)
+#pragma unroll
+            for (int k = 0; k < MLP_MAX_KSTEPS; ++k) w[t][k] = b0.frag(t, k);
+    }
+    // identity fragments: A[n][k'] = (n == 16 ks2 + k') for the lane's k' = 8h + j
+    bf16x8 idf[2];
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+        const int dd = (lane & 31) - 16 * ks2 - 8 * (lane >> 5);
+        u32x4 v;
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) v[p2] = (dd == 2 * p2 ? 0x3F80u : 0u) | (dd == 2 * p2 + 1 ? 0x3F800000u : 0u);
+        idf[ks2] = __builtin_bit_cast(bf16x8, v);
+    }
+#pragma unroll 1
+    for (int l = 0; l < n; ++l) {
+        const StackDesc nn = stack_desc(first + (l + 2 < n ? l + 2 : n - 1));          // arrives during this layer
+        const int dbg = MLP_MAX_UNITS + 2 + 8 * (l < 6 ? l : 6);
+        stack_layer<LEAKY>(cur, nxt, smem, wave, lane, w, seed, idf, dbg);
+        cur = nxt;
+        nxt = nn;
+        if (l + 1 < n) lds_barrier();
+        DHAUG_LSTAMP(dbg + 6)
     }
 }
 
 // data-movement units.  LOAD zero-fills columns [cols, ceil64(cols)) so that the consuming GEMM may read whole chunks.
+// (row, col-group) walker for a workgroup-strided sweep of a [MLP_BM][q] grid: no division inside the loops
+struct Sweep {
+    int row, c, dr, dc, q;
+    __device__ __forceinline__ Sweep(int tid, int q_) : q(q_) {
+        row = tid / q_; c = tid - row * q_; dr = MLP_THREADS / q_; dc = MLP_THREADS - dr * q_;
+    }
+    __device__ __forceinline__ void next() {
+        row += dr; c += dc;
+        if (c >= q) { c -= q; ++row; }
+    }
+};
+
+constexpr int MOVE_BATCH = 8;                                                // global accesses in flight per thread
+
 __device__ __forceinline__ void move_unit(UnitPtr u, unsigned char* smem, long long m0, long long M, int tid) {
     const int kind = u->kind, cols = u->cols;
     const long long ld = u->ld;
     if (kind == U_LOAD_F32) {
         const float* g = static_cast<const float*>(u->g);
         unsigned char* dst = buf_base(smem, u->dst);
-        const int pb = buf_pitch_bytes(u->dst), q4 = ((cols + 63) & ~63) >> 2, total = MLP_BM * q4;
-        for (int e = tid; e < total; e += MLP_THREADS) {
-            const int row = e / q4, c4 = e - row * q4;
-            const long long gm = m0 + row;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gm < M && c4 * 4 < cols) v = *reinterpret_cast<const f32x4*>(g + gm * ld + c4 * 4);
-            uint2 o;
-            o.x = (uint32_t)dhaug_f32_to_bf16(v[0]) | ((uint32_t)dhaug_f32_to_bf16(v[1]) << 16);
-            o.y = (uint32_t)dhaug_f32_to_bf16(v[2]) | ((uint32_t)dhaug_f32_to_bf16(v[3]) << 16);
-            *reinterpret_cast<uint2*>(dst + chunk_off(row, c4 >> 1, pb) + ((c4 & 1) << 3)) = o;
+        const int pb = buf_pitch_bytes(u->dst), q4 = ((cols + 63) & ~63) >> 2;
+        Sweep sw(tid, q4);
+        while (sw.row < MLP_BM) {
+            f32x4 v[MOVE_BATCH];
+            int off[MOVE_BATCH];
+#pragma unroll
+            for (int i = 0; i < MOVE_BATCH; ++i) {
+                const long long gm = m0 + sw.row;
+                v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                off[i] = sw.row < MLP_BM ? chunk_off(sw.row, sw.c >> 1, pb) + ((sw.c & 1) << 3) : -1;
+                if (sw.row < MLP_BM && gm < M && sw.c * 4 < cols) v[i] = *reinterpret_cast<const f32x4*>(g + gm * ld + sw.c * 4);
+                sw.next();
+            }
+#pragma unroll
+            for (int i = 0; i < MOVE_BATCH; ++i) {
+                uint2 o;
+                o.x = pack_bf16x2(v[i][0], v[i][1]);
+                o.y = pack_bf16x2(v[i][2], v[i][3]);
+                if (off[i] >= 0) *reinterpret_cast<uint2*>(dst + off[i]) = o;
+            }
         }
         return;
     }
@@ -269,18 +504,40 @@ __device__ __forceinline__ void move_unit(UnitPtr u, unsigned char* smem, long l
     const int id = kind == U_LOAD_BF16 ? u->dst : u->src;
     unsigned char* img = buf_base(smem, id);
     const int pb = buf_pitch_bytes(id);
-    const int q8 = (kind == U_LOAD_BF16 ? ((cols + 63) & ~63) : cols) >> 3, total = MLP_BM * q8;
-    for (int e = tid; e < total; e += MLP_THREADS) {
-        const int row = e / q8, c = e - row * q8;
-        const long long gm = m0 + row;
-        uint4* l = reinterpret_cast<uint4*>(img + chunk_off(row, c, pb));
-        uint4* gg = reinterpret_cast<uint4*>(g + gm * ld + c * 8);
-        if (kind == U_LOAD_BF16) *l = (gm < M && c * 8 < cols) ? *gg : make_uint4(0, 0, 0, 0);
-        else if (gm < M) *gg = *l;
+    const int q8 = (kind == U_LOAD_BF16 ? ((cols + 63) & ~63) : cols) >> 3;
+    Sweep sw(tid, q8);
+    if (kind == U_LOAD_BF16) {
+        while (sw.row < MLP_BM) {
+            uint4 v[MOVE_BATCH];
+            int off[MOVE_BATCH];
+#pragma unroll
+            for (int i = 0; i < MOVE_BATCH; ++i) {
+                const long long gm = m0 + sw.row;
+                v[i] = make_uint4(0, 0, 0, 0);
+                off[i] = sw.row < MLP_BM ? chunk_off(sw.row, sw.c, pb) : -1;
+                if (sw.row < MLP_BM && gm < M && sw.c * 8 < cols) v[i] = *reinterpret_cast<const uint4*>(g + gm * ld + sw.c * 8);
+                sw.next();
+            }
+#pragma unroll
+            for (int i = 0; i < MOVE_BATCH; ++i)
+                if (off[i] >= 0) *reinterpret_cast<uint4*>(img + off[i]) = v[i];
+        }
+    } else {
+        for (; sw.row < MLP_BM; sw.next())
+            if (m0 + sw.row < M)
+                *reinterpret_cast<uint4*>(g + (m0 + sw.row) * ld + sw.c * 8) = *reinterpret_cast<const uint4*>(img + chunk_off(sw.row, sw.c, pb));
     }
 }
 
-__global__ __launch_bounds__(MLP_THREADS, 2) void fused_mlp_kernel(Program prog, long long M) {
+__device__ __forceinline__ void store_output(UnitPtr u, unsigned char* smem, long long m0, long long M, int tid) {
+    const float* st = reinterpret_cast<const float*>(buf_base(smem, u->dst));
+    float* out = static_cast<float*>(const_cast<void*>(u->g));
+    const long long ld = u->ld;
+    for (Sweep sw(tid, u->N); sw.row < MLP_BM; sw.next())
+        if (m0 + sw.row < M) out[(m0 + sw.row) * ld + sw.c] = st[sw.row * OUT_PITCH + sw.c];
+}
+
+__global__ __launch_bounds__(MLP_THREADS, 1) void fused_mlp_kernel(Program prog, long long M) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -291,24 +548,46 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void fused_mlp_kernel(Program prog,
         (const unsigned char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
     UnitPtr units = (UnitPtr)(ka + __builtin_offsetof(Program, u));
     const int nunits = *(const int __attribute__((address_space(4)))*)(ka + __builtin_offsetof(Program, nunits));
+    const int min_run = *(const int __attribute__((address_space(4)))*)(ka + __builtin_offsetof(Program, min_run));
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long m0 = tile * MLP_BM;
 #pragma unroll 1
         for (int i = 0; i < nunits; ++i) {
             UnitPtr u = units + i;
+            DHAUG_STAMP(i)
             if (u->kind != U_GEMM) {
                 move_unit(u, smem, m0, M, tid);
             } else {
                 const int nch1 = chunks_of(u->ksteps), nch = nch1 + chunks_of(u->ksteps2);
-                switch (nch * 16 + nch1) {                         // validated on the host: one of these cases
-                    case 1 * 16 + 1: gemm_layer<1, 1>(u, smem, wave, lane); break;
-                    case 2 * 16 + 2: gemm_layer<2, 2>(u, smem, wave, lane); break;
-                    case 2 * 16 + 1: gemm_layer<2, 1>(u, smem, wave, lane); break;
-                    case 4 * 16 + 4: gemm_layer<4, 4>(u, smem, wave, lane); break;
-                    case 4 * 16 + 2: gemm_layer<4, 2>(u, smem, wave, lane); break;
-                    case 8 * 16 + 4: gemm_layer<8, 4>(u, smem, wave, lane); break;
-                    default: break;
+                // run of consecutive plain 256 -> 256 layers?
+                int run = 0, leaky = 0;
+                while (i + run < nunits && units[i + run].kind == U_GEMM && units[i + run].ksteps == 16 &&
+                       units[i + run].ksteps2 == 0 && units[i + run].N > 224 && !(units[i + run].flags & F_OUT_F32) &&
+                       units[i + run].src < 2 && units[i + run].dst < 2 && units[i + run].res < 2) {
+                    leaky |= units[i + run].act == DHAUG_ACT_LRELU;
+                    ++run;
                 }
+                if (run >= min_run) {
+                    if (leaky) gemm_stack<true>(u, run, smem, wave, lane);
+                    else gemm_stack<false>(u, run, smem, wave, lane);
+                    i += run - 1;
+                    __syncthreads();
+                    continue;                                                // (stamps of the run's inner layers stay 0)
+                }
+                const int nslices = (u->N + 31) >> 5;
+#define DHAUG_SHAPES(NS)                                                                   \
+    switch (nch * 16 + nch1) {                                 /* validated on the host */ \
+        case 1 * 16 + 1: gemm_single<1, 1, NS>(u, smem, wave, lane); break;                 \
+        case 2 * 16 + 2: gemm_single<2, 2, NS>(u, smem, wave, lane); break;                 \
+        case 2 * 16 + 1: gemm_single<2, 1, NS>(u, smem, wave, lane); break;                 \
+        case 4 * 16 + 4: gemm_single<4, 4, NS>(u, smem, wave, lane); break;                 \
+        case 4 * 16 + 2: gemm_single<4, 2, NS>(u, smem, wave, lane); break;                 \
+        case 8 * 16 + 4: gemm_single<8, 4, NS>(u, smem, wave, lane); break;                 \
+        default: break;                                                                    \
+    }
+                if (wave + 4 < nslices) { DHAUG_SHAPES(2) }
+                else if (wave < nslices) { DHAUG_SHAPES(1) }
+#undef DHAUG_SHAPES
                 if (u->flags & F_OUT_F32) {
                     __syncthreads();
                     store_output(u, smem, m0, M, tid);
@@ -316,6 +595,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void fused_mlp_kernel(Program prog,
             }
             __syncthreads();
         }
+        DHAUG_STAMP(nunits)
     }
     (void)prog;
 }
@@ -359,6 +639,7 @@ int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* 
     if (M == 0) return DHAUG_OK;
     Program prog;
     prog.nunits = nunits;
+    prog.min_run = getenv("DHAUG_MLP_NOSTACK") ? 1 << 20 : 2;                // debugging aid: layer-at-a-time path only
     for (int i = 0; i < nunits; ++i) {
         const dhaug_mlp_unit& s = units[i];
         Unit& u = prog.u[i];
@@ -408,9 +689,15 @@ int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* 
         configured = true;
     }
     const long long ntiles = (M + MLP_BM - 1) / MLP_BM;
-    const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);           // two resident workgroups per CU
+    const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);           // one persistent workgroup per CU
     hipLaunchKernelGGL(fused_mlp_kernel, dim3(grid), dim3(MLP_THREADS), MLP_LDS_BYTES, (hipStream_t)stream, prog, (long long)M);
     return dhaug_launch_status();
 }
 
 }  // extern "C"
+
+#ifdef DHAUG_MLP_TIMING
+extern "C" int dhaug_debug_mlp_stamps(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_stamps), sizeof(long long) * (n < MLP_MAX_UNITS + 64 ? n : MLP_MAX_UNITS + 64));
+}
+#endif

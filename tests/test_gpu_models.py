@@ -291,7 +291,7 @@ def test_fused_forward_matches_layerwise(M, D, B):
     assert maxabs(head_f, ref) <= 2e-2 * ref.abs().max().item()
     sd3 = {k: v.detach().cpu() for k, v in D3.state_dict().items()}
     r3 = O.d3_forward(x3.cpu(), sd3, precision="bf16")
-    assert relerr(l3_f, r3) <= 3e-2
+    assert maxabs(l3_f, r3) <= 2e-2 * r3.abs().max().item()          # bf16 chains: measured against the logit scale
     # weights change -> the packed fragments are rebuilt
     with torch.no_grad():
         D2.layer_pred.bias.add_(1.0)

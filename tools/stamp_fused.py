@@ -1,0 +1,26 @@
+"""Development aid: per-unit shader-clock stamps of the fused kernel (needs a lib built with -DDHAUG_MLP_TIMING)."""
+import ctypes, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import dhaug_amd
+from dhaug_amd import fused, _lib
+from dhaug_amd.selfcheck import synth_args
+from dhaug_amd.models_Fk_GAN import Fk_discriminator, Fk_generator, forward_kinematics_DH_model as fkm
+B = 65536
+args = synth_args(B, 256)
+fk = fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+G = Fk_generator.Fk_Generator(fk, args, "cuda").cuda()
+D3 = Fk_discriminator.Fk_3D_Discriminator("cuda", args).cuda()
+z = torch.randn(B, 128, device="cuda"); x3 = torch.randn(B, 16, 3, device="cuda") * 0.3
+L = _lib.lib()
+N = 64 + 64
+buf = (ctypes.c_longlong * N)()
+with torch.no_grad():
+    for name, fn in (("G", lambda: fused.generator_head(G, z)), ("D3", lambda: fused.critic3d(D3, x3))):
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        L.dhaug_debug_mlp_stamps(buf, N)
+        st = [buf[i] for i in range(N)]
+        idx = [i for i, v in enumerate(st) if v]
+        base = st[idx[0]]
+        print(name, " ".join("%d:%d" % (i, st[i] - base) for i in idx))
