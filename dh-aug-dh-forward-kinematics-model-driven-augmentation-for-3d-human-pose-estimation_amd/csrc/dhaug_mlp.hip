@@ -285,7 +285,7 @@ __device__ long long g_mlp_stamps[MLP_MAX_UNITS + 64];
 #endif
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef bf16x8 WFull[MLP_NS][MLP_MAX_KSTEPS];
+typedef bf16x8 WHalf[MLP_NS][MLP_MAX_KSTEPS / 2];                     // fragments of k-steps 0..7 or 8..15
 
 // what a stack layer needs from its unit, fetched (scalar loads) one layer ahead so that no layer starts by waiting
 // on the constant cache
@@ -294,35 +294,39 @@ struct StackDesc {
     float slope;
     const float* bias;
     const uint16_t* w;
+    int narrow;                 // 1: the network's output layer (N <= 64): every wave holds slices 0 and 1
 };
 __device__ __forceinline__ StackDesc stack_desc(UnitPtr u) {
     StackDesc d;
     d.src = u->src; d.dst = u->dst; d.res = u->res; d.act = u->act; d.slope = u->slope; d.bias = u->bias; d.w = u->w;
+    d.narrow = (u->flags & F_OUT_F32) ? 1 : 0;
     return d;
 }
 
-// per-lane base pointers of a layer's fragments: [t][half] points at k-step 4 / 12 of slice wave + 4t, so that every
-// fragment is base + a 13-bit signed immediate ((k - 4) * 1024 bytes)
+// per-lane base pointers of a layer's fragments ([slice][KS k-steps][64 lanes][8]): [t][half] points at k-step 4 / 12
+// of slice wave + 4t, so that every fragment is base + a 13-bit signed immediate ((k - 4) * 1024 bytes)
+template <int KS = MLP_MAX_KSTEPS>
 struct WBase {
     const uint16_t* p[MLP_NS][2];
-    __device__ __forceinline__ WBase(const uint16_t* w, int wave, int lane) {
+    // the wave's slices are s0 and s0 + sstride (wave, wave + 4 in a full-width layer)
+    __device__ __forceinline__ WBase(const uint16_t* w, int s0, int sstride, int lane) {
 #pragma unroll
         for (int t = 0; t < MLP_NS; ++t)
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) p[t][hh] = w + ((long long)((wave + 4 * t) * MLP_MAX_KSTEPS + 4 + 8 * hh) * 64 + lane) * 8;
+            for (int hh = 0; hh < 2; ++hh) p[t][hh] = w + ((long long)((s0 + sstride * t) * KS + 4 + 8 * hh) * 64 + lane) * 8;
     }
     __device__ __forceinline__ bf16x8 frag(int t, int k) const {
         return *reinterpret_cast<const bf16x8*>(p[t][k >> 3] + ((k & 7) - 4) * 512);
     }
 };
 
-__device__ __forceinline__ void load_seed(const float* bias, int wave, int lane, f32x16 (&seed)[MLP_NS]) {
+__device__ __forceinline__ void load_seed(const float* bias, int s0, int sstride, int lane, f32x16 (&seed)[MLP_NS]) {
     const int h = lane >> 5;
 #pragma unroll
     for (int t = 0; t < MLP_NS; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 32 * (wave + 4 * t) + 4 * h + 8 * g);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 32 * (s0 + sstride * t) + 4 * h + 8 * g);
 #pragma unroll
             for (int e = 0; e < 4; ++e) seed[t][4 * g + e] = b4[e];
         }
@@ -343,20 +347,33 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 // tile and pinned there (sched_barrier).  LEAKY stacks (the 2D critic) pay mul + max per element instead.
 // One body per stack: a second instantiation inside the layer loop would make the register allocator shuffle the
 // 128 weight registers between the bodies' assignments at every layer boundary.
-template <bool LEAKY>
+// RESMODE 0: no residual, 1: residual, 2: decided at run time (the identity fragments are zeroed for a layer without).
+// KS < 16: the narrow layer that feeds a stack (K = 16 KS <= 128, no residual); its own fragments sit in `wlo`, and
+// BOTH halves of the following layer's are requested while it runs (tile 1: low, tile 2: high).
+template <bool LEAKY, int RESMODE, int KS = MLP_MAX_KSTEPS>
 __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc& nd, unsigned char* smem, int wave, int lane,
-                                            WFull& w, f32x16 (&seed)[MLP_NS], const bf16x8 (&idf)[2], int dbg) {
+                                            const WHalf& wlo, WHalf& nlo, WHalf& whi, f32x16 (&seed)[MLP_NS],
+                                            const bf16x8 (&idf)[2], int dbg) {
     DHAUG_LSTAMP(dbg)
-    constexpr int STEPS = MLP_NS * MLP_MAX_KSTEPS;                          // 32 weight MFMAs and 32 accumulator elements per tile
+    static_assert(KS == 16 || ((KS == 4 || KS == 8) && RESMODE == 0), "layer shape");
+    constexpr bool LEAD = KS < MLP_MAX_KSTEPS;
+    constexpr int PAIRS = 16 / KS;                                           // accumulator element pairs retired per k-step
     constexpr int TILE_BYTES = 32 * BUF01_PITCH * 2;                         // 16 384
     const int r31 = lane & 31, h = lane >> 5, x = lane & 15;
     f32x16 nseed[MLP_NS];
-    load_seed(nd.bias, wave, lane, nseed);
-    const WBase nb(nd.w, wave, lane);
+    const int ns0 = nd.narrow ? 0 : wave, nss = nd.narrow ? 1 : 4;
+    load_seed(nd.bias, ns0, nss, lane, nseed);
+    const WBase<> nb(nd.w, ns0, nss, lane);
     const unsigned char* src = buf_base(smem, d.src);
     unsigned char* dst = buf_base(smem, d.dst);
     const bool has_res = d.res >= 0;
     const unsigned char* res = buf_base(smem, has_res ? d.res : 0);
+    bf16x8 idl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const bf16x8 zf = {0, 0, 0, 0, 0, 0, 0, 0};
+        idl[i] = (RESMODE == 2 && !has_res) ? zf : idf[i];
+    }
     const float neg = act_neg(d.act, d.slope);
     const uint32_t lb = d.act == DHAUG_ACT_RELU ? 0u : 0x80008000u;        // packed int16 lower bound
     const int lfx = r31 * (BUF01_PITCH * 2) | ((x >> 1) << 5) | ((h ^ (x & 1)) << 4);      // ^ (k << 5): chunk 2k+h of row
@@ -366,8 +383,8 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
     f32x16 acc[2][MLP_NS];                                                   // tile mt accumulates while tile mt-1 drains
     bf16x8 fx[4], rx[4];
     uint32_t ov = 0;
-    auto fx_load = [&](int s) {                                              // s = 16 * tile + k-step
-        fx[s & 3] = *reinterpret_cast<const bf16x8*>(src + (lfx ^ ((s % MLP_MAX_KSTEPS) << 5)) + (s / MLP_MAX_KSTEPS) * TILE_BYTES);
+    auto fx_load = [&](int s) {                                              // s = KS * tile + k-step
+        fx[s & 3] = *reinterpret_cast<const bf16x8*>(src + (lfx ^ ((s % KS) << 5)) + (s / KS) * TILE_BYTES);
     };
 #pragma unroll
     for (int s = 0; s < FXD; ++s) fx_load(s);
@@ -393,47 +410,101 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
 #pragma unroll
     for (int mt = 0; mt < MLP_MT; ++mt) {
 #pragma unroll
-        for (int k = 0; k < MLP_MAX_KSTEPS; ++k) {
-            const int s = mt * MLP_MAX_KSTEPS + k;
-            if (s + FXD < MLP_MT * MLP_MAX_KSTEPS) fx_load(s + FXD);
-            if (k < 4)                                                       // this tile's residual fragments, used after k = 15
+        for (int k = 0; k < KS; ++k) {
+            const int s = mt * KS + k;
+            if (s + FXD < MLP_MT * KS) fx_load(s + FXD);
+            if (RESMODE != 0 && k < 4)                                       // this tile's residual fragments, used after k = 15
                 rx[k] = *reinterpret_cast<const bf16x8*>(res + (lrx ^ ((k >> 1) << 8 | (k & 1) << 5)) + mt * TILE_BYTES);
 #pragma unroll
             for (int t = 0; t < MLP_NS; ++t) {
-                acc[mt & 1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t][k], fx[s & 3], k == 0 ? seed[t] : acc[mt & 1][t], 0, 0, 0);
-                if (mt == MLP_MT - 1) w[t][k] = nb.frag(t, k);
-                if (mt > 0 && t == 1) element_pair(acc[(mt - 1) & 1], mt - 1, MLP_NS * k);
+                acc[mt & 1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k < 8 ? wlo[t][k & 7] : whi[t][k & 7], fx[s & 3],
+                                                                         k == 0 ? seed[t] : acc[mt & 1][t], 0, 0, 0);
+                // the next layer's weights.  The vector-memory return path moves 64 B/clk: a layer's 128 KB of
+                // fragments are half its MFMA time, so they must not bunch up.  k-steps 0..7 go to the second low
+                // set, one fragment every fourth MFMA of tiles 1 and 2; k-steps 8..15 replace this layer's right
+                // behind their last use in tile 3.
+                if (!LEAD) {
+                    if ((mt == 1 || mt == 2) && (k & 1) == 1 && t == 1) {
+                        const int f = (mt - 1) * 8 + (k >> 1);               // 0..15 -> (slice f >> 3, k-step f & 7)
+                        nlo[f >> 3][f & 7] = nb.frag(f >> 3, f & 7);
+                    }
+                    if (mt == MLP_MT - 1 && k >= 8) whi[t][k & 7] = nb.frag(t, k);
+                } else if (mt == 1 || mt == 2) {                             // 16 fragments over the tile's 2 KS MFMAs
+#pragma unroll
+                    for (int q = 0; q < 8 / KS; ++q) {
+                        const int f = (MLP_NS * k + t) * (8 / KS) + q;       // 0..15
+                        if (mt == 1) nlo[f >> 3][f & 7] = nb.frag(f >> 3, f & 7);
+                        else whi[f >> 3][f & 7] = nb.frag(f >> 3, 8 + (f & 7));
+                    }
+                }
+                if (mt > 0 && t == 1) {
+#pragma unroll
+                    for (int q = 0; q < PAIRS; ++q) element_pair(acc[(mt - 1) & 1], mt - 1, 2 * (PAIRS * k + q));
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (has_res) {
+        if (RESMODE != 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)                                      // i = 2t + ks2
-                acc[mt & 1][i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(idf[i & 1], rx[i], acc[mt & 1][i >> 1], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {                                    // (t, ks2) = (i & 1, i >> 1): alternate the accumulators
+                acc[mt & 1][i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(idl[i >> 1], rx[2 * (i & 1) + (i >> 1)], acc[mt & 1][i & 1], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         DHAUG_LSTAMP(dbg + 1 + mt)
     }
 #pragma unroll
-    for (int j = 0; j < STEPS; j += 2) element_pair(acc[(MLP_MT - 1) & 1], MLP_MT - 1, j);
+    for (int j = 0; j < 32; j += 2) element_pair(acc[(MLP_MT - 1) & 1], MLP_MT - 1, j);
     DHAUG_LSTAMP(dbg + 5)
 #pragma unroll
     for (int t = 0; t < MLP_NS; ++t) seed[t] = nseed[t];
 }
 
-template <bool LEAKY>
-__device__ __forceinline__ void gemm_stack(UnitPtr first, int n, unsigned char* smem, int wave, int lane) {
-    StackDesc cur = stack_desc(first), nxt = stack_desc(first + (n > 1 ? 1 : 0));
-    WFull w;
-    f32x16 seed[MLP_NS];
-    load_seed(cur.bias, wave, lane, seed);
-    {
-        const WBase b0(cur.w, wave, lane);
+// The network's output layer (N <= 64, K = 256) behind a stack: wave w computes rows [32w, 32w+32) for slices 0 and 1
+// with the fragments the last stack layer requested for it, and leaves act(.) as fp32 in the staging image
+// [128][OUT_PITCH] of buffer dst (store_output copies it out).
+__device__ __forceinline__ void tail_layer(const StackDesc& d, unsigned char* smem, int wave, int lane, const WHalf& wlo,
+                                           const WHalf& whi, const f32x16 (&seed)[MLP_NS]) {
+    constexpr int TILE_BYTES = 32 * BUF01_PITCH * 2;
+    const int r31 = lane & 31, h = lane >> 5, x = lane & 15;
+    const unsigned char* src = buf_base(smem, d.src) + wave * TILE_BYTES;
+    float* st = reinterpret_cast<float*>(buf_base(smem, d.dst)) + (32 * wave + r31) * OUT_PITCH + 4 * h;
+    const float neg = act_neg(d.act, d.slope);
+    const int lfx = r31 * (BUF01_PITCH * 2) | ((x >> 1) << 5) | ((h ^ (x & 1)) << 4);
+    bf16x8 fx[4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fx[k] = *reinterpret_cast<const bf16x8*>(src + (lfx ^ (k << 5)));
+    f32x16 acc[MLP_NS];
+#pragma unroll
+    for (int k = 0; k < MLP_MAX_KSTEPS; ++k) {
+        if (k + 3 < MLP_MAX_KSTEPS) fx[(k + 3) & 3] = *reinterpret_cast<const bf16x8*>(src + (lfx ^ ((k + 3) << 5)));
 #pragma unroll
         for (int t = 0; t < MLP_NS; ++t)
-#pragma unroll
-            for (int k = 0; k < MLP_MAX_KSTEPS; ++k) w[t][k] = b0.frag(t, k);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k < 8 ? wlo[t][k & 7] : whi[t][k & 7], fx[k & 3],
+                                                             k == 0 ? seed[t] : acc[t], 0, 0, 0);
     }
+#pragma unroll
+    for (int t = 0; t < MLP_NS; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[t][4 * g + e], neg);
+            *reinterpret_cast<f32x4*>(st + 32 * t + 8 * g) = v;
+        }
+}
+
+// A run of n full-width layers, optionally fed by one narrow layer (lead_ks = 4 or 8 k-steps, 0: none) and optionally
+// followed by the network's output layer (`tail`).
+// ALT: the layers alternate (no residual, residual) -- the myResNet blocks -- and n is even
+template <bool LEAKY, bool ALT>
+__device__ __forceinline__ void gemm_stack(UnitPtr lead, int lead_ks, UnitPtr first, int n, bool tail, unsigned char* smem,
+                                           int wave, int lane) {
+    // units first[0 .. nt): the n full-width layers and, if `tail`, the output layer behind them
+    const int nt = n + (tail ? 1 : 0);
+    StackDesc cur = stack_desc(first), nxt = stack_desc(first + (nt > 1 ? 1 : 0));
+    WHalf loA, loB, hi;
+    f32x16 seed[MLP_NS];
     // identity fragments: A[n][k'] = (n == 16 ks2 + k') for the lane's k' = 8h + j
     bf16x8 idf[2];
 #pragma unroll
@@ -444,15 +515,67 @@ __device__ __forceinline__ void gemm_stack(UnitPtr first, int n, unsigned char* 
         for (int p2 = 0; p2 < 4; ++p2) v[p2] = (dd == 2 * p2 ? 0x3F80u : 0u) | (dd == 2 * p2 + 1 ? 0x3F800000u : 0u);
         idf[ks2] = __builtin_bit_cast(bf16x8, v);
     }
+    if (lead_ks != 0) {
+        const StackDesc ld = stack_desc(lead);
+        load_seed(ld.bias, wave, 4, lane, seed);
+        if (lead_ks == 8) {
+            const WBase<8> b(ld.w, wave, 4, lane);
+#pragma unroll
+            for (int t = 0; t < MLP_NS; ++t)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) loB[t][k] = b.frag(t, k);
+            stack_layer<LEAKY, 0, 8>(ld, cur, smem, wave, lane, loB, loA, hi, seed, idf, MLP_MAX_UNITS + 50);
+        } else {
+            const WBase<4> b(ld.w, wave, 4, lane);
+#pragma unroll
+            for (int t = 0; t < MLP_NS; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) loB[t][k] = b.frag(t, k);
+            stack_layer<LEAKY, 0, 4>(ld, cur, smem, wave, lane, loB, loA, hi, seed, idf, MLP_MAX_UNITS + 50);
+        }
+        lds_barrier();
+        DHAUG_LSTAMP(MLP_MAX_UNITS + 56)
+    } else {
+        load_seed(cur.bias, wave, 4, lane, seed);
+        const WBase<> b0(cur.w, wave, 4, lane);
+#pragma unroll
+        for (int t = 0; t < MLP_NS; ++t)
+#pragma unroll
+            for (int k = 0; k < MLP_MAX_KSTEPS / 2; ++k) {
+                loA[t][k] = b0.frag(t, k);
+                hi[t][k] = b0.frag(t, k + 8);
+            }
+    }
+    // two layers per trip: the low weight sets swap roles without moving
+    int l = 0;
 #pragma unroll 1
-    for (int l = 0; l < n; ++l) {
-        const StackDesc nn = stack_desc(first + (l + 2 < n ? l + 2 : n - 1));          // arrives during this layer
-        const int dbg = MLP_MAX_UNITS + 2 + 8 * (l < 6 ? l : 6);
-        stack_layer<LEAKY>(cur, nxt, smem, wave, lane, w, seed, idf, dbg);
-        cur = nxt;
-        nxt = nn;
-        if (l + 1 < n) lds_barrier();
+    for (; l + 2 <= n; l += 2) {
+        const StackDesc n2 = stack_desc(first + (l + 2 < nt ? l + 2 : nt - 1));         // arrive during the layers
+        const StackDesc n3 = stack_desc(first + (l + 3 < nt ? l + 3 : nt - 1));
+        const int dbg = MLP_MAX_UNITS + 2 + 8 * (l < 4 ? l : 4);
+        stack_layer<LEAKY, ALT ? 0 : 2>(cur, nxt, smem, wave, lane, loA, loB, hi, seed, idf, dbg);
+        lds_barrier();
         DHAUG_LSTAMP(dbg + 6)
+        stack_layer<LEAKY, ALT ? 1 : 2>(nxt, n2, smem, wave, lane, loB, loA, hi, seed, idf, dbg + 8);
+        cur = n2;
+        nxt = n3;
+        if (l + 2 < nt) lds_barrier();
+        DHAUG_LSTAMP(dbg + 14)
+    }
+    const bool odd = !ALT && l < n;
+    if (odd) {
+        stack_layer<LEAKY, 2>(cur, nxt, smem, wave, lane, loA, loB, hi, seed, idf, MLP_MAX_UNITS + 2);
+        cur = nxt;
+        if (tail) lds_barrier();
+    }
+    if (tail) {                                                              // one call site: the low set is moved, not re-instantiated
+        if (odd) {
+#pragma unroll
+            for (int t = 0; t < MLP_NS; ++t)
+#pragma unroll
+                for (int k = 0; k < MLP_MAX_KSTEPS / 2; ++k) loA[t][k] = loB[t][k];
+        }
+        tail_layer(cur, smem, wave, lane, loA, hi, seed);
     }
 }
 
@@ -469,7 +592,11 @@ struct Sweep {
     }
 };
 
-constexpr int MOVE_BATCH = 8;                                                // global accesses in flight per thread
+#ifdef MOVE_BATCH_OVERRIDE
+constexpr int MOVE_BATCH = MOVE_BATCH_OVERRIDE;
+#else
+constexpr int MOVE_BATCH = 16;
+#endif                                                // global accesses in flight per thread
 
 __device__ __forceinline__ void move_unit(UnitPtr u, unsigned char* smem, long long m0, long long M, int tid) {
     const int kind = u->kind, cols = u->cols;
@@ -556,22 +683,42 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void fused_mlp_kernel(Program prog,
             UnitPtr u = units + i;
             DHAUG_STAMP(i)
             if (u->kind != U_GEMM) {
+                // a STORE is not waited for where it is issued (lds_barrier orders only its LDS reads); the LOAD that
+                // reads the parked rows back drains the workgroup's stores first
+                if (u->kind == U_LOAD_BF16) __syncthreads();
                 move_unit(u, smem, m0, M, tid);
+                if (u->kind == U_STORE_BF16) {
+                    lds_barrier();
+                    continue;
+                }
             } else {
                 const int nch1 = chunks_of(u->ksteps), nch = nch1 + chunks_of(u->ksteps2);
-                // run of consecutive plain 256 -> 256 layers?
-                int run = 0, leaky = 0;
-                while (i + run < nunits && units[i + run].kind == U_GEMM && units[i + run].ksteps == 16 &&
-                       units[i + run].ksteps2 == 0 && units[i + run].N > 224 && !(units[i + run].flags & F_OUT_F32) &&
-                       units[i + run].src < 2 && units[i + run].dst < 2 && units[i + run].res < 2) {
-                    leaky |= units[i + run].act == DHAUG_ACT_LRELU;
+                // a run of consecutive plain 256 -> 256 layers, possibly fed by this (narrow) layer?
+                const bool wide = u->ksteps2 == 0 && u->N > 224 && !(u->flags & F_OUT_F32) && u->src < 2 && u->dst < 2;
+                const int ks4 = (u->ksteps + 3) & ~3;                        // the fragment blob and the LOAD pad to whole chunks
+                const int lead_ks = (wide && u->res < 0 && ks4 <= 8) ? ks4 : 0;
+                const int i0 = i + (lead_ks != 0);
+                int run = 0, leaky = lead_ks != 0 && u->act == DHAUG_ACT_LRELU, alt = 1;
+                while (i0 + run < nunits && units[i0 + run].kind == U_GEMM && units[i0 + run].ksteps == 16 &&
+                       units[i0 + run].ksteps2 == 0 && units[i0 + run].N > 224 && !(units[i0 + run].flags & F_OUT_F32) &&
+                       units[i0 + run].src < 2 && units[i0 + run].dst < 2 && units[i0 + run].res < 2) {
+                    leaky |= units[i0 + run].act == DHAUG_ACT_LRELU;
+                    alt &= (units[i0 + run].res >= 0) == ((run & 1) == 1);
                     ++run;
                 }
                 if (run >= min_run) {
-                    if (leaky) gemm_stack<true>(u, run, smem, wave, lane);
-                    else gemm_stack<false>(u, run, smem, wave, lane);
-                    i += run - 1;
+                    UnitPtr f0 = units + i0, tu = f0 + run;
+                    const bool tail = i0 + run < nunits && tu->kind == U_GEMM && (tu->flags & F_OUT_F32) && tu->ksteps == 16 &&
+                                      tu->ksteps2 == 0 && tu->N <= 64 && tu->src < 2 && tu->dst < 2 && tu->res < 0;
+                    if (leaky) gemm_stack<true, false>(u, lead_ks, f0, run, tail, smem, wave, lane);
+                    else if (alt && !(run & 1)) gemm_stack<false, true>(u, lead_ks, f0, run, tail, smem, wave, lane);
+                    else gemm_stack<false, false>(u, lead_ks, f0, run, tail, smem, wave, lane);
+                    i = i0 + run - 1 + (tail ? 1 : 0);
                     __syncthreads();
+                    if (tail) {
+                        store_output(tu, smem, m0, M, tid);
+                        __syncthreads();
+                    }
                     continue;                                                // (stamps of the run's inner layers stay 0)
                 }
                 const int nslices = (u->N + 31) >> 5;

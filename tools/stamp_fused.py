@@ -11,16 +11,18 @@ args = synth_args(B, 256)
 fk = fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
 G = Fk_generator.Fk_Generator(fk, args, "cuda").cuda()
 D3 = Fk_discriminator.Fk_3D_Discriminator("cuda", args).cuda()
+D2 = Fk_discriminator.Fk_2D_Discriminator(args, 16).cuda()
+x2 = torch.randn(B, 16, 2, device="cuda") * 0.3
 z = torch.randn(B, 128, device="cuda"); x3 = torch.randn(B, 16, 3, device="cuda") * 0.3
 L = _lib.lib()
 N = 64 + 64
 buf = (ctypes.c_longlong * N)()
 with torch.no_grad():
-    for name, fn in (("G", lambda: fused.generator_head(G, z)), ("D3", lambda: fused.critic3d(D3, x3))):
+    for name, fn in (("G", lambda: fused.generator_head(G, z)), ("D3", lambda: fused.critic3d(D3, x3)), ("D2", lambda: fused.critic2d(D2, x2)), ("D3", lambda: fused.critic3d(D3, x3))):
         for _ in range(3): fn()
         torch.cuda.synchronize()
         L.dhaug_debug_mlp_stamps(buf, N)
         st = [buf[i] for i in range(N)]
-        idx = [i for i, v in enumerate(st) if v]
+        idx = [i for i, v in enumerate(st[:34]) if v]
         base = st[idx[0]]
         print(name, " ".join("%d:%d" % (i, st[i] - base) for i in idx))
