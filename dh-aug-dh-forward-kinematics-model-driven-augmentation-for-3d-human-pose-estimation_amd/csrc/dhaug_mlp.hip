@@ -114,8 +114,8 @@ __device__ __forceinline__ void load_chunk(const uint16_t* w1, const uint16_t* w
 //
 // Software pipeline, pinned with sched_barrier because hipcc otherwise interleaves the weight loads with the MFMAs
 // and then waits for the youngest load (vmcnt(0..2)) at every step:
-//   k-step k :  [4 ds_read_b128 of the activation fragments of k+1]  [8 global loads of chunk c+2, once per chunk]
-//               -- sched_barrier --   8 MFMAs (2 slices x 4 row tiles) on the fragments read during step k-1
+//   k-step k :  [4 ds_read_b128 of the activation fragments of k+2]  [8 global loads of chunk c+2, once per chunk]
+//               -- sched_barrier --   8 MFMAs (2 slices x 4 row tiles) on the fragments read during step k-2
 // NS = feature slices this wave really owns in this layer (2: slices wave and wave+4; 1: only slice wave -- layers
 // narrower than 160 features); waves with no slice skip the layer.
 // `ring` belongs to the caller: with PRELOADED the first two chunks are already in flight in ring[0], ring[1];
@@ -138,7 +138,8 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
     const int pbs2 = NCH1 < NCH ? buf_pitch_bytes(u->src2) : pbs1;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     constexpr int KT = NCH * MLP_CH;                            // k-steps in total
-    bf16x8 fx[2][MLP_MT];
+    bf16x8 fx[3][MLP_MT];                                       // activation fragments: read two k-steps ahead (one wave per
+                                                                // SIMD: nobody else hides the LDS latency)
     auto read_frags = [&](int k, bf16x8 (&f)[MLP_MT]) {              // k is a compile-time constant after unrolling
         const bool second = k >= NCH1 * MLP_CH;
         const unsigned char* src = second ? src2 : src1;
@@ -149,10 +150,11 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
             f[mt] = *reinterpret_cast<const bf16x8*>(src + chunk_off(32 * mt + r31, 2 * kk + h, pbs));
     };
     read_frags(0, fx[0]);
+    if (KT > 1) read_frags(1, fx[1]);
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
         const int c = k / MLP_CH, q = k % MLP_CH;
-        if (k + 1 < KT) read_frags(k + 1, fx[(k + 1) & 1]);
+        if (k + 2 < KT) read_frags(k + 2, fx[(k + 2) % 3]);
         if (q == 0) {
             if (c + 2 < NCH) {
                 if (c + 2 == 2) load_chunk<2 < NCH ? 2 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[2]);
@@ -168,7 +170,7 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
         for (int mt = 0; mt < MLP_MT; ++mt)
 #pragma unroll
             for (int t = 0; t < NS; ++t)
-                acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[c % 3][t][q], fx[k & 1][mt], k == 0 ? zero : acc[t][mt],
+                acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[c % 3][t][q], fx[k % 3][mt], k == 0 ? zero : acc[t][mt],
                                                                     0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
