@@ -517,6 +517,197 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ws_kernel(GemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 256-feature layers of the training path (M x K -> M x 256, K = 128 or 256, bf16 in / bf16 out, optional bias, bf16
+// residual, activation): HBM-bound (A, the residual and C once each), so the kernel is built to keep the memory
+// system busy rather than the matrix pipe:
+//   * one persistent workgroup per CU (4 waves, 512 registers each); wave w holds the weight rows of feature slices
+//     w and w+4 for the whole launch (weight-stationary, 2*KS fragments);
+//   * 64-row tiles, two LDS images each for the operand rows and the residual rows.  The rows of tile i+1 travel
+//     global -> LDS without touching registers (global_load_lds_dwordx4) while tile i is computed; the swizzle is
+//     applied on the global side (lane p of a row fetches chunk p ^ (row & 15); its LDS slot is fixed by the lane);
+//   * the residual joins on the matrix pipe (two identity k-steps per slice against its LDS image), the bias seeds
+//     the accumulators; the epilogue packs to bf16 into an LDS image that the workgroup then streams out as whole
+//     512-byte rows;
+//   * barriers order LDS traffic only; the one vmcnt(0) per tile sits after the tile's MFMAs, where the copy issued
+//     before them has had the whole tile to land.
+// LDS: 2 x 32 KB operand images + 2 x 32 KB residual images + 32 KB output image = 160 KB, 16-byte chunks XOR-swizzled
+// by row & 15 (conflict-free ds_read_b128 fragment reads).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int F_BM = 64, F_PITCH = 512, F_IMG = F_BM * F_PITCH;             // 32 768 bytes per image
+constexpr int F_LDS_BYTES = 5 * F_IMG;
+
+__device__ __forceinline__ void f_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ uint32_t f_pack_bf16x2(float a, float b) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2));
+}
+
+__device__ __forceinline__ void f_copy16(const void* g, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
+                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
+template <int KS, bool RES>
+__global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmArgs p) {
+    static_assert(KS == 8 || KS == 16, "K = 128 or 256");
+    constexpr int S = 2 * KS;                                                // 16-byte chunks per operand row
+    constexpr int XP = S * 16;                                               // operand image pitch (bytes)
+    constexpr int RCH = F_BM * 32 / 256;                                     // output chunks per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sX = smem;                                                // [2][F_IMG]
+    unsigned char* sR = smem + 2 * F_IMG;                                    // [2][F_IMG]
+    unsigned char* sO = smem + 4 * F_IMG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r31 = lane & 31, h = lane >> 5, x = lane & 15;
+    const long long mtiles = p.M / F_BM, g = gridDim.x;
+
+    auto copy_tile = [&](long long mt, int buf) {                            // asynchronous: counted in vmcnt
+        const long long m0 = (mt < mtiles ? mt : mtiles - 1) * F_BM;         // tiles past the end re-read the last one
+        {
+            constexpr int RW = 1024 / XP;                                    // rows per wave instruction
+#pragma unroll
+            for (int i = 0; i < S / 4; ++i) {
+                const int row0 = (wave * (S / 4) + i) * RW, row = row0 + lane / S, c = (lane % S) ^ (row & 15);
+                f_copy16(p.A + (m0 + row) * p.lda + c * 8, sX + buf * F_IMG + row0 * XP);
+            }
+        }
+        if (RES) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row0 = (wave * 8 + i) * 2, row = row0 + (lane >> 5), c = (lane & 31) ^ (row & 15);
+                f_copy16(p.res + (m0 + row) * p.ld_res + c * 8, sR + buf * F_IMG + row0 * F_PITCH);
+            }
+        }
+    };
+    long long mt = blockIdx.x;
+    if (mt >= mtiles) return;
+    copy_tile(mt, 0);
+    copy_tile(mt + g, 1);
+
+    bf16x8 wf[2][KS];
+    f32x16 seed[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const uint16_t* wrow = p.B + (long long)(32 * (wave + 4 * t) + r31) * p.ldb + 8 * h;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) wf[t][k] = *reinterpret_cast<const bf16x8*>(wrow + 16 * k);
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias != nullptr) b4 = *reinterpret_cast<const f32x4*>(p.bias + 32 * (wave + 4 * t) + 4 * h + 8 * gq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) seed[t][4 * gq + e] = b4[e];
+        }
+    }
+    bf16x8 idf[2];                                                           // A[n][k'] = (n == 16 j + k'), k' = 8h + i
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int dd = r31 - 16 * j - 8 * h;
+        unsigned v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (dd == 2 * q ? 0x3F80u : 0u) | (dd == 2 * q + 1 ? 0x3F800000u : 0u);
+        const uint4 u = make_uint4(v[0], v[1], v[2], v[3]);
+        idf[j] = __builtin_bit_cast(bf16x8, u);
+    }
+    const float neg = p.act == DHAUG_ACT_RELU ? 0.0f : (p.act == DHAUG_ACT_LRELU ? p.slope : 1.0f);
+    const int lfx = r31 * XP | ((x >> 1) << 5) | ((h ^ (x & 1)) << 4);                   // ^ (k << 5): chunk 2k+h of row
+    const int lrx = (r31 * F_PITCH | ((x >> 1) << 5) | ((h ^ (x & 1)) << 4)) ^ (wave << 6);   // ^ (t << 8 | j << 5)
+    const int lep = r31 * F_PITCH | (((4 * wave) ^ x) << 4) | (h << 3);                  // ^ ((16t+g) << 4)
+    constexpr int XHALF = 32 * XP, HALF = 32 * F_PITCH;                                   // second 32-row half of an image
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f_lds_barrier();
+    int buf = 0;
+    for (; mt < mtiles; mt += g, buf ^= 1) {
+        const unsigned char* X = sX + buf * F_IMG;
+        const unsigned char* R = sR + buf * F_IMG;
+        f32x16 acc[2][2];
+        bf16x8 fx[4];
+        constexpr int NST = 2 * KS, D = 3;                                   // (half, k) steps; fragment prefetch distance
+        auto fx_load = [&](int st) { fx[st & 3] = *reinterpret_cast<const bf16x8*>(X + (lfx ^ ((st % KS) << 5)) + (st / KS) * XHALF); };
+#pragma unroll
+        for (int st = 0; st < D; ++st) fx_load(st);
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const int hf = st / KS, k = st % KS;
+            if (st + D < NST) fx_load(st + D);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                acc[hf][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][k], fx[st & 3], k == 0 ? seed[t] : acc[hf][t], 0, 0, 0);
+        }
+        if (RES) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const bf16x8 rf = *reinterpret_cast<const bf16x8*>(R + (lrx ^ (t << 8 | j << 5)) + hf * HALF);
+                        acc[hf][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(idf[j], rf, acc[hf][t], 0, 0, 0);
+                    }
+        }
+        // epilogue -> output image
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = acc[hf][t][4 * gq + e];
+                        v[e] = fmaxf(a, a * neg);
+                    }
+                    uint2 o;
+                    o.x = f_pack_bf16x2(v[0], v[1]);
+                    o.y = f_pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(sO + (lep ^ ((16 * t + gq) << 4)) + hf * HALF) = o;
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the next tile's rows have landed
+        f_lds_barrier();                                                     // output image complete; image buf is free
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 o[RCH];
+#pragma unroll
+        for (int i = 0; i < RCH; ++i) {
+            const int q = tid + 256 * i, row = q >> 5, c = q & 31;
+            o[i] = *reinterpret_cast<const u32x4*>(sO + row * F_PITCH + ((c ^ (row & 15)) << 4));
+        }
+        copy_tile(mt + 2 * g, buf);
+        f_lds_barrier();                                                     // output image free again
+        const long long m0 = mt * F_BM;
+#pragma unroll
+        for (int i = 0; i < RCH; ++i) {
+            const int q = tid + 256 * i, row = q >> 5, c = q & 31;
+            *reinterpret_cast<u32x4*>(p.cb + (m0 + row) * p.ldcb + c * 8) = o[i];
+        }
+    }
+}
+
+template <int KS>
+int launch_nt256(hipStream_t s, const GemmArgs& p) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<KS, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<KS, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    const long long mtiles = p.M / F_BM;
+    const unsigned grid = (unsigned)(mtiles < 256 ? mtiles : 256);
+    if (p.res != nullptr) hipLaunchKernelGGL((gemm_nt256_kernel<KS, true>), dim3(grid), dim3(256), F_LDS_BYTES, s, p);
+    else hipLaunchKernelGGL((gemm_nt256_kernel<KS, false>), dim3(grid), dim3(256), F_LDS_BYTES, s, p);
+    return dhaug_launch_status();
+}
+
 template <int KSTEPS>
 int launch_ws(hipStream_t s, const GemmArgs& p) {
     static bool configured = false;
@@ -571,6 +762,15 @@ int dhaug_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t l
     hipStream_t s = (hipStream_t)stream;
     const long long width = (c_bf16 && p.npad > N) ? p.npad : N;
     p.W = width;
+    // the training path's 256-wide layers
+    if (N == 256 && width == 256 && K <= 256 && M % F_BM == 0 && c_bf16 != nullptr && c_f32 == nullptr && residual_f32 == nullptr &&
+        (bias == nullptr || dhaug_aligned16(bias)) && getenv("DHAUG_GEMM_GENERIC") == nullptr && getenv("DHAUG_GEMM_NO256") == nullptr) {
+        switch (K / 16) {
+            case 8: return launch_nt256<8>(s, p);
+            case 16: return launch_nt256<16>(s, p);
+            default: break;
+        }
+    }
     if (width > 64 && K <= 256 && getenv("DHAUG_GEMM_GENERIC") == nullptr) {
         switch (K / 16) {
             case 1: return launch_ws<1>(s, p);

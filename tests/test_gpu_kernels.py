@@ -220,6 +220,39 @@ def test_gemm_nt_epilogues(ops, act, slope):
     assert maxabs(cf2, ref2) <= 3e-5 * ref2.abs().max().item()
 
 
+@pytest.mark.parametrize("M,K,act,slope,use_bias,use_res", [(4096, 256, 1, 0.0, True, True), (65536, 256, 2, 0.01, True, False),
+                                                            (192, 128, 0, 0.0, False, True), (64, 256, 1, 0.0, False, False),
+                                                            (33280, 128, 1, 0.0, True, True)])
+def test_gemm_nt_256wide(ops, M, K, act, slope, use_bias, use_res):
+    """The weight-stationary 256-feature kernel of the training path (rows copied global->LDS, residual on the matrix
+    pipe): bf16 output bit-identical to rounding the fp64 reference except where fp32 accumulation order moves a value
+    across a rounding boundary (<= 1 bf16 ulp), and identical to the generic kernel's within the same bound."""
+    import os
+    N = 256
+    gen = torch.Generator().manual_seed(M + K + act)
+    A = _bf(torch.randn(M, K, generator=gen)).cuda()
+    B = _bf(torch.randn(N, K, generator=gen) / K ** 0.5).cuda()
+    bias = torch.randn(N, generator=gen).cuda() if use_bias else None
+    res = _bf(torch.randn(M, N, generator=gen)).cuda() if use_res else None
+    z = A.float().cpu().double() @ B.float().cpu().double().t()
+    if use_bias:
+        z = z + bias.cpu().double()
+    if use_res:
+        z = z + res.float().cpu().double()
+    ref = z if act == 0 else (torch.relu(z) if act == 1 else torch.nn.functional.leaky_relu(z, slope))
+    cb, _ = ops.gemm_nt(A, B, N, K, bias=bias, res_bf16=res, act=act, slope=slope, out_bf16=True)
+    os.environ["DHAUG_GEMM_NO256"] = "1"
+    try:
+        cb_gen, _ = ops.gemm_nt(A, B, N, K, bias=bias, res_bf16=res, act=act, slope=slope, out_bf16=True)
+    finally:
+        os.environ.pop("DHAUG_GEMM_NO256")
+    scale = ref.abs().max().item()
+    assert cb.shape == (M, N)
+    assert maxabs(cb.float(), ref) <= 2.0 ** -8 * scale                     # one bf16 rounding of the result
+    assert maxabs(cb.float(), cb_gen.float()) <= 2.0 ** -7 * scale           # at most an ulp apart
+    assert (cb.float() != cb_gen.float()).float().mean().item() < 1e-3      # and almost always identical
+
+
 @pytest.mark.parametrize("terms,tol", [(3, 3e-5), (6, 2e-6)])
 def test_gemm_split_terms(ops, terms, tol):
     """x = hi + lo (3 products) / hi + mid + lo (6 products): bf16 MFMA passes that reproduce an fp32 product."""
