@@ -121,7 +121,7 @@ def main():
     def step_fwd():
         with torch.no_grad():
             fw = G(z).reshape(-1, 16, 3)
-            l3 = D3(ops.center_flip(fw, True, False))
+            l3 = D3(fw, center=True)
             _, p2 = ops.world_to_camera_project(fw, quat, trans, cam9, want3d=False)
             l2 = D2(p2)
         return l3, l2

@@ -15,6 +15,7 @@ SIGNATURES = {
     "dhaug_gen_tail_backward": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "dhaug_bone_length": [_vp, _vp, _i64, _vp],
     "dhaug_kcs_forward": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "dhaug_center_kcs_forward": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "dhaug_kcs_backward": [_vp, _vp, _vp, _i64, _i32, _vp],
     "dhaug_kcs_jvp": [_vp, _vp, _vp, _i64, _i32, _vp],
     "dhaug_world_to_camera_project": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],

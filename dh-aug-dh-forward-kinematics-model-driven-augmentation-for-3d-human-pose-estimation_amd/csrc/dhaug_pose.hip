@@ -50,7 +50,7 @@ __device__ __forceinline__ void bones(const V3* p, V3* b, float* len) {
 template <int MODE>
 __global__ __launch_bounds__(TILE) void kcs_forward_kernel(const float* __restrict__ pose, float* __restrict__ out_f32,
                                                            uint16_t* __restrict__ out_bf16, long long ld_bf16,
-                                                           int with_lengths, long long N) {
+                                                           int with_lengths, long long N, float* __restrict__ centered = nullptr) {
     __shared__ float lp[TILE * PS];
     __shared__ float lo[TILE * 31];
     const int lane = threadIdx.x;
@@ -64,6 +64,15 @@ __global__ __launch_bounds__(TILE) void kcs_forward_kernel(const float* __restri
         float len[15];
         load_joints(lp, lane < rows ? lane : 0, p);
         bones(p, b, len);
+        if (centered != nullptr) {                             // root-relative copy (the 3D critic's input), same pass
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                lp[lane * PS + 3 * j] = p[j].x - p[0].x; lp[lane * PS + 3 * j + 1] = p[j].y - p[0].y; lp[lane * PS + 3 * j + 2] = p[j].z - p[0].z;
+            }
+            __syncthreads();
+            rows_out<48, PS>(lp, centered + base * 48, rows, lane);
+        }
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < 15; ++i) lo[lane * 15 + i] = len[i];
@@ -387,6 +396,17 @@ int dhaug_kcs_forward(const float* pose16, float* out_f32, uint16_t* out_bf16, i
     }
     hipLaunchKernelGGL(kcs_forward_kernel<1>, dim3(grid1d((N + TILE - 1) / TILE, 1)), dim3(TILE), 0, (hipStream_t)stream,
                        pose16, out_f32, out_bf16, (long long)ld_bf16, with_lengths, (long long)N);
+    return dhaug_launch_status();
+}
+
+int dhaug_center_kcs_forward(const float* pose16, float* centered, uint16_t* out_bf16, int64_t ld_bf16, int64_t N,
+                             int with_lengths, void* stream) {
+    DHAUG_CHECK(N >= 0, DHAUG_EINVAL);
+    if (N == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(pose16); DHAUG_CHECK_PTR(centered); DHAUG_CHECK_PTR(out_bf16);
+    DHAUG_CHECK(ld_bf16 >= (with_lengths ? 30 : 15) && ld_bf16 % 8 == 0 && dhaug_aligned16(out_bf16), DHAUG_EALIGN);
+    hipLaunchKernelGGL(kcs_forward_kernel<1>, dim3(grid1d((N + TILE - 1) / TILE, 1)), dim3(TILE), 0, (hipStream_t)stream,
+                       pose16, (float*)nullptr, out_bf16, (long long)ld_bf16, with_lengths, (long long)N, centered);
     return dhaug_launch_status();
 }
 

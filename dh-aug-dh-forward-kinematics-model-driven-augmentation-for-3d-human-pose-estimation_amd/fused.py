@@ -187,9 +187,13 @@ def critic2d(D, x):
     return D._fused.run(dict(x=x), x.shape[0])
 
 
-def critic3d(D, x):
+def critic3d(D, x, center=False):
+    """center=True: x is a world/camera-space pose; its root-relative copy and the KCS operand come from one pass"""
     if not hasattr(D, "_fused"):
         D._fused = FusedNet(D, D3)
     x = x.reshape(-1, 48).contiguous()
-    _, kcs = ops.kcs_forward(x, True, f32=False, bf16_ld=32)
+    if center:
+        x, kcs = ops.center_kcs_forward(x, 32, True)
+    else:
+        _, kcs = ops.kcs_forward(x, True, f32=False, bf16_ld=32)
     return D._fused.run(dict(x=x, kcs=kcs), x.shape[0])[0]

@@ -107,6 +107,16 @@ def kcs_forward(pose16, with_lengths=True, f32=True, bf16_ld=0):
     return of, ob
 
 
+def center_kcs_forward(pose16, bf16_ld=32, with_lengths=True):
+    """root-relative pose (N,48) fp32 and the bf16 KCS operand of the 3D critic in one pass over the pose"""
+    x = _dev(pose16, torch.float32, "center_kcs_forward").reshape(-1, 48)
+    N = x.shape[0]
+    xc = torch.empty((N, 48), dtype=torch.float32, device=x.device)
+    ob = torch.empty((N, bf16_ld), dtype=BF16, device=x.device)
+    _lib.call("dhaug_center_kcs_forward", _p(x), _p(xc), _p(ob), bf16_ld, N, int(with_lengths), _stream())
+    return xc, ob
+
+
 def kcs_backward(pose16, grad_feat, with_lengths=True):
     x = _dev(pose16, torch.float32, "kcs_backward").reshape(-1, 48)
     g = _dev(grad_feat, torch.float32, "kcs_backward").reshape(x.shape[0], 30 if with_lengths else 15)

@@ -100,6 +100,12 @@ int dhaug_bone_length(const float* pose16, float* bone_len, int64_t N, void* str
 int dhaug_kcs_forward(const float* pose16, float* out_f32, uint16_t* out_bf16, int64_t ld_bf16,
                       int64_t N, int with_lengths, void* stream);
 
+/* The 3D critic's two inputs in one pass over the pose: centered (N,16,3) = pose16 - pose16[:,0] (the
+ * `inputs_3d - inputs_3d[:, :1]` at R/models_Fk_GAN/model_fk_gan_train.py critic calls) and the bf16 KCS operand of
+ * dhaug_kcs_forward (KCS is translation invariant, so it is the same feature the critic computes from `centered`). */
+int dhaug_center_kcs_forward(const float* pose16, float* centered, uint16_t* out_bf16, int64_t ld_bf16,
+                             int64_t N, int with_lengths, void* stream);
+
 /* VJP of dhaug_kcs_forward: grad_feat (N,30|15) fp32 -> grad_pose16 (N,16,3). */
 int dhaug_kcs_backward(const float* pose16, const float* grad_feat, float* grad_pose16, int64_t N,
                        int with_lengths, void* stream);

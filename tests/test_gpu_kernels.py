@@ -344,3 +344,15 @@ def test_random_bl_aug_golden(ops, golden):
     P, C = O.PA_PARENT, O.PA_CHILD
     L = (out[:, P] - out[:, C]).norm(dim=2).cpu()
     assert maxabs(L, torch.tensor(BL_TEMPLATES)[g["idx"].long()]) <= 2e-6
+
+
+@pytest.mark.parametrize("N", [1, 63, 64, 1000, 65536])
+def test_center_kcs_forward(ops, N):
+    """one pass = center_flip(center) + kcs_forward on the result, bit for bit"""
+    x = (GU.synth_pose16(N, seed=N) + torch.randn(N, 1, 3, generator=torch.Generator().manual_seed(N))).cuda()
+    xc, kb = ops.center_kcs_forward(x, 32, True)
+    ref_c = ops.center_flip(x, True, False).reshape(N, 48)
+    _, ref_k = ops.kcs_forward(x, True, f32=False, bf16_ld=32)
+    assert maxabs(xc, ref_c) == 0.0
+    assert torch.equal(kb.view(torch.int16), ref_k.view(torch.int16))
+    assert maxabs(xc.reshape(N, 16, 3), (x - x[:, :1]).cpu()) == 0.0

@@ -292,6 +292,9 @@ def test_fused_forward_matches_layerwise(M, D, B):
     sd3 = {k: v.detach().cpu() for k, v in D3.state_dict().items()}
     r3 = O.d3_forward(x3.cpu(), sd3, precision="bf16")
     assert maxabs(l3_f, r3) <= 2e-2 * r3.abs().max().item()          # bf16 chains: measured against the logit scale
+    # centring folded into the KCS pass
+    xw = x3 + 0.3
+    assert maxabs(D3(xw, center=True), fused.critic3d(D3, (xw - xw[:, :1]))) <= 2e-2 * l3_l.abs().max().item() + 1e-6
     # weights change -> the packed fragments are rebuilt
     with torch.no_grad():
         D2.layer_pred.bias.add_(1.0)
