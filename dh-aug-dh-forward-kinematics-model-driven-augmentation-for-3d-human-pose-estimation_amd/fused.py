@@ -18,8 +18,9 @@ _vp = ctypes.c_void_p
 
 
 def supported(*dims):
-    """hidden widths the fused kernel handles: whole 64-column chunks, at most 256 (three LDS buffers)"""
-    return all(d <= 256 and d % 64 == 0 for d in dims)
+    """hidden widths the fused kernel has layer shapes for (1, 2 or 4 chunks of 64 columns); other widths run layer by
+    layer"""
+    return all(d in (64, 128, 256) for d in dims)
 
 
 class _Layer:
