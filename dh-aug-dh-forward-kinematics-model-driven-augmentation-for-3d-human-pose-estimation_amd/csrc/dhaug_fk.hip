@@ -2,7 +2,7 @@
 //
 // Mapping: one wave (64 lanes) = one tile of 64 poses; one lane = one pose, whole skeleton in registers
 // (dhaug_fk_math.h).  A workgroup is a single wave so that LDS (the occupancy limiter here) is allocated
-// in 14.5 KB units: up to 10 workgroups per CU.
+// in small units: the forward kernels stage half tiles (6.3 KB per wave, 25 waves per CU).
 //
 // HBM <-> lane transposition goes through LDS: the tile's input rows are contiguous in memory
 // (64 x 37 angles, 64 x 15 lengths, 64 x 3 root), so the wave copies them with 16-byte-per-lane coalesced
@@ -82,6 +82,41 @@ __device__ __forceinline__ void load_pose(const float* __restrict__ l0, const fl
 
 constexpr int kTo32[16] = {0, 1, 2, 3, 6, 7, 8, 12, 13, 15, 17, 18, 19, 25, 26, 27};
 
+// Global rows <-> lanes through a HALF-tile LDS image (32 rows): the two halves of the wave take turns, all 64 lanes
+// copy.  Halving the image is what sets the occupancy of these kernels: 64 x 55 input floats + padding cost 14.8 KB per
+// wave (10 waves per CU, VALU 55 % busy, 69 % of wave time waiting); 32 x 49 floats are 6.3 KB (25 waves per CU).
+template <int W>
+__device__ __forceinline__ void rows_to_lanes(const float* __restrict__ g, float* __restrict__ lds, int rows, int lane,
+                                              float* __restrict__ v) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int nr = rows - 32 * half < 0 ? 0 : (rows - 32 * half > 32 ? 32 : rows - 32 * half);
+        stage_in(g + 32 * half * W, lds, nr * W, lane);
+        __syncthreads();
+        if ((lane >> 5) == half) {
+            const int r = (lane & 31) < nr ? (lane & 31) : 0;      // idle lanes recompute a valid row (never stored)
+#pragma unroll
+            for (int j = 0; j < W; ++j) v[j] = lds[r * W + j];
+        }
+        __syncthreads();
+    }
+}
+template <int W, int S>
+__device__ __forceinline__ void lanes_to_rows(const float* __restrict__ v, float* __restrict__ lds, float* __restrict__ g,
+                                              int rows, int lane) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int nr = rows - 32 * half < 0 ? 0 : (rows - 32 * half > 32 ? 32 : rows - 32 * half);
+        if ((lane >> 5) == half) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) lds[(lane & 31) * S + j] = v[j];
+        }
+        __syncthreads();
+        stage_out<W, S>(lds, g + 32 * half * W, nr, lane);
+        __syncthreads();
+    }
+}
+
 template <int MODE, int OUTJ, bool PREANGLE>
 __global__ __launch_bounds__(TILE) void fk_forward_kernel(const float* __restrict__ in0,
                                                           const float* __restrict__ bone_len,
@@ -93,60 +128,53 @@ __global__ __launch_bounds__(TILE) void fk_forward_kernel(const float* __restric
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
     const long long ntiles = (N + TILE - 1) / TILE;
-    float* l0 = smem;                                          // 64 x W0
-    float* l1 = l0 + TILE * L::W0 + ((TILE * L::W0) & 3 ? 4 - ((TILE * L::W0) & 3) : 0);
-    float* l2 = l1 + TILE * 15;
     const bool has2 = in2 != nullptr;
 
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long base = tile * TILE;
         const int rows = (int)((N - base) < TILE ? (N - base) : TILE);
-        stage_in(in0 + base * L::W0, l0, rows * L::W0, lane);
-        stage_in(bone_len + base * 15, l1, rows * 15, lane);
-        if (has2) stage_in(in2 + base * L::W2, l2, rows * L::W2, lane);
-        __syncthreads();
+        float v0[L::W0], bl[15], v2[L::W2];
+        rows_to_lanes<L::W0>(in0 + base * L::W0, smem, rows, lane, v0);
+        rows_to_lanes<15>(bone_len + base * 15, smem, rows, lane, bl);
+#pragma unroll
+        for (int j = 0; j < L::W2; ++j) v2[j] = 0.0f;
+        if (has2) rows_to_lanes<L::W2>(in2 + base * L::W2, smem, rows, lane, v2);
 
-        float ang[37], bl[15], th[35];
+        float ang[37];
         V3 root, p[16];
-        const int src = lane < rows ? lane : 0;                // idle lanes recompute row 0 (never stored)
-        load_pose<MODE, PREANGLE>(l0, l1, l2, has2, src, ang, bl, root, th);
-        if (MODE == 0 && !has2) root = mk(0.f, 0.f, 0.f);
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 37; ++j) ang[j] = v0[j < L::W0 ? j : 0];
+            root = mk(v2[0], v2[1], v2[2]);
+        } else {
+            float th[35];
+#pragma unroll
+            for (int j = 0; j < 35; ++j) th[j] = tanh_acc(v0[j < L::W0 ? j : 0]);
+            tail_angles<PREANGLE>(th, ang);
+            root = mk(th[32] * 10.0f, th[33] * 10.0f, th[34] * 10.0f);
+#pragma unroll
+            for (int j = 0; j < 15; ++j)
+                bl[j] = kJitterCol[j] < 0 ? bl[j] : bl[j] * (1.0f + v2[kJitterCol[j] < 0 ? 0 : (kJitterCol[j] < L::W2 ? kJitterCol[j] : 0)]);
+        }
         fk_pose(ang, bl, p);
-        __syncthreads();                                       // all lanes have consumed the input image
 
-        float* lo = smem;
+        float o[OW];
         if (OUTJ == 16) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                lo[lane * OS + 3 * j + 0] = p[j].x + root.x;
-                lo[lane * OS + 3 * j + 1] = p[j].y + root.y;
-                lo[lane * OS + 3 * j + 2] = p[j].z + root.z;
-            }
+            for (int j = 0; j < 16; ++j) { o[3 * j] = p[j].x + root.x; o[3 * j + 1] = p[j].y + root.y; o[3 * j + 2] = p[j].z + root.z; }
         } else {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) {                     // rows the reference never writes stay = root
-                lo[lane * OS + 3 * j + 0] = root.x; lo[lane * OS + 3 * j + 1] = root.y; lo[lane * OS + 3 * j + 2] = root.z;
-            }
+            for (int j = 0; j < 32; ++j) { o[3 * j] = root.x; o[3 * j + 1] = root.y; o[3 * j + 2] = root.z; }   // rows the reference never writes stay = root
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const int s = kTo32[j];
-                lo[lane * OS + 3 * s + 0] = p[j].x + root.x;
-                lo[lane * OS + 3 * s + 1] = p[j].y + root.y;
-                lo[lane * OS + 3 * s + 2] = p[j].z + root.z;
+                const int sidx = kTo32[j];
+                o[3 * sidx] = p[j].x + root.x; o[3 * sidx + 1] = p[j].y + root.y; o[3 * sidx + 2] = p[j].z + root.z;
             }
             // slot 14 ('Neck/Nose') = slot 15 ('Head'), forward_kinematics_DH_model.py:787-793
-            lo[lane * OS + 42] = p[9].x + root.x; lo[lane * OS + 43] = p[9].y + root.y; lo[lane * OS + 44] = p[9].z + root.z;
+            o[42] = p[9].x + root.x; o[43] = p[9].y + root.y; o[44] = p[9].z + root.z;
         }
-        __syncthreads();
-        stage_out<OW, OS>(lo, out + base * OW, rows, lane);
-        if (MODE == 1 && angles_out != nullptr) {
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 37; ++j) lo[lane * 37 + j] = ang[j];
-            __syncthreads();
-            stage_out<37, 37>(lo, angles_out + base * 37, rows, lane);
-        }
-        __syncthreads();
+        lanes_to_rows<OW, OS>(o, smem, out + base * OW, rows, lane);
+        if (MODE == 1 && angles_out != nullptr) lanes_to_rows<37, 37>(ang, smem, angles_out + base * 37, rows, lane);
     }
 }
 
@@ -234,8 +262,8 @@ int launch_tiles(K kernel, size_t lds_bytes, long long N, void* stream, Args... 
     return dhaug_launch_status();
 }
 
-constexpr size_t fwd_lds(int w_in, int w_out) {
-    size_t a = (size_t)TILE * (w_in + 3) * 4, b = (size_t)TILE * (w_out + 1) * 4;   // +3: 16-byte padding slack
+constexpr size_t fwd_lds(int w_in, int w_out) {                                    // half-tile images (rows_to_lanes)
+    size_t a = (size_t)(TILE / 2) * (w_in + 1) * 4, b = (size_t)(TILE / 2) * (w_out + 1) * 4;
     return a > b ? a : b;
 }
 
@@ -252,9 +280,9 @@ int dhaug_fk_forward(const float* angles, const float* bone_len, const float* ro
     DHAUG_CHECK(dhaug_aligned16(angles) && dhaug_aligned16(bone_len) && dhaug_aligned16(root) && dhaug_aligned16(out),
                 DHAUG_EALIGN);
     if (out_joints == 16)
-        return launch_tiles(fk_forward_kernel<0, 16, true>, fwd_lds(55, 48), N, stream, angles, bone_len, root, out,
+        return launch_tiles(fk_forward_kernel<0, 16, true>, fwd_lds(37, 48), N, stream, angles, bone_len, root, out,
                             (float*)nullptr);
-    return launch_tiles(fk_forward_kernel<0, 32, true>, fwd_lds(55, 96), N, stream, angles, bone_len, root, out,
+    return launch_tiles(fk_forward_kernel<0, 32, true>, fwd_lds(37, 96), N, stream, angles, bone_len, root, out,
                         (float*)nullptr);
 }
 
@@ -276,9 +304,9 @@ int dhaug_gen_tail_forward(const float* head, const float* bone_len, const float
     DHAUG_CHECK_PTR(head); DHAUG_CHECK_PTR(bone_len); DHAUG_CHECK_PTR(fake16);
     DHAUG_CHECK(dhaug_aligned16(head) && dhaug_aligned16(bone_len) && dhaug_aligned16(scaler), DHAUG_EALIGN);
     if (use_preangle)
-        return launch_tiles(fk_forward_kernel<1, 16, true>, fwd_lds(58, 48), N, stream, head, bone_len, scaler, fake16,
+        return launch_tiles(fk_forward_kernel<1, 16, true>, fwd_lds(37, 48), N, stream, head, bone_len, scaler, fake16,
                             angles_out);
-    return launch_tiles(fk_forward_kernel<1, 16, false>, fwd_lds(58, 48), N, stream, head, bone_len, scaler, fake16,
+    return launch_tiles(fk_forward_kernel<1, 16, false>, fwd_lds(37, 48), N, stream, head, bone_len, scaler, fake16,
                         angles_out);
 }
 
