@@ -9,10 +9,12 @@
 //     chunks XOR-swizzled by (row & 15) -> conflict-free ds_read_b128 of MFMA B-operand fragments;
 //   * weights: pre-packed on the host side in MFMA A-operand fragment order (dhaug_pack_wfrag): for every
 //     32-feature slice and 16-wide k-step one contiguous 1 KB block = 64 lanes x 16 B, so a wave's weight load is
-//     a perfectly coalesced global_load_dwordx4 served by L2; wave w owns feature slices w and w+4 of the layer and
-//     streams their fragments through a 3-slot register ring, 4 k-steps per slot, two slots ahead of the MFMAs
-//     (each fragment feeds 8 MFMAs: 2 slices x 4 row tiles); the first two slots of the NEXT layer are requested
-//     before the current layer's epilogue, so L2 latency hides behind MFMA work across layer boundaries too;
+//     a perfectly coalesced global_load_dwordx4 served by L2; wave w owns feature slices w and w+4 of the layer.
+//     Two execution paths share these images:
+//       - gemm_stack: runs of full-width layers (the residual stacks, the narrow layer feeding them, the output
+//         layer behind them) with register-resident weights and the epilogue riding the matrix pipe -- see there;
+//       - gemm_layer: any other layer, one at a time, fragments through a 3-slot register ring (4 k-steps per slot,
+//         two slots ahead of the MFMAs; each fragment feeds 8 MFMAs: 2 slices x 4 row tiles);
 //   * MFMA issued swapped (A = weights, B = activations): a lane of the 32x32 accumulator owns one batch row and
 //     4 consecutive features per register quad -> epilogue (bias, residual from LDS, ReLU/LeakyReLU, bf16 pack)
 //     writes 8 bytes per lane straight into the next layer's operand image.  In-place residual layers
@@ -118,19 +120,14 @@ __device__ __forceinline__ void load_chunk(const uint16_t* w1, const uint16_t* w
 //               -- sched_barrier --   8 MFMAs (2 slices x 4 row tiles) on the fragments read during step k-2
 // NS = feature slices this wave really owns in this layer (2: slices wave and wave+4; 1: only slice wave -- layers
 // narrower than 160 features); waves with no slice skip the layer.
-// `ring` belongs to the caller: with PRELOADED the first two chunks are already in flight in ring[0], ring[1];
-// `nxt` (may be null) is a following layer of the SAME shape whose first two chunks are requested right after the
-// last MFMA has issued, i.e. before this layer's epilogue and barrier (gemm_stack).
-template <int NCH, int NCH1, int NS, bool PRELOADED>
-__device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int wave, int lane, bf16x8 (&ring)[3][NS][MLP_CH],
-                                           UnitPtr nxt) {
+template <int NCH, int NCH1, int NS>
+__device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int wave, int lane) {
+    bf16x8 ring[3][NS][MLP_CH];
     const int r31 = lane & 31, h = lane >> 5;
     const uint16_t* w1 = u->w;
     const uint16_t* w2 = NCH1 < NCH ? u->w2 : u->w;
-    if constexpr (!PRELOADED) {
-        load_chunk<0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[0]);
-        if constexpr (NCH > 1) load_chunk<1, NCH, NCH1, NS>(w1, w2, wave, lane, ring[1]);
-    }
+    load_chunk<0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[0]);
+    if constexpr (NCH > 1) load_chunk<1, NCH, NCH1, NS>(w1, w2, wave, lane, ring[1]);
     f32x16 acc[NS][MLP_MT];
     const unsigned char* src1 = buf_base(smem, u->src);
     const int pbs1 = buf_pitch_bytes(u->src);
@@ -174,13 +171,6 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
                                                                     0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (nxt != nullptr) {                                       // the ring is dead: every MFMA of this layer has issued
-        const uint16_t* n1 = nxt->w;
-        const uint16_t* n2 = NCH1 < NCH ? nxt->w2 : nxt->w;
-        load_chunk<0, NCH, NCH1, NS>(n1, n2, wave, lane, ring[0]);
-        if constexpr (NCH > 1) load_chunk<1, NCH, NCH1, NS>(n1, n2, wave, lane, ring[1]);
-    }
-
     const int nslices = (u->N + 31) >> 5;
     const bool to_global = (u->flags & F_OUT_F32) != 0;
     unsigned char* dst = buf_base(smem, u->dst);
@@ -251,8 +241,7 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
 
 template <int NCH, int NCH1, int NS>
 __device__ __forceinline__ void gemm_single(UnitPtr u, unsigned char* smem, int wave, int lane) {
-    bf16x8 ring[3][NS][MLP_CH];
-    gemm_layer<NCH, NCH1, NS, false>(u, smem, wave, lane, ring, nullptr);
+    gemm_layer<NCH, NCH1, NS>(u, smem, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
