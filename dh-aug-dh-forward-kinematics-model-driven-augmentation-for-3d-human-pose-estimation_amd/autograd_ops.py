@@ -51,6 +51,7 @@ class _Packed:
 
 # Bumped by every optimizer step (the fused Adam kernel writes the masters through raw pointers, which torch's
 # version counter does not see); every packed copy made under an older epoch is stale.
+DIRECT_WGRAD = True       # LinearFn.backward may accumulate weight/bias gradients straight into FusedAdam's flat bucket
 WEIGHT_EPOCH = 0
 
 
@@ -145,11 +146,11 @@ def _raw_linear_t(g, W, prec, out_f32):
     return cf
 
 
-def _raw_outer(g, x, N, K, prec, colsum=None):
+def _raw_outer(g, x, N, K, prec, colsum=None, out=None):
     if prec == "bf16":
         gb = _operand(g, ceil16(N)) if g.dtype != BF16 else g
         xb = _operand(x, ceil16(K)) if x.dtype != BF16 else x
-        return ops.gemm_tn(gb, xb, N, K, colsum=colsum)
+        return ops.gemm_tn(gb, xb, N, K, colsum=colsum, out=out, accumulate=out is not None)
     Np, Kp, T = ceil16(N), ceil16(K), TERMS[prec]
     g3 = ops.split_bf16(g, 0, T, Np)          # activation-side layout: hi / mid / lo live in fixed segments
     x3 = ops.split_bf16(x, 0, T, Kp)
@@ -173,6 +174,8 @@ class LinearFn(torch.autograd.Function):
         y = _raw_linear(x, W, bias, res, act, slope, prec, out_f32)
         ctx.save_for_backward(x, W, y if act != ACT_NONE else None)
         ctx.cfg = (act, slope, prec, bias is not None, None if res is None else (res.dtype, res.shape))
+        # gradient slots of a FusedAdam flat bucket (set by the optimizer), see backward
+        ctx.slots = (getattr(W, "_dhaug_grad_slot", None), getattr(bias, "_dhaug_grad_slot", None) if bias is not None else None)
         return y
 
     @staticmethod
@@ -186,7 +189,15 @@ class LinearFn(torch.autograd.Function):
             gx = LinearTFn.apply(gz, W, prec, x.dtype != BF16)
         want_b = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            if want_b and prec == "bf16" and not torch.is_grad_enabled():
+            wslot, bslot = ctx.slots
+            if (DIRECT_WGRAD and prec == "bf16" and not torch.is_grad_enabled() and wslot is not None and W.grad is wslot
+                    and (not want_b or bslot is not None)):
+                # first-order pass under a FusedAdam bucket: the weight-gradient GEMM accumulates straight into the
+                # parameter's slot of the flat gradient (and the bias gradient, A^T * ones on the MFMA pipe, into the
+                # bias slot): no zero-fill of a temporary, no AccumulateGrad add.  autograd sees "no gradient" for W/b.
+                _raw_outer(gz, x, N, K, prec, colsum=bslot if want_b else None, out=wslot)
+                want_b = False
+            elif want_b and prec == "bf16" and not torch.is_grad_enabled():
                 # first-order pass: the weight-gradient GEMM also emits the bias gradient (A^T * ones on the MFMA pipe)
                 gb = torch.empty((N,), dtype=torch.float32, device=gz.device)
                 gW = _raw_outer(gz, x, N, K, prec, colsum=gb)

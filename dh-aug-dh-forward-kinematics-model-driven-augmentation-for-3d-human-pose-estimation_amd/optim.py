@@ -34,6 +34,7 @@ class FusedAdam(torch.optim.Optimizer):
             p.data = self.flat_param[off:off + k].view(p.shape)
             gv = self.flat_grad[off:off + k].view(p.shape)
             p.grad = gv
+            p._dhaug_grad_slot = gv             # autograd_ops.LinearFn.backward accumulates into it directly
             self._views.append(gv)
             off += k
         self.step_count = 0
