@@ -324,6 +324,111 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Weight gradients of the training path's regular shapes (N1, N2 multiples of 64, batch slice a multiple of 128 rows):
+// same 64 x 64 output tiles and XCD-local slices as gemm_tn_kernel, but the operand rows travel global -> LDS without
+// registers (global_load_lds_dwordx4), 128 rows per stage, two stages in flight, and the barriers order LDS traffic
+// only -- the register-staged loop above drains its own prefetch at every __syncthreads().
+// LDS stage: [128 rows][64 cols] bf16, rows contiguous (the copy fixes a lane's LDS slot), 16-byte chunk c of row r
+// stored at position c ^ (4 * ((r >> 1) & 1)): the four rows x four column groups of a transpose-read then cover all
+// 64 banks once (the copy applies the permutation on the global side).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void f_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ uint32_t f_pack_bf16x2(float a, float b) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2));
+}
+
+__device__ __forceinline__ void f_copy16(const void* g, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
+                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
+constexpr int TF_ROWS = 128;                                    // contraction rows per stage
+constexpr int TF_STAGE = TF_ROWS * 128;                         // bytes per operand stage
+__device__ __forceinline__ int tf_sw(int row) { return ((row >> 1) & 1) << 2; }
+
+__device__ __forceinline__ bf16x8 tf_frag(const unsigned char* stage, int kbase, int col0, int lane) {
+    const int li = lane & 15, q = li >> 2, pp = li & 3;
+    const int c = (col0 >> 3) + (pp >> 1), in = (pp & 1) << 3;
+    const int r0 = kbase + q, r1 = r0 + 4;
+    typedef bf16x4 __attribute__((address_space(3))) * lds_ptr;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(stage + r0 * 128 + ((c ^ tf_sw(r0)) << 4) + in));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(stage + r1 * 128 + ((c ^ tf_sw(r1)) << 4) + in));
+    bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn64_kernel(TnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];       // [2 stages][A | B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w1 = wave >> 1, w2 = wave & 1;                    // 2 x 2 waves, one 32 x 32 MFMA tile each
+    const long long nt2 = p.N2 / TN_BN;
+    long long tile, split;
+    if ((p.nsplits & 7) == 0) {
+        const long long xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        tile = local % p.ntiles;
+        split = xcd + 8 * (local / p.ntiles);
+    } else {
+        tile = blockIdx.x % p.ntiles;
+        split = blockIdx.x / p.ntiles;
+    }
+    const long long n1_0 = (tile / nt2) * TN_BN, n2_0 = (tile % nt2) * TN_BN;
+    const long long ms = split * p.rows_per_split;
+    long long me = ms + p.rows_per_split;
+    if (me > p.M) me = p.M;
+    if (ms >= me) return;
+    const int nst = (int)((me - ms) / TF_ROWS);                 // whole stages (checked on the host)
+
+    auto copy_stage = [&](int st, int buf) {                    // asynchronous: 8 copies per lane, counted in vmcnt
+        const long long m0 = ms + (long long)st * TF_ROWS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row0 = (wave * 4 + i) * 8, row = row0 + (lane >> 3), c = (lane & 7) ^ tf_sw(row);
+            f_copy16(p.A + (m0 + row) * p.lda + n1_0 + c * 8, tsm + buf * 2 * TF_STAGE + row0 * 128);
+            f_copy16(p.B + (m0 + row) * p.ldb + n2_0 + c * 8, tsm + buf * 2 * TF_STAGE + TF_STAGE + row0 * 128);
+        }
+    };
+    f32x16 acc, accs;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; accs[r] = 0.0f; }
+    const bool do_cs = p.colsum != nullptr && (tile % nt2) == 0 && w2 == 0;
+    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const int grp = lane >> 4;                                  // 16-lane group: columns 16*(grp&1), k half grp>>1
+
+    copy_stage(0, 0);
+    if (nst > 1) copy_stage(1, 1);
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // this stage landed, the next may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        f_lds_barrier();
+        const unsigned char* sa = tsm + buf * 2 * TF_STAGE;
+        const unsigned char* sb = sa + TF_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < TF_ROWS / 16; ++ks) {
+            const int kbase = 16 * ks + 8 * (grp >> 1);
+            const bf16x8 fa = tf_frag(sa, kbase, w1 * 32 + 16 * (grp & 1), lane);
+            const bf16x8 fb = tf_frag(sb, kbase, w2 * 32 + 16 * (grp & 1), lane);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+            if (do_cs) accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, ones, accs, 0, 0, 0);
+        }
+        f_lds_barrier();                                        // every wave is done with this stage
+        if (st + 2 < nst) copy_stage(st + 2, buf);
+    }
+    const long long n2 = n2_0 + w2 * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long long n1 = n1_0 + w1 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        atomicAdd(p.C + n1 * p.ldc + n2, acc[r]);
+        if (do_cs && (lane & 31) == 0) atomicAdd(p.colsum + n1, accs[r]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Weight-stationary NT kernel for the layer shapes of this path (M = batch, huge; N <= a few hundred; K <= 256).
 //
 // The first version above is bound by exposed global-load latency (its time is flat in K).  Here a workgroup
@@ -536,20 +641,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ws_kernel(GemmArgs p) {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int F_BM = 64, F_PITCH = 512, F_IMG = F_BM * F_PITCH;             // 32 768 bytes per image
 constexpr int F_LDS_BYTES = 5 * F_IMG;
-
-__device__ __forceinline__ void f_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-__device__ __forceinline__ uint32_t f_pack_bf16x2(float a, float b) {
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const f2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2));
-}
-
-__device__ __forceinline__ void f_copy16(const void* g, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
-                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
-}
 
 template <int KS, bool RES>
 __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmArgs p) {
@@ -829,6 +920,24 @@ int dhaug_gemm_tn_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
     if (rows < 4 * BK) rows = 4 * BK;
     splits = (M + rows - 1) / rows;
     if (splits > 8) splits = (splits + 7) / 8 * 8;              // multiple of 8: XCD-local tile groups (empty slices exit)
+    if (N1 % TN_BN == 0 && N2 % TN_BN == 0 && M % TF_ROWS == 0 && M >= 4 * TF_ROWS && getenv("DHAUG_GEMM_GENERIC") == nullptr) {
+        long long sp = 512 / tiles;                              // two resident workgroups per CU (LDS 64 KB each)
+        if (sp < 1) sp = 1;
+        long long r2 = ((M + sp - 1) / sp + TF_ROWS - 1) / TF_ROWS * TF_ROWS;
+        if (r2 < 2 * TF_ROWS) r2 = 2 * TF_ROWS;
+        sp = (M + r2 - 1) / r2;
+        if (sp > 8) sp = (sp + 7) / 8 * 8;
+        static bool configured = false;
+        if (!configured) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn64_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TF_STAGE);
+            if (e != hipSuccess) return (int)e;
+            configured = true;
+        }
+        TnArgs pf{A, lda, B, ldb, C, ldc, colsum_a, M, N1, N2, r2, tiles, sp};
+        hipLaunchKernelGGL(gemm_tn64_kernel, dim3((unsigned)(tiles * sp)), dim3(256), 4 * TF_STAGE, s, pf);
+        return dhaug_launch_status();
+    }
     TnArgs p{A, lda, B, ldb, C, ldc, colsum_a, M, N1, N2, rows, tiles, splits};
     hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, p);
     return dhaug_launch_status();
