@@ -25,6 +25,7 @@ SIGNATURES = {
     "dhaug_project_to_2d": [_vp, _vp, _vp, _i64, _vp],
     "dhaug_center_flip": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "dhaug_center_flip_backward": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    "dhaug_gemm_bf16_dmask": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _f32, _vp, _i64, _i64, _i64, _i64, _vp],
     "dhaug_gemm_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i32,
                         _f32, _vp],
     "dhaug_gemm_tn_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp],

@@ -302,6 +302,72 @@ class ReshapeGradFn(torch.autograd.Function):
         return ReshapeGradFn.apply(gg, ctx.info), None
 
 
+class ResBlockFn(torch.autograd.Function):
+    """y = act(fc2(act(fc1(x))) + x) for bf16 activations of width D (myResNet, R/models_Fk_GAN/special_operate.py:490-510).
+    First-order backward in 2 + 2 GEMM launches per block: the hidden layer's activation backward rides the epilogue of
+    the GEMM that produces its input gradient, the skip connection is that of the block's input gradient GEMM, and
+    weight / bias gradients go where LinearFn puts them.  Under create_graph (WGAN-GP) the backward is the composite
+    of the differentiable pieces, exactly what two LinearFn nodes would record."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, act, slope, prec):
+        h = _raw_linear(x, W1, b1, None, act, slope, prec, False)
+        y = _raw_linear(h, W2, b2, x, act, slope, prec, False)
+        ctx.save_for_backward(x, h, y, W1, W2)
+        ctx.cfg = (act, slope, prec)
+        ctx.slots = tuple(getattr(t, "_dhaug_grad_slot", None) for t in (W1, b1, W2, b2))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, h, y, W1, W2 = ctx.saved_tensors
+        act, slope, prec = ctx.cfg
+        D = W1.shape[0]
+        if torch.is_grad_enabled():                             # differentiable composite (double backward)
+            gz2 = ActBwdFn.apply(gy.contiguous(), y, act, slope)
+            gh = LinearTFn.apply(gz2, W2, prec, False)
+            gz1 = ActBwdFn.apply(gh, h, act, slope)
+            gx = LinearTFn.apply(gz1, W1, prec, False) + gz2
+            gW2 = OuterFn.apply(gz2, h, D, D, prec) if ctx.needs_input_grad[3] else None
+            gW1 = OuterFn.apply(gz1, x, D, D, prec) if ctx.needs_input_grad[1] else None
+            gb2 = ColSumFn.apply(gz2, D) if ctx.needs_input_grad[4] else None
+            gb1 = ColSumFn.apply(gz1, D) if ctx.needs_input_grad[2] else None
+            return gx, gW1, gb1, gW2, gb2, None, None, None
+        gy = gy.contiguous()
+        if gy.dtype != BF16:
+            gy = ops.cast_pad_bf16(gy, D)
+        gz2 = ops.act_backward(gy, y, act, slope)
+        gz1 = ops.gemm_nt_dmask(gz2, _w_nn(W2, prec), D, D, h, act, slope)              # (gz2 W2) * act'(h)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.gemm_nt_dmask(gz1, _w_nn(W1, prec), D, D, y, ACT_NONE, 0.0, res_bf16=gz2)   # gz1 W1 + gz2
+        grads = [None, None, None, None]                        # W1, b1, W2, b2
+        for k, (gz, inp, W) in enumerate(((gz1, x, W1), (gz2, h, W2))):
+            wslot, bslot = ctx.slots[2 * k], ctx.slots[2 * k + 1]
+            need_w, need_b = ctx.needs_input_grad[1 + 2 * k], ctx.needs_input_grad[2 + 2 * k]
+            if not need_w:
+                if need_b:
+                    grads[2 * k + 1] = ops.colsum(gz, N=D)
+                continue
+            if DIRECT_WGRAD and wslot is not None and W.grad is wslot and (not need_b or bslot is not None):
+                _raw_outer(gz, inp, D, D, prec, colsum=bslot if need_b else None, out=wslot)
+            else:
+                gb = torch.empty((D,), dtype=torch.float32, device=gz.device) if need_b else None
+                grads[2 * k] = _raw_outer(gz, inp, D, D, prec, colsum=gb)
+                grads[2 * k + 1] = gb
+        return gx, grads[0], grads[1], grads[2], grads[3], None, None, None
+
+
+def res_block(x, W1, b1, W2, b2, act=ACT_RELU, slope=0.0, prec="bf16"):
+    """myResNet forward; one autograd node when the activations are bf16 hidden states of a 16-aligned width"""
+    D = W1.shape[0]
+    if (prec == "bf16" and x.dtype == BF16 and x.is_cuda and W1.shape == (D, D) and W2.shape == (D, D) and D % 16 == 0
+            and x.shape[1] == D and b1 is not None and b2 is not None):
+        return ResBlockFn.apply(x, W1, b1, W2, b2, act, slope, prec)
+    h = linear(x, W1, b1, None, act, slope, prec)
+    return linear(h, W2, b2, x, act, slope, prec)
+
+
 def linear(x, W, bias=None, res=None, act=ACT_NONE, slope=0.0, prec="bf16", out_f32=False):
     return LinearFn.apply(x, W, bias, res, act, slope, prec, out_f32 or prec != "bf16")
 

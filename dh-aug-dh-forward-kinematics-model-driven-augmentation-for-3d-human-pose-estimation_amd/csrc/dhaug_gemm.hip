@@ -35,6 +35,7 @@ struct GemmArgs {
     float* cf; long long ldcf;
     long long M, N, K, W;          // W = output width covered by tiles (N, or the zero-padded width)
     int act; float slope;
+    const uint16_t* dmask; long long ld_dmask; float dneg;   // optional: result *= (dmask > 0 ? 1 : dneg)  (nt256 kernel only)
 };
 
 // branch-free activation: v > 0 ? v : v * neg, neg = 0 (ReLU) / slope (LeakyReLU) / 1 (identity)
@@ -642,8 +643,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ws_kernel(GemmArgs p) {
 constexpr int F_BM = 64, F_PITCH = 512, F_IMG = F_BM * F_PITCH;             // 32 768 bytes per image
 constexpr int F_LDS_BYTES = 5 * F_IMG;
 
-template <int KS, bool RES>
+// MODE 0: plain, 1: + bf16 residual, 2: result * act'(dmask) (the layer's output feeds an activation backward)
+template <int KS, int MODE>
 __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmArgs p) {
+    constexpr bool RES = MODE == 1, MASK = MODE == 2;
     static_assert(KS == 8 || KS == 16, "K = 128 or 256");
     constexpr int S = 2 * KS;                                                // 16-byte chunks per operand row
     constexpr int XP = S * 16;                                               // operand image pitch (bytes)
@@ -667,11 +670,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmArgs p) {
                 f_copy16(p.A + (m0 + row) * p.lda + c * 8, sX + buf * F_IMG + row0 * XP);
             }
         }
-        if (RES) {
+        if (RES || MASK) {                                       // the second image: residual rows or the mask source
+            const uint16_t* src = RES ? p.res : p.dmask;
+            const long long ld = RES ? p.ld_res : p.ld_dmask;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int row0 = (wave * 8 + i) * 2, row = row0 + (lane >> 5), c = (lane & 31) ^ (row & 15);
-                f_copy16(p.res + (m0 + row) * p.ld_res + c * 8, sR + buf * F_IMG + row0 * F_PITCH);
+                f_copy16(src + (m0 + row) * ld + c * 8, sR + buf * F_IMG + row0 * F_PITCH);
             }
         }
     };
@@ -755,6 +760,14 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmArgs p) {
                         const float a = acc[hf][t][4 * gq + e];
                         v[e] = fmaxf(a, a * neg);
                     }
+                    if (MASK) {                                              // this lane's 4 mask-source values (bf16)
+                        const uint2 y = *reinterpret_cast<const uint2*>(R + (lep ^ ((16 * t + gq) << 4)) + hf * HALF);
+                        const short y0 = (short)(y.x & 0xffffu), y1 = (short)(y.x >> 16), y2 = (short)(y.y & 0xffffu), y3 = (short)(y.y >> 16);
+                        v[0] = y0 > 0 ? v[0] : v[0] * p.dneg;                // a positive bf16 is a positive int16
+                        v[1] = y1 > 0 ? v[1] : v[1] * p.dneg;
+                        v[2] = y2 > 0 ? v[2] : v[2] * p.dneg;
+                        v[3] = y3 > 0 ? v[3] : v[3] * p.dneg;
+                    }
                     uint2 o;
                     o.x = f_pack_bf16x2(v[0], v[1]);
                     o.y = f_pack_bf16x2(v[2], v[3]);
@@ -784,18 +797,22 @@ template <int KS>
 int launch_nt256(hipStream_t s, const GemmArgs& p) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<KS, false>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<KS, 0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<KS, true>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<KS, 1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<KS, 2>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
     const long long mtiles = p.M / F_BM;
     const unsigned grid = (unsigned)(mtiles < 256 ? mtiles : 256);
-    if (p.res != nullptr) hipLaunchKernelGGL((gemm_nt256_kernel<KS, true>), dim3(grid), dim3(256), F_LDS_BYTES, s, p);
-    else hipLaunchKernelGGL((gemm_nt256_kernel<KS, false>), dim3(grid), dim3(256), F_LDS_BYTES, s, p);
+    if (p.dmask != nullptr) hipLaunchKernelGGL((gemm_nt256_kernel<KS, 2>), dim3(grid), dim3(256), F_LDS_BYTES, s, p);
+    else if (p.res != nullptr) hipLaunchKernelGGL((gemm_nt256_kernel<KS, 1>), dim3(grid), dim3(256), F_LDS_BYTES, s, p);
+    else hipLaunchKernelGGL((gemm_nt256_kernel<KS, 0>), dim3(grid), dim3(256), F_LDS_BYTES, s, p);
     return dhaug_launch_status();
 }
 
@@ -832,10 +849,11 @@ int launch_nt(Kern kern, long long grid, size_t lds, hipStream_t s, const GemmAr
 
 extern "C" {
 
-int dhaug_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias,
-                    const uint16_t* residual, int64_t ld_res, const float* residual_f32, int64_t ld_res_f32,
-                    uint16_t* c_bf16, int64_t ldc_bf16, int64_t n_pad_zero,
-                    float* c_f32, int64_t ldc_f32, int64_t M, int64_t N, int64_t K, int act, float slope, void* stream) {
+static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias,
+                          const uint16_t* residual, int64_t ld_res, const float* residual_f32, int64_t ld_res_f32,
+                          uint16_t* c_bf16, int64_t ldc_bf16, int64_t n_pad_zero,
+                          float* c_f32, int64_t ldc_f32, int64_t M, int64_t N, int64_t K, int act, float slope,
+                          const uint16_t* dmask, int64_t ld_dmask, float dneg, bool* mask_done, void* stream) {
     DHAUG_CHECK(M >= 0 && N >= 1 && K >= 16, DHAUG_EINVAL);
     DHAUG_CHECK(act >= DHAUG_ACT_NONE && act <= DHAUG_ACT_LRELU, DHAUG_EINVAL);
     if (M == 0) return DHAUG_OK;
@@ -849,13 +867,17 @@ int dhaug_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t l
     if (c_bf16) DHAUG_CHECK(ldc_bf16 % 8 == 0 && ldc_bf16 >= N && n_pad_zero <= ldc_bf16 && dhaug_aligned16(c_bf16), DHAUG_EALIGN);
     if (c_f32) DHAUG_CHECK(ldc_f32 >= N && ((ldc_f32 & 3) != 0 || dhaug_aligned16(c_f32)), DHAUG_EALIGN);
     GemmArgs p{A, lda, B, ldb, bias, residual, ld_res, residual_f32, ld_res_f32, c_bf16, ldc_bf16, c_bf16 ? (n_pad_zero > N ? n_pad_zero : N) : 0,
-               c_f32, ldc_f32, M, N, K, N, act, slope};
+               c_f32, ldc_f32, M, N, K, N, act, slope, nullptr, 0, 1.0f};
     hipStream_t s = (hipStream_t)stream;
     const long long width = (c_bf16 && p.npad > N) ? p.npad : N;
     p.W = width;
     // the training path's 256-wide layers
     if (N == 256 && width == 256 && K <= 256 && M % F_BM == 0 && c_bf16 != nullptr && c_f32 == nullptr && residual_f32 == nullptr &&
         (bias == nullptr || dhaug_aligned16(bias)) && getenv("DHAUG_GEMM_GENERIC") == nullptr && getenv("DHAUG_GEMM_NO256") == nullptr) {
+        if (dmask != nullptr && residual == nullptr && (K == 128 || K == 256)) {   // mask in the epilogue (second LDS image)
+            p.dmask = dmask; p.ld_dmask = ld_dmask; p.dneg = dneg;
+            *mask_done = true;
+        }
         switch (K / 16) {
             case 8: return launch_nt256<8>(s, p);
             case 16: return launch_nt256<16>(s, p);
@@ -890,6 +912,30 @@ int dhaug_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t l
         size_t lds = (size_t)2 * (BM + BN) * BK * 2, ctile = (size_t)BM * (BN + 4) * 4;
         return launch_nt(gemm_nt_kernel<BM, BN, 4, 1>, grid, lds > ctile ? lds : ctile, s, p);
     }
+}
+
+int dhaug_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias,
+                    const uint16_t* residual, int64_t ld_res, const float* residual_f32, int64_t ld_res_f32,
+                    uint16_t* c_bf16, int64_t ldc_bf16, int64_t n_pad_zero,
+                    float* c_f32, int64_t ldc_f32, int64_t M, int64_t N, int64_t K, int act, float slope, void* stream) {
+    bool done = false;
+    return gemm_bf16_impl(A, lda, B, ldb, bias, residual, ld_res, residual_f32, ld_res_f32, c_bf16, ldc_bf16, n_pad_zero, c_f32,
+                          ldc_f32, M, N, K, act, slope, nullptr, 0, 1.0f, &done, stream);
+}
+
+int dhaug_gemm_bf16_dmask(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* residual,
+                          int64_t ld_res, const uint16_t* dmask, int64_t ld_dmask, int dmask_act, float dmask_slope,
+                          uint16_t* c_bf16, int64_t ldc_bf16, int64_t M, int64_t N, int64_t K, void* stream) {
+    DHAUG_CHECK(dmask_act >= DHAUG_ACT_NONE && dmask_act <= DHAUG_ACT_LRELU, DHAUG_EINVAL);
+    DHAUG_CHECK_PTR(c_bf16);
+    if (dmask_act == DHAUG_ACT_NONE) dmask = nullptr;
+    if (dmask) DHAUG_CHECK(ld_dmask % 8 == 0 && ld_dmask >= N && dhaug_aligned16(dmask) && N % 8 == 0, DHAUG_EALIGN);
+    const float dneg = dmask_act == DHAUG_ACT_RELU ? 0.0f : dmask_slope;
+    bool done = false;
+    int rc = gemm_bf16_impl(A, lda, B, ldb, nullptr, residual, ld_res, nullptr, 0, c_bf16, ldc_bf16, N, nullptr, 0, M, N, K,
+                            DHAUG_ACT_NONE, 0.0f, dmask, ld_dmask, dneg, &done, stream);
+    if (rc != DHAUG_OK || dmask == nullptr || done || M == 0) return rc;
+    return dhaug_act_backward_bf16(c_bf16, ldc_bf16, dmask, ld_dmask, c_bf16, ldc_bf16, M, N, dmask_act, dmask_slope, stream);
 }
 
 int dhaug_gemm_tn_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,

@@ -19,8 +19,7 @@ class myResNet(nn.Module):
         self.fc2 = nn.Linear(DIM, DIM)
 
     def forward(self, input, prec="bf16"):
-        h = A.linear(input, self.fc1.weight, self.fc1.bias, None, A.ACT_RELU, 0.0, prec)
-        return A.linear(h, self.fc2.weight, self.fc2.bias, input, A.ACT_RELU, 0.0, prec)
+        return A.res_block(input, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, A.ACT_RELU, 0.0, prec)
 
 
 def Fk_get_boneVecByPose3d(x, num_joints=16):

@@ -246,6 +246,17 @@ def gemm_nt(A, B, N, K, bias=None, res_bf16=None, res_f32=None, act=0, slope=0.0
     return cb, cf
 
 
+def gemm_nt_dmask(A, B, N, K, dmask, dmask_act, dmask_slope=0.0, res_bf16=None):
+    """(A[M,K] B[N,K]^T + res) * act'(dmask): input gradient of a layer + activation backward of its producer, bf16 (M,N)"""
+    assert A.dtype == BF16 and B.dtype == BF16 and dmask.dtype == BF16 and N % 8 == 0
+    M = A.shape[0]
+    out = torch.empty((M, N), dtype=BF16, device=A.device)
+    _lib.call("dhaug_gemm_bf16_dmask", _p(A), A.stride(0), _p(B), B.stride(0), _p(res_bf16),
+              0 if res_bf16 is None else res_bf16.stride(0), _p(dmask), dmask.stride(0), dmask_act, float(dmask_slope),
+              _p(out), N, M, N, K, _stream())
+    return out
+
+
 def gemm_tn(A, B, N1, N2, out=None, accumulate=False, M=None, lda=None, ldb=None, colsum=None):
     """C[N1,N2] (+)= A[M,N1]^T B[M,N2], bf16 operands, fp32 result; colsum (fp32 [N1], optional) (+)= column sums of A."""
     assert A.dtype == BF16 and B.dtype == BF16

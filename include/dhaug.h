@@ -178,6 +178,16 @@ int dhaug_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t l
                     float* c_f32, int64_t ldc_f32,
                     int64_t M, int64_t N, int64_t K, int act, float slope, void* stream);
 
+/* Input gradient of a layer whose input came out of an activation, in one pass:
+ *   c_bf16[M,N] = ( A[M,K] * B[N,K]^T + residual[M,N] ) * act'(dmask[M,N])      act'(y) = y > 0 ? 1 : (ReLU 0 | LeakyReLU slope)
+ * i.e. LinearT followed by the activation backward of the producing layer (the `loss.backward()` of
+ * R/models_Fk_GAN/special_operate.py:490-510 myResNet: gh * relu'(h)); dmask_act = DHAUG_ACT_NONE gives the plain
+ * product.  256-wide layers apply the mask in the GEMM epilogue, other shapes run the GEMM and
+ * dhaug_act_backward_bf16 in place. */
+int dhaug_gemm_bf16_dmask(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* residual,
+                          int64_t ld_res, const uint16_t* dmask, int64_t ld_dmask, int dmask_act, float dmask_slope,
+                          uint16_t* c_bf16, int64_t ldc_bf16, int64_t M, int64_t N, int64_t K, void* stream);
+
 /* Weight-gradient GEMM: C[N1,N2] (+)= A[M,N1]^T * B[M,N2], contraction over the batch dimension M
  * (split across workgroups, fp32 atomics into C).  bf16 operands, fp32 result.  `accumulate` != 0 adds
  * into C, otherwise C is overwritten (zeroed by the library on the stream first).  colsum_a (optional, fp32 [N1])

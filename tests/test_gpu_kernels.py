@@ -356,3 +356,24 @@ def test_center_kcs_forward(ops, N):
     assert maxabs(xc, ref_c) == 0.0
     assert torch.equal(kb.view(torch.int16), ref_k.view(torch.int16))
     assert maxabs(xc.reshape(N, 16, 3), (x - x[:, :1]).cpu()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K,act,slope,use_res", [(4096, 256, 256, 1, 0.0, False), (4096, 256, 256, 2, 0.01, False),
+                                                   (1024, 256, 128, 1, 0.0, True), (1000, 104, 256, 1, 0.0, False)])
+def test_gemm_nt_dmask(ops, M, N, K, act, slope, use_res):
+    """(A B^T + res) * act'(y): mask in the 256-wide kernel's epilogue, GEMM + dhaug_act_backward_bf16 elsewhere"""
+    gen = torch.Generator().manual_seed(M + N + act)
+    A = _bf(torch.randn(M, K, generator=gen)).cuda()
+    B = _bf(torch.randn(N, K, generator=gen) / K ** 0.5).cuda()
+    y = _bf(torch.randn(M, N, generator=gen)).cuda()
+    y[::7, ::5] = 0.0                                            # exact zeros take the "negative" branch, as in act_backward
+    res = _bf(torch.randn(M, N, generator=gen)).cuda() if use_res else None
+    z = A.float().cpu().double() @ B.float().cpu().double().t()
+    if use_res:
+        z = z + res.float().cpu().double()
+    neg = 0.0 if act == 1 else slope
+    ref = torch.where(y.float().cpu() > 0, z, z * neg)
+    out = ops.gemm_nt_dmask(A, B, N, K, y, act, slope, res_bf16=res)
+    assert out.shape == (M, N)
+    assert maxabs(out.float(), ref) <= 2.0 ** -7 * ref.abs().max().item()
+    assert (out.float().cpu()[y.float().cpu() <= 0].abs().max().item() == 0.0) if act == 1 else True
