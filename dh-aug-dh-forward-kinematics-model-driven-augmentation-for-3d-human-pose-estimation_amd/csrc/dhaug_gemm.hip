@@ -348,25 +348,35 @@ __device__ __forceinline__ void f_copy16(const void* g, unsigned char* lds_wave_
 }
 
 constexpr int TF_ROWS = 128;                                    // contraction rows per stage
-constexpr int TF_STAGE = TF_ROWS * 128;                         // bytes per operand stage
-__device__ __forceinline__ int tf_sw(int row) { return ((row >> 1) & 1) << 2; }
 
+// fragment of 8 contraction rows x 16 columns from a stage whose rows hold CH 16-byte chunks (CH = 8: 64 columns,
+// chunk c of row r at position c ^ (4 * ((r >> 1) & 1)); CH = 16: 128 columns, position c ^ (4 * (r & 3))): in both
+// layouts the four rows x four column groups of a transpose-read cover all 64 banks once
+template <int CH>
+__device__ __forceinline__ int tf_sw(int row) { return CH == 8 ? ((row >> 1) & 1) << 2 : (row & 3) << 2; }
+
+template <int CH>
 __device__ __forceinline__ bf16x8 tf_frag(const unsigned char* stage, int kbase, int col0, int lane) {
     const int li = lane & 15, q = li >> 2, pp = li & 3;
     const int c = (col0 >> 3) + (pp >> 1), in = (pp & 1) << 3;
     const int r0 = kbase + q, r1 = r0 + 4;
     typedef bf16x4 __attribute__((address_space(3))) * lds_ptr;
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(stage + r0 * 128 + ((c ^ tf_sw(r0)) << 4) + in));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(stage + r1 * 128 + ((c ^ tf_sw(r1)) << 4) + in));
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(stage + r0 * (CH * 16) + ((c ^ tf_sw<CH>(r0)) << 4) + in));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(stage + r1 * (CH * 16) + ((c ^ tf_sw<CH>(r1)) << 4) + in));
     bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return f;
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn64_kernel(TnArgs p) {
+// TM x 64 output tile (TM = 64 or 128 rows of C = columns of A), one batch slice.
+template <int TM>
+__global__ __launch_bounds__(256, TM == 64 ? 2 : 1) void gemm_tn64_kernel(TnArgs p) {
+    constexpr int CHA = TM / 8, RT = TM / 64;                   // chunks per A row, MFMA row tiles per wave
+    constexpr int SA = TF_ROWS * TM * 2, SB = TF_ROWS * 128;    // stage bytes
+    constexpr int NCOPY = (TF_ROWS * CHA + TF_ROWS * 8) / 256;  // copies per lane and stage
     extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];       // [2 stages][A | B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w1 = wave >> 1, w2 = wave & 1;                    // 2 x 2 waves, one 32 x 32 MFMA tile each
+    const int w1 = wave >> 1, w2 = wave & 1;                    // 2 x 2 waves: rows [RT*32*w1, ...), columns [32*w2, +32)
     const long long nt2 = p.N2 / TN_BN;
     long long tile, split;
     if ((p.nsplits & 7) == 0) {
@@ -377,25 +387,33 @@ __global__ __launch_bounds__(256, 2) void gemm_tn64_kernel(TnArgs p) {
         tile = blockIdx.x % p.ntiles;
         split = blockIdx.x / p.ntiles;
     }
-    const long long n1_0 = (tile / nt2) * TN_BN, n2_0 = (tile % nt2) * TN_BN;
+    const long long n1_0 = (tile / nt2) * TM, n2_0 = (tile % nt2) * TN_BN;
     const long long ms = split * p.rows_per_split;
     long long me = ms + p.rows_per_split;
     if (me > p.M) me = p.M;
     if (ms >= me) return;
     const int nst = (int)((me - ms) / TF_ROWS);                 // whole stages (checked on the host)
 
-    auto copy_stage = [&](int st, int buf) {                    // asynchronous: 8 copies per lane, counted in vmcnt
+    auto copy_stage = [&](int st, int buf) {                    // asynchronous: NCOPY copies per lane, counted in vmcnt
         const long long m0 = ms + (long long)st * TF_ROWS;
+        unsigned char* base = tsm + buf * (SA + SB);
+#pragma unroll
+        for (int i = 0; i < TF_ROWS * CHA / 256; ++i) {
+            constexpr int RW = 64 / CHA;                        // rows per wave instruction
+            const int row0 = (wave * (TF_ROWS * CHA / 256) + i) * RW, row = row0 + lane / CHA, c = (lane % CHA) ^ tf_sw<CHA>(row);
+            f_copy16(p.A + (m0 + row) * p.lda + n1_0 + c * 8, base + row0 * (CHA * 16));
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row0 = (wave * 4 + i) * 8, row = row0 + (lane >> 3), c = (lane & 7) ^ tf_sw(row);
-            f_copy16(p.A + (m0 + row) * p.lda + n1_0 + c * 8, tsm + buf * 2 * TF_STAGE + row0 * 128);
-            f_copy16(p.B + (m0 + row) * p.ldb + n2_0 + c * 8, tsm + buf * 2 * TF_STAGE + TF_STAGE + row0 * 128);
+            const int row0 = (wave * 4 + i) * 8, row = row0 + (lane >> 3), c = (lane & 7) ^ tf_sw<8>(row);
+            f_copy16(p.B + (m0 + row) * p.ldb + n2_0 + c * 8, base + SA + row0 * 128);
         }
     };
-    f32x16 acc, accs;
+    f32x16 acc[RT], accs[RT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; accs[r] = 0.0f; }
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; accs[t][r] = 0.0f; }
     const bool do_cs = p.colsum != nullptr && (tile % nt2) == 0 && w2 == 0;
     const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
     const int grp = lane >> 4;                                  // 16-lane group: columns 16*(grp&1), k half grp>>1
@@ -404,29 +422,38 @@ __global__ __launch_bounds__(256, 2) void gemm_tn64_kernel(TnArgs p) {
     if (nst > 1) copy_stage(1, 1);
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1;
-        if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // this stage landed, the next may still fly
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (st + 1 < nst) {                                     // this stage landed, the next may still fly
+            if (NCOPY == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         f_lds_barrier();
-        const unsigned char* sa = tsm + buf * 2 * TF_STAGE;
-        const unsigned char* sb = sa + TF_STAGE;
+        const unsigned char* sa = tsm + buf * (SA + SB);
+        const unsigned char* sb = sa + SA;
 #pragma unroll
         for (int ks = 0; ks < TF_ROWS / 16; ++ks) {
             const int kbase = 16 * ks + 8 * (grp >> 1);
-            const bf16x8 fa = tf_frag(sa, kbase, w1 * 32 + 16 * (grp & 1), lane);
-            const bf16x8 fb = tf_frag(sb, kbase, w2 * 32 + 16 * (grp & 1), lane);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
-            if (do_cs) accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, ones, accs, 0, 0, 0);
+            const bf16x8 fb = tf_frag<8>(sb, kbase, w2 * 32 + 16 * (grp & 1), lane);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const bf16x8 fa = tf_frag<CHA>(sa, kbase, (w1 * RT + t) * 32 + 16 * (grp & 1), lane);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+                if (do_cs) accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, ones, accs[t], 0, 0, 0);
+            }
         }
         f_lds_barrier();                                        // every wave is done with this stage
         if (st + 2 < nst) copy_stage(st + 2, buf);
     }
     const long long n2 = n2_0 + w2 * 32 + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const long long n1 = n1_0 + w1 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        atomicAdd(p.C + n1 * p.ldc + n2, acc[r]);
-        if (do_cs && (lane & 31) == 0) atomicAdd(p.colsum + n1, accs[r]);
-    }
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long n1 = n1_0 + (w1 * RT + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            atomicAdd(p.C + n1 * p.ldc + n2, acc[t][r]);
+            if (do_cs && (lane & 31) == 0) atomicAdd(p.colsum + n1, accs[t][r]);
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -967,21 +994,30 @@ int dhaug_gemm_tn_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
     splits = (M + rows - 1) / rows;
     if (splits > 8) splits = (splits + 7) / 8 * 8;              // multiple of 8: XCD-local tile groups (empty slices exit)
     if (N1 % TN_BN == 0 && N2 % TN_BN == 0 && M % TF_ROWS == 0 && M >= 4 * TF_ROWS && getenv("DHAUG_GEMM_GENERIC") == nullptr) {
-        long long sp = 512 / tiles;                              // two resident workgroups per CU (LDS 64 KB each)
+        // 128 x 64 tiles (one workgroup per CU) re-read less from L2 but measured slower (35 vs 27 us at 65536 x 256 x 256):
+        // the loop is bound by requests in flight, not by L2 bandwidth.  Kept selectable for experiments.
+        const bool wide = N1 % 128 == 0 && getenv("DHAUG_TN_WIDE") != nullptr;
+        const long long tl = wide ? tiles / 2 : tiles;
+        long long sp = (wide ? 256 : 512) / tl;
         if (sp < 1) sp = 1;
         long long r2 = ((M + sp - 1) / sp + TF_ROWS - 1) / TF_ROWS * TF_ROWS;
         if (r2 < 2 * TF_ROWS) r2 = 2 * TF_ROWS;
         sp = (M + r2 - 1) / r2;
         if (sp > 8) sp = (sp + 7) / 8 * 8;
+        const int lds = wide ? 2 * (TF_ROWS * 256 + TF_ROWS * 128) : 2 * (TF_ROWS * 128 + TF_ROWS * 128);
         static bool configured = false;
         if (!configured) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn64_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TF_STAGE);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn64_kernel<64>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TF_ROWS * 128 + TF_ROWS * 128));
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn64_kernel<128>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TF_ROWS * 256 + TF_ROWS * 128));
             if (e != hipSuccess) return (int)e;
             configured = true;
         }
-        TnArgs pf{A, lda, B, ldb, C, ldc, colsum_a, M, N1, N2, r2, tiles, sp};
-        hipLaunchKernelGGL(gemm_tn64_kernel, dim3((unsigned)(tiles * sp)), dim3(256), 4 * TF_STAGE, s, pf);
+        TnArgs pf{A, lda, B, ldb, C, ldc, colsum_a, M, N1, N2, r2, tl, sp};
+        if (wide) hipLaunchKernelGGL(gemm_tn64_kernel<128>, dim3((unsigned)(tl * sp)), dim3(256), lds, s, pf);
+        else hipLaunchKernelGGL(gemm_tn64_kernel<64>, dim3((unsigned)(tl * sp)), dim3(256), lds, s, pf);
         return dhaug_launch_status();
     }
     TnArgs p{A, lda, B, ldb, C, ldc, colsum_a, M, N1, N2, rows, tiles, splits};
