@@ -41,6 +41,7 @@ class _Layer:
             self.ksteps.append(ks)
         self.bias = torch.zeros(256, dtype=torch.float32, device=W.device)
         self.bias[:N] = b
+        self.zero = torch.zeros(256, dtype=torch.float32, device=W.device) if len(splits) > 1 else None
 
 
 def _unit(kind, flags=0, src=-1, dst=-1, res=-1, src2=-1, ksteps2=0, ksteps=0, n=0, act=0, slope=0.0, cols=0, ld=0,
@@ -156,20 +157,22 @@ def _d3_layers(D):
 
 def _d3_program(D, L, inputs, M):
     x, kcs = inputs["x"], inputs["kcs"]
-    Dd = D.previous[0].weight.shape[0]
     out = torch.empty((M, 1), dtype=torch.float32, device=x.device)
-    scratch = torch.empty((M, 256), dtype=torch.bfloat16, device=x.device)     # KCS-branch output parked in L2/HBM
+    mp = L["merge_previous.0"]
     u = [_unit(LOAD_BF16, dst=1, cols=32, ld=kcs.stride(0), g=kcs), _gemm(L["special_KCS_previous.0"], 1, 0, ACT_RELU)]
     _res_blocks(L, u, ("special_KCS_block1", "special_KCS_block2", "special_KCS_block3"))
-    u.append(_unit(STORE_BF16, src=0, cols=256, ld=256, g=scratch))
+    # cat(kcs_out, pos_out) -> merge layer, in two halves: LDS cannot hold the KCS branch's 64 KB result beside the two
+    # images the pose branch needs, so its share of the merge layer's pre-activation (W[:, :D] kcs_out + bias, 100 wide)
+    # waits in buffer 2 as bf16 and the pose branch's share is added to it as a residual (one extra bf16 rounding of a
+    # partial sum; the alternative was a 33.5 MB round trip through L2)
+    u.append(_unit(GEMM, src=0, dst=2, ksteps=mp.ksteps[0], n=mp.N, act=ACT_NONE, w=mp.w[0], bias=mp.bias))
     u += [_unit(LOAD_F32, dst=1, cols=48, ld=x.stride(0), g=x), _gemm(L["previous.0"], 1, 0, ACT_RELU)]
     _res_blocks(L, u, ("block1", "block2", "block3"))
-    u.append(_unit(LOAD_BF16, dst=1, cols=256, ld=256, g=scratch))
-    u.append(_gemm(L["merge_previous.0"], 1, 2, ACT_RELU, src2=0))             # cat(kcs_out, pos_out) -> buffer 2
+    u.append(_unit(GEMM, src=0, dst=2, res=2, ksteps=mp.ksteps[1], n=mp.N, act=ACT_RELU, w=mp.w[1], bias=mp.zero))
     u.append(_gemm(L["merge_block1.fc1"], 2, 0, ACT_RELU))
     u.append(_gemm(L["merge_block1.fc2"], 0, 2, ACT_RELU, res=2))
     u.append(_gemm(L["output"], 2, 0, ACT_NONE, out=out))
-    return u, (out, scratch)
+    return u, (out,)
 
 
 D3 = dict(layers=_d3_layers, program=_d3_program)
