@@ -76,9 +76,10 @@ class _GeneratorBase(nn.Module):
         if bone_len_scaler is not None:
             s = bone_len_scaler.to(device=self.boneLength.device, dtype=torch.float32)
         elif mode == "different":
-            s = torch.randint(-200, 200, (B, 8), device=self.boneLength.device).float() / 1000.0
+            # integers drawn straight into fp32 (same values as .float() of the int64 draw, one launch fewer)
+            s = torch.randint(-200, 200, (B, 8), device=self.boneLength.device, dtype=torch.float32).div_(1000.0)
         elif mode == "same":            # crashes in the reference; implemented as documented
-            s = (torch.randint(-200, 200, (B, 1), device=self.boneLength.device).float() / 1000.0).repeat(1, 8)
+            s = torch.randint(-200, 200, (B, 1), device=self.boneLength.device, dtype=torch.float32).div_(1000.0).repeat(1, 8)
         elif mode == "":
             return None
         else:
