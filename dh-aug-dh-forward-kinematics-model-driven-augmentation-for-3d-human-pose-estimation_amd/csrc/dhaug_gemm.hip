@@ -664,6 +664,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ws_kernel(GemmArgs p) {
 //     512-byte rows;
 //   * barriers order LDS traffic only; the one vmcnt(0) per tile sits after the tile's MFMAs, where the copy issued
 //     before them has had the whole tile to land.
+// Measured anatomy at 65536 x 256 x 256 (no residual, 23 us): 10.8 us of data movement and synchronisation + 9 us of MFMA
+// phases + 7 us of store phases, simply added up -- one workgroup per CU runs its tile as a serial chain.  A 32-row /
+// two-workgroups-per-CU variant overlaps them (K = 128: 16.3 -> 14.1 us) but spills at K = 256 (128 weight registers in a
+// 256-register budget: 45 us); a third operand image and exact vmcnt accounting changed nothing.  Next step: split the
+// tile's phases across two wave groups of one workgroup.
 // LDS: 2 x 32 KB operand images + 2 x 32 KB residual images + 32 KB output image = 160 KB, 16-byte chunks XOR-swizzled
 // by row & 15 (conflict-free ds_read_b128 fragment reads).
 // ---------------------------------------------------------------------------------------------------------------
@@ -818,6 +823,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmArgs p) {
             *reinterpret_cast<u32x4*>(p.cb + (m0 + row) * p.ldcb + c * 8) = o[i];
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // no copy may land in LDS after the workgroup is gone
 }
 
 template <int KS>

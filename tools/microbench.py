@@ -28,6 +28,9 @@ for (M, N, K) in ((65536, 256, 256), (65536, 256, 128), (65536, 256, 48), (65536
     t = timeit(lambda: ops.gemm_nt(A, B, N, K, bias=bias, res_bf16=res, act=1, out_bf16=True))
     by = M * K * 2 + M * N * 2 * 2 + N * K * 2
     print("gemm_nt M=%d N=%4d K=%4d %8.1f us  %7.1f TFLOP/s  %6.1f GB/s" % (M, N, K, t * 1e6, 2 * M * N * K / t / 1e12, by / t / 1e9))
+    if N == 256 and K <= 256:
+        t = timeit(lambda: ops.gemm_nt(A, B, N, K, out_bf16=True))
+        print("gemm_nt M=%d N=%4d K=%4d %8.1f us  (no bias / residual / activation: %6.1f GB/s)" % (M, N, K, t * 1e6, (M * K * 2 + M * N * 2) / t / 1e9))
 for (M, N1, N2) in ((65536, 256, 256), (65536, 256, 48), (65536, 100, 512)):
     A = torch.randn(M, (N1 + 7) // 8 * 8, device=dev).to(torch.bfloat16); B = torch.randn(M, (N2 + 7) // 8 * 8, device=dev).to(torch.bfloat16)
     t = timeit(lambda: ops.gemm_tn(A, B, N1, N2))
