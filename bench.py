@@ -180,7 +180,7 @@ def main():
         roofline = {"kernel": "fused_mlp_kernel (Fk_3D_Discriminator forward, M=%d, D=%d, 17 layers in one launch)" % (B, D),
                     "bound": "mfma", "achieved": 2.0 * d3_mac * B / tg / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": 2.0 * d3_mac * B / tg / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                    "traffic": pmc_traffic("fused_mlp_kernel") if (B, D) == (65536, 256) else None,
+                    "traffic": pmc_traffic("fused_mlp_kernel", "d3_") if (B, D) == (65536, 256) else None,
                     "avg_us": tg * 1e6, "algorithmic_flop_per_pose": 2 * d3_mac}
         xb = torch.randn(B, D, device=dev).to(torch.bfloat16)
         wb = (torch.randn(D, D, device=dev) / D ** 0.5).to(torch.bfloat16)
@@ -224,14 +224,15 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel_substr):
+def pmc_traffic(kernel_substr, prefix=""):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summaries (profiles/r01_pmc_*_summary.csv,
-    collected with separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).  The largest dispatch of the
-    kernel is the one bench.py times.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts half of the
+    collected by tools/collect_profiles.sh with separate --pmc FETCH_SIZE / WRITE_SIZE passes).  The largest dispatch
+    of the kernel is the one bench.py times; prefix "d3_" selects the passes that ran the 3D critic's launch alone (the
+    three networks share one kernel name).  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts half of the
     bytes of wide coalesced reads -> doubled; both counters are in KiB."""
     import csv
     tot = 0.0
-    for tag, mult in (("fetch", 2.0), ("write", 1.0)):
+    for tag, mult in ((prefix + "fetch", 2.0), (prefix + "write", 1.0)):
         path = os.path.join(ROOT, "profiles", "r01_pmc_%s_summary.csv" % tag)
         if not os.path.exists(path):
             return None

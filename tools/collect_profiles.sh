@@ -14,8 +14,18 @@ cp gpurun_out/prof_step/r_kernel_stats.csv $O/${R}_step_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -o r -- $B > gpurun_out/pmc_$c.log 2>&1 || exit 1
 done
+# the three networks share one kernel name: the 3D critic's launch (the bench's roofline kernel) is measured on its own
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_d3_$c -o r -- python tools/prof_fused_d3.py > gpurun_out/pmc_d3_$c.log 2>&1 || exit 1
+done
 python - <<PY
 import csv, collections
+for c, tag in (("FETCH_SIZE", "d3_fetch"), ("WRITE_SIZE", "d3_write")):
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open("gpurun_out/pmc_d3_%s/r_counter_collection.csv" % c))
+         if r["Counter_Name"] == c and "fused_mlp" in r["Kernel_Name"]]
+    with open("$O/${R}_pmc_%s_summary.csv" % tag, "w") as f:
+        f.write("kernel,counter,dispatches,mean,max\n")
+        f.write("fused_mlp_kernel[Fk_3D_Discriminator M=65536 D=256],%s,%d,%g,%g\n" % (c, len(v), sum(v) / len(v), max(v)))
 for c, tag in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write"), ("SQ_VALU_MFMA_BUSY_CYCLES", "mfma")):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open("gpurun_out/pmc_%s/r_counter_collection.csv" % c)):
