@@ -1,0 +1,1 @@
+"""common: part of the MI355X-native DH-AUG hot path."""

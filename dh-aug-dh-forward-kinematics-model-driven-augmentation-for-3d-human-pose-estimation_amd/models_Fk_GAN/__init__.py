@@ -1,0 +1,1 @@
+"""models_Fk_GAN: part of the MI355X-native DH-AUG hot path."""

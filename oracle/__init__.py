@@ -1,0 +1,1 @@
+"""oracle: part of the MI355X-native DH-AUG hot path."""
