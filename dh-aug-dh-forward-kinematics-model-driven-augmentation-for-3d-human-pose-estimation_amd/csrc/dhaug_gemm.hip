@@ -826,6 +826,213 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // no copy may land in LDS after the workgroup is gone
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same layer with the tile's serial chain cut in two (gemm_nt256_kernel above: 10.8 us of movement + 9 us of MFMA
+// phases + 7 us of store phases, added up).  512 threads, two roles, one LDS-only barrier per 32-row tile:
+//   waves 0..3 (compute): MFMAs of tile i from its LDS images, epilogue (bias from an LDS copy, residual on the matrix
+//                         pipe, activation, mask), bf16 result into output image i % 2;
+//   waves 4..7 (movers) : request tile i+NX-1's rows into the image tile i-1 released (global_load_lds_dwordx4), stream
+//                         tile i-1's output image out as whole 512-byte rows, and make sure tile i+1 has landed before
+//                         the barrier.
+// Two waves per SIMD: 256 registers each, so a compute wave keeps the weights (2 * KS fragments = 128 registers at
+// K = 256) but no bias seeds.  Tile j lives in operand image j % NX (NX = 4 without a second operand, 3 with one).
+// LDS: NX (x2 with a second operand) images of 16 KB + two output images + bias 1 KB = 97 / 129 KB.
+// ---------------------------------------------------------------------------------------------------------------
+template <int KS, int MODE>
+__global__ __launch_bounds__(512, 1) void gemm_nt256s_kernel(GemmArgs p) {
+    constexpr bool RES = MODE == 1, MASK = MODE == 2, SECOND = MODE != 0;
+    static_assert(KS == 8 || KS == 16, "K = 128 or 256");
+    constexpr int BM = 32;
+    constexpr int NX = SECOND ? 3 : 4;                                       // operand images in the ring: NX - 1 tiles ahead
+    constexpr int S = 2 * KS, XP = S * 16;                                   // chunks per operand row, operand pitch (bytes)
+    constexpr int IMG = BM * F_PITCH;                                        // bytes per image (operand images use XP <= 512)
+    constexpr int NCX = BM * S / 256, NCR = SECOND ? BM * 32 / 256 : 0;      // copies per mover lane: operand / second operand
+    constexpr int RCH = BM * 32 / 256;                                       // output chunks per mover lane
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sX = smem;                                                // [NX][IMG]
+    unsigned char* sR = smem + NX * IMG;                                     // [NX][IMG]  (MODE 1/2)
+    unsigned char* sO = smem + (SECOND ? 2 : 1) * NX * IMG;                  // [2][IMG]
+    float* sBias = reinterpret_cast<float*>(sO + 2 * IMG);                   // [256]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool mover = wave >= 4;
+    const int cw = wave & 3;                                                 // index within the role
+    const int r31 = lane & 31, h = lane >> 5, x = lane & 15;
+    const long long mtiles = p.M / BM, g = gridDim.x;
+    const long long mt0 = blockIdx.x;
+    if (mt0 >= mtiles) return;
+    const int nt = (int)((mtiles - mt0 + g - 1) / g);                        // tiles of this workgroup
+
+    if (mover) {
+        auto copy_tile = [&](int i, int buf) {                               // asynchronous, counted in vmcnt
+            const long long m0 = (mt0 + (long long)i * g) * BM;
+            constexpr int RW = 1024 / XP;                                    // rows per wave instruction
+#pragma unroll
+            for (int q = 0; q < NCX; ++q) {
+                const int row0 = (cw * NCX + q) * RW, row = row0 + lane / S, c = (lane % S) ^ (row & 15);
+                f_copy16(p.A + (m0 + row) * p.lda + c * 8, sX + buf * IMG + row0 * XP);
+            }
+            if (SECOND) {
+                const uint16_t* src = RES ? p.res : p.dmask;
+                const long long ld = RES ? p.ld_res : p.ld_dmask;
+#pragma unroll
+                for (int q = 0; q < NCR; ++q) {
+                    const int row0 = (cw * NCR + q) * 2, row = row0 + (lane >> 5), c = (lane & 31) ^ (row & 15);
+                    f_copy16(src + (m0 + row) * ld + c * 8, sR + buf * IMG + row0 * F_PITCH);
+                }
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < NX - 1; ++i)
+            if (i < nt) copy_tile(i, i);
+        if (cw == 0) {                                                       // bias -> LDS (zeros without one)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sBias[lane + 64 * q] = p.bias != nullptr ? p.bias[lane + 64 * q] : 0.0f;
+        }
+        if (nt >= NX - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NX - 2) * (NCX + NCR)) : "memory");   // tile 0 landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        f_lds_barrier();
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int mtid = tid - 256;
+        for (int i = 0; i <= nt; ++i) {                                      // iteration i: tile i is being computed
+            // tile j lives in image j % NX.  The image of tile i-1 was released at the last barrier (image NX-1 has not
+            // been used yet in iteration 0): it takes tile i+NX-1, so NX-1 tiles are in flight or landed ahead of tile i
+            if (i + NX - 1 < nt) copy_tile(i + NX - 1, (i + NX - 1) % NX);
+            if (i >= 1) {                                                    // stream tile i-1 out
+                const unsigned char* O = sO + ((i - 1) & 1) * IMG;
+                const long long m0 = (mt0 + (long long)(i - 1) * g) * BM;
+                u32x4 o[RCH];
+#pragma unroll
+                for (int q = 0; q < RCH; ++q) {
+                    const int e = mtid + 256 * q, row = e >> 5, c = e & 31;
+                    o[q] = *reinterpret_cast<const u32x4*>(O + row * F_PITCH + ((c ^ (row & 15)) << 4));
+                }
+#pragma unroll
+                for (int q = 0; q < RCH; ++q) {
+                    const int e = mtid + 256 * q, row = e >> 5, c = e & 31;
+                    *reinterpret_cast<u32x4*>(p.cb + (m0 + row) * p.ldcb + c * 8) = o[q];
+                }
+            }
+            if (i == nt) break;
+            // tile i+1 must be in LDS when the compute waves leave the barrier.  vmcnt retires in issue order; younger
+            // than tile i+1's copies are the copies of tiles i+2 .. i+NX-1 and min(i, NX-1) sets of row stores.  Near the
+            // end, where some of those tiles do not exist, everything is drained instead.
+            if (i + NX - 1 >= nt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (i == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NX - 2) * (NCX + NCR)) : "memory");
+            else if (i == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NX - 2) * (NCX + NCR) + RCH) : "memory");
+            else if (i == 2 || NX == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NX - 2) * (NCX + NCR) + 2 * RCH) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NX - 2) * (NCX + NCR) + 3 * RCH) : "memory");
+            f_lds_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ---- compute waves ----
+    bf16x8 wf[2][KS];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const uint16_t* wrow = p.B + (long long)(32 * (cw + 4 * t) + r31) * p.ldb + 8 * h;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) wf[t][k] = *reinterpret_cast<const bf16x8*>(wrow + 16 * k);
+    }
+    bf16x8 idf[2];                                                           // A[n][k'] = (n == 16 j + k'), k' = 8h + i
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int dd = r31 - 16 * j - 8 * h;
+        unsigned v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (dd == 2 * q ? 0x3F80u : 0u) | (dd == 2 * q + 1 ? 0x3F800000u : 0u);
+        const uint4 u = make_uint4(v[0], v[1], v[2], v[3]);
+        idf[j] = __builtin_bit_cast(bf16x8, u);
+    }
+    const float neg = p.act == DHAUG_ACT_RELU ? 0.0f : (p.act == DHAUG_ACT_LRELU ? p.slope : 1.0f);
+    const int lfx = r31 * XP | ((x >> 1) << 5) | ((h ^ (x & 1)) << 4);                   // ^ (k << 5): chunk 2k+h of row
+    const int lrx = (r31 * F_PITCH | ((x >> 1) << 5) | ((h ^ (x & 1)) << 4)) ^ (cw << 6);     // ^ (t << 8 | j << 5)
+    const int lep = r31 * F_PITCH | (((4 * cw) ^ x) << 4) | (h << 3);                    // ^ ((16t+g) << 4)
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f_lds_barrier();                                                         // tile 0 and the bias are in LDS
+    for (int i = 0; i < nt; ++i) {
+        const unsigned char* X = sX + (i % NX) * IMG;
+        const unsigned char* R = sR + (i % NX) * IMG;
+        unsigned char* O = sO + (i & 1) * IMG;
+        f32x16 acc[2];
+        bf16x8 fx[4];
+        constexpr int D = 3;
+#pragma unroll
+        for (int k = 0; k < D; ++k) fx[k] = *reinterpret_cast<const bf16x8*>(X + (lfx ^ (k << 5)));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            // pinned: left alone the scheduler sinks each fragment read next to its MFMA and waits out the LDS latency
+            // at every k-step
+            if (k + D < KS) fx[(k + D) & 3] = *reinterpret_cast<const bf16x8*>(X + (lfx ^ ((k + D) << 5)));
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][k], fx[k & 3], k == 0 ? zero : acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (RES) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf16x8 rf = *reinterpret_cast<const bf16x8*>(R + (lrx ^ (t << 8 | j << 5)));
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(idf[j], rf, acc[t], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + 32 * (cw + 4 * t) + 4 * h + 8 * gq);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = acc[t][4 * gq + e] + b4[e];
+                    v[e] = fmaxf(a, a * neg);
+                }
+                if (MASK) {                                                  // this lane's 4 mask-source values (bf16)
+                    const uint2 y = *reinterpret_cast<const uint2*>(R + (lep ^ ((16 * t + gq) << 4)));
+                    const short y0 = (short)(y.x & 0xffffu), y1 = (short)(y.x >> 16), y2 = (short)(y.y & 0xffffu), y3 = (short)(y.y >> 16);
+                    v[0] = y0 > 0 ? v[0] : v[0] * p.dneg;                    // a positive bf16 is a positive int16
+                    v[1] = y1 > 0 ? v[1] : v[1] * p.dneg;
+                    v[2] = y2 > 0 ? v[2] : v[2] * p.dneg;
+                    v[3] = y3 > 0 ? v[3] : v[3] * p.dneg;
+                }
+                uint2 o;
+                o.x = f_pack_bf16x2(v[0], v[1]);
+                o.y = f_pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(O + (lep ^ ((16 * t + gq) << 4))) = o;
+            }
+        f_lds_barrier();                                                     // output image i complete, operand image i released
+    }
+}
+
+template <int KS, int MODE>
+int launch_nt256s_mode(hipStream_t s, const GemmArgs& p) {
+    constexpr int BM = 32, NX = MODE == 0 ? 4 : 3;
+    constexpr int LDS = ((MODE == 0 ? 1 : 2) * NX + 2) * BM * F_PITCH + 1024;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256s_kernel<KS, MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    const long long mtiles = p.M / BM;
+    const unsigned grid = (unsigned)(mtiles < 256 ? mtiles : 256);
+    hipLaunchKernelGGL((gemm_nt256s_kernel<KS, MODE>), dim3(grid), dim3(512), LDS, s, p);
+    return dhaug_launch_status();
+}
+
+template <int KS>
+int launch_nt256s(hipStream_t s, const GemmArgs& p) {
+    if (p.dmask != nullptr) return launch_nt256s_mode<KS, 2>(s, p);
+    if (p.res != nullptr) return launch_nt256s_mode<KS, 1>(s, p);
+    return launch_nt256s_mode<KS, 0>(s, p);
+}
+
 template <int KS>
 int launch_nt256(hipStream_t s, const GemmArgs& p) {
     static bool configured = false;
@@ -910,6 +1117,10 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
         if (dmask != nullptr && residual == nullptr && (K == 128 || K == 256)) {   // mask in the epilogue (second LDS image)
             p.dmask = dmask; p.ld_dmask = ld_dmask; p.dneg = dneg;
             *mask_done = true;
+        }
+        if (getenv("DHAUG_NT256_SINGLE") == nullptr) {                        // two-role kernel (default)
+            if (K == 128) return launch_nt256s<8>(s, p);
+            if (K == 256) return launch_nt256s<16>(s, p);
         }
         switch (K / 16) {
             case 8: return launch_nt256<8>(s, p);
