@@ -946,7 +946,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256s_kernel(GemmArgs p) {
         const uint4 u = make_uint4(v[0], v[1], v[2], v[3]);
         idf[j] = __builtin_bit_cast(bf16x8, u);
     }
-    const float neg = p.act == DHAUG_ACT_RELU ? 0.0f : (p.act == DHAUG_ACT_LRELU ? p.slope : 1.0f);
+    const bool leaky = p.act == DHAUG_ACT_LRELU;
+    const float neg = p.slope;
+    const uint32_t lb = p.act == DHAUG_ACT_RELU ? 0u : 0x80008000u;         // packed int16 lower bound
     const int lfx = r31 * XP | ((x >> 1) << 5) | ((h ^ (x & 1)) << 4);                   // ^ (k << 5): chunk 2k+h of row
     const int lrx = (r31 * F_PITCH | ((x >> 1) << 5) | ((h ^ (x & 1)) << 4)) ^ (cw << 6);     // ^ (t << 8 | j << 5)
     const int lep = r31 * F_PITCH | (((4 * cw) ^ x) << 4) | (h << 3);                    // ^ ((16t+g) << 4)
@@ -988,9 +990,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256s_kernel(GemmArgs p) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + 32 * (cw + 4 * t) + 4 * h + 8 * gq);
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float a = acc[t][4 * gq + e] + b4[e];
-                    v[e] = fmaxf(a, a * neg);
+                for (int e = 0; e < 4; ++e) v[e] = acc[t][4 * gq + e] + b4[e];
+                if (leaky) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * neg);
                 }
                 if (MASK) {                                                  // this lane's 4 mask-source values (bf16)
                     const uint2 y = *reinterpret_cast<const uint2*>(R + (lep ^ ((16 * t + gq) << 4)));
@@ -1000,9 +1003,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256s_kernel(GemmArgs p) {
                     v[2] = y2 > 0 ? v[2] : v[2] * p.dneg;
                     v[3] = y3 > 0 ? v[3] : v[3] * p.dneg;
                 }
+                // ReLU / identity on the packed pair: a negative bf16 is a negative int16 (lower bound 0 or INT16_MIN)
+                typedef short s16x2 __attribute__((ext_vector_type(2)));
                 uint2 o;
-                o.x = f_pack_bf16x2(v[0], v[1]);
-                o.y = f_pack_bf16x2(v[2], v[3]);
+                o.x = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, f_pack_bf16x2(v[0], v[1])),
+                                                                             __builtin_bit_cast(s16x2, lb)));
+                o.y = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, f_pack_bf16x2(v[2], v[3])),
+                                                                             __builtin_bit_cast(s16x2, lb)));
                 *reinterpret_cast<uint2*>(O + (lep ^ ((16 * t + gq) << 4))) = o;
             }
         f_lds_barrier();                                                     // output image i complete, operand image i released
