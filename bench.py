@@ -120,9 +120,8 @@ def main():
 
     def step_fwd():
         with torch.no_grad():
-            fw = G(z).reshape(-1, 16, 3)
-            l3 = D3(fw, center=True)
-            _, p2 = ops.world_to_camera_project(fw, quat, trans, cam9, want3d=False)
+            fw, xc, kcs, p2 = G.sample_for_critics(z, (quat, trans, cam9))    # FK tail + critic inputs, one launch
+            l3 = D3(xc, kcs=kcs)
             l2 = D2(p2)
         return l3, l2
 

@@ -117,12 +117,22 @@ __device__ __forceinline__ void lanes_to_rows(const float* __restrict__ v, float
     }
 }
 
-template <int MODE, int OUTJ, bool PREANGLE>
+// Optional outputs of the generator tail for the critics (all may be null): the root-relative pose and its bf16 KCS
+// operand (3D critic), the H36M projection through one camera (2D critic) -- the joints are in registers here, a
+// separate pass would read them back from HBM.
+struct TailExtra {
+    float* centered;            // (N,48)
+    uint16_t* kcs;              // (N,32) bf16: 15 cosines, 15 lengths, 2 zeros
+    float* proj2d;              // (N,32)
+    float q[4], t[3], c[9];     // camera
+};
+
+template <int MODE, int OUTJ, bool PREANGLE, bool EXTRA = false>
 __global__ __launch_bounds__(TILE) void fk_forward_kernel(const float* __restrict__ in0,
                                                           const float* __restrict__ bone_len,
                                                           const float* __restrict__ in2,
                                                           float* __restrict__ out, float* __restrict__ angles_out,
-                                                          long long N) {
+                                                          TailExtra ex, long long N) {
     using L = InLayout<MODE>;
     constexpr int OW = OUTJ * 3, OS = OW + 1;                  // output row width / odd LDS stride
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -175,6 +185,33 @@ __global__ __launch_bounds__(TILE) void fk_forward_kernel(const float* __restric
         }
         lanes_to_rows<OW, OS>(o, smem, out + base * OW, rows, lane);
         if (MODE == 1 && angles_out != nullptr) lanes_to_rows<37, 37>(ang, smem, angles_out + base * 37, rows, lane);
+        if (EXTRA && MODE == 1 && OUTJ == 16) {
+            if (ex.centered != nullptr) {
+                float cc[48];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { cc[3 * j] = o[3 * j] - o[0]; cc[3 * j + 1] = o[3 * j + 1] - o[1]; cc[3 * j + 2] = o[3 * j + 2] - o[2]; }
+                lanes_to_rows<48, 49>(cc, smem, ex.centered + base * 48, rows, lane);
+            }
+            if (ex.kcs != nullptr) {
+                V3 pw[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) pw[j] = mk(o[3 * j], o[3 * j + 1], o[3 * j + 2]);
+                float f[32];
+                kcs_features(pw, f);
+                f[30] = 0.0f; f[31] = 0.0f;
+                float pk[16];                                   // bf16 pairs travel as dwords
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    pk[i] = __builtin_bit_cast(float, (uint32_t)dhaug_f32_to_bf16(f[2 * i]) | ((uint32_t)dhaug_f32_to_bf16(f[2 * i + 1]) << 16));
+                lanes_to_rows<16, 17>(pk, smem, reinterpret_cast<float*>(ex.kcs) + base * 16, rows, lane);
+            }
+            if (ex.proj2d != nullptr) {
+                float pr[32];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) w2c_project(mk(o[3 * j], o[3 * j + 1], o[3 * j + 2]), ex.q, ex.t, ex.c, pr[2 * j], pr[2 * j + 1]);
+                lanes_to_rows<32, 33>(pr, smem, ex.proj2d + base * 32, rows, lane);
+            }
+        }
     }
 }
 
@@ -281,9 +318,9 @@ int dhaug_fk_forward(const float* angles, const float* bone_len, const float* ro
                 DHAUG_EALIGN);
     if (out_joints == 16)
         return launch_tiles(fk_forward_kernel<0, 16, true>, fwd_lds(37, 48), N, stream, angles, bone_len, root, out,
-                            (float*)nullptr);
+                            (float*)nullptr, TailExtra{});
     return launch_tiles(fk_forward_kernel<0, 32, true>, fwd_lds(37, 96), N, stream, angles, bone_len, root, out,
-                        (float*)nullptr);
+                        (float*)nullptr, TailExtra{});
 }
 
 int dhaug_fk_backward(const float* angles, const float* bone_len, const float* grad_out16, float* grad_angles,
@@ -305,9 +342,31 @@ int dhaug_gen_tail_forward(const float* head, const float* bone_len, const float
     DHAUG_CHECK(dhaug_aligned16(head) && dhaug_aligned16(bone_len) && dhaug_aligned16(scaler), DHAUG_EALIGN);
     if (use_preangle)
         return launch_tiles(fk_forward_kernel<1, 16, true>, fwd_lds(37, 48), N, stream, head, bone_len, scaler, fake16,
-                            angles_out);
+                            angles_out, TailExtra{});
     return launch_tiles(fk_forward_kernel<1, 16, false>, fwd_lds(37, 48), N, stream, head, bone_len, scaler, fake16,
-                        angles_out);
+                        angles_out, TailExtra{});
+}
+
+int dhaug_gen_tail_forward_critics(const float* head, const float* bone_len, const float* scaler, float* fake16,
+                                   float* centered, uint16_t* kcs_bf16, const float* quat, const float* trans,
+                                   const float* cam9, float* proj2d, int64_t N, int use_preangle, void* stream) {
+    DHAUG_CHECK(N >= 0, DHAUG_EINVAL);
+    if (N == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(head); DHAUG_CHECK_PTR(bone_len); DHAUG_CHECK_PTR(fake16);
+    DHAUG_CHECK(dhaug_aligned16(head) && dhaug_aligned16(bone_len) && dhaug_aligned16(scaler), DHAUG_EALIGN);
+    DHAUG_CHECK(proj2d == nullptr || (quat != nullptr && trans != nullptr && cam9 != nullptr), DHAUG_EINVAL);
+    TailExtra ex{};
+    ex.centered = centered; ex.kcs = kcs_bf16; ex.proj2d = proj2d;
+    if (proj2d != nullptr) {
+        for (int i = 0; i < 4; ++i) ex.q[i] = quat[i];
+        for (int i = 0; i < 3; ++i) ex.t[i] = trans[i];
+        for (int i = 0; i < 9; ++i) ex.c[i] = cam9[i];
+    }
+    if (use_preangle)
+        return launch_tiles(fk_forward_kernel<1, 16, true, true>, fwd_lds(37, 48), N, stream, head, bone_len, scaler, fake16,
+                            (float*)nullptr, ex);
+    return launch_tiles(fk_forward_kernel<1, 16, false, true>, fwd_lds(37, 48), N, stream, head, bone_len, scaler, fake16,
+                        (float*)nullptr, ex);
 }
 
 int dhaug_gen_tail_backward(const float* head, const float* bone_len, const float* scaler, const float* grad_fake16,

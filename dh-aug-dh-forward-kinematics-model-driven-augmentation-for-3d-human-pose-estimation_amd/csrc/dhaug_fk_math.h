@@ -132,6 +132,43 @@ DHAUG_HD V3 rot_apply_t(const Rot& R, V3 g) {      // R^T * g
     return axpy(g.z, R.r2, axpy(g.y, R.r1, g.x * R.r0));
 }
 
+// ---- critic-side features of a 16-joint pose (same arithmetic as dhaug_pose.hip's standalone kernels) ----
+// bone i = joint[c] - joint[p], used_16key_15bone_len_table (R/models_Fk_GAN/forward_kinematics_DH_model.py:46-49)
+DHAUG_HD constexpr int kcs_bone_p(int i) { constexpr int t[15] = {5, 2, 4, 1, 0, 0, 0, 7, 8, 8, 10, 13, 11, 14, 8}; return t[i]; }
+DHAUG_HD constexpr int kcs_bone_c(int i) { constexpr int t[15] = {6, 3, 5, 2, 4, 1, 7, 8, 10, 13, 11, 14, 12, 15, 9}; return t[i]; }
+// KCS cosine pairs (R/models_Fk_GAN/Fk_discriminator.py:81-140)
+DHAUG_HD constexpr int kcs_i(int k) { constexpr int t[15] = {0, 1, 2, 3, 4, 4, 5, 6, 7, 7, 7, 8, 9, 10, 11}; return t[k]; }
+DHAUG_HD constexpr int kcs_j(int k) { constexpr int t[15] = {2, 3, 4, 5, 5, 6, 6, 7, 14, 8, 9, 10, 11, 12, 13}; return t[k]; }
+
+// 15 cosines between adjacent bones, then the 15 bone lengths (special_KCS_Input_transform)
+DHAUG_HD void kcs_features(const V3* __restrict__ p, float* __restrict__ f) {
+    V3 b[15];
+    float len[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) { b[i] = p[kcs_bone_c(i)] - p[kcs_bone_p(i)]; len[i] = sqrtf(dot(b[i], b[i])); }
+#pragma unroll
+    for (int k = 0; k < 15; ++k) f[k] = dot(b[kcs_i(k)], b[kcs_j(k)]) / (len[kcs_i(k)] * len[kcs_j(k)]);
+#pragma unroll
+    for (int i = 0; i < 15; ++i) f[15 + i] = len[i];
+}
+
+// world -> camera by the inverse of quaternion q = (w, x, y, z) after subtracting t, then the H36M projection with
+// c = f(2) c(2) k(3) p(2)  (R/common/camera.py:36-38, 62-94; R/common/quaternion.py:6-24)
+DHAUG_HD void w2c_project(V3 xw, const float* __restrict__ q, const float* __restrict__ t, const float* __restrict__ c,
+                          float& ox, float& oy) {
+    const V3 x = mk(xw.x - t[0], xw.y - t[1], xw.z - t[2]);
+    const V3 qv = mk(-q[1], -q[2], -q[3]);
+    const V3 uv = cross(qv, x);
+    const V3 uuv = cross(qv, uv);
+    const V3 xc = x + 2.0f * (q[0] * uv + uuv);
+    const float u = fminf(fmaxf(xc.x / xc.z, -1.0f), 1.0f), v = fminf(fmaxf(xc.y / xc.z, -1.0f), 1.0f);
+    const float r2 = u * u + v * v;
+    const float radial = 1.0f + (c[4] * r2 + c[5] * (r2 * r2) + c[6] * (r2 * r2 * r2));
+    const float tan = c[7] * u + c[8] * v;
+    ox = c[0] * (u * (radial + tan) + c[7] * r2) + c[2];
+    oy = c[1] * (v * (radial + tan) + c[8] * r2) + c[3];
+}
+
 // theta0 tables (degrees), R/models_Fk_GAN/forward_kinematics_DH_model.py:234-261
 //   right leg  alpha[0,-90,-90,0,0]  theta0[0,-90,180,0,0]     a[+hipR,0,0,thighR,shinR]
 //   left  leg  alpha[0,+90,+90,0,0]  theta0[180,-90,0,0,0]     a[-hipL,0,0,thighL,shinL]

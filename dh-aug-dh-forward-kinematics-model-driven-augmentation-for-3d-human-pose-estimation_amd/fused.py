@@ -191,12 +191,15 @@ def critic2d(D, x):
     return D._fused.run(dict(x=x), x.shape[0])
 
 
-def critic3d(D, x, center=False):
-    """center=True: x is a world/camera-space pose; its root-relative copy and the KCS operand come from one pass"""
+def critic3d(D, x, center=False, kcs=None):
+    """center=True: x is a world/camera-space pose; its root-relative copy and the KCS operand come from one pass.
+    kcs: the bf16 (N,32) operand if the caller already has it (Fk_Generator.sample_for_critics)"""
     if not hasattr(D, "_fused"):
         D._fused = FusedNet(D, D3)
     x = x.reshape(-1, 48).contiguous()
-    if center:
+    if kcs is not None:
+        pass
+    elif center:
         x, kcs = ops.center_kcs_forward(x, 32, True)
     else:
         _, kcs = ops.kcs_forward(x, True, f32=False, bf16_ld=32)

@@ -54,13 +54,13 @@ class Fk_3D_Discriminator(nn.Module):
         self.merge_block1 = myResNet(100)
         self.output = nn.Linear(100, 1)
 
-    def forward(self, input, center=False):
+    def forward(self, input, center=False, kcs=None):
         """center=True scores `input - input[:, :1]` (what every caller of the reference feeds the critic) without a
         separate centring pass where the fused path applies"""
         p = self.precision
         x = input.reshape(-1, 48)
         if p == "bf16" and x.is_cuda and _no_graph(self, x) and fused.supported(self.args.Dis_DenseDim_3D):
-            return fused.critic3d(self, x.float(), center)  # one launch, activations stay in LDS
+            return fused.critic3d(self, x.float(), center, kcs)  # one launch, activations stay in LDS
         if center:
             x = A.center_flip(x.reshape(-1, 16, 3), True, False).reshape(-1, 48)
         k = _branch(A.KcsFn.apply(x, True), self.special_KCS_previous[0],

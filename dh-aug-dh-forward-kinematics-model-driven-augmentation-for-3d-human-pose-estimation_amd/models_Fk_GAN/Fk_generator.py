@@ -111,6 +111,24 @@ class _GeneratorBase(nn.Module):
 
 
 class Fk_Generator(_GeneratorBase):
+    def sample_for_critics(self, input, camera=None, bone_len_scaler=None):
+        """Inference-only forward (no graph) that also returns the critics' inputs from the same launch as the FK tail:
+        (fake (B,16,3) world, centered (B,48), kcs bf16 (B,32), proj2d (B,16,2) | None) -- what
+        R/models_Fk_GAN/model_fk_gan_train.py:305-312,374-376 computes in three more passes over the fake batch."""
+        with torch.no_grad():
+            B = input.shape[0]
+            head = self.trunk(input).reshape(B, 35)
+            if not getattr(self.args, "whether_use_RT", True):
+                head = head.clone()
+                head[:, 28:31] = 0.0
+            scaler = self._scaler(B, bone_len_scaler)
+            bl = self.boneLength
+            if bl.shape[0] != B:
+                raise RuntimeError("boneLength has %d rows, the batch needs %d (call GAN_generator_get_bone_length)"
+                                   % (bl.shape[0], B))
+            self.train_num += 1
+            return ops.gen_tail_forward_critics(head.contiguous(), bl, scaler, bool(self.args.GAN_whether_use_preAngle), camera)
+
     def __init__(self, FK_DH_Class, args, device, INPUT_VEC_DIM=128):
         super().__init__(1, FK_DH_Class, args, device, INPUT_VEC_DIM)
 

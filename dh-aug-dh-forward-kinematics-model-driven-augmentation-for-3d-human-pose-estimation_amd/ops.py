@@ -79,6 +79,26 @@ def gen_tail_forward(head, bone_len, scaler, use_preangle=True, want_angles=Fals
     return fake, ang
 
 
+def gen_tail_forward_critics(head, bone_len, scaler, use_preangle=True, camera=None):
+    """generator tail + what the critics consume in one launch: (fake (N,16,3), centered (N,48), kcs bf16 (N,32),
+    proj2d (N,16,2) | None).  camera = (quat[4], trans[3], cam9[9]) host sequences."""
+    h = _dev(head, torch.float32, "gen_tail_forward_critics").reshape(-1, 35)
+    b = _dev(bone_len, torch.float32, "gen_tail_forward_critics").reshape(-1, 15)
+    s = None if scaler is None else _dev(scaler, torch.float32, "gen_tail_forward_critics").reshape(-1, 8)
+    N = h.shape[0]
+    assert b.shape[0] == N and (s is None or s.shape[0] == N)
+    fake = torch.empty((N, 16, 3), dtype=torch.float32, device=h.device)
+    xc = torch.empty((N, 48), dtype=torch.float32, device=h.device)
+    kcs = torch.empty((N, 32), dtype=BF16, device=h.device)
+    p2 = q = t = c = None
+    if camera is not None:
+        p2 = torch.empty((N, 16, 2), dtype=torch.float32, device=h.device)
+        q, t, c = _host3(camera[0], 4), _host3(camera[1], 3), _host3(camera[2], 9)
+    _lib.call("dhaug_gen_tail_forward_critics", _p(h), _p(b), _p(s), _p(fake), _p(xc), _p(kcs), q, t, c, _p(p2), N,
+              int(bool(use_preangle)), _stream())
+    return fake, xc, kcs, p2
+
+
 def gen_tail_backward(head, bone_len, scaler, grad_fake16, use_preangle=True):
     h = _dev(head, torch.float32, "gen_tail_backward").reshape(-1, 35)
     b = _dev(bone_len, torch.float32, "gen_tail_backward").reshape(-1, 15)

@@ -77,6 +77,17 @@ int dhaug_fk_backward(const float* angles, const float* bone_len, const float* g
 int dhaug_gen_tail_forward(const float* head, const float* bone_len, const float* scaler, float* fake16,
                            float* angles_out, int64_t N, int use_preangle, void* stream);
 
+/* dhaug_gen_tail_forward that also emits what the critics consume, while the joints are still in registers:
+ *   centered (N,16,3) = fake16 - fake16[:,0]                      (R/models_Fk_GAN/model_fk_gan_train.py:312)
+ *   kcs_bf16 (N,32) bf16 = special_KCS_Input_transform(fake16) zero-padded (Fk_discriminator.py:36-146; the operand of
+ *                          dhaug_kcs_forward / dhaug_mlp_forward)
+ *   proj2d   (N,16,2)   = project_to_2d(GAN_torch_world_to_camera(fake16, quat, trans), cam9)   (:374-376;
+ *                          quat[4], trans[3], cam9[9] host arrays as in dhaug_world_to_camera_project)
+ * Any of the three may be NULL. */
+int dhaug_gen_tail_forward_critics(const float* head, const float* bone_len, const float* scaler, float* fake16,
+                                   float* centered, uint16_t* kcs_bf16, const float* quat, const float* trans,
+                                   const float* cam9, float* proj2d, int64_t N, int use_preangle, void* stream);
+
 /* Gradient of dhaug_gen_tail_forward w.r.t. head: grad_fake16 (N,16,3) -> grad_head (N,35)
  * (column 31 = 0).  Recomputes the forward from head. */
 int dhaug_gen_tail_backward(const float* head, const float* bone_len, const float* scaler,

@@ -377,3 +377,28 @@ def test_gemm_nt_dmask(ops, M, N, K, act, slope, use_res):
     assert out.shape == (M, N)
     assert maxabs(out.float(), ref) <= 2.0 ** -7 * ref.abs().max().item()
     assert (out.float().cpu()[y.float().cpu() <= 0].abs().max().item() == 0.0) if act == 1 else True
+
+
+@pytest.mark.parametrize("N,pre", [(1, True), (63, True), (1000, False), (65536, True)])
+def test_gen_tail_forward_critics(ops, N, pre):
+    """the generator tail with the critics' inputs emitted from the same launch == the separate passes"""
+    gen = torch.Generator().manual_seed(N)
+    head = torch.randn(N, 35, generator=gen).cuda()
+    bl = (torch.rand(N, 15, generator=gen) * 0.4 + 0.1).cuda()
+    sc = (torch.randint(-200, 200, (N, 8), generator=gen).float() / 1000.0).cuda()
+    quat = [0.1407056450843811, -0.1500701755285263, -0.755240797996521, 0.6223280429840088]
+    trans = [1.841107, 4.955284, 1.563445]
+    cam9 = [2.29, 2.287, 0.0251, 0.0289, -0.207, 0.2478, -0.00307, -0.00097, -0.00142]
+    fake, xc, kcs, p2 = ops.gen_tail_forward_critics(head, bl, sc, pre, (quat, trans, cam9))
+    ref_fake, _ = ops.gen_tail_forward(head, bl, sc, pre)
+    assert maxabs(fake, ref_fake) <= 1e-6                              # another instantiation: contraction order may differ by an ulp
+    assert maxabs(xc, ops.center_flip(fake, True, False).reshape(N, 48)) == 0.0
+    _, ref_k = ops.kcs_forward(ops.center_flip(fake, True, False), True, f32=False, bf16_ld=32)
+    assert maxabs(kcs.float(), ref_k.float()) <= 2.0 ** -7            # same formula on world vs centred joints: <= 1 bf16 ulp
+    c3, ref_p = ops.world_to_camera_project(fake, quat, trans, cam9)
+    # x/z amplifies an ulp of the joint (1e-6 at |x| ~ 10) by f/|z|: compare in units of that conditioning
+    z = c3[..., 2].abs().clamp_min(1e-3).unsqueeze(-1)
+    assert ((p2 - ref_p).abs() * z).max().item() <= 1e-4
+    assert maxabs(p2, ref_p) <= 1e-2                                  # and stays bounded everywhere (both clamp x/z to +-1)
+    f2, x2, k2, none = ops.gen_tail_forward_critics(head, bl, None, pre, None)
+    assert none is None and f2.shape == (N, 16, 3)

@@ -299,6 +299,13 @@ def test_fused_forward_matches_layerwise(M, D, B):
     # centring folded into the KCS pass
     xw = x3 + 0.3
     assert maxabs(D3(xw, center=True), fused.critic3d(D3, (xw - xw[:, :1]))) <= 2e-2 * l3_l.abs().max().item() + 1e-6
+    # the generator's one-launch critic inputs feed the same critics
+    if D == 256:
+        G.GAN_generator_get_bone_length(x3.reshape(B, 16, 3))
+        torch.manual_seed(11)
+        fw, xc, kc, p2 = G.sample_for_critics(z, ([1.0, 0.0, 0.0, 0.0], [0.0, 0.0, -5.0], [1.1, 1.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]))
+        assert maxabs(D3(xc, kcs=kc), D3(fw.reshape(B, 48), center=True)) <= 2e-2 * l3_l.abs().max().item() + 1e-6
+        assert p2.shape == (B, 16, 2) and torch.isfinite(p2).all()
     # weights change -> the packed fragments are rebuilt
     with torch.no_grad():
         D2.layer_pred.bias.add_(1.0)
