@@ -6,13 +6,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DHAUG_LIB", os.path.join(_HERE, "lib", "libdhaug.so"))
 
 _vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+_u64 = ctypes.c_uint64
 
 # name -> argtypes, in the order of include/dhaug.h
 SIGNATURES = {
     "dhaug_fk_forward": [_vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "dhaug_fk_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "dhaug_gen_tail_forward": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
-    "dhaug_gen_tail_forward_critics": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    "dhaug_gen_tail_forward_critics": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _u64, _u64, _vp, _i64, _i32, _vp],
     "dhaug_gen_tail_backward": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "dhaug_bone_length": [_vp, _vp, _i64, _vp],
     "dhaug_kcs_forward": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],

@@ -125,7 +125,23 @@ struct TailExtra {
     uint16_t* kcs;              // (N,32) bf16: 15 cosines, 15 lengths, 2 zeros
     float* proj2d;              // (N,32)
     float q[4], t[3], c[9];     // camera
+    int draw;                   // 1: draw the bone-length jitter here (Philox4x32-10) instead of reading it
+    unsigned long long seed, offset;
+    float* scaler_out;          // optional (N,8): the jitter that was drawn
 };
+
+// Philox4x32-10 (Salmon et al., SC'11), counter = (pose index, offset), key = seed: 4 x 32 random bits per call
+__device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                           unsigned (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
 
 template <int MODE, int OUTJ, bool PREANGLE, bool EXTRA = false>
 __global__ __launch_bounds__(TILE) void fk_forward_kernel(const float* __restrict__ in0,
@@ -148,7 +164,19 @@ __global__ __launch_bounds__(TILE) void fk_forward_kernel(const float* __restric
         rows_to_lanes<15>(bone_len + base * 15, smem, rows, lane, bl);
 #pragma unroll
         for (int j = 0; j < L::W2; ++j) v2[j] = 0.0f;
-        if (has2) rows_to_lanes<L::W2>(in2 + base * L::W2, smem, rows, lane, v2);
+        if (EXTRA && MODE == 1 && ex.draw) {
+            // s = randint(-200, 200) / 1000 per pose and jitter column (R/models_Fk_GAN/Fk_generator.py:196-203)
+            const unsigned long long idx = (unsigned long long)(base + lane);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                unsigned r[4];
+                philox4x32((unsigned)idx, (unsigned)(idx >> 32), (unsigned)ex.offset + half, (unsigned)(ex.offset >> 32),
+                           (unsigned)ex.seed, (unsigned)(ex.seed >> 32), r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v2[(4 * half + j) < L::W2 ? 4 * half + j : 0] = (float)((int)(r[j] % 400u) - 200) / 1000.0f;
+            }
+            if (ex.scaler_out != nullptr) lanes_to_rows<8, 9>(v2, smem, ex.scaler_out + base * 8, rows, lane);
+        } else if (has2) rows_to_lanes<L::W2>(in2 + base * L::W2, smem, rows, lane, v2);
 
         float ang[37];
         V3 root, p[16];
@@ -349,14 +377,17 @@ int dhaug_gen_tail_forward(const float* head, const float* bone_len, const float
 
 int dhaug_gen_tail_forward_critics(const float* head, const float* bone_len, const float* scaler, float* fake16,
                                    float* centered, uint16_t* kcs_bf16, const float* quat, const float* trans,
-                                   const float* cam9, float* proj2d, int64_t N, int use_preangle, void* stream) {
+                                   const float* cam9, float* proj2d, int draw_scaler, uint64_t rng_seed,
+                                   uint64_t rng_offset, float* scaler_out, int64_t N, int use_preangle, void* stream) {
     DHAUG_CHECK(N >= 0, DHAUG_EINVAL);
     if (N == 0) return DHAUG_OK;
     DHAUG_CHECK_PTR(head); DHAUG_CHECK_PTR(bone_len); DHAUG_CHECK_PTR(fake16);
     DHAUG_CHECK(dhaug_aligned16(head) && dhaug_aligned16(bone_len) && dhaug_aligned16(scaler), DHAUG_EALIGN);
     DHAUG_CHECK(proj2d == nullptr || (quat != nullptr && trans != nullptr && cam9 != nullptr), DHAUG_EINVAL);
+    DHAUG_CHECK(!(draw_scaler && scaler != nullptr), DHAUG_EINVAL);
     TailExtra ex{};
     ex.centered = centered; ex.kcs = kcs_bf16; ex.proj2d = proj2d;
+    ex.draw = draw_scaler ? 1 : 0; ex.seed = rng_seed; ex.offset = rng_offset; ex.scaler_out = draw_scaler ? scaler_out : nullptr;
     if (proj2d != nullptr) {
         for (int i = 0; i < 4; ++i) ex.q[i] = quat[i];
         for (int i = 0; i < 3; ++i) ex.t[i] = trans[i];

@@ -121,13 +121,21 @@ class Fk_Generator(_GeneratorBase):
             if not getattr(self.args, "whether_use_RT", True):
                 head = head.clone()
                 head[:, 28:31] = 0.0
-            scaler = self._scaler(B, bone_len_scaler)
             bl = self.boneLength
             if bl.shape[0] != B:
                 raise RuntimeError("boneLength has %d rows, the batch needs %d (call GAN_generator_get_bone_length)"
                                    % (bl.shape[0], B))
             self.train_num += 1
-            return ops.gen_tail_forward_critics(head.contiguous(), bl, scaler, bool(self.args.GAN_whether_use_preAngle), camera)
+            pre = bool(self.args.GAN_whether_use_preAngle)
+            if bone_len_scaler is None and self.args.bone_len_scaler == "different":
+                # the jitter is drawn inside the tail kernel from the device generator's (seed, offset) stream: same
+                # distribution as torch.randint(-200, 200) / 1000, reproducible under torch.manual_seed
+                g = torch.cuda.default_generators[head.device.index if head.device.index is not None else torch.cuda.current_device()]
+                off = g.get_offset()
+                g.set_offset(off + 8)
+                return ops.gen_tail_forward_critics(head.contiguous(), bl, None, pre, camera, rng=(g.initial_seed(), off))
+            scaler = self._scaler(B, bone_len_scaler)
+            return ops.gen_tail_forward_critics(head.contiguous(), bl, scaler, pre, camera)
 
     def __init__(self, FK_DH_Class, args, device, INPUT_VEC_DIM=128):
         super().__init__(1, FK_DH_Class, args, device, INPUT_VEC_DIM)

@@ -79,9 +79,10 @@ def gen_tail_forward(head, bone_len, scaler, use_preangle=True, want_angles=Fals
     return fake, ang
 
 
-def gen_tail_forward_critics(head, bone_len, scaler, use_preangle=True, camera=None):
+def gen_tail_forward_critics(head, bone_len, scaler, use_preangle=True, camera=None, rng=None, want_scaler=False):
     """generator tail + what the critics consume in one launch: (fake (N,16,3), centered (N,48), kcs bf16 (N,32),
-    proj2d (N,16,2) | None).  camera = (quat[4], trans[3], cam9[9]) host sequences."""
+    proj2d (N,16,2) | None).  camera = (quat[4], trans[3], cam9[9]) host sequences.  rng = (seed, offset): draw the
+    bone-length jitter in the kernel (scaler must be None); want_scaler appends the (N,8) draw to the result."""
     h = _dev(head, torch.float32, "gen_tail_forward_critics").reshape(-1, 35)
     b = _dev(bone_len, torch.float32, "gen_tail_forward_critics").reshape(-1, 15)
     s = None if scaler is None else _dev(scaler, torch.float32, "gen_tail_forward_critics").reshape(-1, 8)
@@ -94,8 +95,12 @@ def gen_tail_forward_critics(head, bone_len, scaler, use_preangle=True, camera=N
     if camera is not None:
         p2 = torch.empty((N, 16, 2), dtype=torch.float32, device=h.device)
         q, t, c = _host3(camera[0], 4), _host3(camera[1], 3), _host3(camera[2], 9)
-    _lib.call("dhaug_gen_tail_forward_critics", _p(h), _p(b), _p(s), _p(fake), _p(xc), _p(kcs), q, t, c, _p(p2), N,
-              int(bool(use_preangle)), _stream())
+    so = torch.empty((N, 8), dtype=torch.float32, device=h.device) if (rng is not None and want_scaler) else None
+    _lib.call("dhaug_gen_tail_forward_critics", _p(h), _p(b), _p(s), _p(fake), _p(xc), _p(kcs), q, t, c, _p(p2),
+              int(rng is not None), 0 if rng is None else int(rng[0]) & (2 ** 64 - 1), 0 if rng is None else int(rng[1]), _p(so),
+              N, int(bool(use_preangle)), _stream())
+    if want_scaler:
+        return fake, xc, kcs, p2, so
     return fake, xc, kcs, p2
 
 

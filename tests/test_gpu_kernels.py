@@ -402,3 +402,28 @@ def test_gen_tail_forward_critics(ops, N, pre):
     assert maxabs(p2, ref_p) <= 1e-2                                  # and stays bounded everywhere (both clamp x/z to +-1)
     f2, x2, k2, none = ops.gen_tail_forward_critics(head, bl, None, pre, None)
     assert none is None and f2.shape == (N, 16, 3)
+
+
+def test_gen_tail_in_kernel_jitter(ops):
+    """bone-length jitter drawn inside the tail kernel (Philox4x32-10): integers in [-200, 200) / 1000, uniform,
+    reproducible for a (seed, offset), different for another offset, and the pose equals the one computed from the
+    same jitter passed explicitly"""
+    N = 65536
+    gen = torch.Generator().manual_seed(3)
+    head = torch.randn(N, 35, generator=gen).cuda()
+    bl = (torch.rand(N, 15, generator=gen) * 0.4 + 0.1).cuda()
+    fake, xc, kcs, p2, sc = ops.gen_tail_forward_critics(head, bl, None, True, None, rng=(1234, 16), want_scaler=True)
+    k = (sc * 1000.0).round()
+    assert maxabs(k.cpu() / 1000.0, sc) == 0.0 and k.min().item() >= -200 and k.max().item() <= 199   # true division, as on the host
+    counts = torch.bincount((k + 200).long().reshape(-1).cpu(), minlength=400).double()
+    expect = N * 8 / 400.0
+    chi2 = ((counts - expect) ** 2 / expect).sum().item()
+    assert chi2 < 399 + 5 * (2 * 399) ** 0.5                          # chi-square, 399 dof, 5 sigma
+    cols = k.cpu().double()
+    assert (torch.corrcoef(cols.t()) - torch.eye(8, dtype=torch.float64)).abs().max().item() < 0.02
+    again = ops.gen_tail_forward_critics(head, bl, None, True, None, rng=(1234, 16), want_scaler=True)
+    assert maxabs(again[4], sc) == 0.0 and maxabs(again[0], fake) == 0.0
+    other = ops.gen_tail_forward_critics(head, bl, None, True, None, rng=(1234, 24), want_scaler=True)
+    assert (other[4] != sc).float().mean().item() > 0.99
+    explicit = ops.gen_tail_forward_critics(head, bl, sc, True, None)
+    assert maxabs(explicit[0], fake) == 0.0
