@@ -185,7 +185,7 @@ def main():
         wb = (torch.randn(D, D, device=dev) / D ** 0.5).to(torch.bfloat16)
         bias = torch.zeros(D, device=dev)
         tl = event_time(lambda: ops.gemm_nt(xb, wb, D, D, bias=bias, res_bf16=xb, act=1, out_bf16=True), 50, 10)
-        roofline_layer = {"kernel": "gemm_nt256_kernel<16,1> (training path: one M=%d, N=K=%d layer, bias+residual+ReLU)" % (B, D),
+        roofline_layer = {"kernel": "gemm_nt256s_kernel<16,1> (training path: one M=%d, N=K=%d layer, bias+residual+ReLU)" % (B, D),
                           "bound": "hbm", "achieved": (3 * B * D * 2 + D * D * 2) / tl / 1e9, "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "frac": (3 * B * D * 2 + D * D * 2) / tl / 1e9 / HBM_PEAK_GBS, "traffic": None,
                           "avg_us": tl * 1e6, "tflops": 2.0 * B * D * D / tl / 1e12}

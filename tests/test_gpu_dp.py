@@ -1,0 +1,99 @@
+"""Data-parallel critic step on the GPU kernels: two replicas (two processes sharing the one card, rendezvous over gloo
+on 127.0.0.1) each take half of the golden critic batch through train_Fk_discriminator; after the flat-bucket
+exchange + fused Adam the parameters of BOTH replicas must equal the reference's single-process full-batch step
+(tests/golden/critic_step_*_D32.npz), i.e. sharding the augmentation batch changes nothing but the wall clock.
+WGAN-GP's three terms are batch means, so mean-of-shard-gradients == full-batch gradient (equal shards)."""
+import argparse
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, tag, q):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import numpy as np
+    import torch.distributed as dist
+    import golden_util as GU
+    import dhaug_amd
+    from dhaug_amd import parallel
+    from dhaug_amd.models_Fk_GAN import Fk_discriminator as dis, model_fk_gan_train as train
+    from test_gpu_models import make_args, maxabs
+    parallel.init_from_env("gloo")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "critic_step_%s_D32.npz" % tag))
+    g = {k: torch.from_numpy(z[k]) for k in z.files}
+    B = g["real"].shape[0]
+    b, e = parallel.shard_range(B, rank, world)
+    args = make_args(batch_size=e - b)
+    shapes = GU.shapes_d3(32) if tag == "d3" else GU.shapes_d2(32)
+    net = dis.Fk_3D_Discriminator("cuda", args) if tag == "d3" else dis.Fk_2D_Discriminator(args, 16)
+    if rank == 0:                                # replicas start from rank 0's weights
+        net.load_state_dict(GU.seeded_state_dict(shapes, int(g["weight_seed"])))
+    net.precision = "bf16x6"
+    net = net.cuda()
+    parallel.broadcast_parameters([net])
+    opt = train.FusedAdam(net.parameters(), lr=1e-4, betas=(0.5, 0.9))
+    assert opt.world_size() == world
+    W, C = train.train_Fk_discriminator(net, g["real"][b:e].clone(), g["fake"][b:e].clone(),
+                                        argparse.Namespace(train_iter_num=1), None, "Fk_" + tag, opt, args,
+                                        alpha=g["alpha"][b:e].cuda())
+    # the scalars are per-shard means; their average over the ranks is the reference's value
+    s = torch.stack([W, C]).float().cpu()
+    dist.all_reduce(s)
+    s /= world
+    bad = []
+    if abs(s[0].item() - g["Wasserstein_D"].item()) > 1e-5:
+        bad.append(("W", s[0].item(), g["Wasserstein_D"].item()))
+    if abs(s[1].item() - g["D_cost"].item()) > 1e-4 * max(1.0, abs(g["D_cost"].item())):
+        bad.append(("C", s[1].item(), g["D_cost"].item()))
+    for k, p in net.named_parameters():
+        gref = g["grad__" + k]
+        # flat_grad holds the SUM over the replicas; the Adam kernel applies 1/world
+        if maxabs(p.grad / world, gref) > 2e-5 + 2e-4 * gref.abs().max().item():
+            bad.append(("grad", k, maxabs(p.grad / world, gref)))
+        well = gref.abs() > max(1e-3 * gref.abs().max().item(), 1e-7)
+        if well.any() and maxabs(p.cpu()[well], g["new__" + k][well]) > 2e-6:
+            bad.append(("new", k, maxabs(p.cpu()[well], g["new__" + k][well])))
+        if maxabs(p, g["new__" + k]) > 1.01e-4:
+            bad.append(("new_all", k, maxabs(p, g["new__" + k])))
+    # replicas stay bit-identical after the step
+    flat = opt.flat_param.detach().cpu()
+    other = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    if not all(torch.equal(o, flat) for o in other):
+        bad.append(("replicas diverged",))
+    q.put((rank, bad))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tag", ["d3", "d2"])
+def test_two_replica_critic_step_equals_full_batch(tag):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + (7 if tag == "d2" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, tag, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted(q.get(timeout=300) for _ in procs)
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()                          # exact child only
+    assert [r[0] for r in res] == [0, 1]
+    for r in res:
+        assert not r[1], r
+    assert all(p.exitcode == 0 for p in procs)
