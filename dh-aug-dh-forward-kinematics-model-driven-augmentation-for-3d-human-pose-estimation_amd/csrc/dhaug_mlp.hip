@@ -46,7 +46,10 @@ enum { U_LOAD_F32 = 0, U_LOAD_BF16 = 1, U_STORE_BF16 = 2, U_GEMM = 3 };
 enum { F_OUT_F32 = 4 };
 
 struct Unit {
-    int kind, flags;
+    int kind;
+    int plan;                   // how the kernel runs the unit, decided on the host (plan_unit): kind and plan are all the
+                                // dispatch reads, and it reads them one unit ahead
+    int flags;
     int src, dst, res;          // LDS buffer ids (0,1: pitch 256; 2: pitch 128), -1 = none
     int src2, ksteps2;          // optional second source (layers fed by a concatenation), ksteps2 = 0: none
     int ksteps, N, act;
@@ -58,6 +61,9 @@ struct Unit {
     const uint16_t* w2;         // fragments of the second source
     const float* bias;          // GEMM: fp32 [32 * nslices] (zero padded)
 };
+// plan of a GEMM unit.  Stack: bits 0-3 lead k-steps, 4-9 run.  Single layer: bits 16-23 shape (chunks * 16 + chunks of
+// source 1), 24-27 feature slices
+enum { PLAN_STACK = 1 << 13, PLAN_LEAKY = 1 << 10, PLAN_ALT = 1 << 11, PLAN_TAIL = 1 << 12, PLAN_OUT = 1 << 28 };
 
 struct Program {
     int nunits;
@@ -85,9 +91,30 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {          // 
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16v2));
 }
 
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t pk_relu(uint32_t packed, uint32_t lb) {     // v_pk_max_i16
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, packed), __builtin_bit_cast(s16x2_t, lb)));
+}
+
 constexpr int MLP_CH = 4;                                            // k-steps per ring slot (64 k)
 constexpr int OUT_PITCH = 68;                                        // floats per row of the fp32 output staging image
 typedef const Unit __attribute__((address_space(4))) * UnitPtr;      // units are read from the kernarg segment (s_load)
+
+#ifdef DHAUG_MLP_TIMING
+#ifndef DHAUG_STAMP_TID
+#define DHAUG_STAMP_TID 0
+#endif
+// development aid (not built by default): shader-clock stamps of workgroup 0 at every unit boundary of its first tile
+__device__ long long g_mlp_stamps[5 * MLP_MAX_UNITS + 68];
+#define DHAUG_STAMP(idx)                                                      \
+    if (blockIdx.x == 0 && tid == 0 && tile == 0) g_mlp_stamps[idx] = (long long)__builtin_readcyclecounter();
+#define DHAUG_LSTAMP(idx) \
+    if (blockIdx.x == 0 && threadIdx.x == DHAUG_STAMP_TID) g_mlp_stamps[idx] = (long long)__builtin_readcyclecounter();
+#else
+#define DHAUG_STAMP(idx)
+#define DHAUG_LSTAMP(idx)
+#endif
 
 // K is processed in chunks of 64 (4 k-steps); sources narrower than a multiple of 64 are zero-filled by their
 // producer (LOAD units pad, GEMM epilogues write whole 32-feature slices) and the packed weights are zero there.
@@ -121,7 +148,11 @@ __device__ __forceinline__ void load_chunk(const uint16_t* w1, const uint16_t* w
 // NS = feature slices this wave really owns in this layer (2: slices wave and wave+4; 1: only slice wave -- layers
 // narrower than 160 features); waves with no slice skip the layer.
 template <int NCH, int NCH1, int NS>
-__device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int wave, int lane) {
+__device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int wave, int lane, int dbg) {
+    DHAUG_LSTAMP(dbg)
+    // opaque: everything derived from the lane id below is recomputed per call (a few VALU) instead of being hoisted out
+    // of the unit loop and parked on registers the stacks need
+    asm volatile("" : "+v"(lane));
     bf16x8 ring[3][NS][MLP_CH];
     const int r31 = lane & 31, h = lane >> 5;
     const uint16_t* w1 = u->w;
@@ -133,7 +164,16 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
     const int pbs1 = buf_pitch_bytes(u->src);
     const unsigned char* src2 = NCH1 < NCH ? buf_base(smem, u->src2) : src1;
     const int pbs2 = NCH1 < NCH ? buf_pitch_bytes(u->src2) : pbs1;
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // the bias is the accumulators' start value (requested here, first used by the first MFMA)
+    f32x16 seed[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(u->bias + 32 * (wave + 4 * t) + 4 * h + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) seed[t][4 * g + e] = b4[e];
+        }
     constexpr int KT = NCH * MLP_CH;                            // k-steps in total
     bf16x8 fx[3][MLP_MT];                                       // activation fragments: read two k-steps ahead (one wave per
                                                                 // SIMD: nobody else hides the LDS latency)
@@ -167,29 +207,57 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
         for (int mt = 0; mt < MLP_MT; ++mt)
 #pragma unroll
             for (int t = 0; t < NS; ++t)
-                acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[c % 3][t][q], fx[k % 3][mt], k == 0 ? zero : acc[t][mt],
+                acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[c % 3][t][q], fx[k % 3][mt], k == 0 ? seed[t] : acc[t][mt],
                                                                     0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+    DHAUG_LSTAMP(dbg + 1)
     const int nslices = (u->N + 31) >> 5;
     const bool to_global = (u->flags & F_OUT_F32) != 0;
     unsigned char* dst = buf_base(smem, u->dst);
     const int pbd = buf_pitch_bytes(u->dst);
     const int resid = u->res;
-    const unsigned char* res = resid >= 0 ? buf_base(smem, resid) : nullptr;
-    const int pbr = resid >= 0 ? buf_pitch_bytes(resid) : 0;
-    const float neg = act_neg(u->act, u->slope);
+    if (resid >= 0 && !to_global) {
+        // residual: two more k-steps against identity fragments (A[n][k'] = (n == 16 ks2 + k'), the lane's k' = 8h + j),
+        // B = the residual image's chunks of this slice -- exact (1.0 * bf16 accumulated in fp32), no unpack on the VALU
+        const unsigned char* res = buf_base(smem, resid);
+        const int pbr = buf_pitch_bytes(resid);
+        bf16x8 idf[2];
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+            const int dd = r31 - 16 * ks2 - 8 * h;
+            u32x4_t v;
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) v[p2] = (dd == 2 * p2 ? 0x3F80u : 0u) | (dd == 2 * p2 + 1 ? 0x3F800000u : 0u);
+            idf[ks2] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int slice = wave + 4 * t;
+            if (slice >= nslices) continue;
+            bf16x8 rf[MLP_MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MLP_MT; ++mt)
+#pragma unroll
+                for (int ks2 = 0; ks2 < 2; ++ks2)
+                    rf[mt][ks2] = *reinterpret_cast<const bf16x8*>(res + chunk_off(32 * mt + r31, 4 * slice + 2 * ks2 + h, pbr));
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+                for (int mt = 0; mt < MLP_MT; ++mt)
+                    acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(idf[ks2], rf[mt][ks2], acc[t][mt], 0, 0, 0);
+        }
+    }
+    const int act = u->act;
     // epilogue: this lane owns row (32 mt + r31), features 32*slice + 8g + 4h .. +3
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
         const int slice = wave + 4 * t;
         if (slice >= nslices) continue;                        // wave-uniform: slices beyond N are never stored
-        f32x4 bias[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const f32x4*>(u->bias + 32 * slice + 4 * h + 8 * g);
         if (to_global) {
             // network output (<= 64 features): fp32 staging image [128][OUT_PITCH] in buffer dst, copied out
             // cooperatively by store_output() after the barrier
+            const float neg = act_neg(act, u->slope);
             float* st = reinterpret_cast<float*>(dst);
 #pragma unroll
             for (int mt = 0; mt < MLP_MT; ++mt)
@@ -197,42 +265,35 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[t][mt][4 * g + e] + bias[g][e], neg);
+                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[t][mt][4 * g + e], neg);
                     *reinterpret_cast<f32x4*>(st + (32 * mt + r31) * OUT_PITCH + 32 * slice + 4 * h + 8 * g) = v;
                 }
-        } else if (res != nullptr) {
+        } else if (act != DHAUG_ACT_LRELU) {
+            // ReLU on the packed pair: max as int16 against 0 (a negative bf16 is a negative int16); against INT16_MIN it
+            // is the identity
+            const uint32_t lb = act == DHAUG_ACT_RELU ? 0u : 0x80008000u;
 #pragma unroll
             for (int mt = 0; mt < MLP_MT; ++mt) {
                 const int row = 32 * mt + r31;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int c = 4 * slice + g;                         // 16-byte chunk = 8 features
-                    const uint2 rr = *reinterpret_cast<const uint2*>(res + chunk_off(row, c, pbr) + (h << 3));
-                    float v[4];
-                    v[0] = acc[t][mt][4 * g + 0] + bias[g][0] + __builtin_bit_cast(float, rr.x << 16);
-                    v[1] = acc[t][mt][4 * g + 1] + bias[g][1] + __builtin_bit_cast(float, rr.x & 0xffff0000u);
-                    v[2] = acc[t][mt][4 * g + 2] + bias[g][2] + __builtin_bit_cast(float, rr.y << 16);
-                    v[3] = acc[t][mt][4 * g + 3] + bias[g][3] + __builtin_bit_cast(float, rr.y & 0xffff0000u);
                     uint2 o;
-                    o.x = pack_bf16x2(act_fn(v[0], neg), act_fn(v[1], neg));
-                    o.y = pack_bf16x2(act_fn(v[2], neg), act_fn(v[3], neg));
-                    *reinterpret_cast<uint2*>(dst + chunk_off(row, c, pbd) + (h << 3)) = o;
+                    o.x = pk_relu(pack_bf16x2(acc[t][mt][4 * g + 0], acc[t][mt][4 * g + 1]), lb);
+                    o.y = pk_relu(pack_bf16x2(acc[t][mt][4 * g + 2], acc[t][mt][4 * g + 3]), lb);
+                    *reinterpret_cast<uint2*>(dst + chunk_off(row, 4 * slice + g, pbd) + (h << 3)) = o;
                 }
             }
         } else {
+            const float neg = u->slope;
 #pragma unroll
             for (int mt = 0; mt < MLP_MT; ++mt) {
                 const int row = 32 * mt + r31;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int c = 4 * slice + g;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[t][mt][4 * g + e] + bias[g][e], neg);
                     uint2 o;
-                    o.x = pack_bf16x2(v[0], v[1]);
-                    o.y = pack_bf16x2(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(dst + chunk_off(row, c, pbd) + (h << 3)) = o;
+                    o.x = pack_bf16x2(act_fn(acc[t][mt][4 * g + 0], neg), act_fn(acc[t][mt][4 * g + 1], neg));
+                    o.y = pack_bf16x2(act_fn(acc[t][mt][4 * g + 2], neg), act_fn(acc[t][mt][4 * g + 3], neg));
+                    *reinterpret_cast<uint2*>(dst + chunk_off(row, 4 * slice + g, pbd) + (h << 3)) = o;
                 }
             }
         }
@@ -240,8 +301,9 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
 }
 
 template <int NCH, int NCH1, int NS>
-__device__ __forceinline__ void gemm_single(UnitPtr u, unsigned char* smem, int wave, int lane) {
-    gemm_layer<NCH, NCH1, NS>(u, smem, wave, lane);
+__device__ __forceinline__ void gemm_single(UnitPtr u, unsigned char* smem, int wave, int lane, int dbg) {
+    gemm_layer<NCH, NCH1, NS>(u, smem, wave, lane, dbg);
+    DHAUG_LSTAMP(dbg + 2)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -260,20 +322,6 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-#ifdef DHAUG_MLP_TIMING
-#ifndef DHAUG_STAMP_TID
-#define DHAUG_STAMP_TID 0
-#endif
-// development aid (not built by default): shader-clock stamps of workgroup 0 at every unit boundary of its first tile
-__device__ long long g_mlp_stamps[MLP_MAX_UNITS + 64];
-#define DHAUG_STAMP(idx)                                                      \
-    if (blockIdx.x == 0 && tid == 0 && tile == 0) g_mlp_stamps[idx] = (long long)__builtin_readcyclecounter();
-#define DHAUG_LSTAMP(idx) \
-    if (blockIdx.x == 0 && threadIdx.x == DHAUG_STAMP_TID) g_mlp_stamps[idx] = (long long)__builtin_readcyclecounter();
-#else
-#define DHAUG_STAMP(idx)
-#define DHAUG_LSTAMP(idx)
-#endif
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef bf16x8 WHalf[MLP_NS][MLP_MAX_KSTEPS / 2];                     // fragments of k-steps 0..7 or 8..15
@@ -666,45 +714,46 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void fused_mlp_kernel(Program prog,
         (const unsigned char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
     UnitPtr units = (UnitPtr)(ka + __builtin_offsetof(Program, u));
     const int nunits = *(const int __attribute__((address_space(4)))*)(ka + __builtin_offsetof(Program, nunits));
-    const int min_run = *(const int __attribute__((address_space(4)))*)(ka + __builtin_offsetof(Program, min_run));
+    int hk = units->kind, hp = units->plan;                                   // header of the next unit to run
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long m0 = tile * MLP_BM;
+        int i = 0;
 #pragma unroll 1
-        for (int i = 0; i < nunits; ++i) {
+        while (i < nunits) {
             UnitPtr u = units + i;
+            const int kind = hk, plan = hp;
+            // where the program continues, and that unit's header: requested now, used after this unit
+            int ni = i + 1;
+            if (kind == U_GEMM && (plan & PLAN_STACK)) ni = i + ((plan & 15) != 0) + ((plan >> 4) & 63) + ((plan & PLAN_TAIL) ? 1 : 0);
+            {
+                UnitPtr nu = units + (ni < nunits ? ni : 0);
+                hk = nu->kind;
+                hp = nu->plan;
+            }
             DHAUG_STAMP(i)
-            if (u->kind != U_GEMM) {
+            DHAUG_LSTAMP(MLP_MAX_UNITS + 64 + 4 * i)
+            const int ui = i;
+            i = ni;
+            (void)ui;
+            if (kind != U_GEMM) {
                 // a STORE is not waited for where it is issued (lds_barrier orders only its LDS reads); the LOAD that
                 // reads the parked rows back drains the workgroup's stores first
-                if (u->kind == U_LOAD_BF16) __syncthreads();
+                if (kind == U_LOAD_BF16) __syncthreads();
                 move_unit(u, smem, m0, M, tid);
-                if (u->kind == U_STORE_BF16) {
+                if (kind == U_STORE_BF16) {
                     lds_barrier();
                     continue;
                 }
             } else {
-                const int nch1 = chunks_of(u->ksteps), nch = nch1 + chunks_of(u->ksteps2);
-                // a run of consecutive plain 256 -> 256 layers, possibly fed by this (narrow) layer?
-                const bool wide = u->ksteps2 == 0 && u->N > 224 && !(u->flags & F_OUT_F32) && u->src < 2 && u->dst < 2;
-                const int ks4 = (u->ksteps + 3) & ~3;                        // the fragment blob and the LOAD pad to whole chunks
-                const int lead_ks = (wide && u->res < 0 && ks4 <= 8) ? ks4 : 0;
-                const int i0 = i + (lead_ks != 0);
-                int run = 0, leaky = lead_ks != 0 && u->act == DHAUG_ACT_LRELU, alt = 1;
-                while (i0 + run < nunits && units[i0 + run].kind == U_GEMM && units[i0 + run].ksteps == 16 &&
-                       units[i0 + run].ksteps2 == 0 && units[i0 + run].N > 224 && !(units[i0 + run].flags & F_OUT_F32) &&
-                       units[i0 + run].src < 2 && units[i0 + run].dst < 2 && units[i0 + run].res < 2) {
-                    leaky |= units[i0 + run].act == DHAUG_ACT_LRELU;
-                    alt &= (units[i0 + run].res >= 0) == ((run & 1) == 1);
-                    ++run;
-                }
-                if (run >= min_run) {
-                    UnitPtr f0 = units + i0, tu = f0 + run;
-                    const bool tail = i0 + run < nunits && tu->kind == U_GEMM && (tu->flags & F_OUT_F32) && tu->ksteps == 16 &&
-                                      tu->ksteps2 == 0 && tu->N <= 64 && tu->src < 2 && tu->dst < 2 && tu->res < 0;
-                    if (leaky) gemm_stack<true, false>(u, lead_ks, f0, run, tail, smem, wave, lane);
-                    else if (alt && !(run & 1)) gemm_stack<false, true>(u, lead_ks, f0, run, tail, smem, wave, lane);
+                if (plan & PLAN_STACK) {
+                    // a run of consecutive plain 256 -> 256 layers, possibly fed by this (narrow) layer and followed by
+                    // the output layer
+                    const int lead_ks = plan & 15, run = (plan >> 4) & 63;
+                    const bool tail = (plan & PLAN_TAIL) != 0;
+                    UnitPtr f0 = u + (lead_ks != 0), tu = f0 + run;
+                    if (plan & PLAN_LEAKY) gemm_stack<true, false>(u, lead_ks, f0, run, tail, smem, wave, lane);
+                    else if (plan & PLAN_ALT) gemm_stack<false, true>(u, lead_ks, f0, run, tail, smem, wave, lane);
                     else gemm_stack<false, false>(u, lead_ks, f0, run, tail, smem, wave, lane);
-                    i = i0 + run - 1 + (tail ? 1 : 0);
                     __syncthreads();
                     if (tail) {
                         store_output(tu, smem, m0, M, tid);
@@ -712,26 +761,27 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void fused_mlp_kernel(Program prog,
                     }
                     continue;                                                // (stamps of the run's inner layers stay 0)
                 }
-                const int nslices = (u->N + 31) >> 5;
+                const int nslices = (plan >> 24) & 15, dbg = MLP_MAX_UNITS + 64 + 4 * ui;
 #define DHAUG_SHAPES(NS)                                                                   \
-    switch (nch * 16 + nch1) {                                 /* validated on the host */ \
-        case 1 * 16 + 1: gemm_single<1, 1, NS>(u, smem, wave, lane); break;                 \
-        case 2 * 16 + 2: gemm_single<2, 2, NS>(u, smem, wave, lane); break;                 \
-        case 2 * 16 + 1: gemm_single<2, 1, NS>(u, smem, wave, lane); break;                 \
-        case 4 * 16 + 4: gemm_single<4, 4, NS>(u, smem, wave, lane); break;                 \
-        case 4 * 16 + 2: gemm_single<4, 2, NS>(u, smem, wave, lane); break;                 \
-        case 8 * 16 + 4: gemm_single<8, 4, NS>(u, smem, wave, lane); break;                 \
+    switch ((plan >> 16) & 255) {                              /* validated on the host */ \
+        case 1 * 16 + 1: gemm_single<1, 1, NS>(u, smem, wave, lane, dbg); break;                 \
+        case 2 * 16 + 2: gemm_single<2, 2, NS>(u, smem, wave, lane, dbg); break;                 \
+        case 2 * 16 + 1: gemm_single<2, 1, NS>(u, smem, wave, lane, dbg); break;                 \
+        case 4 * 16 + 4: gemm_single<4, 4, NS>(u, smem, wave, lane, dbg); break;                 \
+        case 4 * 16 + 2: gemm_single<4, 2, NS>(u, smem, wave, lane, dbg); break;                 \
+        case 8 * 16 + 4: gemm_single<8, 4, NS>(u, smem, wave, lane, dbg); break;                 \
         default: break;                                                                    \
     }
                 if (wave + 4 < nslices) { DHAUG_SHAPES(2) }
                 else if (wave < nslices) { DHAUG_SHAPES(1) }
 #undef DHAUG_SHAPES
-                if (u->flags & F_OUT_F32) {
+                if (plan & PLAN_OUT) {
                     __syncthreads();
                     store_output(u, smem, m0, M, tid);
                 }
             }
             __syncthreads();
+            DHAUG_LSTAMP(MLP_MAX_UNITS + 64 + 4 * ui + 3)
         }
         DHAUG_STAMP(nunits)
     }
@@ -749,6 +799,35 @@ __global__ __launch_bounds__(256) void pack_wfrag_kernel(const float* __restrict
         const int n = 32 * s + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
         dst[i] = (n < N && k < K) ? dhaug_f32_to_bf16(W[(long long)n * ldw + k0 + k]) : (uint16_t)0;
     }
+}
+
+// how unit i is executed (see the dispatch in fused_mlp_kernel): a run of >= min_run full-width 256 -> 256 layers goes to
+// gemm_stack, together with the narrow layer (K <= 128) feeding it and the <= 64-wide fp32 output layer behind it
+int plan_unit(const Program& p, int i) {
+    const Unit* U = p.u;
+    const Unit& u = U[i];
+    if (u.kind != U_GEMM) return 0;
+    const bool wide = u.ksteps2 == 0 && u.N > 224 && !(u.flags & F_OUT_F32) && u.src < 2 && u.dst < 2;
+    const int ks4 = (u.ksteps + 3) & ~3;                                 // the fragment blob and the LOAD pad to whole chunks
+    const int lead_ks = (wide && u.res < 0 && ks4 <= 8) ? ks4 : 0;
+    const int i0 = i + (lead_ks != 0);
+    int run = 0, leaky = lead_ks != 0 && u.act == DHAUG_ACT_LRELU, alt = 1;
+    while (i0 + run < p.nunits && U[i0 + run].kind == U_GEMM && U[i0 + run].ksteps == 16 && U[i0 + run].ksteps2 == 0 &&
+           U[i0 + run].N > 224 && !(U[i0 + run].flags & F_OUT_F32) && U[i0 + run].src < 2 && U[i0 + run].dst < 2 &&
+           U[i0 + run].res < 2) {
+        leaky |= U[i0 + run].act == DHAUG_ACT_LRELU;
+        alt &= (U[i0 + run].res >= 0) == ((run & 1) == 1);
+        ++run;
+    }
+    if (run < p.min_run || run > 63) {
+        const int c1 = (u.ksteps + 3) / 4, c2 = (u.ksteps2 + 3) / 4;
+        return (((c1 + c2) * 16 + c1) << 16) | (((u.N + 31) >> 5) << 24) | ((u.flags & F_OUT_F32) ? PLAN_OUT : 0);
+    }
+    const Unit* tu = U + i0 + run;
+    const bool tail = i0 + run < p.nunits && tu->kind == U_GEMM && (tu->flags & F_OUT_F32) && tu->ksteps == 16 &&
+                      tu->ksteps2 == 0 && tu->N <= 64 && tu->src < 2 && tu->dst < 2 && tu->res < 0;
+    return PLAN_STACK | lead_ks | (run << 4) | (leaky ? PLAN_LEAKY : 0) | ((!leaky && alt && !(run & 1)) ? PLAN_ALT : 0) |
+           (tail ? PLAN_TAIL : 0);
 }
 
 }  // namespace
@@ -819,6 +898,7 @@ int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* 
             DHAUG_CHECK(u.kind == U_LOAD_F32 ? (u.ld % 4 == 0) : (u.ld % 8 == 0), DHAUG_EALIGN);
         }
     }
+    for (int i = 0; i < prog.nunits; ++i) prog.u[i].plan = plan_unit(prog, i);
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel),
@@ -836,6 +916,6 @@ int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* 
 
 #ifdef DHAUG_MLP_TIMING
 extern "C" int dhaug_debug_mlp_stamps(long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_stamps), sizeof(long long) * (n < MLP_MAX_UNITS + 64 ? n : MLP_MAX_UNITS + 64));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_stamps), sizeof(long long) * (n < 5 * MLP_MAX_UNITS + 68 ? n : 5 * MLP_MAX_UNITS + 68));
 }
 #endif

@@ -15,7 +15,7 @@ D2 = Fk_discriminator.Fk_2D_Discriminator(args, 16).cuda()
 x2 = torch.randn(B, 16, 2, device="cuda") * 0.3
 z = torch.randn(B, 128, device="cuda"); x3 = torch.randn(B, 16, 3, device="cuda") * 0.3
 L = _lib.lib()
-N = 64 + 64
+N = 5 * 32 + 68
 buf = (ctypes.c_longlong * N)()
 with torch.no_grad():
     for name, fn in (("G", lambda: fused.generator_head(G, z)), ("D3", lambda: fused.critic3d(D3, x3)), ("D2", lambda: fused.critic2d(D2, x2)), ("D3", lambda: fused.critic3d(D3, x3))):
@@ -26,3 +26,13 @@ with torch.no_grad():
         idx = [i for i, v in enumerate(st[:34]) if v]
         base = st[idx[0]]
         print(name, " ".join("%d:%d" % (i, st[i] - base) for i in idx))
+        # stamps inside the last stack of the last tile (index - 32: see gemm_stack / stack_layer)
+        idx2 = [i for i, v in enumerate(st[32:96], 32) if v]
+        if idx2:
+            b2 = min(st[i] for i in idx2)
+            print("   stack:", " ".join("%d:%d" % (i - 32, st[i] - b2) for i in idx2))
+        # last tile, per unit: start, [generic GEMM: after the k loop, after the epilogue], after the trailing barrier
+        us = [u for u in range(32) if st[96 + 4 * u]]
+        if us:
+            b3 = st[96 + 4 * us[0]]
+            print("   units(last tile):", " | ".join("%d: %s" % (u, " ".join(str(st[96 + 4 * u + j] - b3) if st[96 + 4 * u + j] else "-" for j in range(4))) for u in us))
