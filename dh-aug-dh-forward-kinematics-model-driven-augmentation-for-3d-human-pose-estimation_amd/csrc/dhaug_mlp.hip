@@ -106,14 +106,30 @@ typedef const Unit __attribute__((address_space(4))) * UnitPtr;      // units ar
 #define DHAUG_STAMP_TID 0
 #endif
 // development aid (not built by default): shader-clock stamps of workgroup 0 at every unit boundary of its first tile
-__device__ long long g_mlp_stamps[5 * MLP_MAX_UNITS + 68];
+__device__ long long g_mlp_stamps[5 * MLP_MAX_UNITS + 68 + MLP_MAX_UNITS + 1];
 #define DHAUG_STAMP(idx)                                                      \
-    if (blockIdx.x == 0 && tid == 0 && tile == 0) g_mlp_stamps[idx] = (long long)__builtin_readcyclecounter();
+    if (blockIdx.x == 0 && tid == 0) g_mlp_stamps[tile == 0 ? (idx) : 5 * MLP_MAX_UNITS + 68 + (idx)] = (long long)__builtin_readcyclecounter();
+#ifdef DHAUG_MLP_TIMING_UNITS                                 /* unit boundaries only: the layer bodies compile as shipped */
+#define DHAUG_LSTAMP(idx)
+#else
 #define DHAUG_LSTAMP(idx) \
     if (blockIdx.x == 0 && threadIdx.x == DHAUG_STAMP_TID) g_mlp_stamps[idx] = (long long)__builtin_readcyclecounter();
+#endif
 #else
 #define DHAUG_STAMP(idx)
 #define DHAUG_LSTAMP(idx)
+#endif
+// ends the basic block (a never-taken scalar branch the compiler cannot see through): the 32-row tiles of a stack layer
+// are scheduled and register-allocated one at a time instead of as one 1 200-instruction block
+#if defined(DHAUG_MLP_TIMING) && !defined(DHAUG_MLP_TIMING_UNITS)
+#define DHAUG_BB_SPLIT()
+#else
+#define DHAUG_BB_SPLIT()                                  \
+    {                                                     \
+        int z_ = 0;                                       \
+        asm volatile("" : "+s"(z_));                      \
+        if (z_) asm volatile("s_nop 0");                  \
+    }
 #endif
 
 // K is processed in chunks of 64 (4 k-steps); sources narrower than a multiple of 64 are zero-filled by their
@@ -342,20 +358,23 @@ __device__ __forceinline__ StackDesc stack_desc(UnitPtr u) {
     return d;
 }
 
-// per-lane base pointers of a layer's fragments ([slice][KS k-steps][64 lanes][8]): [t][half] points at k-step 4 / 12
-// of slice wave + 4t, so that every fragment is base + a 13-bit signed immediate ((k - 4) * 1024 bytes)
+// a layer's fragments ([slice][KS k-steps][64 lanes][8]) are fetched with buffer loads: a scalar resource that starts at
+// the wave's first slice, ONE per-lane offset (16 * lane) for everything, slice and k-step as scalar offset + immediate
+// (measured beside MFMAs, tools/ubench/vmem_gap.hip: a buffer_load_dwordx4 costs ~4 issue cycles, a global_load_dwordx4 with
+// its 64-bit per-lane address ~14 -- and eight lane-dependent base pointers would sit in registers for the whole kernel)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 template <int KS = MLP_MAX_KSTEPS>
 struct WBase {
-    const uint16_t* p[MLP_NS][2];
+    __amdgpu_buffer_rsrc_t rs;
+    int lane16, sstride;
     // the wave's slices are s0 and s0 + sstride (wave, wave + 4 in a full-width layer)
-    __device__ __forceinline__ WBase(const uint16_t* w, int s0, int sstride, int lane) {
-#pragma unroll
-        for (int t = 0; t < MLP_NS; ++t)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) p[t][hh] = w + ((long long)((s0 + sstride * t) * KS + 4 + 8 * hh) * 64 + lane) * 8;
+    __device__ __forceinline__ WBase(const uint16_t* w, int s0, int sstride_, int lane) {
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(w) + (long long)s0 * KS * 512, 0, 0x7fffffff, 0x27000);
+        lane16 = lane * 16;
+        sstride = sstride_;
     }
     __device__ __forceinline__ bf16x8 frag(int t, int k) const {
-        return *reinterpret_cast<const bf16x8*>(p[t][k >> 3] + ((k & 7) - 4) * 512);
+        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (t * sstride * KS + k) * 1024, 0));
     }
 };
 
@@ -399,9 +418,8 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
     constexpr int PAIRS = 16 / KS;                                           // accumulator element pairs retired per k-step
     constexpr int TILE_BYTES = 32 * BUF01_PITCH * 2;                         // 16 384
     const int r31 = lane & 31, h = lane >> 5, x = lane & 15;
-    f32x16 nseed[MLP_NS];
-    const int ns0 = nd.narrow ? 0 : wave, nss = nd.narrow ? 1 : 4;
-    load_seed(nd.bias, ns0, nss, lane, nseed);
+    f32x16 nseed[MLP_NS];                                                    // requested in the last tile: asked for at the layer's start
+    const int ns0 = nd.narrow ? 0 : wave, nss = nd.narrow ? 1 : 4;           // they are parked right away, behind a full vmcnt drain
     const WBase<> nb(nd.w, ns0, nss, lane);
     const unsigned char* src = buf_base(smem, d.src);
     unsigned char* dst = buf_base(smem, d.dst);
@@ -421,47 +439,90 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
     constexpr int FXD = 3;                                                   // fx prefetch distance in k-steps
     f32x16 acc[2][MLP_NS];                                                   // tile mt accumulates while tile mt-1 drains
     bf16x8 fx[4], rx[4];
-    uint32_t ov = 0;
+    // the eight swizzled chunk addresses of a row's first 256 bytes, kept in registers for the layer (opaque, so that they
+    // are not re-derived from parked constants with two VALU ops in front of every read); k-steps 8..15 and the tile are
+    // immediate offsets
+    typedef const unsigned char __attribute__((address_space(3))) * LdsPtr;
+    uint32_t fxa[8];
+    {
+        const uint32_t sb = (uint32_t)(uintptr_t)(LdsPtr)src;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            fxa[i] = sb + (uint32_t)(lfx ^ (i << 5));
+            asm volatile("" : "+v"(fxa[i]));
+        }
+    }
     auto fx_load = [&](int s) {                                              // s = KS * tile + k-step
-        fx[s & 3] = *reinterpret_cast<const bf16x8*>(src + (lfx ^ ((s % KS) << 5)) + (s / KS) * TILE_BYTES);
+        const int k = s % KS;
+        fx[s & 3] = *reinterpret_cast<const bf16x8 __attribute__((address_space(3)))*>((LdsPtr)(uintptr_t)fxa[k & 7] + ((k >> 3) << 8) +
+                                                                                     (s / KS) * TILE_BYTES);
     };
 #pragma unroll
     for (int s = 0; s < FXD; ++s) fx_load(s);
-    // elements j, j+1 (j even) of tile `mt` (held in `a`): j = 16t + 4g + e
-    auto element_pair = [&](const f32x16 (&a)[MLP_NS], int mt, int j) {
+    // the epilogue write addresses (chunk 4(wave+4t)+g of the lane's row): four swizzle variants in registers, t and the
+    // tile are immediate offsets
+    uint32_t wa[4];
+    {
+        const uint32_t db = (uint32_t)(uintptr_t)(LdsPtr)dst;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            wa[g] = db + (uint32_t)(lep ^ (g << 4));
+            asm volatile("" : "+v"(wa[g]));
+        }
+    }
+    typedef unsigned char __attribute__((address_space(3))) * LdsWPtr;
+    // elements j, j+1 (j even) of a tile held in `a`: j = 16t + 4g + e -> activation, packed bf16 pair
+    auto pair_pack = [&](const f32x16 (&a)[MLP_NS], int j) -> uint32_t {
         const int t = j >> 4, g = (j >> 2) & 3, e = j & 3;
         const float v0 = a[t][4 * g + e], v1 = a[t][4 * g + e + 1];
-        uint32_t o;
-        if (!LEAKY) {
-            o = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16x2(v0, v1)),
-                                                                       __builtin_bit_cast(s16x2, lb)));
-        } else {
-            o = pack_bf16x2(act_fn(v0, neg), act_fn(v1, neg));
-        }
-        if (e == 0) {
-            ov = o;
-        } else {
-            uint2 oo;
-            oo.x = ov; oo.y = o;
-            *reinterpret_cast<uint2*>(dst + (lep ^ ((16 * t + g) << 4)) + mt * TILE_BYTES) = oo;
-        }
+        if (!LEAKY)
+            return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16x2(v0, v1)),
+                                                                          __builtin_bit_cast(s16x2, lb)));
+        return pack_bf16x2(act_fn(v0, neg), act_fn(v1, neg));
     };
+    // the four elements j .. j+3 (j a multiple of 4) of tile `mt`: one ds_write_b64
+    auto quad_store = [&](int mt, int j, uint32_t p0, uint32_t p1) {
+        const int t = j >> 4, g = (j >> 2) & 3;
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 oo = {p0, p1};
+#ifdef ABL_NOWRITE
+        asm volatile("" :: "v"(oo));
+#else
+        *reinterpret_cast<u32x2 __attribute__((address_space(3)))*>((LdsWPtr)(uintptr_t)wa[g] + (t << 8) + mt * TILE_BYTES) = oo;
+#endif
+    };
+    // A wave has one issue port and every MFMA leaves a 28-cycle gap behind it; measured issue costs (tools/ubench/
+    // mfma_gap.hip): VALU 4, ds_read_b128 ~26, ds_write_b64 ~28, a 16-byte global load ~16.  What exceeds a gap's 28 cycles
+    // is lost on the matrix pipe, what stays below is not won back, so the filler is dealt out evenly and pinned
+    // (sched_barrier on both sides of every MFMA).  Per two k-steps (4 MFMAs):
+    //   after (k even, t0)  activation fragment of k+3                       ~30
+    //   after (k even, t1)  ds_write_b64 of the two pairs packed one step ago ~28
+    //   after (k odd,  t0)  activation fragment of k+3                       ~30
+    //   after (k odd,  t1)  one fragment of the next layer's weights + pack/ReLU of two pairs of the previous tile ~32
+    uint32_t st0 = 0, st1 = 0;                                               // packed pairs waiting for their store
 #pragma unroll
     for (int mt = 0; mt < MLP_MT; ++mt) {
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const int s = mt * KS + k;
-            if (s + FXD < MLP_MT * KS) fx_load(s + FXD);
-            if (RESMODE != 0 && k < 4)                                       // this tile's residual fragments, used after k = 15
-                rx[k] = *reinterpret_cast<const bf16x8*>(res + (lrx ^ ((k >> 1) << 8 | (k & 1) << 5)) + mt * TILE_BYTES);
 #pragma unroll
             for (int t = 0; t < MLP_NS; ++t) {
                 acc[mt & 1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k < 8 ? wlo[t][k & 7] : whi[t][k & 7], fx[s & 3],
                                                                          k == 0 ? seed[t] : acc[mt & 1][t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t == 0) {
+                    if (mt == MLP_MT - 1 && k == 0) load_seed(nd.bias, ns0, nss, lane, nseed);
+#ifndef ABL_NOREAD
+                    if (s + FXD < MLP_MT * KS) fx_load(s + FXD);
+#endif
+                    if (RESMODE != 0 && k < 4)                               // this tile's residual fragments, used after k = 15
+                        rx[k] = *reinterpret_cast<const bf16x8*>(res + (lrx ^ ((k >> 1) << 8 | (k & 1) << 5)) + mt * TILE_BYTES);
+                }
                 // the next layer's weights.  The vector-memory return path moves 64 B/clk: a layer's 128 KB of
                 // fragments are half its MFMA time, so they must not bunch up.  k-steps 0..7 go to the second low
                 // set, one fragment every fourth MFMA of tiles 1 and 2; k-steps 8..15 replace this layer's right
                 // behind their last use in tile 3.
+#ifndef ABL_NOWLOAD
                 if (!LEAD) {
                     if ((mt == 1 || mt == 2) && (k & 1) == 1 && t == 1) {
                         const int f = (mt - 1) * 8 + (k >> 1);               // 0..15 -> (slice f >> 3, k-step f & 7)
@@ -476,9 +537,24 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
                         else whi[f >> 3][f & 7] = nb.frag(f >> 3, 8 + (f & 7));
                     }
                 }
-                if (mt > 0 && t == 1) {
+#endif
+                if (t == 1) {
+                    if (!LEAD) {                                             // pairs 2(k-1), 2k are packed at odd k, stored at k+1
+                        if (mt > 0 && (k & 1)) {
+                            st0 = pair_pack(acc[(mt - 1) & 1], 2 * k - 2);
+                            st1 = pair_pack(acc[(mt - 1) & 1], 2 * k);
+                        } else if (mt > 0 && k >= 2) {
+                            quad_store(mt - 1, 2 * k - 4, st0, st1);
+                        } else if (mt > 1 && k == 0) {
+                            quad_store(mt - 2, 28, st0, st1);
+                        }
+                    } else if (mt > 0) {
 #pragma unroll
-                    for (int q = 0; q < PAIRS; ++q) element_pair(acc[(mt - 1) & 1], mt - 1, 2 * (PAIRS * k + q));
+                        for (int q = 0; q < PAIRS; q += 2) {
+                            const int j = 2 * (PAIRS * k + q);
+                            quad_store(mt - 1, j, pair_pack(acc[(mt - 1) & 1], j), pair_pack(acc[(mt - 1) & 1], j + 2));
+                        }
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -491,9 +567,12 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
             __builtin_amdgcn_sched_barrier(0);
         }
         DHAUG_LSTAMP(dbg + 1 + mt)
+        DHAUG_BB_SPLIT()
     }
+    if (!LEAD) quad_store(MLP_MT - 2, 28, st0, st1);
 #pragma unroll
-    for (int j = 0; j < 32; j += 2) element_pair(acc[(MLP_MT - 1) & 1], MLP_MT - 1, j);
+    for (int j = 0; j < 32; j += 4)
+        quad_store(MLP_MT - 1, j, pair_pack(acc[(MLP_MT - 1) & 1], j), pair_pack(acc[(MLP_MT - 1) & 1], j + 2));
     DHAUG_LSTAMP(dbg + 5)
 #pragma unroll
     for (int t = 0; t < MLP_NS; ++t) seed[t] = nseed[t];
@@ -916,6 +995,6 @@ int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* 
 
 #ifdef DHAUG_MLP_TIMING
 extern "C" int dhaug_debug_mlp_stamps(long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_stamps), sizeof(long long) * (n < 5 * MLP_MAX_UNITS + 68 ? n : 5 * MLP_MAX_UNITS + 68));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_stamps), sizeof(long long) * (n < 6 * MLP_MAX_UNITS + 69 ? n : 6 * MLP_MAX_UNITS + 69));
 }
 #endif

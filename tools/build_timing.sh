@@ -9,7 +9,7 @@ mkdir -p $O
 F="--offload-arch=gfx950 -O3 -fPIC -ffp-contract=fast -fno-signed-zeros -ffinite-math-only -Iinclude -I$P/csrc"
 for s in $P/csrc/*.hip; do
   b=$(basename $s .hip)
-  X=""; [ $b = dhaug_mlp ] && X="-mllvm -amdgpu-mfma-vgpr-form -DDHAUG_MLP_TIMING"
+  X=""; [ $b = dhaug_mlp ] && X="-mllvm -amdgpu-mfma-vgpr-form -DDHAUG_MLP_TIMING $DHAUG_EXTRA_HIPFLAGS $TIMING_MODE"
   /opt/rocm/bin/hipcc $F $X -c $s -o $O/$b.o &
 done
 wait

@@ -15,7 +15,7 @@ D2 = Fk_discriminator.Fk_2D_Discriminator(args, 16).cuda()
 x2 = torch.randn(B, 16, 2, device="cuda") * 0.3
 z = torch.randn(B, 128, device="cuda"); x3 = torch.randn(B, 16, 3, device="cuda") * 0.3
 L = _lib.lib()
-N = 5 * 32 + 68
+N = 6 * 32 + 69
 buf = (ctypes.c_longlong * N)()
 with torch.no_grad():
     for name, fn in (("G", lambda: fused.generator_head(G, z)), ("D3", lambda: fused.critic3d(D3, x3)), ("D2", lambda: fused.critic2d(D2, x2)), ("D3", lambda: fused.critic3d(D3, x3))):
@@ -32,6 +32,10 @@ with torch.no_grad():
             b2 = min(st[i] for i in idx2)
             print("   stack:", " ".join("%d:%d" % (i - 32, st[i] - b2) for i in idx2))
         # last tile, per unit: start, [generic GEMM: after the k loop, after the epilogue], after the trailing barrier
+        q = st[228:261]
+        idq = [i for i, v in enumerate(q) if v]
+        if idq:
+            print("   later tile:", " ".join("%d:%d" % (i, q[i] - q[idq[0]]) for i in idq))
         us = [u for u in range(32) if st[96 + 4 * u]]
         if us:
             b3 = st[96 + 4 * us[0]]

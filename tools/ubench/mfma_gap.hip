@@ -23,11 +23,13 @@ __global__ __launch_bounds__(256, 1) void k(float* out, long long* cyc) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             if (NR == 3) { ring[(j + 3) & 3] = *reinterpret_cast<const bf16x8*>(p + (((j + 3) * 1024) & 65535)); r = ring[j & 3]; }
+            if (NR == 4) { ring[(2 * j + 3) & 3] = *reinterpret_cast<const bf16x8*>(p + (((2 * j + 3) * 1024) & 65535)); r = ring[(2 * j) & 3]; }
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, r, c0, 0, 0, 0);
 #pragma unroll
             for (int v = 0; v < NV; ++v) f[v & 7] = fmaxf(f[v & 7] * 1.0001f, 0.5f);
             if (NR == 1 || NR == 2) r = *reinterpret_cast<const bf16x8*>(p + ((j * 1024) & 65535));
             __builtin_amdgcn_sched_barrier(0);
+            if (NR == 4) { ring[(2 * j + 4) & 3] = *reinterpret_cast<const bf16x8*>(p + (((2 * j + 4) * 1024) & 65535)); r = ring[(2 * j + 1) & 3]; }
             c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, r, c1, 0, 0, 0);
 #pragma unroll
             for (int v = 0; v < NV; ++v) f[(v + 4) & 7] = fmaxf(f[(v + 4) & 7] * 1.0001f, 0.5f);
@@ -57,13 +59,14 @@ void run(float* out, long long* cyc) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
     const double n = 64.0 * 32;
-    printf("AG=%d NW=%d NV=%d NR=%d: %.1f counter ticks per MFMA, %.2f ns per MFMA (kernel %.1f us) -> counter %.2f GHz\n", NV * 2, NR, c / n,
+    printf("VALU/gap=%d NR=%d AG=%d NW=%d: %.1f counter ticks per MFMA, %.2f ns per MFMA (kernel %.1f us) -> counter %.2f GHz\n", NV * 2, NR, AG, NW, c / n,
            ms * 1e6 / n, ms * 1e3, c / (ms * 1e6));
 }
 
 int main() {
     float* out; long long* cyc;
     hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 8);
+    run<0, 4>(out, cyc); run<0, 3>(out, cyc);
     run<0, 0>(out, cyc); run<3, 0>(out, cyc); run<4, 0>(out, cyc);
     run<0, 0, 1>(out, cyc); run<2, 0, 1>(out, cyc);
     run<0, 3>(out, cyc); run<1, 3>(out, cyc); run<2, 3>(out, cyc);
