@@ -43,7 +43,7 @@ constexpr int BUF2_BYTES = MLP_BM * BUF2_PITCH * 2;                 // 32 768
 constexpr int MLP_LDS_BYTES = 2 * BUF01_BYTES + BUF2_BYTES;         // 163 840: all of the CU's LDS
 
 enum { U_LOAD_F32 = 0, U_LOAD_BF16 = 1, U_STORE_BF16 = 2, U_GEMM = 3 };
-enum { F_OUT_F32 = 4 };
+enum { F_OUT_F32 = 4, F_DOT_OUT = 16 };
 
 struct Unit {
     int kind;
@@ -63,7 +63,7 @@ struct Unit {
 };
 // plan of a GEMM unit.  Stack: bits 0-3 lead k-steps, 4-9 run.  Single layer: bits 16-23 shape (chunks * 16 + chunks of
 // source 1), 24-27 feature slices
-enum { PLAN_STACK = 1 << 13, PLAN_LEAKY = 1 << 10, PLAN_ALT = 1 << 11, PLAN_TAIL = 1 << 12, PLAN_OUT = 1 << 28 };
+enum { PLAN_STACK = 1 << 13, PLAN_LEAKY = 1 << 10, PLAN_ALT = 1 << 11, PLAN_TAIL = 1 << 12, PLAN_OUT = 1 << 28, PLAN_DOT = 1 << 29 };
 
 struct Program {
     int nunits;
@@ -190,6 +190,17 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
 #pragma unroll
             for (int e = 0; e < 4; ++e) seed[t][4 * g + e] = b4[e];
         }
+    // DOT_OUT (see the epilogue): the lane's 16 weights of the folded logit layer and its bias, requested up front
+    constexpr bool CAN_DOT = NS == 1 && NCH <= 2 && NCH1 == NCH;             // (shapes checked on the host)
+    const bool dot_out = CAN_DOT && (u->flags & F_DOT_OUT);
+    f32x4 dv[4];
+    float dbias = 0.f;
+    if (dot_out) {
+        const float* v = reinterpret_cast<const float*>(u->w2);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dv[g] = *reinterpret_cast<const f32x4*>(v + 32 * wave + 8 * g + 4 * h);
+        dbias = (wave == 0 && h == 0) ? v[256] : 0.f;
+    }
     constexpr int KT = NCH * MLP_CH;                            // k-steps in total
     bf16x8 fx[3][MLP_MT];                                       // activation fragments: read two k-steps ahead (one wave per
                                                                 // SIMD: nobody else hides the LDS latency)
@@ -265,6 +276,39 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
         }
     }
     const int act = u->act;
+    if (dot_out) {
+        // this layer feeds nothing but a 1-wide linear layer (a critic's logit): instead of storing the activation image and
+        // running one more unit over it, every lane multiplies its 16 features per row (rounded to bf16 and activated
+        // exactly as they would have been stored) with that layer's weights and leaves per-(wave, half) partial sums in
+        // buffer dst as fp32 [8][128]; dot_output() adds them up.  w2 = fp32 [257]: the weights (bf16 values, zero beyond
+        // N) and the bias at [256] (joins wave 0's partial sum).
+        const float neg = u->slope;
+        const uint32_t lb = act == DHAUG_ACT_RELU ? 0u : 0x80008000u;
+        // two partial sums per row tile (even / odd feature groups): eight independent FMA chains, not four serial ones
+        float part[MLP_MT][2];
+#pragma unroll
+        for (int mt = 0; mt < MLP_MT; ++mt) { part[mt][0] = dbias; part[mt][1] = 0.f; }
+        auto dot_pairs = [&](auto activate) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; e += 2)
+#pragma unroll
+                    for (int mt = 0; mt < MLP_MT; ++mt) {
+                        const uint32_t pk = activate(acc[0][mt][4 * g + e], acc[0][mt][4 * g + e + 1]);
+                        part[mt][g & 1] = fmaf(__builtin_bit_cast(float, pk << 16), dv[g][e], part[mt][g & 1]);
+                        part[mt][g & 1] = fmaf(__builtin_bit_cast(float, pk & 0xffff0000u), dv[g][e + 1], part[mt][g & 1]);
+                    }
+        };
+        if (wave < nslices) {
+            if (act != DHAUG_ACT_LRELU) dot_pairs([&](float a0, float a1) { return pk_relu(pack_bf16x2(a0, a1), lb); });
+            else dot_pairs([&](float a0, float a1) { return pack_bf16x2(act_fn(a0, neg), act_fn(a1, neg)); });
+        }
+        float* st = reinterpret_cast<float*>(dst) + (2 * wave + h) * MLP_BM + r31;
+#pragma unroll
+        for (int mt = 0; mt < MLP_MT; ++mt) st[32 * mt] = part[mt][0] + part[mt][1];
+        return;
+    }
     // epilogue: this lane owns row (32 mt + r31), features 32*slice + 8g + 4h .. +3
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
@@ -774,6 +818,16 @@ __device__ __forceinline__ void move_unit(UnitPtr u, unsigned char* smem, long l
     }
 }
 
+// logits of a layer flagged DOT_OUT: sum of the 2 x (waves that own a slice) partial sums + the bias
+__device__ __forceinline__ void dot_output(UnitPtr u, unsigned char* smem, long long m0, long long M, int tid) {
+    if (tid >= MLP_BM || m0 + tid >= M) return;
+    const float* st = reinterpret_cast<const float*>(buf_base(smem, u->dst));
+    const int nw = min(4, (u->N + 31) >> 5);
+    float s = 0.f;
+    for (int i = 0; i < 2 * nw; ++i) s += st[i * MLP_BM + tid];
+    static_cast<float*>(const_cast<void*>(u->g))[(m0 + tid) * u->ld] = s;
+}
+
 __device__ __forceinline__ void store_output(UnitPtr u, unsigned char* smem, long long m0, long long M, int tid) {
     const float* st = reinterpret_cast<const float*>(buf_base(smem, u->dst));
     float* out = static_cast<float*>(const_cast<void*>(u->g));
@@ -833,10 +887,10 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void fused_mlp_kernel(Program prog,
                     if (plan & PLAN_LEAKY) gemm_stack<true, false>(u, lead_ks, f0, run, tail, smem, wave, lane);
                     else if (plan & PLAN_ALT) gemm_stack<false, true>(u, lead_ks, f0, run, tail, smem, wave, lane);
                     else gemm_stack<false, false>(u, lead_ks, f0, run, tail, smem, wave, lane);
-                    __syncthreads();
+                    lds_barrier();
                     if (tail) {
                         store_output(tu, smem, m0, M, tid);
-                        __syncthreads();
+                        lds_barrier();                       // (not __syncthreads: nobody waits for the stores to be acknowledged)
                     }
                     continue;                                                // (stamps of the run's inner layers stay 0)
                 }
@@ -855,11 +909,15 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void fused_mlp_kernel(Program prog,
                 else if (wave < nslices) { DHAUG_SHAPES(1) }
 #undef DHAUG_SHAPES
                 if (plan & PLAN_OUT) {
-                    __syncthreads();
+                    lds_barrier();
                     store_output(u, smem, m0, M, tid);
                 }
+                if (plan & PLAN_DOT) {
+                    lds_barrier();
+                    dot_output(u, smem, m0, M, tid);
+                }
             }
-            __syncthreads();
+            lds_barrier();
             DHAUG_LSTAMP(MLP_MAX_UNITS + 64 + 4 * ui + 3)
         }
         DHAUG_STAMP(nunits)
@@ -886,13 +944,13 @@ int plan_unit(const Program& p, int i) {
     const Unit* U = p.u;
     const Unit& u = U[i];
     if (u.kind != U_GEMM) return 0;
-    const bool wide = u.ksteps2 == 0 && u.N > 224 && !(u.flags & F_OUT_F32) && u.src < 2 && u.dst < 2;
+    const bool wide = u.ksteps2 == 0 && u.N > 224 && !(u.flags & (F_OUT_F32 | F_DOT_OUT)) && u.src < 2 && u.dst < 2;
     const int ks4 = (u.ksteps + 3) & ~3;                                 // the fragment blob and the LOAD pad to whole chunks
     const int lead_ks = (wide && u.res < 0 && ks4 <= 8) ? ks4 : 0;
     const int i0 = i + (lead_ks != 0);
     int run = 0, leaky = lead_ks != 0 && u.act == DHAUG_ACT_LRELU, alt = 1;
     while (i0 + run < p.nunits && U[i0 + run].kind == U_GEMM && U[i0 + run].ksteps == 16 && U[i0 + run].ksteps2 == 0 &&
-           U[i0 + run].N > 224 && !(U[i0 + run].flags & F_OUT_F32) && U[i0 + run].src < 2 && U[i0 + run].dst < 2 &&
+           U[i0 + run].N > 224 && !(U[i0 + run].flags & (F_OUT_F32 | F_DOT_OUT)) && U[i0 + run].src < 2 && U[i0 + run].dst < 2 &&
            U[i0 + run].res < 2) {
         leaky |= U[i0 + run].act == DHAUG_ACT_LRELU;
         alt &= (U[i0 + run].res >= 0) == ((run & 1) == 1);
@@ -900,7 +958,8 @@ int plan_unit(const Program& p, int i) {
     }
     if (run < p.min_run || run > 63) {
         const int c1 = (u.ksteps + 3) / 4, c2 = (u.ksteps2 + 3) / 4;
-        return (((c1 + c2) * 16 + c1) << 16) | (((u.N + 31) >> 5) << 24) | ((u.flags & F_OUT_F32) ? PLAN_OUT : 0);
+        return (((c1 + c2) * 16 + c1) << 16) | (((u.N + 31) >> 5) << 24) | ((u.flags & F_OUT_F32) ? PLAN_OUT : 0) |
+               ((u.flags & F_DOT_OUT) ? PLAN_DOT : 0);
     }
     const Unit* tu = U + i0 + run;
     const bool tail = i0 + run < p.nunits && tu->kind == U_GEMM && (tu->flags & F_OUT_F32) && tu->ksteps == 16 &&
@@ -961,6 +1020,11 @@ int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* 
                 const int c1 = (u.ksteps + 3) / 4, c2 = (u.ksteps2 + 3) / 4, sh = (c1 + c2) * 16 + c1;
                 const bool ok = sh == 17 || sh == 34 || sh == 33 || sh == 68 || sh == 66 || sh == 132;
                 DHAUG_CHECK(ok, DHAUG_EUNSUPPORTED);
+            }
+            if (u.flags & F_DOT_OUT) {
+                DHAUG_CHECK(u.ksteps <= 8 && u.N <= 128, DHAUG_EUNSUPPORTED);     // the shapes that carry this epilogue
+                DHAUG_CHECK(!(u.flags & F_OUT_F32) && u.ksteps2 == 0 && u.g != nullptr && u.ld >= 1 && u.w2 != nullptr &&
+                            dhaug_aligned16(u.w2) && (u.dst == 0 || u.dst == 1) && u.dst != u.src && u.dst != u.res, DHAUG_EINVAL);
             }
             if (u.flags & F_OUT_F32) {
                 DHAUG_CHECK(u.g != nullptr && u.ld >= u.N && u.N <= 64, DHAUG_EUNSUPPORTED);

@@ -13,7 +13,7 @@ from . import _lib, ops
 from .autograd_ops import ACT_LRELU, ACT_NONE, ACT_RELU
 
 LOAD_F32, LOAD_BF16, STORE_BF16, GEMM = 0, 1, 2, 3
-F_OUT_F32 = 4
+F_OUT_F32, F_DOT_OUT = 4, 16
 _vp = ctypes.c_void_p
 
 
@@ -42,6 +42,10 @@ class _Layer:
         self.bias = torch.zeros(256, dtype=torch.float32, device=W.device)
         self.bias[:N] = b
         self.zero = torch.zeros(256, dtype=torch.float32, device=W.device) if len(splits) > 1 else None
+        if N == 1:                                            # logit layer folded into its producer (DHAUG_MLP_F_DOT_OUT)
+            self.dot = torch.zeros(260, dtype=torch.float32, device=W.device)
+            self.dot[:K] = W[0].to(torch.bfloat16).float()
+            self.dot[256] = b[0]
 
 
 def _unit(kind, flags=0, src=-1, dst=-1, res=-1, src2=-1, ksteps2=0, ksteps=0, n=0, act=0, slope=0.0, cols=0, ld=0,
@@ -170,8 +174,10 @@ def _d3_program(D, L, inputs, M):
     _res_blocks(L, u, ("block1", "block2", "block3"))
     u.append(_unit(GEMM, src=0, dst=2, res=2, ksteps=mp.ksteps[1], n=mp.N, act=ACT_RELU, w=mp.w[1], bias=mp.zero))
     u.append(_gemm(L["merge_block1.fc1"], 2, 0, ACT_RELU))
-    u.append(_gemm(L["merge_block1.fc2"], 0, 2, ACT_RELU, res=2))
-    u.append(_gemm(L["output"], 2, 0, ACT_NONE, out=out))
+    # the logit layer (100 -> 1) rides in the epilogue of the layer before it
+    fc2 = _gemm(L["merge_block1.fc2"], 0, 1, ACT_RELU, res=2)
+    fc2.flags, fc2.g, fc2.ld, fc2.w2 = F_DOT_OUT, out.data_ptr(), out.stride(0), L["output"].dot.data_ptr()
+    u.append(fc2)
     return u, (out,)
 
 

@@ -246,6 +246,10 @@ int dhaug_pack_wfrag(const float* W, int64_t ldw, uint16_t* dst, int64_t N, int6
 #define DHAUG_MLP_STORE_BF16  2   /* buffer src columns [0, cols) -> global bf16 (M, ld)                              */
 #define DHAUG_MLP_GEMM        3   /* one layer: dst = act(W * src [+ W2 * src2] + bias + res)                          */
 #define DHAUG_MLP_F_OUT_F32   4   /* network output (n <= 64): fp32 (M, ld) to g, staged through buffer dst (0 or 1)    */
+#define DHAUG_MLP_F_DOT_OUT  16   /* GEMM whose only consumer is a 1-wide linear layer (a critic's logit): the activation  */
+                                  /* is not stored; its dot product with w2 = fp32 [257] (that layer's weights as bf16      */
+                                  /* values, zero beyond n, bias at [256]) goes to g (M, ld) column 0 as fp32; dst (0 or 1,  */
+                                  /* not src / res) is scratch for the partial sums                                          */
 typedef struct dhaug_mlp_unit {
     int kind, flags;
     int src, dst, res;            /* buffer ids, -1 = none; dst may equal res (in-place residual), never src        */
