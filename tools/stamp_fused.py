@@ -6,7 +6,7 @@ import dhaug_amd
 from dhaug_amd import fused, _lib
 from dhaug_amd.selfcheck import synth_args
 from dhaug_amd.models_Fk_GAN import Fk_discriminator, Fk_generator, forward_kinematics_DH_model as fkm
-B = 65536
+B = int(os.environ.get("STAMP_B", "65536"))
 args = synth_args(B, 256)
 fk = fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
 G = Fk_generator.Fk_Generator(fk, args, "cuda").cuda()
