@@ -15,6 +15,8 @@ for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -o r -- $B > gpurun_out/pmc_$c.log 2>&1 || exit 1
 done
 # the three networks share one kernel name: the 3D critic's launch (the bench's roofline kernel) is measured on its own
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_d3 -o r -- python tools/prof_fused_d3.py > gpurun_out/prof_d3.log 2>&1 || exit 1
+cp gpurun_out/prof_d3/r_kernel_stats.csv $O/${R}_d3_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_d3_$c -o r -- python tools/prof_fused_d3.py > gpurun_out/pmc_d3_$c.log 2>&1 || exit 1
 done
