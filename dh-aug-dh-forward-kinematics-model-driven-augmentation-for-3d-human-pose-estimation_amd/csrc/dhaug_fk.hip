@@ -17,6 +17,12 @@ namespace {
 
 constexpr int TILE = 64;
 
+// A workgroup is ONE wave, and a wave's LDS instructions execute in issue order: between the phases of the LDS
+// transposition nothing has to be waited for except the LDS counter (and the compiler must not move accesses across).
+// __syncthreads() here would also drain vmcnt, i.e. wait for every global store of the previous phase to be acknowledged
+// (measured on the generator tail: 46 % of the wave's time, SQ_WAIT_ANY / SQ_WAVE_CYCLES).
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // coalesced copy of `count` floats global -> LDS (same linear layout); base of g is 16-byte aligned
 __device__ __forceinline__ void stage_in(const float* __restrict__ g, float* __restrict__ l, int count, int lane) {
     const int n4 = count >> 2;
@@ -27,9 +33,44 @@ __device__ __forceinline__ void stage_in(const float* __restrict__ g, float* __r
     if (lane < rem) l[(n4 << 2) + lane] = g[(n4 << 2) + lane];
 }
 
-// LDS image with row stride LSTRIDE (odd) -> contiguous global rows of W floats
-template <int W, int LSTRIDE>
+// LDS image with row stride LSTRIDE (odd) -> contiguous global rows of W floats.  One wave per workgroup has nobody to
+// hide latency behind, so the copies are fully unrolled: all LDS reads of a pass are issued before the first store
+// (a rolled loop pays one LDS round trip per dword), and rows of a multiple of 4 floats leave as 16-byte stores.
+template <int W, int LSTRIDE, int ROWS = TILE / 2>
 __device__ __forceinline__ void stage_out(const float* __restrict__ l, float* __restrict__ g, int rows, int lane) {
+    if constexpr (W % 4 == 0) {
+        constexpr int K = (ROWS * W / 4 + TILE - 1) / TILE;           // float4 per lane
+        float4 t[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int e = 4 * (lane + TILE * k), r = e / W, j = e - r * W;
+            const float* src = l + r * LSTRIDE + j;
+            if (r < ROWS) t[k] = make_float4(src[0], src[1], src[2], src[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int e = 4 * (lane + TILE * k), r = e / W;
+            if (r < rows) *reinterpret_cast<float4*>(g + e) = t[k];
+        }
+    } else {
+        constexpr int K = (ROWS * W + TILE - 1) / TILE;
+        float t[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int e = lane + TILE * k, r = e / W, j = e - r * W;
+            if (r < ROWS) t[k] = l[r * LSTRIDE + j];
+        }
+        const int count = rows * W;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int e = lane + TILE * k;
+            if (e < count) g[e] = t[k];
+        }
+    }
+}
+// (rolled form: the backward kernels sit at 232-244 registers, two waves per SIMD; the unrolled copy costs them a wave)
+template <int W, int LSTRIDE>
+__device__ __forceinline__ void stage_out_rolled(const float* __restrict__ l, float* __restrict__ g, int rows, int lane) {
     const int count = rows * W;
     for (int e = lane; e < count; e += TILE) {
         const int r = e / W, j = e - r * W;
@@ -85,21 +126,58 @@ constexpr int kTo32[16] = {0, 1, 2, 3, 6, 7, 8, 12, 13, 15, 17, 18, 19, 25, 26, 
 // Global rows <-> lanes through a HALF-tile LDS image (32 rows): the two halves of the wave take turns, all 64 lanes
 // copy.  Halving the image is what sets the occupancy of these kernels: 64 x 55 input floats + padding cost 14.8 KB per
 // wave (10 waves per CU, VALU 55 % busy, 69 % of wave time waiting); 32 x 49 floats are 6.3 KB (25 waves per CU).
+// global rows -> lanes in two steps, so that the loads of ALL inputs of a tile are in flight together: issue() requests
+// both half tiles (16 bytes per lane and request, fully unrolled), commit() runs them through the half-tile LDS image.
+template <int W>
+struct RowLoad {
+    static constexpr int N4 = (TILE / 2) * W / 4;                     // whole float4 per half tile
+    static constexpr int REM = (TILE / 2) * W - 4 * N4;               // (< 4 floats: W odd)
+    static constexpr int K = (N4 + TILE - 1) / TILE;
+    float4 t[2][K];
+    float tail[2];
+    __device__ __forceinline__ void issue(const float* __restrict__ g, int rows, int lane) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int nr = rows - 32 * half < 0 ? 0 : (rows - 32 * half > 32 ? 32 : rows - 32 * half);
+            const int n4 = (nr * W) >> 2, rem = (nr * W) & 3;
+            const float* gh = g + 32 * half * W;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int i = lane + TILE * k;
+                t[half][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < n4) t[half][k] = reinterpret_cast<const float4*>(gh)[i];
+            }
+            tail[half] = 0.f;
+            if (lane < rem) tail[half] = gh[(n4 << 2) + lane];
+        }
+    }
+    __device__ __forceinline__ void commit(float* __restrict__ lds, int rows, int lane, float* __restrict__ v) const {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int nr = rows - 32 * half < 0 ? 0 : (rows - 32 * half > 32 ? 32 : rows - 32 * half);
+            const int n4 = (nr * W) >> 2, rem = (nr * W) & 3;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int i = lane + TILE * k;
+                if (i < n4) reinterpret_cast<float4*>(lds)[i] = t[half][k];
+            }
+            if (lane < rem) lds[(n4 << 2) + lane] = tail[half];
+            wave_lds_sync();
+            if ((lane >> 5) == half) {
+                const int r = (lane & 31) < nr ? (lane & 31) : 0;      // idle lanes recompute a valid row (never stored)
+#pragma unroll
+                for (int j = 0; j < W; ++j) v[j] = lds[r * W + j];
+            }
+            wave_lds_sync();
+        }
+    }
+};
 template <int W>
 __device__ __forceinline__ void rows_to_lanes(const float* __restrict__ g, float* __restrict__ lds, int rows, int lane,
                                               float* __restrict__ v) {
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int nr = rows - 32 * half < 0 ? 0 : (rows - 32 * half > 32 ? 32 : rows - 32 * half);
-        stage_in(g + 32 * half * W, lds, nr * W, lane);
-        __syncthreads();
-        if ((lane >> 5) == half) {
-            const int r = (lane & 31) < nr ? (lane & 31) : 0;      // idle lanes recompute a valid row (never stored)
-#pragma unroll
-            for (int j = 0; j < W; ++j) v[j] = lds[r * W + j];
-        }
-        __syncthreads();
-    }
+    RowLoad<W> ld;
+    ld.issue(g, rows, lane);
+    ld.commit(lds, rows, lane, v);
 }
 template <int W, int S>
 __device__ __forceinline__ void lanes_to_rows(const float* __restrict__ v, float* __restrict__ lds, float* __restrict__ g,
@@ -111,9 +189,9 @@ __device__ __forceinline__ void lanes_to_rows(const float* __restrict__ v, float
 #pragma unroll
             for (int j = 0; j < W; ++j) lds[(lane & 31) * S + j] = v[j];
         }
-        __syncthreads();
+        wave_lds_sync();
         stage_out<W, S>(lds, g + 32 * half * W, nr, lane);
-        __syncthreads();
+        wave_lds_sync();
     }
 }
 
@@ -160,8 +238,14 @@ __global__ __launch_bounds__(TILE) void fk_forward_kernel(const float* __restric
         const long long base = tile * TILE;
         const int rows = (int)((N - base) < TILE ? (N - base) : TILE);
         float v0[L::W0], bl[15], v2[L::W2];
-        rows_to_lanes<L::W0>(in0 + base * L::W0, smem, rows, lane, v0);
-        rows_to_lanes<15>(bone_len + base * 15, smem, rows, lane, bl);
+        {
+            RowLoad<L::W0> ld0;
+            RowLoad<15> ld1;
+            ld0.issue(in0 + base * L::W0, rows, lane);
+            ld1.issue(bone_len + base * 15, rows, lane);
+            ld0.commit(smem, rows, lane, v0);
+            ld1.commit(smem, rows, lane, bl);
+        }
 #pragma unroll
         for (int j = 0; j < L::W2; ++j) v2[j] = 0.0f;
         if (EXTRA && MODE == 1 && ex.draw) {
@@ -295,9 +379,9 @@ __global__ __launch_bounds__(TILE) void fk_backward_kernel(const float* __restri
             for (int j = 0; j < 15; ++j) o1[lane * 15 + j] = gbl[j];
             o2[lane * 3 + 0] = groot.x; o2[lane * 3 + 1] = groot.y; o2[lane * 3 + 2] = groot.z;
             __syncthreads();
-            stage_out<37, 37>(o0, g0 + base * 37, rows, lane);
-            stage_out<15, 15>(o1, g1 + base * 15, rows, lane);
-            stage_out<3, 3>(o2, g2 + base * 3, rows, lane);
+            stage_out_rolled<37, 37>(o0, g0 + base * 37, rows, lane);
+            stage_out_rolled<15, 15>(o1, g1 + base * 15, rows, lane);
+            stage_out_rolled<3, 3>(o2, g2 + base * 3, rows, lane);
         } else {
             float* o0 = smem;                                  // 64 x 35
             float gh[35];
@@ -312,7 +396,7 @@ __global__ __launch_bounds__(TILE) void fk_backward_kernel(const float* __restri
 #pragma unroll
             for (int c = 0; c < 35; ++c) o0[lane * 35 + c] = gh[c] * fmaf(-th[c], th[c], 1.0f);
             __syncthreads();
-            stage_out<35, 35>(o0, g0 + base * 35, rows, lane);
+            stage_out_rolled<35, 35>(o0, g0 + base * 35, rows, lane);
         }
         __syncthreads();
     }

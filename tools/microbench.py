@@ -20,6 +20,8 @@ for N in (65536, 1 << 20, 1 << 22):
     g = torch.randn(N, 48, device=dev); head = torch.randn(N, 35, device=dev); sc = torch.randint(-200, 200, (N, 8), device=dev) / 1000.
     t = timeit(lambda: ops.fk_forward(a, bl, rt)); print("fk_forward   N=%8d %8.1f us  %7.1f Mposes/s  %6.1f GB/s (412 B/pose)" % (N, t * 1e6, N / t / 1e6, 412 * N / t / 1e9))
     t = timeit(lambda: ops.gen_tail_forward(head, bl, sc)); print("gen_tail_fwd N=%8d %8.1f us  %7.1f Mposes/s  %6.1f GB/s (424 B/pose)" % (N, t * 1e6, N / t / 1e6, 424 * N / t / 1e9))
+    cam = ([0.7, 0.1, -0.1, 0.7], [0.1, 0.2, 5.0], [1.1, 1.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0])
+    t = timeit(lambda: ops.gen_tail_forward_critics(head, bl, None, True, cam, (1234, 0))); print("tail+critics N=%8d %8.1f us  %7.1f Mposes/s" % (N, t * 1e6, N / t / 1e6))
     t = timeit(lambda: ops.fk_backward(a, bl, g)); print("fk_backward  N=%8d %8.1f us  %7.1f Mposes/s" % (N, t * 1e6, N / t / 1e6))
     t = timeit(lambda: ops.kcs_forward(g, True, False, 32)); print("kcs_fwd bf16 N=%8d %8.1f us  %6.1f GB/s" % (N, t * 1e6, (192 + 64) * N / t / 1e9))
 for (M, N, K) in ((65536, 256, 256), (65536, 256, 128), (65536, 256, 48), (65536, 100, 512), (65536, 35, 256), (65536, 1, 112), (65536, 256, 768)):
