@@ -33,6 +33,48 @@ __device__ __forceinline__ void stage_in(const float* __restrict__ g, float* __r
     if (lane < rem) l[(n4 << 2) + lane] = g[(n4 << 2) + lane];
 }
 
+// contiguous block of up to CMAX floats global -> LDS in two steps (see RowLoad): issue() puts every 16-byte request of
+// the block in flight, commit() writes the LDS image -- linear, or with row stride LSTRIDE for rows of W floats
+// (W a multiple of 4, so that a request never spans two rows)
+template <int CMAX>
+struct BlockLoad {
+    static constexpr int K = ((CMAX + 3) / 4 + TILE - 1) / TILE;
+    float4 t[K];
+    float tail;
+    __device__ __forceinline__ void issue(const float* __restrict__ g, int count, int lane) {
+        const int n4 = count >> 2, rem = count & 3;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int i = lane + TILE * k;
+            t[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < n4) t[k] = reinterpret_cast<const float4*>(g)[i];
+        }
+        tail = lane < rem ? g[(n4 << 2) + lane] : 0.f;
+    }
+    __device__ __forceinline__ void commit(float* __restrict__ l, int count, int lane) const {
+        const int n4 = count >> 2, rem = count & 3;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int i = lane + TILE * k;
+            if (i < n4) reinterpret_cast<float4*>(l)[i] = t[k];
+        }
+        if (lane < rem) l[(n4 << 2) + lane] = tail;
+    }
+    template <int W, int LSTRIDE>
+    __device__ __forceinline__ void commit_strided(float* __restrict__ l, int count, int lane) const {
+        static_assert(W % 4 == 0, "row width");
+        const int n4 = count >> 2;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int i = lane + TILE * k, e = 4 * i, r = e / W, j = e - r * W;
+            if (i < n4) {
+                float* d = l + r * LSTRIDE + j;
+                d[0] = t[k].x; d[1] = t[k].y; d[2] = t[k].z; d[3] = t[k].w;
+            }
+        }
+    }
+};
+
 // LDS image with row stride LSTRIDE (odd) -> contiguous global rows of W floats.  One wave per workgroup has nobody to
 // hide latency behind, so the copies are fully unrolled: all LDS reads of a pass are issued before the first store
 // (a rolled loop pays one LDS round trip per dword), and rows of a multiple of 4 floats leave as 16-byte stores.
@@ -355,10 +397,20 @@ __global__ __launch_bounds__(TILE) void fk_backward_kernel(const float* __restri
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long base = tile * TILE;
         const int rows = (int)((N - base) < TILE ? (N - base) : TILE);
-        stage_in(in0 + base * L::W0, l0, rows * L::W0, lane);
-        stage_in(bone_len + base * 15, l1, rows * 15, lane);
-        if (MODE == 1 && has2) stage_in(in2 + base * L::W2, l2, rows * L::W2, lane);
-        stage_in_strided<48, GS>(grad_out + base * 48, lg, rows, lane);
+        {                                                      // all four inputs of the tile in flight together
+            BlockLoad<TILE * L::W0> b0;
+            BlockLoad<TILE * 15> b1;
+            BlockLoad<TILE * L::W2> b2;
+            BlockLoad<TILE * 48> bg;
+            b0.issue(in0 + base * L::W0, rows * L::W0, lane);
+            b1.issue(bone_len + base * 15, rows * 15, lane);
+            if (MODE == 1 && has2) b2.issue(in2 + base * L::W2, rows * L::W2, lane);
+            bg.issue(grad_out + base * 48, rows * 48, lane);
+            b0.commit(l0, rows * L::W0, lane);
+            b1.commit(l1, rows * 15, lane);
+            if (MODE == 1 && has2) b2.commit(l2, rows * L::W2, lane);
+            bg.template commit_strided<48, GS>(lg, rows * 48, lane);
+        }
         __syncthreads();
 
         float ang[37], bl[15], th[35], gang[37], gbl[15];
