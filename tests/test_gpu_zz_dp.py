@@ -16,7 +16,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, tag, q):
+def _worker(rank, world, port, tag, q, gpu_ready):
+    try:
+        _run(rank, world, port, tag, q, gpu_ready)
+    except BaseException as ex:                            # report instead of dying silently (the parent fails fast)
+        import traceback
+        q.put((rank, [("exception", repr(ex), traceback.format_exc())]))
+        raise
+
+
+def _run(rank, world, port, tag, q, gpu_ready):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -29,6 +38,11 @@ def _worker(rank, world, port, tag, q):
     from dhaug_amd import parallel
     from dhaug_amd.models_Fk_GAN import Fk_discriminator as dis, model_fk_gan_train as train
     from test_gpu_models import make_args, maxabs
+    dist.init_process_group("gloo")                        # rendezvous first (no GPU call yet) ...
+    if rank > 0:                                           # ... then the replicas, which share one card, bring the GPU up
+        gpu_ready[rank - 1].wait(timeout=240)              # one process at a time
+    torch.zeros(1, device="cuda").add_(1).item()
+    gpu_ready[rank].set()
     parallel.init_from_env("gloo")
     z = np.load(os.path.join(ROOT, "tests", "golden", "critic_step_%s_D32.npz" % tag))
     g = {k: torch.from_numpy(z[k]) for k in z.files}
@@ -83,17 +97,29 @@ def test_two_replica_critic_step_equals_full_batch(tag):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000) + (7 if tag == "d2" else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, tag, q)) for r in range(2)]
+    ready = [ctx.Event() for _ in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, tag, q, ready)) for r in range(2)]
     for p in procs:
         p.start()
+    res = []
     try:
-        res = sorted(q.get(timeout=300) for _ in procs)
+        import queue as _queue
+        import time
+        deadline = time.monotonic() + 300
+        while len(res) < len(procs) and time.monotonic() < deadline:
+            try:
+                res.append(q.get(timeout=2))
+            except _queue.Empty:
+                dead = [p for p in procs if p.exitcode not in (None, 0)]
+                if dead:                                  # a replica died without reporting: do not wait for the timeout
+                    break
+        res.sort()
     finally:
         for p in procs:
             p.join(timeout=60)
             if p.is_alive():
                 p.kill()                          # exact child only
-    assert [r[0] for r in res] == [0, 1]
+    assert [r[0] for r in res] == [0, 1], "replica exit codes %s, reported %s" % ([p.exitcode for p in procs], res)
     for r in res:
         assert not r[1], r
     assert all(p.exitcode == 0 for p in procs)
