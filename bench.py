@@ -197,7 +197,7 @@ def main():
         tf_b = event_time(step_fk, 50, 10)
         roofline_fk = {"kernel": "fk_forward_kernel<0,16,true>", "bound": "hbm", "achieved": FK_BYTES_PER_POSE * nfk / tf / 1e9,
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": FK_BYTES_PER_POSE * nfk / tf / 1e9 / HBM_PEAK_GBS,
-                       "traffic": pmc_traffic("fk_forward_kernel<0; 16; true>"), "algorithmic_bytes": FK_BYTES_PER_POSE * nfk, "poses_per_launch": nfk, "avg_us": tf * 1e6,
+                       "traffic": pmc_traffic("fk_forward_kernel<0; 16; true; false>"), "algorithmic_bytes": FK_BYTES_PER_POSE * nfk, "poses_per_launch": nfk, "avg_us": tf * 1e6,
                        "at_batch": {"poses": B, "avg_us": tf_b * 1e6, "achieved": FK_BYTES_PER_POSE * B / tf_b / 1e9}}
         del a4, b4, r4
 
