@@ -264,7 +264,7 @@ __device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2
 }
 
 template <int MODE, int OUTJ, bool PREANGLE, bool EXTRA = false>
-__global__ __launch_bounds__(TILE) void fk_forward_kernel(const float* __restrict__ in0,
+__global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu((MODE == 0 && OUTJ == 16) ? 3 : 1))) void fk_forward_kernel(const float* __restrict__ in0,
                                                           const float* __restrict__ bone_len,
                                                           const float* __restrict__ in2,
                                                           float* __restrict__ out, float* __restrict__ angles_out,
