@@ -81,6 +81,7 @@ def main():
     from dhaug_amd.selfcheck import synth_args
     from dhaug_amd.models_Fk_GAN import model_fk_gan_train as T
     from dhaug_amd.models_Fk_GAN.forward_kinematics_DH_model import Forward_Kinematics_DH_Model
+    from dhaug_amd.models_Fk_GAN.Fk_discriminator import score_fake_pair
     from dhaug_amd.common.camera import camera_params9
     from dhaug_amd.common.h36m_dataset import h36m_cameras_extrinsic_params, h36m_cameras_intrinsic_params
     dhaug_amd._lib.lib()
@@ -121,8 +122,7 @@ def main():
     def step_fwd():
         with torch.no_grad():
             fw, xc, kcs, p2 = G.sample_for_critics(z, (quat, trans, cam9))    # FK tail + critic inputs, one launch
-            l3 = D3(xc, kcs=kcs)
-            l2 = D2(p2)
+            l3, l2 = score_fake_pair(D3, D2, xc, kcs, p2)                      # both critics, one launch
         return l3, l2
 
     def step_gan():

@@ -197,6 +197,26 @@ def critic2d(D, x):
     return D._fused.run(dict(x=x), x.shape[0])
 
 
+def critics(D3_mod, D2_mod, x3, kcs, x2):
+    """both critics of one batch in ONE launch (the 3D critic's program, then the 2D critic's, per 128-row tile): one
+    kernel start-up and one dispatch gap less than critic3d() + critic2d().  x3 (N,48) root-relative pose, kcs (N,32)
+    bf16 operand, x2 (N,16,2) | (N,32) projection -> (logit3d (N,1), logit2d (N,1))"""
+    if not hasattr(D3_mod, "_fused"):
+        D3_mod._fused = FusedNet(D3_mod, D3)
+    if not hasattr(D2_mod, "_fused"):
+        D2_mod._fused = FusedNet(D2_mod, D2)
+    x3 = x3.reshape(-1, 48).contiguous()
+    x2 = x2.reshape(-1, 32).contiguous()
+    M = x3.shape[0]
+    assert x2.shape[0] == M and kcs.shape[0] == M
+    u3, (o3,) = D3["program"](D3_mod, D3_mod._fused._fresh(), dict(x=x3, kcs=kcs), M)
+    u2, o2 = D2["program"](D2_mod, D2_mod._fused._fresh(), dict(x=x2), M)
+    units = u3 + u2
+    arr = (_lib.MlpUnit * len(units))(*units)
+    _lib.call("dhaug_mlp_forward", arr, len(units), M, ops._stream())
+    return o3, o2
+
+
 def critic3d(D, x, center=False, kcs=None):
     """center=True: x is a world/camera-space pose; its root-relative copy and the KCS operand come from one pass.
     kcs: the bf16 (N,32) operand if the caller already has it (Fk_Generator.sample_for_critics)"""

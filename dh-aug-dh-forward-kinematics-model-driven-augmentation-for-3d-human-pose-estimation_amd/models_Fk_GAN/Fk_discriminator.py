@@ -180,3 +180,17 @@ class Video_motion_Fk_2D_Discriminator(nn.Module):
         m = A.linear(m, self.merge_previous[0].weight, self.merge_previous[0].bias, None, A.ACT_RELU, 0.0, p)
         m = self.merge_block1(m, p)
         return A.linear(m, self.merge_output.weight, self.merge_output.bias, None, A.ACT_NONE, 0.0, p, out_f32=True)
+
+
+def score_fake_pair(d3d, d2d, pose_centered, kcs, proj2d):
+    """Both critics on one batch of generated poses (the evaluation / sampling passes: no graph is built): one launch
+    where the fused kernel applies (dhaug_mlp_forward over the 3D critic's program followed by the 2D critic's),
+    otherwise the two forward() calls of the reference (R/models_Fk_GAN/model_fk_gan_train.py:463-468).
+    pose_centered (N,16,3)|(N,48) root-relative, kcs (N,32) bf16 or None, proj2d (N,16,2) -> (logit3d, logit2d)"""
+    x3 = pose_centered.reshape(-1, 48)
+    both = (d3d.precision == "bf16" and d2d.precision == "bf16" and x3.is_cuda and kcs is not None and _no_graph(d3d, x3)
+            and _no_graph(d2d, proj2d) and fused.supported(d3d.args.Dis_DenseDim_3D, d2d.args.Dis_DenseDim_2D))
+    if both:
+        return fused.critics(d3d, d2d, x3.float(), kcs, proj2d.float())
+    return d3d(pose_centered, kcs=kcs), d2d(proj2d)
+

@@ -306,6 +306,10 @@ def test_fused_forward_matches_layerwise(M, D, B):
         fw, xc, kc, p2 = G.sample_for_critics(z, ([1.0, 0.0, 0.0, 0.0], [0.0, 0.0, -5.0], [1.1, 1.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]))
         assert maxabs(D3(xc, kcs=kc), D3(fw.reshape(B, 48), center=True)) <= 2e-2 * l3_l.abs().max().item() + 1e-6
         assert p2.shape == (B, 16, 2) and torch.isfinite(p2).all()
+        # both critics in one launch = the two separate launches, bit for bit (same programs, same tiles)
+        with torch.no_grad():
+            m3, m2 = M.dis.score_fake_pair(D3, D2, xc, kc, p2)
+            assert torch.equal(m3, D3(xc, kcs=kc)) and torch.equal(m2, D2(p2))
     # weights change -> the packed fragments are rebuilt
     with torch.no_grad():
         D2.layer_pred.bias.add_(1.0)
