@@ -111,8 +111,16 @@ def train_Fk_discriminator(model_dis, data_real, data_fake, summary, writer, wri
     optimizerD.zero_grad()
     data_real = data_real.to(device)
     data_fake = data_fake.to(device)
-    D_real = MeanFn.apply(model_dis(data_real))
-    D_fake = MeanFn.apply(model_dis(data_fake))
+    # real and fake rows go through the critic as ONE batch (rows are independent; the two means are taken over its halves):
+    # every layer GEMM, weight-gradient GEMM and activation pass of the two passes of the reference
+    # (R/models_Fk_GAN/model_fk_gan_train.py:251-262) runs once over 2B rows instead of twice over B
+    n = data_real.shape[0]
+    if data_fake.shape == data_real.shape:
+        logits = model_dis(torch.cat((data_real, data_fake), 0))
+        D_real, D_fake = MeanFn.apply(logits[:n]), MeanFn.apply(logits[n:])
+    else:
+        D_real = MeanFn.apply(model_dis(data_real))
+        D_fake = MeanFn.apply(model_dis(data_fake))
     real_used_num = frames_from_args(args) if dis_mode != 'motion' else 1
     gradient_penalty = calc_gradient_penalty(model_dis, data_real.detach(), data_fake.detach(),
                                              args.batch_size * real_used_num, args.GAN_LAMBDA, device, alpha=alpha)
