@@ -18,6 +18,8 @@ Precision ("prec"):
     'bf16x6' : x = hi + mid + lo, six product terms, K' = 6K: fp32-grade (2^-24).  Used for the 1e-4 logit parity
                tests against the fp32 reference.
 """
+import os
+
 import torch
 
 from . import ops
@@ -302,6 +304,39 @@ class ReshapeGradFn(torch.autograd.Function):
         return ReshapeGradFn.apply(gg, ctx.info), None
 
 
+class LinearTMaskFn(torch.autograd.Function):
+    """out = (g W + res) * act'(ymask) in ONE launch (dhaug_gemm_bf16_dmask), differentiable: the pieces of a residual
+    block's input-gradient chain under create_graph (WGAN-GP) without separate activation-backward / add kernels.
+    g (M,D) bf16, W (D,D), ymask (M,D) bf16 | None (no mask), res (M,D) bf16 | None.  The backward is composed of the
+    differentiable Functions above (t = go * act'(ymask) is what all three gradients start from)."""
+
+    @staticmethod
+    def forward(ctx, g, W, ymask, res, act, slope, prec):
+        D = W.shape[0]
+        ctx.save_for_backward(g, W, ymask)
+        ctx.cfg = (act if ymask is not None else ACT_NONE, slope, prec, res is not None)
+        return ops.gemm_nt_dmask(g, _w_nn(W, prec), D, D, ymask if ymask is not None else g,
+                                 act if ymask is not None else ACT_NONE, slope, res_bf16=res)
+
+    @staticmethod
+    def backward(ctx, go):
+        g, W, ymask = ctx.saved_tensors
+        act, slope, prec, has_res = ctx.cfg
+        D = W.shape[0]
+        t = ActBwdFn.apply(go.contiguous(), ymask, act, slope) if act != ACT_NONE else go.contiguous()
+        gg = gW = gres = None
+        if ctx.needs_input_grad[0]:
+            gg = LinearFn.apply(t, W, None, None, ACT_NONE, 0.0, prec, False)
+        if ctx.needs_input_grad[1]:
+            gW = OuterFn.apply(g, t, D, D, prec)
+        if has_res and ctx.needs_input_grad[3]:
+            gres = t
+        return gg, gW, None, gres, None, None, None
+
+
+FUSED_GP_CHAIN = os.environ.get("DHAUG_NO_FUSED_GP_CHAIN") is None
+
+
 class ResBlockFn(torch.autograd.Function):
     """y = act(fc2(act(fc1(x))) + x) for bf16 activations of width D (myResNet, R/models_Fk_GAN/special_operate.py:490-510).
     First-order backward in 2 + 2 GEMM launches per block: the hidden layer's activation backward rides the epilogue of
@@ -325,9 +360,13 @@ class ResBlockFn(torch.autograd.Function):
         D = W1.shape[0]
         if torch.is_grad_enabled():                             # differentiable composite (double backward)
             gz2 = ActBwdFn.apply(gy.contiguous(), y, act, slope)
-            gh = LinearTFn.apply(gz2, W2, prec, False)
-            gz1 = ActBwdFn.apply(gh, h, act, slope)
-            gx = LinearTFn.apply(gz1, W1, prec, False) + gz2
+            if FUSED_GP_CHAIN and gz2.dtype == BF16:
+                gz1 = LinearTMaskFn.apply(gz2, W2, h, None, act, slope, prec)         # (gz2 W2) * act'(h)
+                gx = LinearTMaskFn.apply(gz1, W1, None, gz2, act, slope, prec)        # gz1 W1 + gz2
+            else:
+                gh = LinearTFn.apply(gz2, W2, prec, False)
+                gz1 = ActBwdFn.apply(gh, h, act, slope)
+                gx = LinearTFn.apply(gz1, W1, prec, False) + gz2
             gW2 = OuterFn.apply(gz2, h, D, D, prec) if ctx.needs_input_grad[3] else None
             gW1 = OuterFn.apply(gz1, x, D, D, prec) if ctx.needs_input_grad[1] else None
             gb2 = ColSumFn.apply(gz2, D) if ctx.needs_input_grad[4] else None

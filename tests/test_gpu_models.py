@@ -228,6 +228,40 @@ def test_gradient_penalty_and_critic_step(M, golden, tag):
     assert min(cos) > 0.98, cos
 
 
+def test_gradient_penalty_fused_chain_matches_composite(M):
+    """bf16 mode, 256-wide residual blocks: the one-launch pieces of the input-gradient chain under create_graph
+    (LinearTMaskFn: GEMM + activation backward / + skip connection) against the per-kernel composite they replace --
+    same penalty, same parameter gradients up to the one bf16 rounding the fused skip connection saves."""
+    from dhaug_amd import autograd_ops as A
+    args = make_args(batch_size=256, Dis_DenseDim_3D=256)
+    torch.manual_seed(3)
+    net = M.dis.Fk_3D_Discriminator("cuda", args).cuda()
+    net.precision = "bf16"
+    g = torch.Generator().manual_seed(4)
+    real = GU.synth_pose16(256, seed=2); real = (real - real[:, :1]).cuda()
+    fake = (real.cpu() + 0.05 * torch.randn(256, 16, 3, generator=g)).cuda(); fake = fake - fake[:, :1]
+    alpha = torch.rand(256, 1, generator=g).cuda()
+    res = {}
+    for flag in (True, False):
+        A.FUSED_GP_CHAIN = flag
+        try:
+            net.zero_grad(set_to_none=True)
+            gp = M.dis.calc_gradient_penalty(net, real, fake, 256, 10, "cuda", alpha=alpha)
+            gp.backward()
+            res[flag] = (gp.item(), {k: p.grad.detach().float().clone() for k, p in net.named_parameters() if p.grad is not None})
+        finally:
+            A.FUSED_GP_CHAIN = True
+    (gp1, g1), (gp0, g0) = res[True], res[False]
+    assert abs(gp1 - gp0) <= 2e-3 * max(1.0, abs(gp0))
+    assert g1.keys() == g0.keys() and len(g1) >= 30
+    for k in g0:
+        scale = g0[k].abs().max().item()
+        assert maxabs(g1[k], g0[k]) <= 2e-2 * scale + 1e-7, k
+        if scale > 0:
+            cos = torch.nn.functional.cosine_similarity(g1[k].reshape(-1).double(), g0[k].reshape(-1).double(), dim=0).item()
+            assert cos > 0.999, (k, cos)
+
+
 # ------------------------------------------------------------------------------------------- G step
 def test_generator_step_gradients(M, golden):
     """gen_loss = 1*D3(centre(G(z))).mean() + 0.2*D2(project(G(z))).mean(): gradients w.r.t. G's weights against
