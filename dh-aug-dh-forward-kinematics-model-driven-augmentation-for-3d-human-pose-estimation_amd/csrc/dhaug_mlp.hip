@@ -603,7 +603,7 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (RESMODE != 0) {
+        if (RESMODE == 1 || (RESMODE == 2 && has_res)) {                   // (run-time case: a wave-uniform branch at the tile boundary)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                                    // (t, ks2) = (i & 1, i >> 1): alternate the accumulators
                 acc[mt & 1][i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(idl[i >> 1], rx[2 * (i & 1) + (i >> 1)], acc[mt & 1][i & 1], 0, 0, 0);
