@@ -88,6 +88,15 @@ class _GeneratorBase(nn.Module):
             s = s.reshape(B, 1, 8).repeat(1, self.video_frame_num, 1).reshape(-1, 8)
         return s.contiguous()
 
+    @staticmethod
+    def _jitter_stream(head):
+        """(seed, offset) of the device generator for the in-kernel Philox jitter; the offset advances by the 8 draws a
+        pose takes, so consecutive calls continue the stream and torch.manual_seed reproduces it"""
+        g = torch.cuda.default_generators[head.device.index if head.device.index is not None else torch.cuda.current_device()]
+        off = g.get_offset()
+        g.set_offset(off + 8)
+        return g.initial_seed(), off
+
     def forward(self, input, bone_len_scaler=None):
         B, R = input.shape[0], self.video_frame_num
         head = self.trunk(input).reshape(B * R, 35)
@@ -95,11 +104,20 @@ class _GeneratorBase(nn.Module):
         if not use_rt:                   # global rotation off: tanh^-1(0) = 0 on the three rotation columns
             head = head.clone()
             head[:, 28:31] = 0.0
-        scaler = self._scaler(B, bone_len_scaler)
         bl = self.boneLength
         if bl.shape[0] != B * R:
             raise RuntimeError("boneLength has %d rows, the batch needs %d (call GAN_generator_get_bone_length)"
                                % (bl.shape[0], B * R))
+        if (bone_len_scaler is None and self.args.bone_len_scaler == "different" and R == 1 and head.is_cuda
+                and not self.record_angles and not (torch.is_grad_enabled() and head.requires_grad)):
+            # sampling pass (no graph): the jitter is drawn inside the tail kernel (see sample_for_critics) -- same
+            # distribution, two RNG launches fewer than torch.randint + div
+            seed, off = self._jitter_stream(head)
+            fake = ops.gen_tail_forward_critics(head.contiguous(), bl, None, bool(self.args.GAN_whether_use_preAngle), None,
+                                                rng=(seed, off), want_critic_inputs=False)[0]
+            self.train_num += 1
+            return fake.reshape(B, 48)
+        scaler = self._scaler(B, bone_len_scaler)
         fake = A.GenTailFn.apply(head.contiguous(), bl, scaler, bool(self.args.GAN_whether_use_preAngle))
         self.train_num += 1
         if self.record_angles:
@@ -130,10 +148,8 @@ class Fk_Generator(_GeneratorBase):
             if bone_len_scaler is None and self.args.bone_len_scaler == "different":
                 # the jitter is drawn inside the tail kernel from the device generator's (seed, offset) stream: same
                 # distribution as torch.randint(-200, 200) / 1000, reproducible under torch.manual_seed
-                g = torch.cuda.default_generators[head.device.index if head.device.index is not None else torch.cuda.current_device()]
-                off = g.get_offset()
-                g.set_offset(off + 8)
-                return ops.gen_tail_forward_critics(head.contiguous(), bl, None, pre, camera, rng=(g.initial_seed(), off))
+                seed, off = self._jitter_stream(head)
+                return ops.gen_tail_forward_critics(head.contiguous(), bl, None, pre, camera, rng=(seed, off))
             scaler = self._scaler(B, bone_len_scaler)
             return ops.gen_tail_forward_critics(head.contiguous(), bl, scaler, pre, camera)
 

@@ -79,18 +79,20 @@ def gen_tail_forward(head, bone_len, scaler, use_preangle=True, want_angles=Fals
     return fake, ang
 
 
-def gen_tail_forward_critics(head, bone_len, scaler, use_preangle=True, camera=None, rng=None, want_scaler=False):
+def gen_tail_forward_critics(head, bone_len, scaler, use_preangle=True, camera=None, rng=None, want_scaler=False,
+                             want_critic_inputs=True):
     """generator tail + what the critics consume in one launch: (fake (N,16,3), centered (N,48), kcs bf16 (N,32),
     proj2d (N,16,2) | None).  camera = (quat[4], trans[3], cam9[9]) host sequences.  rng = (seed, offset): draw the
-    bone-length jitter in the kernel (scaler must be None); want_scaler appends the (N,8) draw to the result."""
+    bone-length jitter in the kernel (scaler must be None); want_scaler appends the (N,8) draw to the result;
+    want_critic_inputs=False skips the centred pose and the KCS operand (plain sampling with the in-kernel jitter)."""
     h = _dev(head, torch.float32, "gen_tail_forward_critics").reshape(-1, 35)
     b = _dev(bone_len, torch.float32, "gen_tail_forward_critics").reshape(-1, 15)
     s = None if scaler is None else _dev(scaler, torch.float32, "gen_tail_forward_critics").reshape(-1, 8)
     N = h.shape[0]
     assert b.shape[0] == N and (s is None or s.shape[0] == N)
     fake = torch.empty((N, 16, 3), dtype=torch.float32, device=h.device)
-    xc = torch.empty((N, 48), dtype=torch.float32, device=h.device)
-    kcs = torch.empty((N, 32), dtype=BF16, device=h.device)
+    xc = torch.empty((N, 48), dtype=torch.float32, device=h.device) if want_critic_inputs else None
+    kcs = torch.empty((N, 32), dtype=BF16, device=h.device) if want_critic_inputs else None
     p2 = q = t = c = None
     if camera is not None:
         p2 = torch.empty((N, 16, 2), dtype=torch.float32, device=h.device)
