@@ -871,7 +871,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void fused_mlp_kernel(Program prog,
             if (kind != U_GEMM) {
                 // a STORE is not waited for where it is issued (lds_barrier orders only its LDS reads); the LOAD that
                 // reads the parked rows back drains the workgroup's stores first
-                if (kind == U_LOAD_BF16) __syncthreads();
+                if (kind == U_LOAD_BF16 && (plan & 1)) __syncthreads();      // only in programs that park rows with a STORE
                 move_unit(u, smem, m0, M, tid);
                 if (kind == U_STORE_BF16) {
                     lds_barrier();
@@ -943,7 +943,13 @@ __global__ __launch_bounds__(256) void pack_wfrag_kernel(const float* __restrict
 int plan_unit(const Program& p, int i) {
     const Unit* U = p.u;
     const Unit& u = U[i];
-    if (u.kind != U_GEMM) return 0;
+    if (u.kind != U_GEMM) {
+        // a bf16 LOAD may read back rows a STORE of this program parked in global memory: it then drains the workgroup's
+        // stores first (full barrier); programs without a STORE skip that wait for write acknowledgements
+        int parks = 0;
+        for (int j = 0; j < p.nunits; ++j) parks |= U[j].kind == U_STORE_BF16;
+        return u.kind == U_LOAD_BF16 ? parks : 0;
+    }
     const bool wide = u.ksteps2 == 0 && u.N > 224 && !(u.flags & (F_OUT_F32 | F_DOT_OUT)) && u.src < 2 && u.dst < 2;
     const int ks4 = (u.ksteps + 3) & ~3;                                 // the fragment blob and the LOAD pad to whole chunks
     const int lead_ks = (wide && u.res < 0 && ks4 <= 8) ? ks4 : 0;
