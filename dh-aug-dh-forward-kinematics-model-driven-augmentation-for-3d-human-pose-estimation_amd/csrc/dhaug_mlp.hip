@@ -760,6 +760,48 @@ constexpr int MOVE_BATCH = MOVE_BATCH_OVERRIDE;
 constexpr int MOVE_BATCH = 16;
 #endif                                                // global accesses in flight per thread
 
+// one pass of a LOAD: NB global accesses in flight per thread, then their conversions / LDS writes
+template <int NB>
+__device__ __forceinline__ void load_f32_pass(const float* g, long long ld, int cols, unsigned char* dst, int pb, long long m0,
+                                              long long M, Sweep& sw) {
+    f32x4 v[NB];
+    int off[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const long long gm = m0 + sw.row;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        off[i] = sw.row < MLP_BM ? chunk_off(sw.row, sw.c >> 1, pb) + ((sw.c & 1) << 3) : -1;
+        if (sw.row < MLP_BM && gm < M && sw.c * 4 < cols) v[i] = *reinterpret_cast<const f32x4*>(g + gm * ld + sw.c * 4);
+        sw.next();
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        uint2 o;
+        o.x = pack_bf16x2(v[i][0], v[i][1]);
+        o.y = pack_bf16x2(v[i][2], v[i][3]);
+        if (off[i] >= 0) *reinterpret_cast<uint2*>(dst + off[i]) = o;
+    }
+}
+template <int NB>
+__device__ __forceinline__ void load_bf16_pass(const uint16_t* g, long long ld, int cols, unsigned char* img, int pb, long long m0,
+                                               long long M, Sweep& sw) {
+    uint4 v[NB];
+    int off[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const long long gm = m0 + sw.row;
+        v[i] = make_uint4(0, 0, 0, 0);
+        off[i] = sw.row < MLP_BM ? chunk_off(sw.row, sw.c, pb) : -1;
+        if (sw.row < MLP_BM && gm < M && sw.c * 8 < cols) v[i] = *reinterpret_cast<const uint4*>(g + gm * ld + sw.c * 8);
+        sw.next();
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+        if (off[i] >= 0) *reinterpret_cast<uint4*>(img + off[i]) = v[i];
+}
+
+// The bf16 pass size follows the tile: q 16-byte groups per row -> q / 2 per thread (4 for the 32-column KCS operand: a
+// fixed 16 made it walk 12 dead slots per thread, 4 400 -> 2 650 clocks).
 __device__ __forceinline__ void move_unit(UnitPtr u, unsigned char* smem, long long m0, long long M, int tid) {
     const int kind = u->kind, cols = u->cols;
     const long long ld = u->ld;
@@ -769,23 +811,7 @@ __device__ __forceinline__ void move_unit(UnitPtr u, unsigned char* smem, long l
         const int pb = buf_pitch_bytes(u->dst), q4 = ((cols + 63) & ~63) >> 2;
         Sweep sw(tid, q4);
         while (sw.row < MLP_BM) {
-            f32x4 v[MOVE_BATCH];
-            int off[MOVE_BATCH];
-#pragma unroll
-            for (int i = 0; i < MOVE_BATCH; ++i) {
-                const long long gm = m0 + sw.row;
-                v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                off[i] = sw.row < MLP_BM ? chunk_off(sw.row, sw.c >> 1, pb) + ((sw.c & 1) << 3) : -1;
-                if (sw.row < MLP_BM && gm < M && sw.c * 4 < cols) v[i] = *reinterpret_cast<const f32x4*>(g + gm * ld + sw.c * 4);
-                sw.next();
-            }
-#pragma unroll
-            for (int i = 0; i < MOVE_BATCH; ++i) {
-                uint2 o;
-                o.x = pack_bf16x2(v[i][0], v[i][1]);
-                o.y = pack_bf16x2(v[i][2], v[i][3]);
-                if (off[i] >= 0) *reinterpret_cast<uint2*>(dst + off[i]) = o;
-            }
+            load_f32_pass<MOVE_BATCH>(g, ld, cols, dst, pb, m0, M, sw);      // (an 8-deep pass for the 48-column pose measured slower)
         }
         return;
     }
@@ -797,19 +823,8 @@ __device__ __forceinline__ void move_unit(UnitPtr u, unsigned char* smem, long l
     Sweep sw(tid, q8);
     if (kind == U_LOAD_BF16) {
         while (sw.row < MLP_BM) {
-            uint4 v[MOVE_BATCH];
-            int off[MOVE_BATCH];
-#pragma unroll
-            for (int i = 0; i < MOVE_BATCH; ++i) {
-                const long long gm = m0 + sw.row;
-                v[i] = make_uint4(0, 0, 0, 0);
-                off[i] = sw.row < MLP_BM ? chunk_off(sw.row, sw.c, pb) : -1;
-                if (sw.row < MLP_BM && gm < M && sw.c * 8 < cols) v[i] = *reinterpret_cast<const uint4*>(g + gm * ld + sw.c * 8);
-                sw.next();
-            }
-#pragma unroll
-            for (int i = 0; i < MOVE_BATCH; ++i)
-                if (off[i] >= 0) *reinterpret_cast<uint4*>(img + off[i]) = v[i];
+            if (q8 <= 8) load_bf16_pass<4>(g, ld, cols, img, pb, m0, M, sw);
+            else load_bf16_pass<MOVE_BATCH>(g, ld, cols, img, pb, m0, M, sw);
         }
     } else {
         for (; sw.row < MLP_BM; sw.next())
