@@ -800,6 +800,35 @@ __device__ __forceinline__ void load_bf16_pass(const uint16_t* g, long long ld, 
         if (off[i] >= 0) *reinterpret_cast<uint4*>(img + off[i]) = v[i];
 }
 
+// fp32 LOAD when the row's 16-byte groups (Q4 = 16 or 32, zero fill included) divide the workgroup: a thread keeps its
+// column group and walks rows with a constant stride, so the Q4 / 2 accesses of the tile need no per-slot index arithmetic
+// (the generic pass spends ~25 VALU per slot on the sweep, the 64-bit address and the swizzle)
+template <int Q4>
+__device__ __forceinline__ void load_f32_fast(const float* g, long long ld, int cols, unsigned char* dst, int pb, long long m0,
+                                              long long M, int tid) {
+    constexpr int RS = MLP_THREADS / Q4, NB = MLP_BM / RS;            // rows per step, steps
+    const int r0 = tid / Q4, c = tid % Q4;
+    const bool col_live = c * 4 < cols;
+    const float* p = g + (m0 + r0) * ld + c * 4;
+    const long long stride = (long long)RS * ld;
+    f32x4 v[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (col_live && m0 + r0 + i * RS < M) v[i] = *reinterpret_cast<const f32x4*>(p + i * stride);
+    }
+    // LDS: row * pitch + (((c >> 1) ^ (row & 15)) << 4) + (c & 1) * 8; row & 15 is r0 & 15 (RS = 16) or alternates with ^ 8 (RS = 8)
+    const int half = (c & 1) << 3, cc = c >> 1;
+    const int o0 = r0 * pb + ((cc ^ (r0 & 15)) << 4) + half, o1 = r0 * pb + ((cc ^ ((r0 + RS) & 15)) << 4) + half;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        uint2 o;
+        o.x = pack_bf16x2(v[i][0], v[i][1]);
+        o.y = pack_bf16x2(v[i][2], v[i][3]);
+        *reinterpret_cast<uint2*>(dst + ((RS == 16 || !(i & 1)) ? o0 : o1) + i * RS * pb) = o;
+    }
+}
+
 // The bf16 pass size follows the tile: q 16-byte groups per row -> q / 2 per thread (4 for the 32-column KCS operand: a
 // fixed 16 made it walk 12 dead slots per thread, 4 400 -> 2 650 clocks).
 __device__ __forceinline__ void move_unit(UnitPtr u, unsigned char* smem, long long m0, long long M, int tid) {
@@ -809,10 +838,11 @@ __device__ __forceinline__ void move_unit(UnitPtr u, unsigned char* smem, long l
         const float* g = static_cast<const float*>(u->g);
         unsigned char* dst = buf_base(smem, u->dst);
         const int pb = buf_pitch_bytes(u->dst), q4 = ((cols + 63) & ~63) >> 2;
+        // (measured: 128-column noise 6.8k -> 5.6k clocks; the 16-group form for 48 / 32 columns is SLOWER than the generic
+        // pass, 9.5k vs 4.7k -- eight back-to-back requests per thread to rows 3 KB apart -- and is not used)
+        if (q4 == 32) { load_f32_fast<32>(g, ld, cols, dst, pb, m0, M, tid); return; }
         Sweep sw(tid, q4);
-        while (sw.row < MLP_BM) {
-            load_f32_pass<MOVE_BATCH>(g, ld, cols, dst, pb, m0, M, sw);      // (an 8-deep pass for the 48-column pose measured slower)
-        }
+        while (sw.row < MLP_BM) load_f32_pass<MOVE_BATCH>(g, ld, cols, dst, pb, m0, M, sw);
         return;
     }
     uint16_t* g = static_cast<uint16_t*>(const_cast<void*>(u->g));
