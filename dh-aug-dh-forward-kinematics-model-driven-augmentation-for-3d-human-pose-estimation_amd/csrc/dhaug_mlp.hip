@@ -829,9 +829,43 @@ __device__ __forceinline__ void load_f32_fast(const float* g, long long ld, int 
     }
 }
 
+// fp32 LOAD of a tile whose rows are contiguous in memory (ld == cols): the tile is one linear array of 16-byte groups,
+// thread i takes groups i, i + 256, ... -- every lane live, every request a full contiguous 4 KB per wave -- and the
+// (row, group) of each is recovered for the LDS image; the zero fill up to the next multiple of 64 columns is separate.
+template <int NB>
+__device__ __forceinline__ void load_f32_linear(const float* g, int cols, unsigned char* dst, int pb, long long m0, long long M,
+                                                int tid) {
+    const int gpr = cols >> 2, total = MLP_BM * gpr;                         // groups per row, per tile
+    const long long live = (M - m0 < MLP_BM ? M - m0 : (long long)MLP_BM) * gpr;
+    const float* p = g + m0 * cols;
+    const float rc = __builtin_amdgcn_rcpf((float)gpr);                      // idx < 4096: floor((idx + 0.5) / gpr) is exact in fp32
+    f32x4 v[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int idx = tid + MLP_THREADS * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (idx < live) v[i] = *reinterpret_cast<const f32x4*>(p + 4 * idx);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int idx = tid + MLP_THREADS * i, row = (int)(((float)idx + 0.5f) * rc), c = idx - row * gpr;
+        uint2 o;
+        o.x = pack_bf16x2(v[i][0], v[i][1]);
+        o.y = pack_bf16x2(v[i][2], v[i][3]);
+        if (idx < total) *reinterpret_cast<uint2*>(dst + chunk_off(row, c >> 1, pb) + ((c & 1) << 3)) = o;
+    }
+    const int c0 = cols >> 2, np = (((cols + 63) & ~63) >> 2) - c0;          // zero fill, 8-byte groups
+    const float rn = __builtin_amdgcn_rcpf((float)(np > 0 ? np : 1));
+    for (int j = tid; j < MLP_BM * np; j += MLP_THREADS) {
+        const int row = (int)(((float)j + 0.5f) * rn), c = c0 + j - row * np;
+        *reinterpret_cast<uint2*>(dst + chunk_off(row, c >> 1, pb) + ((c & 1) << 3)) = make_uint2(0u, 0u);
+    }
+}
+
 // The bf16 pass size follows the tile: q 16-byte groups per row -> q / 2 per thread (4 for the 32-column KCS operand: a
 // fixed 16 made it walk 12 dead slots per thread, 4 400 -> 2 650 clocks).
 __device__ __forceinline__ void move_unit(UnitPtr u, unsigned char* smem, long long m0, long long M, int tid) {
+    asm volatile("" : "+v"(tid));                                            // opaque (see gemm_layer): nothing derived from it is hoisted
     const int kind = u->kind, cols = u->cols;
     const long long ld = u->ld;
     if (kind == U_LOAD_F32) {
@@ -841,6 +875,9 @@ __device__ __forceinline__ void move_unit(UnitPtr u, unsigned char* smem, long l
         // (measured: 128-column noise 6.8k -> 5.6k clocks; the 16-group form for 48 / 32 columns is SLOWER than the generic
         // pass, 9.5k vs 4.7k -- eight back-to-back requests per thread to rows 3 KB apart -- and is not used)
         if (q4 == 32) { load_f32_fast<32>(g, ld, cols, dst, pb, m0, M, tid); return; }
+        // (measured: 32 columns 4.7k -> 3.6k clocks.  Every 8-accesses-per-thread form tried for the 48-column pose -- this
+        // one, the strided one, an 8-slot generic pass -- took ~9k against the 16-slot generic pass's 4.8k; not understood)
+        if (ld == cols && cols <= 32) { load_f32_linear<4>(g, cols, dst, pb, m0, M, tid); return; }
         Sweep sw(tid, q4);
         while (sw.row < MLP_BM) load_f32_pass<MOVE_BATCH>(g, ld, cols, dst, pb, m0, M, sw);
         return;
