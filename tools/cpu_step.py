@@ -1,0 +1,30 @@
+"""Development aid: host time to ISSUE one forward step (no synchronisation inside the loop) vs its GPU time."""
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import dhaug_amd
+from dhaug_amd import ops
+from dhaug_amd.selfcheck import synth_args
+from dhaug_amd.models_Fk_GAN import model_fk_gan_train as T
+from dhaug_amd.models_Fk_GAN.forward_kinematics_DH_model import Forward_Kinematics_DH_Model
+from dhaug_amd.models_Fk_GAN.Fk_discriminator import score_fake_pair
+B = 65536
+args = synth_args(B, 256)
+fk = Forward_Kinematics_DH_Model(args, ["S1"], None)
+m = T.my_get_poseFk_model(args, None, fk)
+G, D3, D2 = m["model_G"], m["model_d3d"], m["model_d2d"]
+x = torch.randn(B, 16, 3, device="cuda") * 0.3
+G.GAN_generator_get_bone_length(x)
+z = torch.randn(B, 128, device="cuda")
+cam = ([0.7, 0.1, -0.1, 0.7], [0.1, 0.2, 5.0], [1.1, 1.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0])
+def step():
+    with torch.no_grad():
+        fw, xc, kcs, p2 = G.sample_for_critics(z, cam)
+        return score_fake_pair(D3, D2, xc, kcs, p2)
+for _ in range(10): step()
+torch.cuda.synchronize()
+for n in (1, 20, 100):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): step()
+    t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print("steps %3d: issue %.1f us/step, total %.1f us/step" % (n, (t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6))

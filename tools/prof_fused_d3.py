@@ -10,6 +10,6 @@ args = synth_args(B, D)
 D3 = Fk_discriminator.Fk_3D_Discriminator("cuda", args).cuda()
 x3 = torch.randn(B, 16, 3, device="cuda") * 0.3
 with torch.no_grad():
-    for _ in range(25):
+    for _ in range(400):
         fused.critic3d(D3, x3)
 torch.cuda.synchronize()
