@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT || exit 1
 R=${1:-r01}
 O=gpurun_out/profiles
 mkdir -p $O
-B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra"
+B="python bench.py --steps 10 --warmup 3 --prewarm 0.3 --no-cpu-baseline --no-extra"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_fwd -o r -- $B > gpurun_out/prof_fwd.log 2>&1 || exit 1
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_step -o r -- $B --workload gan_step --steps 3 --warmup 1 > gpurun_out/prof_step.log 2>&1 || exit 1
 cp gpurun_out/prof_fwd/r_kernel_stats.csv $O/${R}_fwd_kernel_stats.csv
@@ -38,4 +38,6 @@ for c, tag in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write"), ("SQ_VALU_MFMA_
         for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
             f.write("%s,%s,%d,%g,%g\n" % (k, c, len(v), sum(v) / len(v), max(v)))
 PY
+# the raw traces are large (the merged-back gpurun_out/ is capped at 64 MiB): only the summaries are kept
+rm -rf gpurun_out/prof_fwd gpurun_out/prof_step gpurun_out/prof_d3 gpurun_out/pmc_*
 ls -la $O
