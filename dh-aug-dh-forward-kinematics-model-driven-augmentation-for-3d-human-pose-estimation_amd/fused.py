@@ -73,11 +73,13 @@ class FusedNet:
     """compiled program + packed weights of one module; rebuilt when any parameter changes"""
 
     def __init__(self, module, build):
-        self.module, self.build, self.key, self.layers = module, build, None, None
+        self.module, self.build, self.key, self.layers, self.params = module, build, None, None, None
 
     def _fresh(self):
         from . import autograd_ops as A
-        key = (A.WEIGHT_EPOCH,) + tuple((p.data_ptr(), p._version) for p in self.module.parameters())
+        if self.params is None:                                # (walking the module tree costs more than the launch)
+            self.params = list(self.module.parameters())
+        key = (A.WEIGHT_EPOCH,) + tuple((p.data_ptr(), p._version) for p in self.params)
         if key != self.key:
             self.layers = {name: _Layer(lin, splits) for name, lin, splits in self.build["layers"](self.module)}
             self.key = key
@@ -85,6 +87,7 @@ class FusedNet:
 
     def invalidate(self):
         self.key = None
+        self.params = None
 
     def run(self, inputs, M):
         L = self._fresh()

@@ -28,3 +28,8 @@ for n in (1, 20, 100):
     for _ in range(n): step()
     t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
     print("steps %3d: issue %.1f us/step, total %.1f us/step" % (n, (t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6))
+import cProfile, pstats, io
+pr = cProfile.Profile(); pr.enable()
+for _ in range(200): step()
+pr.disable(); torch.cuda.synchronize()
+st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(18); print(st.getvalue()[:3500])
