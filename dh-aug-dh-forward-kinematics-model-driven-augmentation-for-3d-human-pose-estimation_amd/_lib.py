@@ -80,5 +80,13 @@ def check(rc, name):
         raise RuntimeError("%s failed: %s" % (name, ERRORS.get(rc, "hipError_t %d" % rc)))
 
 
+_fn = {}
+
+
 def call(name, *args):
-    check(getattr(lib(), name)(*args), name)
+    f = _fn.get(name)
+    if f is None:
+        f = _fn[name] = getattr(lib(), name)
+    rc = f(*args)
+    if rc != 0:
+        check(rc, name)

@@ -11,11 +11,13 @@ BF16 = torch.bfloat16
 
 
 def _stream():
-    return _vp(torch.cuda.current_stream().cuda_stream)
+    """raw handle of torch's current stream (an int: argtypes c_void_p converts it; no ctypes object per call)"""
+    return torch.cuda.current_stream().cuda_stream or None
 
 
 def _p(t):
-    return None if t is None else _vp(t.data_ptr())
+    """raw device pointer (int) or None"""
+    return None if t is None else t.data_ptr()
 
 
 def _dev(t, dtype, name):
