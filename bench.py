@@ -162,11 +162,18 @@ def main():
         return t
 
     if a.prewarm > 0:                                   # bring the clocks up (untimed; W warmup steps still follow)
-        t_end = time.perf_counter() + a.prewarm
-        while time.perf_counter() < t_end:
-            for _ in range(20):
+        if world > 1:
+            # a step of the training workload holds a collective: every rank must run the same number of them, so the
+            # pre-warm is a step count here (~prewarm seconds at the single-GPU rates), not a wall-clock loop
+            for _ in range(max(1, int(a.prewarm * (45 if a.workload == "gan_step" else 3500)))):
                 steps[a.workload]()
             torch.cuda.synchronize()
+        else:
+            t_end = time.perf_counter() + a.prewarm
+            while time.perf_counter() < t_end:
+                for _ in range(20):
+                    steps[a.workload]()
+                torch.cuda.synchronize()
     t = timed(steps[a.workload], a.steps, a.warmup)
     value = B * world * a.steps / t
 
