@@ -130,7 +130,7 @@ def main():
 
     def step_fwd():
         with torch.no_grad():
-            fw, xc, kcs, p2 = G.sample_for_critics(z, (quat, trans, cam9))    # FK tail + critic inputs, one launch
+            fw, xc, kcs, p2 = G.sample_for_critics(z, (quat, trans, cam9), inputs_bf16=True)   # FK tail + critic inputs, one launch
             l3, l2 = score_fake_pair(D3, D2, xc, kcs, p2)                      # both critics, one launch
         return l3, l2
 

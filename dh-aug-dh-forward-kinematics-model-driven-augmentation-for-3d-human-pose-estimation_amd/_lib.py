@@ -13,7 +13,7 @@ SIGNATURES = {
     "dhaug_fk_forward": [_vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "dhaug_fk_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "dhaug_gen_tail_forward": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
-    "dhaug_gen_tail_forward_critics": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _u64, _u64, _vp, _i64, _i32, _vp],
+    "dhaug_gen_tail_forward_critics": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _u64, _u64, _vp, _i64, _i32, _i32, _vp],
     "dhaug_gen_tail_backward": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "dhaug_bone_length": [_vp, _vp, _i64, _vp],
     "dhaug_kcs_forward": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],

@@ -241,9 +241,10 @@ __device__ __forceinline__ void lanes_to_rows(const float* __restrict__ v, float
 // operand (3D critic), the H36M projection through one camera (2D critic) -- the joints are in registers here, a
 // separate pass would read them back from HBM.
 struct TailExtra {
-    float* centered;            // (N,48)
+    void* centered;             // (N,48) fp32, or bf16 if in_bf16
     uint16_t* kcs;              // (N,32) bf16: 15 cosines, 15 lengths, 2 zeros
-    float* proj2d;              // (N,32)
+    void* proj2d;               // (N,32) fp32, or bf16 if in_bf16
+    int in_bf16;                // 1: centered / proj2d leave as bf16 (what the critics' LOAD units round them to anyway)
     float q[4], t[3], c[9];     // camera
     int draw;                   // 1: draw the bone-length jitter here (Philox4x32-10) instead of reading it
     unsigned long long seed, offset;
@@ -344,7 +345,15 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu((MODE == 0
                 float cc[48];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) { cc[3 * j] = o[3 * j] - o[0]; cc[3 * j + 1] = o[3 * j + 1] - o[1]; cc[3 * j + 2] = o[3 * j + 2] - o[2]; }
-                lanes_to_rows<48, 49>(cc, smem, ex.centered + base * 48, rows, lane);
+                if (ex.in_bf16) {
+                    float pk[24];                               // bf16 pairs travel as dwords
+#pragma unroll
+                    for (int i = 0; i < 24; ++i)
+                        pk[i] = __builtin_bit_cast(float, (uint32_t)dhaug_f32_to_bf16(cc[2 * i]) | ((uint32_t)dhaug_f32_to_bf16(cc[2 * i + 1]) << 16));
+                    lanes_to_rows<24, 25>(pk, smem, static_cast<float*>(ex.centered) + base * 24, rows, lane);
+                } else {
+                    lanes_to_rows<48, 49>(cc, smem, static_cast<float*>(ex.centered) + base * 48, rows, lane);
+                }
             }
             if (ex.kcs != nullptr) {
                 V3 pw[16];
@@ -363,7 +372,15 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu((MODE == 0
                 float pr[32];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) w2c_project(mk(o[3 * j], o[3 * j + 1], o[3 * j + 2]), ex.q, ex.t, ex.c, pr[2 * j], pr[2 * j + 1]);
-                lanes_to_rows<32, 33>(pr, smem, ex.proj2d + base * 32, rows, lane);
+                if (ex.in_bf16) {
+                    float pk[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        pk[i] = __builtin_bit_cast(float, (uint32_t)dhaug_f32_to_bf16(pr[2 * i]) | ((uint32_t)dhaug_f32_to_bf16(pr[2 * i + 1]) << 16));
+                    lanes_to_rows<16, 17>(pk, smem, static_cast<float*>(ex.proj2d) + base * 16, rows, lane);
+                } else {
+                    lanes_to_rows<32, 33>(pr, smem, static_cast<float*>(ex.proj2d) + base * 32, rows, lane);
+                }
             }
         }
     }
@@ -512,9 +529,10 @@ int dhaug_gen_tail_forward(const float* head, const float* bone_len, const float
 }
 
 int dhaug_gen_tail_forward_critics(const float* head, const float* bone_len, const float* scaler, float* fake16,
-                                   float* centered, uint16_t* kcs_bf16, const float* quat, const float* trans,
-                                   const float* cam9, float* proj2d, int draw_scaler, uint64_t rng_seed,
-                                   uint64_t rng_offset, float* scaler_out, int64_t N, int use_preangle, void* stream) {
+                                   void* centered, uint16_t* kcs_bf16, const float* quat, const float* trans,
+                                   const float* cam9, void* proj2d, int draw_scaler, uint64_t rng_seed,
+                                   uint64_t rng_offset, float* scaler_out, int64_t N, int use_preangle, int inputs_bf16,
+                                   void* stream) {
     DHAUG_CHECK(N >= 0, DHAUG_EINVAL);
     if (N == 0) return DHAUG_OK;
     DHAUG_CHECK_PTR(head); DHAUG_CHECK_PTR(bone_len); DHAUG_CHECK_PTR(fake16);
@@ -522,7 +540,7 @@ int dhaug_gen_tail_forward_critics(const float* head, const float* bone_len, con
     DHAUG_CHECK(proj2d == nullptr || (quat != nullptr && trans != nullptr && cam9 != nullptr), DHAUG_EINVAL);
     DHAUG_CHECK(!(draw_scaler && scaler != nullptr), DHAUG_EINVAL);
     TailExtra ex{};
-    ex.centered = centered; ex.kcs = kcs_bf16; ex.proj2d = proj2d;
+    ex.centered = centered; ex.kcs = kcs_bf16; ex.proj2d = proj2d; ex.in_bf16 = inputs_bf16 ? 1 : 0;
     ex.draw = draw_scaler ? 1 : 0; ex.seed = rng_seed; ex.offset = rng_offset; ex.scaler_out = draw_scaler ? scaler_out : nullptr;
     if (proj2d != nullptr) {
         for (int i = 0; i < 4; ++i) ex.q[i] = quat[i];

@@ -136,7 +136,7 @@ def _d2_program(D, L, inputs, M):
     x = inputs["x"]
     out = torch.empty((M, 1), dtype=torch.float32, device=x.device)
     s = D.slope
-    u = [_unit(LOAD_F32, dst=1, cols=32, ld=x.stride(0), g=x),
+    u = [_unit(LOAD_BF16 if x.dtype == torch.bfloat16 else LOAD_F32, dst=1, cols=32, ld=x.stride(0), g=x),
          _gemm(L["pose_layer_1"], 1, 0, ACT_LRELU, s),                 # d1 -> 0
          _gemm(L["pose_layer_2"], 0, 1, ACT_LRELU, s),                 # d2 -> 1
          _gemm(L["pose_layer_3"], 1, 0, ACT_LRELU, s, res=0),          # d3 = lrelu(L3 d2 + d1) -> 0 (in place)
@@ -173,7 +173,8 @@ def _d3_program(D, L, inputs, M):
     # waits in buffer 2 as bf16 and the pose branch's share is added to it as a residual (one extra bf16 rounding of a
     # partial sum; the alternative was a 33.5 MB round trip through L2)
     u.append(_unit(GEMM, src=0, dst=2, ksteps=mp.ksteps[0], n=mp.N, act=ACT_NONE, w=mp.w[0], bias=mp.bias))
-    u += [_unit(LOAD_F32, dst=1, cols=48, ld=x.stride(0), g=x), _gemm(L["previous.0"], 1, 0, ACT_RELU)]
+    u += [_unit(LOAD_BF16 if x.dtype == torch.bfloat16 else LOAD_F32, dst=1, cols=48, ld=x.stride(0), g=x),
+          _gemm(L["previous.0"], 1, 0, ACT_RELU)]
     _res_blocks(L, u, ("block1", "block2", "block3"))
     u.append(_unit(GEMM, src=0, dst=2, res=2, ksteps=mp.ksteps[1], n=mp.N, act=ACT_RELU, w=mp.w[1], bias=mp.zero))
     u.append(_gemm(L["merge_block1.fc1"], 2, 0, ACT_RELU))
@@ -208,7 +209,7 @@ def critics(D3_mod, D2_mod, x3, kcs, x2):
         D3_mod._fused = FusedNet(D3_mod, D3)
     if not hasattr(D2_mod, "_fused"):
         D2_mod._fused = FusedNet(D2_mod, D2)
-    x3 = x3.reshape(-1, 48).contiguous()
+    x3 = x3.reshape(-1, 48).contiguous()                    # fp32, or bf16 as Fk_Generator.sample_for_critics can emit them
     x2 = x2.reshape(-1, 32).contiguous()
     M = x3.shape[0]
     assert x2.shape[0] == M and kcs.shape[0] == M

@@ -191,6 +191,7 @@ def score_fake_pair(d3d, d2d, pose_centered, kcs, proj2d):
     both = (d3d.precision == "bf16" and d2d.precision == "bf16" and x3.is_cuda and kcs is not None and _no_graph(d3d, x3)
             and _no_graph(d2d, proj2d) and fused.supported(d3d.args.Dis_DenseDim_3D, d2d.args.Dis_DenseDim_2D))
     if both:
-        return fused.critics(d3d, d2d, x3.float(), kcs, proj2d.float())
-    return d3d(pose_centered, kcs=kcs), d2d(proj2d)
+        keep = lambda t: t if t.dtype == torch.bfloat16 else t.float()      # bf16 inputs are loaded as they are
+        return fused.critics(d3d, d2d, keep(x3), kcs, keep(proj2d))
+    return d3d(pose_centered.float(), kcs=kcs), d2d(proj2d.float())
 

@@ -129,10 +129,12 @@ class _GeneratorBase(nn.Module):
 
 
 class Fk_Generator(_GeneratorBase):
-    def sample_for_critics(self, input, camera=None, bone_len_scaler=None):
+    def sample_for_critics(self, input, camera=None, bone_len_scaler=None, inputs_bf16=False):
         """Inference-only forward (no graph) that also returns the critics' inputs from the same launch as the FK tail:
         (fake (B,16,3) world, centered (B,48), kcs bf16 (B,32), proj2d (B,16,2) | None) -- what
-        R/models_Fk_GAN/model_fk_gan_train.py:305-312,374-376 computes in three more passes over the fake batch."""
+        R/models_Fk_GAN/model_fk_gan_train.py:305-312,374-376 computes in three more passes over the fake batch.
+        inputs_bf16: centered / proj2d as bf16, the precision the bf16 critics read them in anyway (score_fake_pair gives
+        bit-identical logits either way; half the bytes between the two launches)."""
         with torch.no_grad():
             B = input.shape[0]
             head = self.trunk(input).reshape(B, 35)
@@ -149,9 +151,10 @@ class Fk_Generator(_GeneratorBase):
                 # the jitter is drawn inside the tail kernel from the device generator's (seed, offset) stream: same
                 # distribution as torch.randint(-200, 200) / 1000, reproducible under torch.manual_seed
                 seed, off = self._jitter_stream(head)
-                return ops.gen_tail_forward_critics(head.contiguous(), bl, None, pre, camera, rng=(seed, off))
+                return ops.gen_tail_forward_critics(head.contiguous(), bl, None, pre, camera, rng=(seed, off),
+                                                    inputs_bf16=inputs_bf16)
             scaler = self._scaler(B, bone_len_scaler)
-            return ops.gen_tail_forward_critics(head.contiguous(), bl, scaler, pre, camera)
+            return ops.gen_tail_forward_critics(head.contiguous(), bl, scaler, pre, camera, inputs_bf16=inputs_bf16)
 
     def __init__(self, FK_DH_Class, args, device, INPUT_VEC_DIM=128):
         super().__init__(1, FK_DH_Class, args, device, INPUT_VEC_DIM)

@@ -82,27 +82,29 @@ def gen_tail_forward(head, bone_len, scaler, use_preangle=True, want_angles=Fals
 
 
 def gen_tail_forward_critics(head, bone_len, scaler, use_preangle=True, camera=None, rng=None, want_scaler=False,
-                             want_critic_inputs=True):
+                             want_critic_inputs=True, inputs_bf16=False):
     """generator tail + what the critics consume in one launch: (fake (N,16,3), centered (N,48), kcs bf16 (N,32),
     proj2d (N,16,2) | None).  camera = (quat[4], trans[3], cam9[9]) host sequences.  rng = (seed, offset): draw the
     bone-length jitter in the kernel (scaler must be None); want_scaler appends the (N,8) draw to the result;
-    want_critic_inputs=False skips the centred pose and the KCS operand (plain sampling with the in-kernel jitter)."""
+    want_critic_inputs=False skips the centred pose and the KCS operand (plain sampling with the in-kernel jitter);
+    inputs_bf16: the centred pose and the projection leave as bf16 (the rounding the critics apply on load anyway)."""
     h = _dev(head, torch.float32, "gen_tail_forward_critics").reshape(-1, 35)
     b = _dev(bone_len, torch.float32, "gen_tail_forward_critics").reshape(-1, 15)
     s = None if scaler is None else _dev(scaler, torch.float32, "gen_tail_forward_critics").reshape(-1, 8)
     N = h.shape[0]
     assert b.shape[0] == N and (s is None or s.shape[0] == N)
     fake = torch.empty((N, 16, 3), dtype=torch.float32, device=h.device)
-    xc = torch.empty((N, 48), dtype=torch.float32, device=h.device) if want_critic_inputs else None
+    idt = BF16 if inputs_bf16 else torch.float32
+    xc = torch.empty((N, 48), dtype=idt, device=h.device) if want_critic_inputs else None
     kcs = torch.empty((N, 32), dtype=BF16, device=h.device) if want_critic_inputs else None
     p2 = q = t = c = None
     if camera is not None:
-        p2 = torch.empty((N, 16, 2), dtype=torch.float32, device=h.device)
+        p2 = torch.empty((N, 16, 2), dtype=idt, device=h.device)
         q, t, c = _host3(camera[0], 4), _host3(camera[1], 3), _host3(camera[2], 9)
     so = torch.empty((N, 8), dtype=torch.float32, device=h.device) if (rng is not None and want_scaler) else None
     _lib.call("dhaug_gen_tail_forward_critics", _p(h), _p(b), _p(s), _p(fake), _p(xc), _p(kcs), q, t, c, _p(p2),
               int(rng is not None), 0 if rng is None else int(rng[0]) & (2 ** 64 - 1), 0 if rng is None else int(rng[1]), _p(so),
-              N, int(bool(use_preangle)), _stream())
+              N, int(bool(use_preangle)), int(bool(inputs_bf16)), _stream())
     if want_scaler:
         return fake, xc, kcs, p2, so
     return fake, xc, kcs, p2

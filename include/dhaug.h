@@ -85,11 +85,14 @@ int dhaug_gen_tail_forward(const float* head, const float* bone_len, const float
  *                          quat[4], trans[3], cam9[9] host arrays as in dhaug_world_to_camera_project)
  * Any of the three may be NULL.  draw_scaler != 0 (scaler must be NULL): the bone-length jitter
  * `randint(-200, 200, (N, 8)) / 1000` (Fk_generator.py:196-203) is drawn inside the kernel with Philox4x32-10 keyed by
- * rng_seed, counter (pose index, rng_offset); scaler_out (N,8), if given, receives the draw. */
+ * rng_seed, counter (pose index, rng_offset); scaler_out (N,8), if given, receives the draw.
+ * inputs_bf16 != 0: centered and proj2d are written as bf16 (N,48) / (N,32) -- the rounding the critics' first layer
+ * applies to them anyway (dhaug_mlp_forward LOAD units), at half the bytes. */
 int dhaug_gen_tail_forward_critics(const float* head, const float* bone_len, const float* scaler, float* fake16,
-                                   float* centered, uint16_t* kcs_bf16, const float* quat, const float* trans,
-                                   const float* cam9, float* proj2d, int draw_scaler, uint64_t rng_seed,
-                                   uint64_t rng_offset, float* scaler_out, int64_t N, int use_preangle, void* stream);
+                                   void* centered, uint16_t* kcs_bf16, const float* quat, const float* trans,
+                                   const float* cam9, void* proj2d, int draw_scaler, uint64_t rng_seed,
+                                   uint64_t rng_offset, float* scaler_out, int64_t N, int use_preangle, int inputs_bf16,
+                                   void* stream);
 
 /* Gradient of dhaug_gen_tail_forward w.r.t. head: grad_fake16 (N,16,3) -> grad_head (N,35)
  * (column 31 = 0).  Recomputes the forward from head. */

@@ -344,6 +344,14 @@ def test_fused_forward_matches_layerwise(M, D, B):
         with torch.no_grad():
             m3, m2 = M.dis.score_fake_pair(D3, D2, xc, kc, p2)
             assert torch.equal(m3, D3(xc, kcs=kc)) and torch.equal(m2, D2(p2))
+            # critic inputs handed over as bf16 (the rounding the LOAD units apply to fp32 inputs): same logits, bit for bit
+            torch.manual_seed(11)
+            fwb, xcb, kcb, p2b = G.sample_for_critics(z, ([1.0, 0.0, 0.0, 0.0], [0.0, 0.0, -5.0], [1.1, 1.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]),
+                                                      inputs_bf16=True)
+            assert xcb.dtype == torch.bfloat16 and p2b.dtype == torch.bfloat16 and torch.equal(fwb, fw) and torch.equal(kcb, kc)
+            assert torch.equal(xcb, xc.to(torch.bfloat16)) and torch.equal(p2b, p2.to(torch.bfloat16))
+            b3, b2 = M.dis.score_fake_pair(D3, D2, xcb, kcb, p2b)
+            assert torch.equal(b3, m3) and torch.equal(b2, m2)
     # weights change -> the packed fragments are rebuilt
     with torch.no_grad():
         D2.layer_pred.bias.add_(1.0)
