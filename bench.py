@@ -71,11 +71,18 @@ def main():
     ap.add_argument("--dense", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel roofline timing loops (profiling runs)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  It has not touched the GPU (importing
+        # torch does not initialise HIP) and never will: it starts N rank processes and relays rank 0's JSON line.
+        sys.exit(launch_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d)" % (a.gpus, world, a.gpus))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" = RCCL over xGMI on ROCm.  DHAUG_DIST_BACKEND=gloo lets the multi-rank path be rehearsed with all
@@ -87,7 +94,7 @@ def main():
 
     import dhaug_amd
     from dhaug_amd import ops
-    from dhaug_amd.selfcheck import synth_args
+    from dhaug_amd.function_aug.config import synth_args
     from dhaug_amd.models_Fk_GAN import model_fk_gan_train as T
     from dhaug_amd.models_Fk_GAN.forward_kinematics_DH_model import Forward_Kinematics_DH_Model
     from dhaug_amd.models_Fk_GAN.Fk_discriminator import score_fake_pair
@@ -243,6 +250,27 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """One child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, as torch.distributed.run
+    sets them); children are started fresh -- nothing is exec'ed from a process that holds the GPU.  Returns the exit
+    code (0 only if every rank succeeded); rank 0's stdout (the JSON line) is passed through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def pmc_traffic(kernel_substr, prefix=""):

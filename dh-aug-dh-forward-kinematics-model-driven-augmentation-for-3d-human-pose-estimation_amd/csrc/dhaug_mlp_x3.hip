@@ -1,0 +1,414 @@
+// Parity-grade fused forward of the generator trunk / critics: the SAME one-launch unit programs as dhaug_mlp.hip
+// (activations never leave LDS), in fp32-grade arithmetic on the matrix cores.
+//
+// The reference's layers are fp32 nn.Linear (R/models_Fk_GAN/Fk_discriminator.py:180-201,253-266,
+// R/models_Fk_GAN/Fk_generator.py:115-119) and the path's tolerance is 1e-4 relative on the logits; one bf16 pass misses it by
+// two orders of magnitude.  Here every operand is carried as an fp16 PAIR  x = hi + lo  (hi = fp16(x), lo = fp16(x - hi):
+// 22 mantissa bits) and a product is three v_mfma_f32_32x32x16_f16 terms accumulated in fp32:
+//        W x  ~=  Whi Xhi + Whi Xlo + Wlo Xhi                       (the dropped Wlo Xlo is 2^-22 relative)
+// fp16 products are exact in fp32 (11 x 11 bits), so the result differs from fp32 arithmetic by ~2^-21 per operand:
+// measured against the reference's logits 2e-5 in the tests' strict relative metric, 1e-6 of the logit scale.  The F16
+// MFMA runs at the BF16 rate, so this mode costs 3 matrix instructions per k-step instead of 1 -- its roofline is a third
+// of the dense peak in ALGORITHMIC flops.  Range: |x| < 65 504 (fp16); values below 2^-14 keep an ABSOLUTE error of 2^-25.
+//
+// Structure (256 threads = 4 waves = one per SIMD; one persistent workgroup per CU walking 64-row batch tiles):
+//   * activations: fp16 hi / lo planes [64 rows][256] per buffer (two 64 KB buffers + one 32 KB [64][128] buffer = all
+//     160 KB of LDS), 16-byte chunks XOR-swizzled by (row & 15) -> conflict-free ds_read_b128 of MFMA B fragments;
+//   * weights: pre-split and pre-packed in A-fragment order (dhaug_pack_wfrag_f16x2): per (32-feature slice, k-step)
+//     two contiguous 1 KB blocks (hi, lo); wave w owns slices w and w + 4; fragments stream from L2 through a 3-slot
+//     register ring (4 k-steps per slot) -- 12 MFMAs per k-step per wave hide them;
+//   * MFMA issued swapped (A = weights, B = activations): a lane owns one batch row and 4 consecutive features per
+//     register quad; the epilogue (bias = accumulator seed, residual from the LDS planes, activation, hi/lo split) writes
+//     8 + 8 bytes per lane into the next layer's operand planes.  In-place residual layers are safe (own elements only).
+#include "dhaug_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int X3_BM = 64;                                            // batch rows per tile
+constexpr int X3_MT = X3_BM / 32;
+constexpr int X3_THREADS = 256;
+constexpr int X3_CH = 4;                                             // k-steps per ring slot (64 k)
+constexpr int X3_MAX_UNITS = 32;
+constexpr int X3_MAX_KSTEPS = 16;
+constexpr int P01 = 256, P2 = 128;                                   // pitch (elements) of buffers 0/1 and 2
+constexpr int PLANE01 = X3_BM * P01 * 2, PLANE2 = X3_BM * P2 * 2;    // bytes of one fp16 plane
+constexpr int BUF01 = 2 * PLANE01, BUF2 = 2 * PLANE2;                // hi plane, lo plane
+constexpr int X3_LDS_BYTES = 2 * BUF01 + BUF2;                       // 163 840
+constexpr int OUT_PITCH = 68;                                        // floats per row of the fp32 output staging image
+
+enum { U_LOAD_F32 = 0, U_GEMM = 3 };
+enum { F_OUT_F32 = 4 };
+
+struct Unit {
+    int kind, plan, flags;
+    int src, dst, res, src2, ksteps2, ksteps, N, act;
+    float slope;
+    int cols;
+    long long ld;
+    const void* g;
+    const _Float16* w;
+    const _Float16* w2;
+    const float* bias;
+};
+struct Program {
+    int nunits;
+    Unit u[X3_MAX_UNITS];
+};
+typedef const Unit __attribute__((address_space(4))) * UnitPtr;      // units are read from the kernarg segment (s_load)
+
+__device__ __forceinline__ unsigned char* buf_base(unsigned char* smem, int id) {
+    return smem + (id == 0 ? 0 : (id == 1 ? BUF01 : 2 * BUF01));
+}
+__device__ __forceinline__ int buf_pitch_bytes(int id) { return (id == 2 ? P2 : P01) * 2; }
+__device__ __forceinline__ int buf_plane(int id) { return id == 2 ? PLANE2 : PLANE01; }
+__device__ __forceinline__ int chunk_off(int row, int c, int pitch_bytes) { return row * pitch_bytes + ((c ^ (row & 15)) << 4); }
+__device__ __forceinline__ float act_neg(int act, float slope) {
+    return act == DHAUG_ACT_RELU ? 0.0f : (act == DHAUG_ACT_LRELU ? slope : 1.0f);
+}
+__device__ __forceinline__ float act_fn(float v, float neg) { return fmaxf(v, v * neg); }
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// x0, x1 -> packed fp16 pairs (hi, lo) with x = hi + lo to 22 bits
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    const f32x2 v = {x0, x1};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    const f16x2 l = __builtin_convertvector(v - hf, f16x2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
+__device__ __forceinline__ int chunks_of(int ksteps) { return (ksteps + X3_CH - 1) / X3_CH; }
+
+// global loads of chunk C (of the concatenated sources; the first has NCH1 chunks) into a ring slot [slice][k][piece]
+template <int C, int NCH, int NCH1, int NS>
+__device__ __forceinline__ void load_chunk(const _Float16* w1, const _Float16* w2, int wave, int lane, f16x8 (&slot)[NS][X3_CH][2]) {
+    constexpr bool second = C >= NCH1;
+    constexpr int kpad = (second ? NCH - NCH1 : NCH1) * X3_CH;
+    constexpr int k0 = (second ? C - NCH1 : C) * X3_CH;
+    const _Float16* w = second ? w2 : w1;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const _Float16* base = w + ((long long)(wave + 4 * t) * kpad * 2 * 64 + lane) * 8 + (long long)k0 * 2 * 512;
+#pragma unroll
+        for (int q = 0; q < X3_CH; ++q)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) slot[t][q][p] = *reinterpret_cast<const f16x8*>(base + (2 * q + p) * 512);
+    }
+}
+
+// dst = act(W src [+ W2 src2] + bias + res), one layer, self-contained.  NCH chunks of 64 k, the first NCH1 from source 1;
+// NS = feature slices this wave owns in this layer (2: wave and wave + 4; 1: only wave).
+template <int NCH, int NCH1, int NS>
+__device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int wave, int lane) {
+    asm volatile("" : "+v"(lane));                   // lane-derived constants are recomputed per unit, not parked across units
+    f16x8 ring[3][NS][X3_CH][2];
+    const int r31 = lane & 31, h = lane >> 5;
+    const _Float16* w1 = u->w;
+    const _Float16* w2 = NCH1 < NCH ? u->w2 : u->w;
+    load_chunk<0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[0]);
+    if constexpr (NCH > 1) load_chunk<1, NCH, NCH1, NS>(w1, w2, wave, lane, ring[1]);
+    f32x16 acc[NS][X3_MT];
+    const unsigned char* src1 = buf_base(smem, u->src);
+    const int pbs1 = buf_pitch_bytes(u->src), pl1 = buf_plane(u->src);
+    const unsigned char* src2 = NCH1 < NCH ? buf_base(smem, u->src2) : src1;
+    const int pbs2 = NCH1 < NCH ? buf_pitch_bytes(u->src2) : pbs1, pl2 = NCH1 < NCH ? buf_plane(u->src2) : pl1;
+    f32x16 seed[NS];                                 // the bias is the accumulators' start value
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(u->bias + 32 * (wave + 4 * t) + 4 * h + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) seed[t][4 * g + e] = b4[e];
+        }
+    constexpr int KT = NCH * X3_CH;
+    f16x8 fx[3][X3_MT][2];                           // activation fragments (hi, lo), read two k-steps ahead
+    auto read_frags = [&](int k, f16x8 (&f)[X3_MT][2]) {
+        const bool second = k >= NCH1 * X3_CH;
+        const unsigned char* src = second ? src2 : src1;
+        const int pbs = second ? pbs2 : pbs1, pl = second ? pl2 : pl1;
+        const int kk = second ? k - NCH1 * X3_CH : k;
+#pragma unroll
+        for (int mt = 0; mt < X3_MT; ++mt) {
+            const int o = chunk_off(32 * mt + r31, 2 * kk + h, pbs);
+            f[mt][0] = *reinterpret_cast<const f16x8*>(src + o);
+            f[mt][1] = *reinterpret_cast<const f16x8*>(src + pl + o);
+        }
+    };
+    read_frags(0, fx[0]);
+    if (KT > 1) read_frags(1, fx[1]);
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        const int c = k / X3_CH, q = k % X3_CH;
+        if (k + 2 < KT) read_frags(k + 2, fx[(k + 2) % 3]);
+        if (q == 0 && c + 2 < NCH) {
+            if (c + 2 == 2) load_chunk<2 < NCH ? 2 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[2]);
+            if (c + 2 == 3) load_chunk<3 < NCH ? 3 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[0]);
+            if (c + 2 == 4) load_chunk<4 < NCH ? 4 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[1]);
+            if (c + 2 == 5) load_chunk<5 < NCH ? 5 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[2]);
+            if (c + 2 == 6) load_chunk<6 < NCH ? 6 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[0]);
+            if (c + 2 == 7) load_chunk<7 < NCH ? 7 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // small terms first, then hi * hi
+#pragma unroll
+        for (int mt = 0; mt < X3_MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NS; ++t)
+                acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[c % 3][t][q][1], fx[k % 3][mt][0], k == 0 ? seed[t] : acc[t][mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < X3_MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NS; ++t)
+                acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[c % 3][t][q][0], fx[k % 3][mt][1], acc[t][mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < X3_MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NS; ++t)
+                acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[c % 3][t][q][0], fx[k % 3][mt][0], acc[t][mt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int nslices = (u->N + 31) >> 5;
+    const bool to_global = (u->flags & F_OUT_F32) != 0;
+    unsigned char* dst = buf_base(smem, u->dst);
+    const int pbd = buf_pitch_bytes(u->dst), pld = buf_plane(u->dst);
+    const int resid = to_global ? -1 : u->res;
+    const unsigned char* res = buf_base(smem, resid >= 0 ? resid : 0);
+    const int pbr = buf_pitch_bytes(resid >= 0 ? resid : 0), plr = buf_plane(resid >= 0 ? resid : 0);
+    const float neg = act_neg(u->act, u->slope);
+    // epilogue: this lane owns row (32 mt + r31), features 32*slice + 8g + 4h .. +3
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const int slice = wave + 4 * t;
+        if (slice >= nslices) continue;                                      // wave-uniform
+        if (to_global) {
+            float* st = reinterpret_cast<float*>(dst);
+#pragma unroll
+            for (int mt = 0; mt < X3_MT; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[t][mt][4 * g + e], neg);
+                    *reinterpret_cast<f32x4*>(st + (32 * mt + r31) * OUT_PITCH + 32 * slice + 4 * h + 8 * g) = v;
+                }
+            continue;
+        }
+#pragma unroll
+        for (int mt = 0; mt < X3_MT; ++mt) {
+            const int row = 32 * mt + r31;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[t][mt][4 * g + e];
+                if (resid >= 0) {
+                    const int ro = chunk_off(row, 4 * slice + g, pbr) + (h << 3);
+                    const f16x4 rh = *reinterpret_cast<const f16x4*>(res + ro), rl = *reinterpret_cast<const f16x4*>(res + plr + ro);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)rh[e] + (float)rl[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_fn(v[e], neg);
+                uint2 oh, ol;
+                split2(v[0], v[1], oh.x, ol.x);
+                split2(v[2], v[3], oh.y, ol.y);
+                const int o = chunk_off(row, 4 * slice + g, pbd) + (h << 3);
+                *reinterpret_cast<uint2*>(dst + o) = oh;
+                *reinterpret_cast<uint2*>(dst + pld + o) = ol;
+            }
+        }
+    }
+}
+
+// LOAD: global fp32 (M, ld) columns [0, cols) -> hi / lo planes of buffer dst, zero-filled up to the next multiple of 64
+// columns and below row M.  cols and ld even: a thread moves column pairs (8-byte loads, 4-byte LDS writes).
+__device__ __forceinline__ void load_unit(UnitPtr u, unsigned char* smem, long long m0, long long M, int tid) {
+    asm volatile("" : "+v"(tid));
+    const float* g = static_cast<const float*>(u->g);
+    const long long ld = u->ld;
+    const int cols = u->cols, id = u->dst;
+    unsigned char* dst = buf_base(smem, id);
+    const int pb = buf_pitch_bytes(id), pl = buf_plane(id);
+    const int pairs = ((cols + 63) & ~63) >> 1;                              // per row, zero fill included: 32, 64 or 128
+    const int sh = pairs == 32 ? 5 : (pairs == 64 ? 6 : 7);
+    const int total = X3_BM << sh;
+    constexpr int NB = 8;                                                    // loads in flight per thread
+    for (int i0 = tid; i0 < total; i0 += X3_THREADS * NB) {
+        f32x2 v[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int i = i0 + j * X3_THREADS, row = i >> sh, c2 = i & (pairs - 1);
+            v[j] = f32x2{0.f, 0.f};
+            if (i < total && m0 + row < M && 2 * c2 < cols) v[j] = *reinterpret_cast<const f32x2*>(g + (m0 + row) * ld + 2 * c2);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int i = i0 + j * X3_THREADS, row = i >> sh, c2 = i & (pairs - 1);
+            uint32_t hi, lo;
+            split2(v[j][0], v[j][1], hi, lo);
+            if (i < total) {
+                const int o = chunk_off(row, c2 >> 2, pb) + ((c2 & 3) << 2);
+                *reinterpret_cast<uint32_t*>(dst + o) = hi;
+                *reinterpret_cast<uint32_t*>(dst + pl + o) = lo;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void store_output(UnitPtr u, unsigned char* smem, long long m0, long long M, int tid) {
+    const float* st = reinterpret_cast<const float*>(buf_base(smem, u->dst));
+    float* out = static_cast<float*>(const_cast<void*>(u->g));
+    const long long ld = u->ld;
+    const int N = u->N;
+    for (int i = tid; i < X3_BM * N; i += X3_THREADS) {
+        const int row = i / N, c = i - row * N;
+        if (m0 + row < M) out[(m0 + row) * ld + c] = st[row * OUT_PITCH + c];
+    }
+}
+
+__global__ __launch_bounds__(X3_THREADS, 1) void fused_mlp_x3_kernel(Program prog, long long M) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long ntiles = (M + X3_BM - 1) / X3_BM;
+    const unsigned char __attribute__((address_space(4)))* ka =
+        (const unsigned char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    UnitPtr units = (UnitPtr)(ka + __builtin_offsetof(Program, u));
+    const int nunits = *(const int __attribute__((address_space(4)))*)(ka + __builtin_offsetof(Program, nunits));
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long m0 = tile * X3_BM;
+#pragma unroll 1
+        for (int i = 0; i < nunits; ++i) {
+            UnitPtr u = units + i;
+            const int kind = u->kind, plan = u->plan;
+            if (kind == U_LOAD_F32) {
+                load_unit(u, smem, m0, M, tid);
+            } else {
+                const int nslices = (plan >> 24) & 15;
+#define X3_SHAPES(NS)                                                                      \
+    switch ((plan >> 16) & 255) {                              /* validated on the host */ \
+        case 1 * 16 + 1: gemm_layer<1, 1, NS>(u, smem, wave, lane); break;                 \
+        case 2 * 16 + 2: gemm_layer<2, 2, NS>(u, smem, wave, lane); break;                 \
+        case 2 * 16 + 1: gemm_layer<2, 1, NS>(u, smem, wave, lane); break;                 \
+        case 4 * 16 + 4: gemm_layer<4, 4, NS>(u, smem, wave, lane); break;                 \
+        case 4 * 16 + 2: gemm_layer<4, 2, NS>(u, smem, wave, lane); break;                 \
+        case 8 * 16 + 4: gemm_layer<8, 4, NS>(u, smem, wave, lane); break;                 \
+        default: break;                                                                    \
+    }
+                if (wave + 4 < nslices) { X3_SHAPES(2) }
+                else if (wave < nslices) { X3_SHAPES(1) }
+#undef X3_SHAPES
+                if (u->flags & F_OUT_F32) {
+                    lds_barrier();
+                    store_output(u, smem, m0, M, tid);
+                }
+            }
+            lds_barrier();
+        }
+    }
+    (void)prog;
+}
+
+// weights -> hi / lo fp16 fragments.  dst[(((slice*ksteps + ks)*2 + piece)*64 + lane)*8 + j] =
+//   piece(W[32 slice + (lane&31)][k0 + 16 ks + 8 (lane>>5) + j])
+__global__ __launch_bounds__(256) void pack_wfrag_f16x2_kernel(const float* __restrict__ W, long long ldw, _Float16* __restrict__ dst,
+                                                               int N, int K, int k0, int ksteps, int nslices) {
+    const long long total = (long long)nslices * ksteps * 64 * 8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const long long blk = i >> 9;
+        const int ks = (int)(blk % ksteps), s = (int)(blk / ksteps);
+        const int n = 32 * s + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+        const float w = (n < N && k < K) ? W[(long long)n * ldw + k0 + k] : 0.0f;
+        const _Float16 hi = (_Float16)w, lo = (_Float16)(w - (float)hi);
+        const long long o = ((blk * 2) * 64 + lane) * 8 + j;
+        dst[o] = hi;
+        dst[o + 512] = lo;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+/* see include/dhaug.h */
+int dhaug_pack_wfrag_f16x2(const float* W, int64_t ldw, uint16_t* dst, int64_t N, int64_t K, int64_t k0, void* stream) {
+    DHAUG_CHECK(N >= 1 && K >= 1 && k0 >= 0 && ldw >= k0 + K, DHAUG_EINVAL);
+    DHAUG_CHECK_PTR(W); DHAUG_CHECK_PTR(dst);
+    DHAUG_CHECK(dhaug_aligned16(dst), DHAUG_EALIGN);
+    const int ksteps = (int)((K + 63) / 64) * 4, nslices = 8;
+    DHAUG_CHECK(ksteps <= X3_MAX_KSTEPS && N <= 256, DHAUG_EUNSUPPORTED);
+    const long long total = (long long)nslices * ksteps * 512;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(pack_wfrag_f16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, W, (long long)ldw,
+                       reinterpret_cast<_Float16*>(dst), (int)N, (int)K, (int)k0, ksteps, nslices);
+    return dhaug_launch_status();
+}
+
+int dhaug_mlp_forward_x3(const dhaug_mlp_unit* units, int nunits, int64_t M, void* stream) {
+    DHAUG_CHECK(nunits >= 1 && nunits <= X3_MAX_UNITS && M >= 0, DHAUG_EINVAL);
+    DHAUG_CHECK_PTR(units);
+    if (M == 0) return DHAUG_OK;
+    Program prog;
+    prog.nunits = nunits;
+    auto okbuf = [](int b) { return b >= 0 && b <= 2; };
+    auto pitch = [](int b) { return b == 2 ? P2 : P01; };
+    for (int i = 0; i < nunits; ++i) {
+        const dhaug_mlp_unit& s = units[i];
+        Unit& u = prog.u[i];
+        u.kind = s.kind; u.flags = s.flags; u.src = s.src; u.dst = s.dst; u.res = s.res; u.src2 = s.src2; u.ksteps2 = s.ksteps2;
+        u.ksteps = s.ksteps; u.N = s.n; u.act = s.act; u.slope = s.slope; u.cols = s.cols; u.ld = s.ld; u.g = s.g;
+        u.w = static_cast<const _Float16*>(s.w); u.w2 = static_cast<const _Float16*>(s.w2); u.bias = s.bias;
+        u.plan = 0;
+        DHAUG_CHECK(u.kind == U_LOAD_F32 || u.kind == U_GEMM, DHAUG_EUNSUPPORTED);
+        if (u.kind == U_GEMM) {
+            DHAUG_CHECK(okbuf(u.src) && u.ksteps >= 1 && u.ksteps <= X3_MAX_KSTEPS && u.N >= 1 && u.N <= 256, DHAUG_EUNSUPPORTED);
+            DHAUG_CHECK(((u.ksteps + 3) / 4) * 64 <= pitch(u.src), DHAUG_EUNSUPPORTED);
+            DHAUG_CHECK(u.w != nullptr && dhaug_aligned16(u.w) && u.bias != nullptr && dhaug_aligned16(u.bias), DHAUG_EALIGN);
+            DHAUG_CHECK(u.ksteps2 >= 0 && u.ksteps2 <= X3_MAX_KSTEPS, DHAUG_EUNSUPPORTED);
+            DHAUG_CHECK((u.flags & ~F_OUT_F32) == 0, DHAUG_EUNSUPPORTED);
+            if (u.ksteps2 > 0) {
+                DHAUG_CHECK(okbuf(u.src2) && ((u.ksteps2 + 3) / 4) * 64 <= pitch(u.src2) && u.ksteps % 4 == 0, DHAUG_EUNSUPPORTED);
+                DHAUG_CHECK(u.w2 != nullptr && dhaug_aligned16(u.w2), DHAUG_EALIGN);
+            }
+            const int c1 = (u.ksteps + 3) / 4, c2 = (u.ksteps2 + 3) / 4, sh = (c1 + c2) * 16 + c1;
+            DHAUG_CHECK(sh == 17 || sh == 34 || sh == 33 || sh == 68 || sh == 66 || sh == 132, DHAUG_EUNSUPPORTED);
+            if (u.flags & F_OUT_F32) {
+                DHAUG_CHECK(u.g != nullptr && u.ld >= u.N && u.N <= 64, DHAUG_EUNSUPPORTED);
+                DHAUG_CHECK((u.dst == 0 || u.dst == 1) && u.dst != u.src && (u.ksteps2 == 0 || u.dst != u.src2), DHAUG_EINVAL);
+            } else {
+                DHAUG_CHECK(okbuf(u.dst) && u.dst != u.src && (u.ksteps2 == 0 || u.dst != u.src2), DHAUG_EINVAL);
+                DHAUG_CHECK(((u.N + 31) / 32) * 32 <= pitch(u.dst), DHAUG_EUNSUPPORTED);
+                DHAUG_CHECK(u.res < 0 || (okbuf(u.res) && u.res != u.src && (u.ksteps2 == 0 || u.res != u.src2)), DHAUG_EINVAL);
+                DHAUG_CHECK(u.res < 0 || ((u.N + 31) / 32) * 32 <= pitch(u.res), DHAUG_EUNSUPPORTED);
+            }
+            u.plan = (sh << 16) | (((u.N + 31) >> 5) << 24);
+        } else {
+            DHAUG_CHECK(okbuf(u.dst) && u.g != nullptr && u.cols >= 2 && ((u.cols + 63) & ~63) <= pitch(u.dst), DHAUG_EINVAL);
+            DHAUG_CHECK(u.cols % 2 == 0 && u.ld % 2 == 0 && u.ld >= u.cols && (reinterpret_cast<uintptr_t>(u.g) & 7u) == 0, DHAUG_EALIGN);
+        }
+    }
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_x3_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    const long long ntiles = (M + X3_BM - 1) / X3_BM;
+    const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);           // one persistent workgroup per CU
+    hipLaunchKernelGGL(fused_mlp_x3_kernel, dim3(grid), dim3(X3_THREADS), X3_LDS_BYTES, (hipStream_t)stream, prog, (long long)M);
+    return dhaug_launch_status();
+}
+
+}  // extern "C"

@@ -41,3 +41,16 @@ def get_parse_args(argv=None):
     if args.resume and args.evaluate:
         raise SystemExit('Invalid flags: --resume and --evaluate cannot be set at the same time')
     return args
+
+
+def synth_args(batch_size, D=256, **over):
+    """argparse.Namespace with the attributes the hot path reads, for synthetic runs (bench.py, smoke, tools): the
+    reference's defaults except the dense widths (D instead of 1000 for the single-frame networks)"""
+    d = dict(batch_size=batch_size, random_seed=0, GAN_OUTPUT_DIM=35, GAN_LAMBDA=10, GAN_whether_use_preAngle=True,
+             Gen_DenseDim=D, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D, video_Dis_DenseDim_3D=1000, video_Dis_DenseDim_2D=1000,
+             GAN_3d_loss_weight=1.0, GAN_2d_loss_weight=0.2, GAN_3d_motion_loss_weight=1.0, GAN_2d_motion_loss_weight=1.0,
+             bone_len_scaler="different", whether_use_RT=True, flip_GAN_model_input=True, GAN_video_playback_input=True,
+             single_or_multi_train_mode="single", architecture="3,3,3", motion_Dis_whether_use_3dPos_branch=True,
+             motion_Dis_whether_use_3dDiff_branch=True, warmup=2, num_workers=0, single_dis_warmup_epoch=4)
+    d.update(over)
+    return argparse.Namespace(**d)

@@ -15,6 +15,10 @@ from .autograd_ops import ACT_LRELU, ACT_NONE, ACT_RELU
 LOAD_F32, LOAD_BF16, STORE_BF16, GEMM = 0, 1, 2, 3
 F_OUT_F32, F_DOT_OUT = 4, 16
 _vp = ctypes.c_void_p
+# arithmetic of a fused program: "bf16" (dhaug_mlp_forward: one bf16 MFMA pass, bf16 activations in LDS) or "f16x3"
+# (dhaug_mlp_forward_x3: operands as fp16 hi + lo pairs, three MFMA terms, fp32-grade -- the mode that meets the path's
+# 1e-4 logit tolerance against the fp32 reference)
+MODES = ("bf16", "f16x3")
 
 
 def supported(*dims):
@@ -26,7 +30,7 @@ def supported(*dims):
 class _Layer:
     """packed fragments + padded bias of one nn.Linear (optionally split over two input column ranges)"""
 
-    def __init__(self, lin, splits=None):
+    def __init__(self, lin, splits=None, mode="bf16"):
         W, b = lin.weight.detach(), lin.bias.detach()
         N, K = W.shape
         self.N = N
@@ -35,14 +39,18 @@ class _Layer:
         for k0, k in splits:
             ks = (k + 15) // 16
             kpad = (k + 63) // 64 * 4                         # k-steps padded to whole 64-wide chunks
-            blob = torch.empty(8 * kpad * 512, dtype=torch.bfloat16, device=W.device)      # always 8 slices
-            _lib.call("dhaug_pack_wfrag", _vp(W.data_ptr()), K, _vp(blob.data_ptr()), N, k, k0, ops._stream())
+            if mode == "f16x3":                               # hi and lo fp16 fragments per (slice, k-step)
+                blob = torch.empty(2 * 8 * kpad * 512, dtype=torch.float16, device=W.device)
+                _lib.call("dhaug_pack_wfrag_f16x2", _vp(W.data_ptr()), K, _vp(blob.data_ptr()), N, k, k0, ops._stream())
+            else:
+                blob = torch.empty(8 * kpad * 512, dtype=torch.bfloat16, device=W.device)      # always 8 slices
+                _lib.call("dhaug_pack_wfrag", _vp(W.data_ptr()), K, _vp(blob.data_ptr()), N, k, k0, ops._stream())
             self.w.append(blob)
             self.ksteps.append(ks)
         self.bias = torch.zeros(256, dtype=torch.float32, device=W.device)
         self.bias[:N] = b
         self.zero = torch.zeros(256, dtype=torch.float32, device=W.device) if len(splits) > 1 else None
-        if N == 1:                                            # logit layer folded into its producer (DHAUG_MLP_F_DOT_OUT)
+        if N == 1 and mode == "bf16":                         # logit layer folded into its producer (DHAUG_MLP_F_DOT_OUT)
             self.dot = torch.zeros(260, dtype=torch.float32, device=W.device)
             self.dot[:K] = W[0].to(torch.bfloat16).float()
             self.dot[256] = b[0]
@@ -72,8 +80,9 @@ def _gemm(layer, src, dst, act, slope=0.0, res=-1, out=None, src2=-1):
 class FusedNet:
     """compiled program + packed weights of one module; rebuilt when any parameter changes"""
 
-    def __init__(self, module, build):
-        self.module, self.build, self.key, self.layers, self.params = module, build, None, None, None
+    def __init__(self, module, build, mode="bf16"):
+        assert mode in MODES
+        self.module, self.build, self.key, self.layers, self.params, self.mode = module, build, None, None, None, mode
 
     def _fresh(self):
         from . import autograd_ops as A
@@ -81,7 +90,7 @@ class FusedNet:
             self.params = list(self.module.parameters())
         key = (A.WEIGHT_EPOCH,) + tuple((p.data_ptr(), p._version) for p in self.params)
         if key != self.key:
-            self.layers = {name: _Layer(lin, splits) for name, lin, splits in self.build["layers"](self.module)}
+            self.layers = {name: _Layer(lin, splits, self.mode) for name, lin, splits in self.build["layers"](self.module)}
             self.key = key
         return self.layers
 
@@ -92,9 +101,21 @@ class FusedNet:
     def run(self, inputs, M):
         L = self._fresh()
         units, keep = self.build["program"](self.module, L, inputs, M)
-        arr = (_lib.MlpUnit * len(units))(*units)
-        _lib.call("dhaug_mlp_forward", arr, len(units), M, ops._stream())
+        launch(units, M, self.mode)
         return keep
+
+
+def launch(units, M, mode):
+    arr = (_lib.MlpUnit * len(units))(*units)
+    _lib.call("dhaug_mlp_forward" if mode == "bf16" else "dhaug_mlp_forward_x3", arr, len(units), M, ops._stream())
+
+
+def _net(module, build, mode):
+    """the module's compiled program for `mode` (one per arithmetic, cached on the module)"""
+    d = module.__dict__.setdefault("_fused", {})
+    if mode not in d:
+        d[mode] = FusedNet(module, build, mode)
+    return d[mode]
 
 
 def _res_blocks(L, units, names, a=0, b=1, act=ACT_RELU):
@@ -166,7 +187,9 @@ def _d3_program(D, L, inputs, M):
     x, kcs = inputs["x"], inputs["kcs"]
     out = torch.empty((M, 1), dtype=torch.float32, device=x.device)
     mp = L["merge_previous.0"]
-    u = [_unit(LOAD_BF16, dst=1, cols=32, ld=kcs.stride(0), g=kcs), _gemm(L["special_KCS_previous.0"], 1, 0, ACT_RELU)]
+    kload = (_unit(LOAD_BF16, dst=1, cols=32, ld=kcs.stride(0), g=kcs) if kcs.dtype == torch.bfloat16 else
+             _unit(LOAD_F32, dst=1, cols=kcs.shape[1], ld=kcs.stride(0), g=kcs))          # f16x3: the fp32 (N,30) features
+    u = [kload, _gemm(L["special_KCS_previous.0"], 1, 0, ACT_RELU)]
     _res_blocks(L, u, ("special_KCS_block1", "special_KCS_block2", "special_KCS_block3"))
     # cat(kcs_out, pos_out) -> merge layer, in two halves: LDS cannot hold the KCS branch's 64 KB result beside the two
     # images the pose branch needs, so its share of the merge layer's pre-activation (W[:, :D] kcs_out + bias, 100 wide)
@@ -178,59 +201,55 @@ def _d3_program(D, L, inputs, M):
     _res_blocks(L, u, ("block1", "block2", "block3"))
     u.append(_unit(GEMM, src=0, dst=2, res=2, ksteps=mp.ksteps[1], n=mp.N, act=ACT_RELU, w=mp.w[1], bias=mp.zero))
     u.append(_gemm(L["merge_block1.fc1"], 2, 0, ACT_RELU))
-    # the logit layer (100 -> 1) rides in the epilogue of the layer before it
     fc2 = _gemm(L["merge_block1.fc2"], 0, 1, ACT_RELU, res=2)
-    fc2.flags, fc2.g, fc2.ld, fc2.w2 = F_DOT_OUT, out.data_ptr(), out.stride(0), L["output"].dot.data_ptr()
-    u.append(fc2)
+    if hasattr(L["output"], "dot"):
+        # the logit layer (100 -> 1) rides in the epilogue of the layer before it
+        fc2.flags, fc2.g, fc2.ld, fc2.w2 = F_DOT_OUT, out.data_ptr(), out.stride(0), L["output"].dot.data_ptr()
+        u.append(fc2)
+    else:                                                    # f16x3: the logit layer is a unit of its own
+        u += [fc2, _gemm(L["output"], 1, 0, ACT_NONE, out=out)]
     return u, (out,)
 
 
 D3 = dict(layers=_d3_layers, program=_d3_program)
 
 
-def generator_head(G, z):
-    if not hasattr(G, "_fused"):
-        G._fused = FusedNet(G, GEN)
-    return G._fused.run(dict(z=z.contiguous()), z.shape[0])
+def generator_head(G, z, mode="bf16"):
+    return _net(G, GEN, mode).run(dict(z=z.contiguous()), z.shape[0])
 
 
-def critic2d(D, x):
-    if not hasattr(D, "_fused"):
-        D._fused = FusedNet(D, D2)
+def critic2d(D, x, mode="bf16"):
     x = x.reshape(-1, 32).contiguous()
-    return D._fused.run(dict(x=x), x.shape[0])
+    return _net(D, D2, mode).run(dict(x=x), x.shape[0])
 
 
-def critics(D3_mod, D2_mod, x3, kcs, x2):
-    """both critics of one batch in ONE launch (the 3D critic's program, then the 2D critic's, per 128-row tile): one
+def critics(D3_mod, D2_mod, x3, kcs, x2, mode="bf16"):
+    """both critics of one batch in ONE launch (the 3D critic's program, then the 2D critic's, per batch tile): one
     kernel start-up and one dispatch gap less than critic3d() + critic2d().  x3 (N,48) root-relative pose, kcs (N,32)
-    bf16 operand, x2 (N,16,2) | (N,32) projection -> (logit3d (N,1), logit2d (N,1))"""
-    if not hasattr(D3_mod, "_fused"):
-        D3_mod._fused = FusedNet(D3_mod, D3)
-    if not hasattr(D2_mod, "_fused"):
-        D2_mod._fused = FusedNet(D2_mod, D2)
+    bf16 operand (bf16 mode) or (N,30) fp32 features (f16x3), x2 (N,16,2) | (N,32) projection -> (logit3d (N,1), logit2d (N,1))"""
     x3 = x3.reshape(-1, 48).contiguous()                    # fp32, or bf16 as Fk_Generator.sample_for_critics can emit them
     x2 = x2.reshape(-1, 32).contiguous()
     M = x3.shape[0]
     assert x2.shape[0] == M and kcs.shape[0] == M
-    u3, (o3,) = D3["program"](D3_mod, D3_mod._fused._fresh(), dict(x=x3, kcs=kcs), M)
-    u2, o2 = D2["program"](D2_mod, D2_mod._fused._fresh(), dict(x=x2), M)
-    units = u3 + u2
-    arr = (_lib.MlpUnit * len(units))(*units)
-    _lib.call("dhaug_mlp_forward", arr, len(units), M, ops._stream())
+    u3, (o3,) = D3["program"](D3_mod, _net(D3_mod, D3, mode)._fresh(), dict(x=x3, kcs=kcs), M)
+    u2, o2 = D2["program"](D2_mod, _net(D2_mod, D2, mode)._fresh(), dict(x=x2), M)
+    launch(u3 + u2, M, mode)
     return o3, o2
 
 
-def critic3d(D, x, center=False, kcs=None):
+def critic3d(D, x, center=False, kcs=None, mode="bf16"):
     """center=True: x is a world/camera-space pose; its root-relative copy and the KCS operand come from one pass.
-    kcs: the bf16 (N,32) operand if the caller already has it (Fk_Generator.sample_for_critics)"""
-    if not hasattr(D, "_fused"):
-        D._fused = FusedNet(D, D3)
+    kcs: the operand if the caller already has it (Fk_Generator.sample_for_critics)"""
     x = x.reshape(-1, 48).contiguous()
-    if kcs is not None:
+    if mode == "f16x3":
+        if center:
+            x = ops.center_flip(x.reshape(-1, 16, 3), True, False).reshape(-1, 48)
+        if kcs is None or kcs.dtype != torch.float32:
+            kcs, _ = ops.kcs_forward(x, True, f32=True)
+    elif kcs is not None:
         pass
     elif center:
         x, kcs = ops.center_kcs_forward(x, 32, True)
     else:
         _, kcs = ops.kcs_forward(x, True, f32=False, bf16_ld=32)
-    return D._fused.run(dict(x=x, kcs=kcs), x.shape[0])[0]
+    return _net(D, D3, mode).run(dict(x=x, kcs=kcs), x.shape[0])[0]

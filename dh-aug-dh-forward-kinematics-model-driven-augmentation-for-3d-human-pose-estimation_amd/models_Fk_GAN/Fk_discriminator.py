@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from .. import autograd_ops as A
 from .. import fused
-from .Fk_generator import default_precision
+from .Fk_generator import default_precision, graph_precision
 from .special_operate import myResNet
 
 
@@ -59,8 +59,9 @@ class Fk_3D_Discriminator(nn.Module):
         separate centring pass where the fused path applies"""
         p = self.precision
         x = input.reshape(-1, 48)
-        if p == "bf16" and x.is_cuda and _no_graph(self, x) and fused.supported(self.args.Dis_DenseDim_3D):
-            return fused.critic3d(self, x.float(), center, kcs)  # one launch, activations stay in LDS
+        if p in fused.MODES and x.is_cuda and _no_graph(self, x) and fused.supported(self.args.Dis_DenseDim_3D):
+            return fused.critic3d(self, x.float(), center, kcs, p)  # one launch, activations stay in LDS
+        p = graph_precision(p)
         if center:
             x = A.center_flip(x.reshape(-1, 16, 3), True, False).reshape(-1, 48)
         k = _branch(A.KcsFn.apply(x, True), self.special_KCS_previous[0],
@@ -106,8 +107,9 @@ class Fk_2D_Discriminator(nn.Module):
     def forward(self, x):
         p, s, L = self.precision, self.slope, A.ACT_LRELU
         x = x.reshape(-1, 32)
-        if p == "bf16" and x.is_cuda and _no_graph(self, x) and fused.supported(self.args.Dis_DenseDim_2D):
-            return fused.critic2d(self, x.float())
+        if p in fused.MODES and x.is_cuda and _no_graph(self, x) and fused.supported(self.args.Dis_DenseDim_2D):
+            return fused.critic2d(self, x.float(), p)
+        p = graph_precision(p)
         d1 = A.linear(x, self.pose_layer_1.weight, self.pose_layer_1.bias, None, L, s, p)
         d2 = A.linear(d1, self.pose_layer_2.weight, self.pose_layer_2.bias, None, L, s, p)
         d3 = A.linear(d2, self.pose_layer_3.weight, self.pose_layer_3.bias, d1, L, s, p)
@@ -136,10 +138,10 @@ class Video_motion_Fk_3D_Discriminator(nn.Module):
 
     def _b(self, x, name):
         return _branch(x.contiguous(), getattr(self, name + "_previous")[0],
-                       [getattr(self, "%s_block%d" % (name, i)) for i in (1, 2, 3)], self.precision)
+                       [getattr(self, "%s_block%d" % (name, i)) for i in (1, 2, 3)], graph_precision(self.precision))
 
     def forward(self, input):
-        R, p = self.video_frame_num, self.precision
+        R, p = self.video_frame_num, graph_precision(self.precision)
         x = input.reshape(-1, 48)
         kc = A.KcsFn.apply(x, False).reshape(-1, R * 15)
         outs = [self._b(kc, "special_KCS"), self._b(_frame_diff(kc, R, 15), "diff_special_KCS")]
@@ -169,10 +171,10 @@ class Video_motion_Fk_2D_Discriminator(nn.Module):
 
     def _b(self, x, name):
         return _branch(x.contiguous(), getattr(self, name + "_previous")[0],
-                       [getattr(self, "%s_block%d" % (name, i)) for i in (1, 2, 3)], self.precision)
+                       [getattr(self, "%s_block%d" % (name, i)) for i in (1, 2, 3)], graph_precision(self.precision))
 
     def forward(self, input):
-        R, p = self.video_frame_num, self.precision
+        R, p = self.video_frame_num, graph_precision(self.precision)
         x = input.reshape(-1, 32)
         a = self._b(x.reshape(-1, R * 32), "pos_2d")
         b = self._b(_frame_diff(x.reshape(-1, 16, 2)[:, 0, :], R, 2), "root_diff_2d")
@@ -188,8 +190,15 @@ def score_fake_pair(d3d, d2d, pose_centered, kcs, proj2d):
     otherwise the two forward() calls of the reference (R/models_Fk_GAN/model_fk_gan_train.py:463-468).
     pose_centered (N,16,3)|(N,48) root-relative, kcs (N,32) bf16 or None, proj2d (N,16,2) -> (logit3d, logit2d)"""
     x3 = pose_centered.reshape(-1, 48)
-    both = (d3d.precision == "bf16" and d2d.precision == "bf16" and x3.is_cuda and kcs is not None and _no_graph(d3d, x3)
-            and _no_graph(d2d, proj2d) and fused.supported(d3d.args.Dis_DenseDim_3D, d2d.args.Dis_DenseDim_2D))
+    both = (d3d.precision in fused.MODES and d2d.precision == d3d.precision and x3.is_cuda and kcs is not None
+            and _no_graph(d3d, x3) and _no_graph(d2d, proj2d)
+            and fused.supported(d3d.args.Dis_DenseDim_3D, d2d.args.Dis_DenseDim_2D))
+    if both and d3d.precision == "f16x3":                                  # fp32-grade: fp32 inputs, fp32 KCS features
+        from .. import ops
+        x3 = x3.float()
+        if kcs.dtype != torch.float32:
+            kcs, _ = ops.kcs_forward(x3, True, f32=True)
+        return fused.critics(d3d, d2d, x3, kcs, proj2d.float(), "f16x3")
     if both:
         keep = lambda t: t if t.dtype == torch.bfloat16 else t.float()      # bf16 inputs are loaded as they are
         return fused.critics(d3d, d2d, keep(x3), kcs, keep(proj2d))

@@ -23,7 +23,14 @@ GAN_angle_range_table = {"joint%d" % (i + 1): {"range": (_LO[i], _HI[i])} for i 
 
 
 def default_precision():
+    """'bf16' (one bf16 MFMA pass: the throughput arithmetic), 'f16x3' (fp16 hi+lo operands, three MFMA terms: fp32-grade
+    fused forward; passes that build a graph run 'bf16x6'), 'bf16x3' / 'bf16x6' (layer-by-layer split-bf16 GEMMs)"""
     return os.environ.get("DHAUG_PRECISION", "bf16")
+
+
+def graph_precision(p):
+    """arithmetic of the layer-by-layer (autograd) path for a module precision"""
+    return "bf16x6" if p == "f16x3" else p
 
 
 class _GeneratorBase(nn.Module):
@@ -56,7 +63,7 @@ class _GeneratorBase(nn.Module):
     def _use_fused(self, x):
         """one-launch fused forward (csrc/dhaug_mlp.hip) for passes that need no autograd graph"""
         from .. import fused
-        return (self.precision == "bf16" and x.is_cuda and not (torch.is_grad_enabled() and (
+        return (self.precision in fused.MODES and x.is_cuda and not (torch.is_grad_enabled() and (
             x.requires_grad or any(p.requires_grad for p in self.parameters())))
             and fused.supported(self.args.Gen_DenseDim) and self.INPUT_VEC_DIM % 64 == 0
             and self.deconv_out.weight.shape[0] <= 64)
@@ -64,8 +71,8 @@ class _GeneratorBase(nn.Module):
     def trunk(self, z):
         if self._use_fused(z):
             from .. import fused
-            return fused.generator_head(self, z.float())
-        p = self.precision
+            return fused.generator_head(self, z.float(), self.precision)
+        p = graph_precision(self.precision)
         lin = self.preprocess[0]
         x = A.linear(z, lin.weight, lin.bias, None, A.ACT_RELU, 0.0, p)
         x = self.block3(self.block2(self.block1(x, p), p), p)

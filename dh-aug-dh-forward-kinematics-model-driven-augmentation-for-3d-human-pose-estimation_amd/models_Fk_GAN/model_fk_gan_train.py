@@ -114,10 +114,12 @@ def train_Fk_discriminator(model_dis, data_real, data_fake, summary, writer, wri
     # real and fake rows go through the critic as ONE batch (rows are independent; the two means are taken over its halves):
     # every layer GEMM, weight-gradient GEMM and activation pass of the two passes of the reference
     # (R/models_Fk_GAN/model_fk_gan_train.py:251-262) runs once over 2B rows instead of twice over B
-    n = data_real.shape[0]
+    # (the split is on the LOGIT count: a motion critic folds R input rows into one logit)
     if data_fake.shape == data_real.shape:
         logits = model_dis(torch.cat((data_real, data_fake), 0))
-        D_real, D_fake = MeanFn.apply(logits[:n]), MeanFn.apply(logits[n:])
+        h = logits.shape[0] // 2
+        assert logits.shape[0] == 2 * h and h > 0, "critic returned %d logits for a real+fake batch" % logits.shape[0]
+        D_real, D_fake = MeanFn.apply(logits[:h]), MeanFn.apply(logits[h:])
     else:
         D_real = MeanFn.apply(model_dis(data_real))
         D_fake = MeanFn.apply(model_dis(data_fake))
@@ -174,11 +176,66 @@ class FakePairBuffer:
             yield p3[j], p2[j], ['none'] * j.shape[0], c[j]
 
 
+class Draws:
+    """Replayable random draws of one iteration (parity tests): noise / scaler / alpha are lists consumed in the order the
+    reference draws them (R/models_Fk_GAN/model_fk_gan_train.py:303, R/models_Fk_GAN/Fk_generator.py:197,
+    R/models_Fk_GAN/Fk_discriminator.py:210).  An exhausted or absent list means "draw on the device"."""
+
+    def __init__(self, noise=(), scaler=(), alpha=()):
+        self.q = dict(noise=list(noise), scaler=list(scaler), alpha=list(alpha))
+
+    def take(self, kind, device):
+        q = self.q[kind]
+        return q.pop(0).to(device) if q else None
+
+
+def generator_step(args, G, oG, critics, weights, camera, flip, noise=None, scaler=None, frames=1, playback=False):
+    """The G step of both epoch loops (R/models_Fk_GAN/model_fk_gan_train.py:415-484, R/models_Fk_GAN/video_GAN_fun.py:421-566).
+    critics = (D3, D2) or (D3, D2, M3, M2), weights the matching loss weights.  Flipped copies contribute their value
+    but no gradient (.detach().clone() in the reference).  Returns G_cost = -gen_loss (0-dim device tensor)."""
+    device = _device()
+    quat, trans, cam9 = camera
+    set_grad(critics, False)
+    set_grad([G], True)
+    G.zero_grad()
+    oG.zero_grad()
+    if noise is None:
+        noise = torch.randn(args.batch_size, 128, device=device)
+    fw = G(noise, bone_len_scaler=scaler).reshape(-1, 16, 3)
+    _, f2d = A.W2CProjectFn.apply(fw, tuple(quat), tuple(trans), tuple(cam9))
+    fc = A.center_flip(fw, True, False)
+    mean = lambda net, x: MeanFn.apply(net(x))
+    R = frames
+
+    def terms(fc, f2d):
+        t = [mean(critics[0], fc), mean(critics[1], f2d)]
+        if len(critics) == 4:
+            m3, m2 = mean(critics[2], fc.reshape(-1, 48)), mean(critics[3], f2d.reshape(-1, 32))
+            if playback:
+                # reference quirk (SURVEY q6): the 3D clip is viewed as (-1, R, 32) before the frame flip (:467,:521)
+                m3 = (m3 + mean(critics[2], torch.flip(fc.reshape(-1, R, 32), dims=[1]).reshape(-1, 48))) / 2
+                m2 = (m2 + mean(critics[3], torch.flip(f2d.reshape(-1, R, 32), dims=[1]).reshape(-1, 32))) / 2
+            t += [m3, m2]
+        return t
+
+    t = terms(fc, f2d)
+    if flip:
+        with torch.no_grad():
+            tf = terms(ops.center_flip(fc.detach(), False, True), ops.center_flip(f2d.detach(), False, True))
+        t = [(a + b) / 2 for a, b in zip(t, tf)]
+    gen_loss = sum(a * w for a, w in zip(t, weights))
+    (-gen_loss).backward()                                               # gen_loss.backward(mone)
+    oG.step()
+    set_grad(critics, True)
+    return (-gen_loss).detach()
+
+
 def gan_iteration(args, poseFk_dict, inputs_3d, cam_param, target_d2d, train_subjects, summary=None, writer=None,
-                  do_g_step=False, camera=None, rng=np.random):
+                  do_g_step=False, camera=None, rng=np.random, draws=None):
     """One pass of R/models_Fk_GAN/model_fk_gan_train.py:281-489 on one real batch.
     inputs_3d (B,16,3) camera-space real poses, cam_param (B,>=16) with quaternion at [9:13] and translation at
-    [13:16], target_d2d (B,16,2).  Returns dict(pos_3d_cam, pos_2d, cam9, Wasserstein_D_3D, ..., G_cost)."""
+    [13:16], target_d2d (B,16,2).  draws: a Draws object replaying recorded noise / jitter / GP coefficients.
+    Returns dict(pos_3d_cam, pos_2d, cam9, Wasserstein_D_3D, ..., G_cost)."""
     device = _device()
     G, D3, D2 = poseFk_dict['model_G'], poseFk_dict['model_d3d'], poseFk_dict['model_d2d']
     oG, o3, o2 = poseFk_dict['optimizer_G'], poseFk_dict['optimizer_d3d'], poseFk_dict['optimizer_d2d']
@@ -190,46 +247,31 @@ def gan_iteration(args, poseFk_dict, inputs_3d, cam_param, target_d2d, train_sub
     real_c = ops.center_flip(real_world, True, False)                       # :295
     set_grad([D3, D2], True)
     set_grad([G], False)
+    draws = draws or Draws()
+    step = lambda net, r, f, name, opt: train_Fk_discriminator(net, r, f, summary, writer, name, opt, args,
+                                                               alpha=draws.take("alpha", device))
     with torch.no_grad():
-        noise = torch.randn(B, 128, device=device)
-        fake_world = G(noise).reshape(-1, 16, 3)                            # :305-310 (.data: no graph)
+        noise = draws.take("noise", device)
+        if noise is None:
+            noise = torch.randn(B, 128, device=device)
+        fake_world = G(noise, bone_len_scaler=draws.take("scaler", device)).reshape(-1, 16, 3)   # :305-310 (.data: no graph)
     fake_c = ops.center_flip(fake_world, True, False)                        # :312
     out = {}
-    W3, C3 = train_Fk_discriminator(D3, real_c, fake_c, summary, writer, 'Fk_d3d', o3, args)
+    W3, C3 = step(D3, real_c, fake_c, 'Fk_d3d', o3)
     flip = bool(args.flip_GAN_model_input)
     if flip:                                                                 # :319-341
-        W3f, C3f = train_Fk_discriminator(D3, ops.center_flip(real_c, False, True), ops.center_flip(fake_c, False, True),
-                                          summary, writer, 'Fk_d3d', o3, args)
+        W3f, C3f = step(D3, ops.center_flip(real_c, False, True), ops.center_flip(fake_c, False, True), 'Fk_d3d', o3)
         W3, C3 = (W3 + W3f) / 2, (C3 + C3f) / 2
     quat, trans, cam9 = camera if camera is not None else pick_camera(train_subjects, rng)
     pos_3d_cam, pos_2d = ops.world_to_camera_project(fake_world, quat, trans, cam9)      # :374-376
-    W2, C2 = train_Fk_discriminator(D2, target_d2d, pos_2d, summary, writer, 'd2d', o2, args)
+    W2, C2 = step(D2, target_d2d, pos_2d, 'd2d', o2)
     if flip:                                                                 # :387-409
-        W2f, C2f = train_Fk_discriminator(D2, ops.center_flip(target_d2d, False, True),
-                                          ops.center_flip(pos_2d, False, True), summary, writer, 'd2d', o2, args)
+        W2f, C2f = step(D2, ops.center_flip(target_d2d, False, True), ops.center_flip(pos_2d, False, True), 'd2d', o2)
         W2, C2 = (W2 + W2f) / 2, (C2 + C2f) / 2
     G_cost = None
     if do_g_step:                                                            # :415-484
-        set_grad([D3, D2], False)
-        set_grad([G], True)
-        G.zero_grad()
-        oG.zero_grad()
-        noise = torch.randn(B, 128, device=device)
-        fw = G(noise).reshape(-1, 16, 3)
-        _, f2d = A.W2CProjectFn.apply(fw, tuple(quat), tuple(trans), tuple(cam9))
-        fc = A.center_flip(fw, True, False)
-        adv3 = MeanFn.apply(D3(fc))
-        adv2 = MeanFn.apply(D2(f2d))
-        if flip:                        # flipped copies contribute value but no gradient (detach, :455,:459)
-            with torch.no_grad():
-                adv3f = MeanFn.apply(D3(ops.center_flip(fc.detach(), False, True)))
-                adv2f = MeanFn.apply(D2(ops.center_flip(f2d.detach(), False, True)))
-            adv3, adv2 = (adv3 + adv3f) / 2, (adv2 + adv2f) / 2
-        gen_loss = adv3 * args.GAN_3d_loss_weight + adv2 * args.GAN_2d_loss_weight
-        (-gen_loss).backward()                                               # gen_loss.backward(mone)
-        G_cost = (-gen_loss).detach()
-        oG.step()
-        set_grad([D3, D2], True)
+        G_cost = generator_step(args, G, oG, (D3, D2), (args.GAN_3d_loss_weight, args.GAN_2d_loss_weight),
+                                (quat, trans, cam9), flip, draws.take("noise", device), draws.take("scaler", device))
     out.update(pos_3d_cam=pos_3d_cam, pos_2d=pos_2d, cam9=cam9, Wasserstein_D_3D=W3, D_cost_3D=C3,
                Wasserstein_D_2D=W2, D_cost_2D=C2, G_cost=G_cost)
     return out

@@ -9,10 +9,10 @@ Time reversal is a frame permutation (torch.flip, data movement only)."""
 import numpy as np
 import torch
 
-from .. import autograd_ops as A
 from .. import ops
 from ..common import camera as cam
-from .model_fk_gan_train import FakePairBuffer, MeanFn, pick_camera, set_grad, train_Fk_discriminator, _device
+from .model_fk_gan_train import (Draws, FakePairBuffer, generator_step, pick_camera, set_grad, train_Fk_discriminator,
+                                  _device)
 from .video_mode_operate import frames_from_args
 
 
@@ -22,8 +22,12 @@ def _rev(x, R, width):
 
 
 def video_gan_iteration(args, poseFk_dict, inputs_3d, cam_param, inputs_2d, train_subjects, summary, writer=None,
-                        do_g_step=False, camera=None, rng=np.random):
-    """inputs_3d (B,R,16,3) camera-space real clips, cam_param (B,>=16), inputs_2d (B,R,16,2)."""
+                        do_g_step=False, camera=None, rng=np.random, draws=None):
+    """inputs_3d (B,R,16,3) camera-space real clips, cam_param (B,>=16), inputs_2d (B,R,16,2).
+
+    Critic-step conventions of the reference, reproduced: the 3D motion critic steps run with dis_mode='motion' (gradient
+    penalty over B clips of R*48 values, :219-232), the 2D motion critic steps with the default mode (penalty over B*R
+    frames of 32 values with one interpolation coefficient per FRAME, :341-346,:353-358)."""
     device = _device()
     R, B = frames_from_args(args), args.batch_size
     G, D3, D2 = poseFk_dict['model_G'], poseFk_dict['model_d3d'], poseFk_dict['model_d2d']
@@ -39,78 +43,61 @@ def video_gan_iteration(args, poseFk_dict, inputs_3d, cam_param, inputs_2d, trai
     real = ops.center_flip(cam.GAN_torch_camera_to_world_batch(inputs_3d.reshape(-1, 16, 3), camR, camT), True, False)
     set_grad([D3, D2, M3, M2], True)
     set_grad([G], False)
+    draws = draws or Draws()
     with torch.no_grad():
-        fake_world = G(torch.randn(B, 128, device=device)).reshape(-1, 16, 3)
+        noise = draws.take("noise", device)
+        if noise is None:
+            noise = torch.randn(B, 128, device=device)
+        fake_world = G(noise, bone_len_scaler=draws.take("scaler", device)).reshape(-1, 16, 3)
     fake = ops.center_flip(fake_world, True, False)
     avg = lambda a, b: tuple((x + y) / 2 for x, y in zip(a, b))
 
     def critic_pair(net, opt, name, r, f, mode):
-        return train_Fk_discriminator(net, r, f, summary, writer, name, opt, args, dis_mode=mode)
+        return train_Fk_discriminator(net, r, f, summary, writer, name, opt, args, dis_mode=mode,
+                                      alpha=draws.take("alpha", device))
 
-    def motion_steps(net, opt, name, r, f, width):
+    def motion_steps(net, opt, name, back_name, r, f, width, mode):
         """clip + (optionally) time-reversed clip"""
-        res = critic_pair(net, opt, name, r, f, 'motion')
+        res = critic_pair(net, opt, name, r, f, mode)
         if playback:
-            res = avg(res, critic_pair(net, opt, 'back_' + name, _rev(r, R, width), _rev(f, R, width), 'motion'))
+            res = avg(res, critic_pair(net, opt, back_name, _rev(r, R, width), _rev(f, R, width), mode))
         return res
 
     out = {}
     out['d3'] = critic_pair(D3, o3, 'Fk_d3d', real, fake, 'single')
     if motion_on:
-        out['m3'] = motion_steps(M3, om3, 'motion_Fk_d3d', real.reshape(-1, 48), fake.reshape(-1, 48), 48)
+        out['m3'] = motion_steps(M3, om3, 'motion_Fk_d3d', 'back_motion_Fk_d3d', real.reshape(-1, 48), fake.reshape(-1, 48),
+                                 48, 'motion')
     if flip:
         rf, ff = ops.center_flip(real, False, True), ops.center_flip(fake, False, True)
         out['d3'] = avg(out['d3'], critic_pair(D3, o3, 'Fk_d3d', rf, ff, 'single'))
         if motion_on:
-            out['m3'] = avg(out['m3'], motion_steps(M3, om3, 'motion_Fk_d3d', rf.reshape(-1, 48), ff.reshape(-1, 48), 48))
+            out['m3'] = avg(out['m3'], motion_steps(M3, om3, 'motion_Fk_d3d', 'back_flip_motion_Fk_d3d', rf.reshape(-1, 48),
+                                                    ff.reshape(-1, 48), 48, 'motion'))
     quat, trans, cam9 = camera if camera is not None else pick_camera(train_subjects, rng)
     pos_3d_cam, pos_2d = ops.world_to_camera_project(fake_world, quat, trans, cam9)
     real2d = inputs_2d.reshape(-1, 16, 2)
     out['d2'] = critic_pair(D2, o2, 'd2d', real2d, pos_2d, 'single')
     if motion_on:
-        out['m2'] = motion_steps(M2, om2, 'motion_d2d', real2d.reshape(-1, 32), pos_2d.reshape(-1, 32), 32)
+        out['m2'] = motion_steps(M2, om2, 'motion_d2d', 'back_motion_d2d', real2d.reshape(-1, 32), pos_2d.reshape(-1, 32),
+                                 32, 'single')
     if flip:
         r2f, f2f = ops.center_flip(real2d, False, True), ops.center_flip(pos_2d, False, True)
         out['d2'] = avg(out['d2'], critic_pair(D2, o2, 'd2d', r2f, f2f, 'single'))
-        if motion_on:
-            out['m2'] = avg(out['m2'], motion_steps(M2, om2, 'motion_d2d', r2f.reshape(-1, 32), f2f.reshape(-1, 32), 32))
+        if motion_on:            # (the reference logs the flipped motion-2D step under 'd2d', :398-401)
+            out['m2'] = avg(out['m2'], motion_steps(M2, om2, 'd2d', 'back_flip_motion_d2d', r2f.reshape(-1, 32),
+                                                    f2f.reshape(-1, 32), 32, 'single'))
     out['G_cost'] = None
     if do_g_step:
-        set_grad([D3, D2, M3, M2], False)
-        set_grad([G], True)
-        G.zero_grad()
-        oG.zero_grad()
-        fw = G(torch.randn(B, 128, device=device)).reshape(-1, 16, 3)
-        _, f2d = A.W2CProjectFn.apply(fw, tuple(quat), tuple(trans), tuple(cam9))
-        fc = A.center_flip(fw, True, False)
-        mean = lambda net, x: MeanFn.apply(net(x))
-        a3, a2 = mean(D3, fc), mean(D2, f2d)
-        am3 = am2 = 0.0
         if motion_on:
-            am3, am2 = mean(M3, fc.reshape(-1, 48)), mean(M2, f2d.reshape(-1, 32))
-            if playback:
-                # reference quirk (SURVEY q6): the 3D clip is viewed as (-1, R, 32) before the frame flip (:467,:521)
-                am3 = (am3 + mean(M3, torch.flip(fc.reshape(-1, R, 32), dims=[1]).reshape(-1, 48))) / 2
-                am2 = (am2 + mean(M2, torch.flip(f2d.reshape(-1, R, 32), dims=[1]).reshape(-1, 32))) / 2
-        if flip:                                   # flipped copies: value only (detach), as in the reference
-            with torch.no_grad():
-                f3f, f2f = ops.center_flip(fc.detach(), False, True), ops.center_flip(f2d.detach(), False, True)
-                b3, b2 = mean(D3, f3f), mean(D2, f2f)
-                bm3 = bm2 = 0.0
-                if motion_on:
-                    bm3, bm2 = mean(M3, f3f.reshape(-1, 48)), mean(M2, f2f.reshape(-1, 32))
-                    if playback:
-                        bm3 = (bm3 + mean(M3, torch.flip(f3f.reshape(-1, R, 32), dims=[1]).reshape(-1, 48))) / 2
-                        bm2 = (bm2 + mean(M2, torch.flip(f2f.reshape(-1, R, 32), dims=[1]).reshape(-1, 32))) / 2
-            a3, a2 = (a3 + b3) / 2, (a2 + b2) / 2
-            if motion_on:
-                am3, am2 = (am3 + bm3) / 2, (am2 + bm2) / 2
-        gen_loss = a3 * args.GAN_3d_loss_weight + a2 * args.GAN_2d_loss_weight
-        if motion_on:
-            gen_loss = gen_loss + am3 * args.GAN_3d_motion_loss_weight + am2 * args.GAN_2d_motion_loss_weight
-        (-gen_loss).backward()
-        out['G_cost'] = (-gen_loss).detach()
-        oG.step()
+            critics = (D3, D2, M3, M2)
+            weights = (args.GAN_3d_loss_weight, args.GAN_2d_loss_weight, args.GAN_3d_motion_loss_weight,
+                       args.GAN_2d_motion_loss_weight)
+        else:
+            critics, weights = (D3, D2), (args.GAN_3d_loss_weight, args.GAN_2d_loss_weight)
+        out['G_cost'] = generator_step(args, G, oG, critics, weights, (quat, trans, cam9), flip,
+                                       draws.take("noise", device), draws.take("scaler", device), frames=R,
+                                       playback=playback)
         set_grad([D3, D2, M3, M2], True)
     out.update(pos_3d_cam=pos_3d_cam.reshape(B, R, 16, 3), pos_2d=pos_2d.reshape(B, R, 16, 2), cam9=cam9)
     return out

@@ -41,6 +41,30 @@ class FusedAdam(torch.optim.Optimizer):
         self.process_group = process_group
         self.data_parallel = data_parallel      # None: follow torch.distributed state
 
+    def state_dict(self):
+        """torch.optim.Optimizer.state_dict() plus the flat moments and the step count (checkpoint / resume)"""
+        d = super().state_dict()
+        d["dhaug_flat"] = dict(exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), step_count=self.step_count)
+        return d
+
+    def load_state_dict(self, state_dict):
+        flat = state_dict.get("dhaug_flat")
+        super().load_state_dict({k: v for k, v in state_dict.items() if k != "dhaug_flat"})
+        if flat is not None:
+            self.exp_avg.copy_(flat["exp_avg"])
+            self.exp_avg_sq.copy_(flat["exp_avg_sq"])
+            self.step_count = int(flat["step_count"])
+        self._check_views()
+
+    def _check_views(self):
+        """parameters must still be views of the flat buffer (a module.to() / load that re-allocates them breaks that)"""
+        lo = self.flat_param.data_ptr()
+        hi = lo + self.flat_param.numel() * 4
+        for p in self._params:
+            if not (lo <= p.data_ptr() < hi):
+                raise RuntimeError("FusedAdam: a parameter no longer lives in the optimizer's flat buffer (module moved or "
+                                   "re-allocated after the optimizer was built); rebuild the optimizer")
+
     def zero_grad(self, set_to_none=False):
         self.flat_grad.zero_()
         for p, gv in zip(self._params, self._views):
@@ -72,6 +96,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        self._check_views()
         ws = self.exchange()
         self.step_count += 1
         g = self.param_groups[0]

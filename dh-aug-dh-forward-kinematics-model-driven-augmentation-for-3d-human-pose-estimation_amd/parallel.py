@@ -40,3 +40,16 @@ def broadcast_parameters(modules, src=0):
     for m in modules:
         for p in m.parameters():
             dist.broadcast(p.data, src)
+    # the write went through .data (no version bump): every packed bf16 / fragment copy of a weight is stale now
+    from . import autograd_ops as A
+    A.bump_weight_epoch()
+
+
+def broadcast_optimizers(optimizers, src=0):
+    """same, one collective per network: FusedAdam's flat parameter buffer (the parameters are views of it)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    for o in optimizers:
+        dist.broadcast(o.flat_param, src)
+    from . import autograd_ops as A
+    A.bump_weight_epoch()

@@ -518,3 +518,181 @@ def random_bl_aug(x, new_len):
     for k in range(15):
         out[PA_CHILD[k]] = out[PA_PARENT[k]] - nb[:, k]
     return torch.stack(out, dim=1) + root
+
+
+# ----------------------------------------------------------------------------------------------
+# a16 / a18: the epoch loops, restated on parameter dicts (name -> leaf tensor) with torch autograd + torch.optim.Adam.
+# Random draws (noise, bone-length jitter, GP interpolation coefficients, camera choice) are INPUTS here, in the order
+# the reference consumes them; tests/golden/make_golden_loops.py records them from the reference's own run.
+# ----------------------------------------------------------------------------------------------
+class Net:
+    """parameter dict + forward function + Adam(1e-4, (0.5, 0.9)) (R/models_Fk_GAN/model_fk_gan_train.py:112-118)"""
+
+    def __init__(self, sd, fwd):
+        self.p = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+        self.fwd = fwd
+        self.opt = torch.optim.Adam(list(self.p.values()), lr=1e-4, betas=(0.5, 0.9))
+
+    def __call__(self, x):
+        return self.fwd(x, self.p)
+
+    def zero_grad(self):
+        for v in self.p.values():
+            v.grad = None
+
+    def grads(self):
+        return {k: (v.grad.detach().clone() if v.grad is not None else torch.zeros_like(v)) for k, v in self.p.items()}
+
+    def state(self):
+        return {k: v.detach().clone() for k, v in self.p.items()}
+
+
+def critic_step_net(net, real, fake, alpha, gp_rows, lam=10.0):
+    """train_Fk_discriminator (R/models_Fk_GAN/model_fk_gan_train.py:177-230) on a Net; gp_rows = BATCH_SIZE handed to
+    calc_gradient_penalty (args.batch_size * real_used_num).  Returns (Wasserstein_D, D_cost)."""
+    net.zero_grad()
+    d_real, d_fake = net(real).mean(), net(fake).mean()
+    gp = gradient_penalty(net, real.detach().reshape(gp_rows, -1), fake.detach().reshape(gp_rows, -1), alpha, lam)
+    (d_fake - d_real + gp).backward()
+    net.opt.step()
+    return (d_real - d_fake).detach(), (d_fake - d_real + gp).detach()
+
+
+def gan_iteration(G, D3, D2, real_cam3d, cam_param, real2d, camera, noise, scaler, alphas, flip=True, g_step=None,
+                  w3d=1.0, w2d=0.2, lam=10.0):
+    """One pass of R/models_Fk_GAN/model_fk_gan_train.py:281-489.  G/D3/D2: Net objects (G.fwd = (z, p, bone_len,
+    scaler) -> fake (B,48)); camera = (quat (1,4), trans (1,3), cam9 (B,9)); alphas: 4 (B,1) tensors in call order
+    (D3, D3 flipped, D2, D2 flipped); g_step = dict(noise, scaler) on the iterations that step the generator.
+    Returns dict(pos_3d_cam, pos_2d, W3, C3, W2, C2, G_cost, g_grads)."""
+    quat, trans, cam9 = camera
+    B = real_cam3d.shape[0]
+    bl = bone_lengths(real_cam3d)
+    real_w = camera_to_world(real_cam3d.reshape(-1, 16, 3), cam_param[:, 9:13], cam_param[:, 13:16])
+    real_c = real_w - real_w[:, :1]
+    with torch.no_grad():
+        fake_w = G.fwd(noise, G.p, bl, scaler).reshape(-1, 16, 3)
+    fake_c = fake_w - fake_w[:, :1]
+    al = list(alphas)
+    W3, C3 = critic_step_net(D3, real_c, fake_c, al.pop(0), B, lam)
+    if flip:
+        Wf, Cf = critic_step_net(D3, flip_lr(real_c), flip_lr(fake_c), al.pop(0), B, lam)
+        W3, C3 = (W3 + Wf) / 2, (C3 + Cf) / 2
+    pos_3d_cam = world_to_camera(fake_w, quat, trans)
+    pos_2d = project_to_2d(pos_3d_cam, cam9)
+    W2, C2 = critic_step_net(D2, real2d, pos_2d, al.pop(0), B, lam)
+    if flip:
+        Wf, Cf = critic_step_net(D2, flip_lr(real2d), flip_lr(pos_2d), al.pop(0), B, lam)
+        W2, C2 = (W2 + Wf) / 2, (C2 + Cf) / 2
+    out = dict(pos_3d_cam=pos_3d_cam, pos_2d=pos_2d, W3=W3, C3=C3, W2=W2, C2=C2, G_cost=None, g_grads=None)
+    if g_step is not None:                                     # :415-484
+        G.zero_grad()
+        fw = G.fwd(g_step["noise"], G.p, bl, g_step["scaler"]).reshape(-1, 16, 3)
+        f2d = project_to_2d(world_to_camera(fw, quat, trans), cam9)
+        fc = fw - fw[:, :1]
+        a3, a2 = D3(fc).mean(), D2(f2d).mean()
+        if flip:                                               # flipped copies: value only (.detach().clone(), :455,:459)
+            a3 = (a3 + D3(flip_lr(fc)).mean()) / 2
+            a2 = (a2 + D2(flip_lr(f2d)).mean()) / 2
+        gen_loss = a3 * w3d + a2 * w2d
+        grads = torch.autograd.grad(-gen_loss, list(G.p.values()))
+        for v, g in zip(G.p.values(), grads):
+            v.grad = g
+        out["g_grads"] = G.grads()
+        out["d_states"] = dict(d3=D3.state(), d2=D2.state())
+        G.opt.step()
+        out["G_cost"] = (-gen_loss).detach()
+    return out
+
+
+def _rev(x, R, width):
+    return torch.flip(x.reshape(-1, R, width), dims=[1])
+
+
+def video_gan_iteration(G, D3, D2, M3, M2, R, real_cam3d, cam_param, real2d, camera, noise, scaler, alphas, flip=True,
+                        playback=True, motion_on=True, g_step=None, w=(1.0, 0.2, 1.0, 1.0), lam=10.0):
+    """One pass of R/models_Fk_GAN/video_GAN_fun.py:156-566.  real_cam3d (B,R,16,3), cam_param (B,16), real2d (B,R,16,2);
+    camera cam9 has B*R rows; alphas in the reference's call order.  Critic-step conventions of the reference:
+    3D motion critic steps use dis_mode='motion' (GP over B clips of R*48), 2D motion critic steps use the default mode
+    (GP over B*R frames of 32, :341-346).  The G step views the 3D clip as (-1, R, 32) before the time flip (q6, :467,:521)."""
+    quat, trans, cam9 = camera
+    B = real_cam3d.shape[0]
+    bl = bone_lengths(real_cam3d.reshape(-1, 16, 3))
+    cR = cam_param[:, 9:13].unsqueeze(1).repeat(1, R, 1).reshape(-1, 4)
+    cT = cam_param[:, 13:16].unsqueeze(1).repeat(1, R, 1).reshape(-1, 3)
+    real_w = camera_to_world(real_cam3d.reshape(-1, 16, 3), cR, cT)
+    real = (real_w - real_w[:, :1]).reshape(-1, 48)
+    with torch.no_grad():
+        fake_w = G.fwd(noise, G.p, bl, scaler).reshape(-1, 16, 3)
+    fake = (fake_w - fake_w[:, :1]).reshape(-1, 48)
+    al = list(alphas)
+    avg = lambda a, b: tuple((x + y) / 2 for x, y in zip(a, b))
+    out = {}
+
+    def steps3(r, f):
+        d = critic_step_net(D3, r, f, al.pop(0), B * R, lam)
+        m = None
+        if motion_on:
+            m = critic_step_net(M3, r, f, al.pop(0), B, lam)
+        if playback and motion_on:
+            m = avg(m, critic_step_net(M3, _rev(r, R, 48), _rev(f, R, 48), al.pop(0), B, lam))
+        return d, m
+
+    out["d3"], out["m3"] = steps3(real, fake)
+    if flip:
+        fl = lambda x: flip_lr(x.reshape(-1, 16, 3)).reshape(-1, 48)
+        d, m = steps3(fl(real), fl(fake))
+        out["d3"] = avg(out["d3"], d)
+        if motion_on:
+            out["m3"] = avg(out["m3"], m)
+    pos_3d_cam = world_to_camera(fake_w, quat, trans)
+    pos_2d = project_to_2d(pos_3d_cam, cam9)
+    r2 = real2d.reshape(-1, 16, 2)
+
+    def steps2(r, f):
+        d = critic_step_net(D2, r, f, al.pop(0), B * R, lam)
+        m = None
+        if motion_on:
+            m = critic_step_net(M2, r, f, al.pop(0), B * R, lam)
+        if playback and motion_on:
+            m = avg(m, critic_step_net(M2, _rev(r, R, 32), _rev(f, R, 32), al.pop(0), B * R, lam))
+        return d, m
+
+    out["d2"], out["m2"] = steps2(r2, pos_2d)
+    if flip:
+        d, m = steps2(flip_lr(r2), flip_lr(pos_2d))
+        out["d2"] = avg(out["d2"], d)
+        if motion_on:
+            out["m2"] = avg(out["m2"], m)
+    assert not al, "unused GP coefficients"
+    out.update(pos_3d_cam=pos_3d_cam.reshape(B, R, 16, 3), pos_2d=pos_2d.reshape(B, R, 16, 2), G_cost=None, g_grads=None)
+    if g_step is not None:
+        G.zero_grad()
+        fw = G.fwd(g_step["noise"], G.p, bl, g_step["scaler"]).reshape(-1, 16, 3)
+        f2d = project_to_2d(world_to_camera(fw, quat, trans), cam9)
+        fc = fw - fw[:, :1]
+
+        def terms(fc, f2d):
+            a3, a2 = D3(fc).mean(), D2(f2d).mean()
+            am3 = am2 = 0.0
+            if motion_on:
+                am3, am2 = M3(fc).mean(), M2(f2d).mean()
+                if playback:
+                    am3 = (am3 + M3(torch.flip(fc.reshape(-1, R, 32), dims=[1])).mean()) / 2      # q6
+                    am2 = (am2 + M2(torch.flip(f2d.reshape(-1, R, 32), dims=[1])).mean()) / 2
+            return [a3, a2, am3, am2]
+
+        t = terms(fc, f2d)
+        if flip:
+            with torch.no_grad():
+                tf = terms(flip_lr(fc), flip_lr(f2d))
+            t = [(a + b) / 2 for a, b in zip(t, tf)]
+        gen_loss = t[0] * w[0] + t[1] * w[1]
+        if motion_on:
+            gen_loss = gen_loss + t[2] * w[2] + t[3] * w[3]
+        grads = torch.autograd.grad(-gen_loss, list(G.p.values()))
+        for v, g in zip(G.p.values(), grads):
+            v.grad = g
+        out["g_grads"] = G.grads()
+        G.opt.step()
+        out["G_cost"] = (-gen_loss).detach()
+    return out

@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Golden vectors for the LOOPS of the hot path, captured by RUNNING THE REFERENCE's own epoch functions on CPU:
+
+  gan_loop_D32.npz         GAN_solutions_FK_generator, 5 iterations (G step on the 5th), flip on
+                           (R/models_Fk_GAN/model_fk_gan_train.py:236-511) -- SURVEY.md section 8(c) item 8
+  video_loop_D32.npz       video_mode_GAN_solutions_FK_generator, R = 9, 5 iterations, motion critics on, playback and
+                           flip on (R/models_Fk_GAN/video_GAN_fun.py:79-601) incl. the (-1, R, 32) view of quirk q6
+  motion_step_m{3,2}_D32   one train_Fk_discriminator call on each motion critic in the mode the video loop uses for it
+                           (M3: dis_mode='motion', GP over B clips; M2: default mode, GP over B*R frames -- :219-232,:341-346)
+
+Build-container only (imports /root/reference through _ref_import.py).  The reference draws its random numbers from the
+global torch / numpy generators inside the loop; the draws are RECORDED here (torch.randn / rand / randint and the FK
+model's RandomState are wrapped for the duration of the call) and stored with the outputs, so that the build can replay
+exactly the same noise / jitter / interpolation coefficients.  `torch.device("cuda")` inside the reference functions is
+answered with the CPU device; the plotting call at the end of the video epoch is skipped (no arithmetic).  Fixtures are
+data (inputs + outputs); no reference source is stored.
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, ".."))
+import _ref_import as RI                      # noqa: E402
+from golden_util import seeded_state_dict, synth_pose16   # noqa: E402
+from make_golden import save                   # noqa: E402
+
+torch.set_num_threads(1)
+
+
+class Recorder:
+    """records every torch.randn / rand / randint result (in call order) while active"""
+
+    def __init__(self):
+        self.log = []
+
+    def __enter__(self):
+        self.orig = {k: getattr(torch, k) for k in ("randn", "rand", "randint")}
+        for k, f in self.orig.items():
+            setattr(torch, k, self._wrap(k, f))
+        return self
+
+    def _wrap(self, kind, f):
+        def g(*a, **kw):
+            out = f(*a, **kw)
+            self.log.append((kind, out.detach().clone()))
+            return out
+        return g
+
+    def __exit__(self, *exc):
+        for k, f in self.orig.items():
+            setattr(torch, k, f)
+
+    def of(self, kind):
+        return [t for k, t in self.log if k == kind]
+
+
+class RecordingRandomState:
+    """numpy RandomState proxy that logs randint draws (Video_Fk_Generator's jitter source, R/...Fk_generator.py:383)"""
+
+    def __init__(self, rs):
+        self.rs, self.log = rs, []
+
+    def randint(self, *a, **kw):
+        out = self.rs.randint(*a, **kw)
+        self.log.append(np.array(out))
+        return out
+
+    def __getattr__(self, k):
+        return getattr(self.rs, k)
+
+
+def cpu_torch_proxy():
+    cpu = torch.device("cpu")
+    proxy = types.SimpleNamespace(**{k: getattr(torch, k) for k in dir(torch) if not k.startswith("__")})
+    proxy.device = lambda *a, **k: cpu
+    # the recorder patches the real module; route the three RNG entry points through it at call time
+    for k in ("randn", "rand", "randint"):
+        setattr(proxy, k, (lambda kk: (lambda *a, **kw: getattr(torch, kk)(*a, **kw)))(k))
+    return proxy
+
+
+def hook_step(opt, fn):
+    orig = opt.step
+
+    def step(*a, **kw):
+        fn()
+        return orig(*a, **kw)
+    opt.step = step
+
+
+def sd_arrays(prefix, sd):
+    return {prefix + k: v.detach().clone() for k, v in sd.items()}
+
+
+def adam(m):
+    return torch.optim.Adam(m.parameters(), lr=1e-4, betas=(0.5, 0.9))
+
+
+def cam_param_rows(h36m, B, subject="S1", cam_id=1):
+    ext = h36m.h36m_cameras_extrinsic_params[subject][cam_id]
+    cp = np.zeros((B, 16), np.float32)
+    cp[:, 9:13] = np.array(ext["orientation"], np.float32)
+    cp[:, 13:16] = np.array(ext["translation"], np.float32) / 1000.0
+    return cp
+
+
+def chosen_cameras(h36m, subjects, cams):
+    """quaternion / translation [m] of the (subject, camera) pairs the loop drew"""
+    q = np.array([h36m.h36m_cameras_extrinsic_params[subjects[s]][c]["orientation"] for s, c in cams], np.float32)
+    t = np.array([h36m.h36m_cameras_extrinsic_params[subjects[s]][c]["translation"] for s, c in cams], np.float64) / 1000.0
+    return dict(cam_quat=q, cam_trans=t.astype(np.float32))
+
+
+def scalars(writer):
+    names = sorted({n for n, _, _ in writer.scalars})
+    out = {}
+    for n in names:
+        out["scalar__" + n.replace("/", "|")] = np.array([v for m, v, _ in writer.scalars if m == n], np.float64)
+    return out
+
+
+def single_frame_loop(M):
+    train, gen, dis, fkm, h36m = M["train"], M["gen"], M["dis"], M["fkm"], M["h36m"]
+    import utils.utils as ru
+    B, D, ITERS = 64, 32, 5
+    args = RI.make_args(batch_size=B, Gen_DenseDim=D, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D, flip_GAN_model_input=True)
+    train.torch = cpu_torch_proxy()
+    fk = fkm.Forward_Kinematics_DH_Model(args, ["S1", "S5"], None)
+    G = gen.Fk_Generator(fk, args, "cpu")
+    D3 = dis.Fk_3D_Discriminator("cpu", args)
+    D2 = dis.Fk_2D_Discriminator(args, 16)
+    seeds = dict(G=1100, D3=1200, D2=1300)
+    for net, s in ((G, seeds["G"]), (D3, seeds["D3"]), (D2, seeds["D2"])):
+        net.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=s))
+    d = dict(model_G=G, model_d3d=D3, model_d2d=D2, optimizer_G=adam(G), optimizer_d3d=adam(D3), optimizer_d2d=adam(D2))
+    cp = torch.tensor(cam_param_rows(h36m, B))
+    real3d = [synth_pose16(B, seed=800 + i) + torch.tensor([0.1, -0.2, 4.5]) for i in range(ITERS)]
+    real2d = [(torch.rand(B, 16, 2, generator=torch.Generator().manual_seed(850 + i)) - 0.5) * 1.6 for i in range(ITERS)]
+    # a ragged last batch: the reference skips it (:276)
+    data = dict(train_gt2d3d_loader=[(x, None, None, cp) for x in real3d] + [(real3d[0][:5], None, None, cp[:5])],
+                target_2d_loader=real2d + [real2d[0][:5]], target_3d_loader=[None] * (ITERS + 1))
+    summary = ru.Summary("/tmp/dhaug_ref_summary")
+    writer = M["Writer"]()
+    gstep = {}
+
+    def at_g_step():
+        gstep.update(sd_arrays("gstep_d3__", D3.state_dict()))
+        gstep.update(sd_arrays("gstep_d2__", D2.state_dict()))
+        gstep.update({"gstep_grad__" + k: p.grad.detach().clone() for k, p in G.named_parameters()})
+    hook_step(d["optimizer_G"], at_g_step)
+    np.random.seed(4242)
+    torch.manual_seed(777)
+    with Recorder() as rec:
+        train.GAN_solutions_FK_generator(args, d, data, torch.nn.Linear(1, 1), summary, writer, ["S1", "S5"])
+    np.random.seed(4242)
+    cams = np.array([[np.random.randint(0, 2), np.random.randint(0, 4)] for _ in range(ITERS)])
+    ds = data["train_fake2d3d_loader"].dataset
+    out = dict(real3d=torch.stack(real3d), real2d=torch.stack(real2d), cam_param=cp, cams=cams,
+               noise=torch.stack(rec.of("randn")), alpha=torch.stack(rec.of("rand")),
+               scaler=torch.stack(rec.of("randint")).float() / 1000.0,
+               buf_p3=ds._poses_3d, buf_p2=ds._poses_2d, buf_cam=ds._cams,
+               seeds=np.array([seeds["G"], seeds["D3"], seeds["D2"]]), iters=np.array(summary.train_iter_num))
+    assert out["noise"].shape[0] == ITERS + 1 and out["alpha"].shape[0] == 4 * ITERS and out["scaler"].shape[0] == ITERS + 1
+    out.update(chosen_cameras(h36m, ["S1", "S5"], cams))
+    out.update(sd_arrays("final_G__", G.state_dict()))
+    out.update(sd_arrays("final_d3__", D3.state_dict()))
+    out.update(sd_arrays("final_d2__", D2.state_dict()))
+    out.update(gstep)
+    out.update(scalars(writer))
+    save("gan_loop_D32", **out)
+
+
+def motion_shapes(net):
+    return {k: tuple(v.shape) for k, v in net.state_dict().items()}
+
+
+def video_loop(M):
+    train, gen, dis, fkm, h36m = M["train"], M["gen"], M["dis"], M["fkm"], M["h36m"]
+    import importlib
+    import utils.utils as ru
+    cwd = os.getcwd()
+    os.chdir(RI.REF_ROOT)
+    try:
+        video = importlib.import_module("models_Fk_GAN.video_GAN_fun")
+    finally:
+        os.chdir(cwd)
+    video.torch = cpu_torch_proxy()
+    video.my_visual_GAN_video = lambda *a, **k: None          # plotting at the end of the epoch: no arithmetic
+    B, R, D, ITERS = 8, 9, 32, 5
+    ckpt = tempfile.mkdtemp(prefix="dhaug_ref_ckpt_")
+    os.makedirs(os.path.join(ckpt, "tmp"))
+    args = RI.make_args(batch_size=B, Gen_DenseDim=D, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D, video_Dis_DenseDim_3D=D,
+                        video_Dis_DenseDim_2D=D, single_or_multi_train_mode="multi", architecture="3,3",
+                        single_dis_warmup_epoch=0, GAN_video_playback_input=True, flip_GAN_model_input=True,
+                        checkpoint=ckpt, random_seed=3)
+    fk = fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+    fk.random = RecordingRandomState(fk.random)
+    G = gen.Video_Fk_Generator(R, fk, args, "cpu")
+    nets = dict(G=G, d3=dis.Fk_3D_Discriminator("cpu", args), d2=dis.Fk_2D_Discriminator(args, 16),
+                m3=dis.Video_motion_Fk_3D_Discriminator("cpu", args, R), m2=dis.Video_motion_Fk_2D_Discriminator("cpu", args, R))
+    seeds = dict(G=2100, d3=2200, d2=2300, m3=2400, m2=2500)
+    for k, net in nets.items():
+        net.load_state_dict(seeded_state_dict(motion_shapes(net), seed=seeds[k]))
+    d = dict(model_G=G, model_d3d=nets["d3"], model_d2d=nets["d2"], model_motion_d3d=nets["m3"], model_motion_d2d=nets["m2"],
+             optimizer_G=adam(G), optimizer_d3d=adam(nets["d3"]), optimizer_d2d=adam(nets["d2"]),
+             optimizer_motion_d3d=adam(nets["m3"]), optimizer_motion_d2d=adam(nets["m2"]))
+    cp = cam_param_rows(h36m, B)
+    real3d = [(synth_pose16(B * R, seed=900 + i) + torch.tensor([0.1, -0.2, 4.5])).reshape(B, R, 16, 3).numpy() for i in range(ITERS)]
+    real2d = [((torch.rand(B * R, 16, 2, generator=torch.Generator().manual_seed(950 + i)) - 0.5) * 1.6).reshape(B, R, 16, 2).numpy()
+              for i in range(ITERS)]
+
+    class Loader:
+        num_batches = ITERS
+
+        def next_epoch(self):
+            for x3, x2 in zip(real3d, real2d):
+                yield cp, x3, x2
+
+    data = dict(target_GAN_loader=Loader())
+    summary = ru.Summary("/tmp/dhaug_ref_summary")
+    summary.epoch = 1
+    writer = M["Writer"]()
+    gstep = {}
+
+    def at_g_step():
+        for k in ("d3", "d2", "m3", "m2"):
+            gstep.update(sd_arrays("gstep_%s__" % k, nets[k].state_dict()))
+        gstep.update({"gstep_grad__" + k: p.grad.detach().clone() for k, p in G.named_parameters()})
+    hook_step(d["optimizer_G"], at_g_step)
+    np.random.seed(5151)
+    torch.manual_seed(888)
+    with Recorder() as rec:
+        video.video_mode_GAN_solutions_FK_generator(args, d, data, torch.nn.Linear(1, 1), summary, writer, ["S1"])
+    np.random.seed(5151)
+    cams = np.array([[np.random.randint(0, 1), np.random.randint(0, 4)] for _ in range(ITERS)])
+    ds = data["train_fake2d3d_loader"].dataset
+    out = dict(real3d=np.stack(real3d), real2d=np.stack(real2d), cam_param=cp, cams=cams,
+               noise=torch.stack(rec.of("randn")), alpha_list_len=np.array(len(rec.of("rand"))),
+               scaler=np.stack(fk.random.log).astype(np.float32) / 1000.0,
+               buf_p3=ds._poses_3d, buf_p2=ds._poses_2d, buf_cam=ds._cams,
+               seeds=np.array([seeds[k] for k in ("G", "d3", "d2", "m3", "m2")]), iters=np.array(summary.train_iter_num))
+    # GP interpolation coefficients come in two shapes ((B*R,1) for the single-frame critics and the 2D motion critic,
+    # (B,1) for the 3D motion critic): stored in call order, one array each
+    for i, a in enumerate(rec.of("rand")):
+        out["alpha_%03d" % i] = a
+    assert out["noise"].shape[0] == ITERS + 1 and out["scaler"].shape[0] == ITERS + 1 and len(rec.of("randint")) == 0
+    out.update(chosen_cameras(h36m, ["S1"], cams))
+    for k, net in nets.items():
+        out.update(sd_arrays("final_%s__" % k, net.state_dict()))
+    out.update(gstep)
+    out.update(scalars(writer))
+    save("video_loop_D32", **out)
+
+    # ---- one isolated step of each motion critic, in the mode the loop uses for it -------------------------------
+    for tag, mode in (("m3", "motion"), ("m2", "single")):
+        net = (dis.Video_motion_Fk_3D_Discriminator if tag == "m3" else dis.Video_motion_Fk_2D_Discriminator)("cpu", args, R)
+        sd = seeded_state_dict(motion_shapes(net), seed=2600 + len(mode))
+        net.load_state_dict(sd)
+        if tag == "m3":
+            xr = synth_pose16(B * R, seed=61); xr = (xr - xr[:, :1]).reshape(B * R, 48)
+            xf = synth_pose16(B * R, seed=62); xf = (xf - xf[:, :1]).reshape(B * R, 48)
+        else:
+            xr = ((torch.rand(B * R, 16, 2, generator=torch.Generator().manual_seed(63)) - 0.5) * 1.6)
+            xf = ((torch.rand(B * R, 16, 2, generator=torch.Generator().manual_seed(64)) - 0.5) * 1.6)
+        opt = adam(net)
+        one = torch.tensor(1, dtype=torch.float32)
+        grads = {}
+        hook_step(opt, lambda: grads.update({"grad__" + k: p.grad.detach().clone() for k, p in net.named_parameters()}))
+        torch.manual_seed(999)
+        with Recorder() as rec:
+            kw = dict(dis_mode="motion") if mode == "motion" else {}
+            W, C = train.train_Fk_discriminator(net, xr.clone(), xf.clone(), summary, M["Writer"](), "motion_" + tag, opt,
+                                                args, one, one * -1, **kw)
+        newp = {"new__" + k: p.detach().clone() for k, p in net.named_parameters()}
+        save("motion_step_%s_D32" % tag, real=xr, fake=xf, alpha=rec.of("rand")[0], Wasserstein_D=W.detach(),
+             D_cost=C.detach(), weight_seed=np.array(2600 + len(mode)), **grads, **newp)
+
+
+def main():
+    M = RI.load_reference()
+    single_frame_loop(M)
+    video_loop(M)
+
+
+if __name__ == "__main__":
+    main()

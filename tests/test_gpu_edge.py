@@ -1,0 +1,110 @@
+"""GPU: degenerate inputs through the kernels, against what the reference's ATen arithmetic does with them (the oracle).
+
+  * zero-length bones: the KCS cosines divide by the bone lengths (R/models_Fk_GAN/Fk_discriminator.py:36-146) -> 0/0 = NaN
+    in exactly the entries that touch the degenerate bone, finite everywhere else; same through bone_length / KCS-VJP.
+  * NaN / inf through the training-path dense layers (IEEE semantics kept in dhaug_gemm.hip / dhaug_elem.hip): a NaN
+    activation reaches the logit, as with nn.Linear + ReLU.
+  * angles far outside the joint range (+-1e4 deg, 55 turns): the Cody-Waite reduction of the FK kernel stays within
+    1e-5 of the reference arithmetic.
+  * FK is compiled with -ffinite-math-only (documented in __graft_entry__.py): a NaN angle gives an unspecified value for
+    THAT pose only; other poses of the launch are untouched."""
+import pytest
+import torch
+
+import golden_util as GU
+from oracle import dhaug_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import dhaug_amd
+    dhaug_amd._lib.lib()
+    from dhaug_amd import ops
+    return ops
+
+
+def same_nan_pattern(a, b, tol):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert torch.equal(torch.isnan(a), torch.isnan(b)), (torch.isnan(a).sum().item(), torch.isnan(b).sum().item())
+    m = ~torch.isnan(b)
+    assert ((a[m] - b[m]).abs().max().item() if m.any() else 0.0) <= tol
+
+
+def test_kcs_zero_length_bone_is_nan_like_the_reference(ops):
+    x = GU.synth_pose16(70, seed=3)
+    x[3, 6] = x[3, 5]               # left shin collapsed (bone 0): cosine 0 involves it
+    x[17, 9] = x[17, 8]             # neck collapsed (bone 14): cosine 8
+    x[40] = 0.0                     # every bone degenerate
+    ref = O.kcs_features(x)
+    assert torch.isnan(ref[3]).sum().item() == 1 and torch.isnan(ref[40, :15]).all()
+    got, _ = ops.kcs_forward(x.cuda(), True, f32=True)
+    same_nan_pattern(got, ref, 5e-6)
+    same_nan_pattern(ops.kcs_forward(x.cuda(), False, f32=True)[0], O.kcs_features(x, with_lengths=False), 5e-6)
+    same_nan_pattern(ops.bone_length(x.cuda()), O.bone_lengths(x), 1e-6)
+    # the bf16 operand the fused 3D critic reads carries the same NaNs
+    _, kb = ops.kcs_forward(x.cuda(), True, f32=False, bf16_ld=32)
+    assert torch.equal(torch.isnan(kb[:, :30].float().cpu()), torch.isnan(ref))
+    # VJP: NaN rows stay confined to the degenerate poses
+    gf = torch.ones(70, 30)
+    gx = ops.kcs_backward(x.cuda(), gf.cuda(), True).cpu()
+    bad = torch.isnan(gx).reshape(70, -1).any(1)
+    assert bad[3] and bad[17] and bad[40] and bad.sum().item() == 3
+
+
+def test_nan_and_inf_reach_the_logit_on_the_training_path(ops):
+    from dhaug_amd import autograd_ops as A
+    torch.manual_seed(0)
+    W1, b1 = (torch.randn(64, 48) * 0.2).cuda(), torch.zeros(64).cuda()
+    W2, b2 = (torch.randn(64, 64) * 0.2).cuda(), torch.zeros(64).cuda()
+    x = torch.randn(40, 48)
+    x[5, 7] = float("nan")
+    x[9, 3] = float("inf")
+    for prec in ("bf16", "bf16x6"):
+        h = A.linear(x.cuda(), W1, b1, None, A.ACT_RELU, 0.0, prec)
+        y = A.linear(h, W2, b2, None, A.ACT_NONE, 0.0, prec, out_f32=True).cpu()
+        ref = torch.relu(x @ W1.cpu().t()) @ W2.cpu().t()
+        assert torch.isnan(ref[5]).all() and torch.isnan(y[5]).all(), prec           # NaN row stays NaN
+        assert not torch.isfinite(y[9]).any() and not torch.isfinite(ref[9]).any(), prec   # inf row: inf / NaN, never finite
+        ok = torch.ones(40, dtype=torch.bool); ok[5] = ok[9] = False
+        assert torch.isfinite(y[ok]).all()
+    # Adam: a NaN gradient element poisons that element only
+    p, g = torch.ones(1024).cuda(), torch.zeros(1024).cuda()
+    g[17] = float("nan")
+    m, v = torch.zeros(1024).cuda(), torch.zeros(1024).cuda()
+    ops.adam_step(p, g, m, v, 1)
+    assert torch.isnan(p[17]).item() and torch.isfinite(torch.cat((p[:17], p[18:]))).all()
+
+
+def test_fk_angles_far_outside_the_joint_range(ops):
+    g = torch.Generator().manual_seed(9)
+    N = 4096
+    a = (torch.rand(N, 37, generator=g) * 2 - 1) * 1.0e4
+    bl = torch.rand(N, 15, generator=g) * 0.4 + 0.1
+    rt = torch.randn(N, 3, generator=g)
+    out = ops.fk_forward(a.cuda(), bl.cuda(), rt.cuda()).cpu()
+    ref = O.fk_forward16(a, bl, rt)
+    assert (out - ref).abs().max().item() <= 1e-5
+    # and at the edge of the reduction's fast path (131072 rad ~ 7.5e6 deg) the library path takes over seamlessly
+    a2 = a * 1.0e3
+    out2 = ops.fk_forward(a2.cuda(), bl.cuda(), rt.cuda()).cpu()
+    assert (out2 - O.fk_forward16(a2, bl, rt)).abs().max().item() <= 1e-5
+
+
+def test_fk_nan_pose_does_not_leak_into_other_poses(ops):
+    a, bl, rt = GU.synth_fk_inputs(256, seed=12)
+    clean = ops.fk_forward(a.cuda(), bl.cuda(), rt.cuda()).cpu()
+    a2 = a.clone()
+    a2[100, 12] = float("nan")
+    a2[101, 3] = float("inf")
+    out = ops.fk_forward(a2.cuda(), bl.cuda(), rt.cuda()).cpu()
+    keep = torch.ones(256, dtype=torch.bool); keep[100] = keep[101] = False
+    assert torch.equal(out[keep], clean[keep])
+    # zero bone lengths: joints collapse onto their parents exactly as in the reference
+    bl0 = bl.clone(); bl0[:, [0, 12]] = 0.0
+    o0 = ops.fk_forward(a.cuda(), bl0.cuda(), rt.cuda()).cpu()
+    assert (o0 - O.fk_forward16(a, bl0, rt)).abs().max().item() <= 1e-5
+    assert (o0[:, 6] - o0[:, 5]).abs().max().item() <= 1e-6

@@ -1,0 +1,173 @@
+"""GPU parity of the epoch loops against golden vectors captured from the REFERENCE's
+own GAN_solutions_FK_generator / video_mode_GAN_solutions_FK_generator runs with recorded random draws
+(tests/golden/make_golden_loops.py), in the fp32-grade arithmetic ('bf16x6').
+
+What is compared, per loop: the generated pairs of every iteration (pos_3d_cam / 2D -- the product of the epoch), the
+D_real / D_fake / Wasserstein_D series of every critic step in the reference's logging order, the generator's gradients at
+the G step (flip-averaged loss; video: four adversarial terms incl. the (-1, R, 32) view of quirk q6) and every network's
+weights after the five iterations.  Adam's first steps are lr * g / (|g| + eps): elements whose gradient is ~0 are
+ill-conditioned, hence a quantile bound next to the hard bound of (steps * lr)."""
+import argparse
+
+import pytest
+import torch
+
+import golden_util as GU
+import loop_util as LU
+
+pytestmark = pytest.mark.gpu
+
+
+class Writer:
+    def __init__(self):
+        self.s = {}
+
+    def add_scalar(self, name, value, step=None):
+        self.s.setdefault(name.split("/", 1)[1], []).append(float(value))
+
+
+class Summary:
+    def __init__(self, epoch=0):
+        self.epoch, self.train_iter_num, self.train_discrim_iter_num = epoch, 0, 0
+
+
+def maxabs(a, b):
+    return (a.detach().double().cpu() - torch.as_tensor(b).double()).abs().max().item()
+
+
+def weights_close(net, g, prefix, steps, lr=1e-4):
+    worst = 0.0
+    for k, p in net.named_parameters():
+        ref = g[prefix + k].double()
+        e = (p.detach().double().cpu() - ref).abs().reshape(-1)
+        worst = max(worst, e.max().item())
+        assert e.max().item() <= 1.05 * steps * lr, (prefix, k, e.max().item())
+        if e.numel() >= 64:
+            assert torch.quantile(e, 0.98).item() <= 2e-5, (prefix, k, torch.quantile(e, 0.98).item())
+    return worst
+
+
+def scalars_close(w, g, tol):
+    ref = LU.scalar_series(g)
+    assert set(ref) == set(w.s), (sorted(ref), sorted(w.s))
+    for name, r in ref.items():
+        got = torch.tensor(w.s[name], dtype=torch.float64)
+        assert got.shape == r.shape, name
+        assert maxabs(got, r) <= tol * max(1.0, r.abs().max().item()), (name, maxabs(got, r))
+
+
+def grads_close(G, g, rel):
+    for k, p in G.named_parameters():
+        ref = g["gstep_grad__" + k]
+        assert maxabs(p.grad, ref) <= 1e-7 + rel * ref.abs().max().item(), (k, maxabs(p.grad, ref), ref.abs().max().item())
+
+
+@pytest.fixture(scope="module")
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import dhaug_amd
+    dhaug_amd._lib.lib()
+    from dhaug_amd.models_Fk_GAN import forward_kinematics_DH_model, model_fk_gan_train, video_GAN_fun
+    return argparse.Namespace(fkm=forward_kinematics_DH_model, train=model_fk_gan_train, video=video_GAN_fun)
+
+
+def _args(**over):
+    from test_gpu_models import make_args
+    return make_args(**over)
+
+
+def test_single_frame_loop_vs_reference(M, golden):
+    g = golden("gan_loop_D32")
+    iters, B = g["real3d"].shape[0], g["real3d"].shape[1]
+    args = _args(batch_size=B, flip_GAN_model_input=True)
+    fk = M.fkm.Forward_Kinematics_DH_Model(args, ["S1", "S5"], None)
+    d = M.train.my_get_poseFk_model(args, None, fk)
+    for key, sd in zip(("model_G", "model_d3d", "model_d2d"), LU.single_state_dicts(g)):
+        d[key].load_state_dict(sd)
+        d[key].precision = "bf16x6"
+    w, s = Writer(), Summary()
+    p3, p2 = [], []
+    for i in range(iters):
+        last = i == iters - 1
+        draws = M.train.Draws(noise=[g["noise"][i]] + ([g["noise"][iters]] if last else []),
+                              scaler=[g["scaler"][i]] + ([g["scaler"][iters]] if last else []),
+                              alpha=[g["alpha"][4 * i + j] for j in range(4)])
+        cam = (g["cam_quat"][i].tolist(), g["cam_trans"][i].tolist(), g["buf_cam"][i * B].tolist())
+        if last:                                      # critic weights as the G step sees them
+            pass
+        r = M.train.gan_iteration(args, d, g["real3d"][i], g["cam_param"], g["real2d"][i], ["S1", "S5"], s, w,
+                                  do_g_step=last, camera=cam, draws=draws)
+        assert not any(draws.q.values()), "recorded draws left over"
+        p3.append(r["pos_3d_cam"]); p2.append(r["pos_2d"])
+        s.train_iter_num += 1
+    assert maxabs(torch.cat(p3), g["buf_p3"]) <= 2e-5 and maxabs(torch.cat(p2), g["buf_p2"]) <= 2e-5
+    scalars_close(w, g, 2e-4)
+    grads_close(d["model_G"], g, 2e-3)
+    assert r["G_cost"] is not None and torch.isfinite(r["G_cost"]).item()
+    worst = [weights_close(d[k], g, p, n) for k, p, n in (("model_d3d", "final_d3__", 10), ("model_d2d", "final_d2__", 10),
+                                                           ("model_G", "final_G__", 1))]
+    print("single-frame loop: worst weight error D3 %.2e D2 %.2e G %.2e" % tuple(worst))
+
+
+def test_video_loop_vs_reference(M, golden):
+    g = golden("video_loop_D32")
+    iters, B, R = g["real3d"].shape[0], g["real3d"].shape[1], g["real3d"].shape[2]
+    args = _args(batch_size=B, single_or_multi_train_mode="multi", architecture="3,3", single_dis_warmup_epoch=0,
+                 GAN_video_playback_input=True, flip_GAN_model_input=True, GAN_3d_motion_loss_weight=1.0,
+                 GAN_2d_motion_loss_weight=1.0)
+    fk = M.fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+    d = M.train.video_mode_my_get_poseFk_model(args, None, fk, R)
+    names = dict(G="model_G", d3="model_d3d", d2="model_d2d", m3="model_motion_d3d", m2="model_motion_d2d")
+    for tag, sd in LU.video_state_dicts(g, R=R).items():
+        d[names[tag]].load_state_dict(sd)
+        d[names[tag]].precision = "bf16x6"
+    al = LU.video_alphas(g)
+    per = len(al) // iters
+    w, s = Writer(), Summary(epoch=1)
+    p3, p2 = [], []
+    for i in range(iters):
+        last = i == iters - 1
+        draws = M.train.Draws(noise=[g["noise"][i]] + ([g["noise"][iters]] if last else []),
+                              scaler=[g["scaler"][i]] + ([g["scaler"][iters]] if last else []),
+                              alpha=al[per * i:per * (i + 1)])
+        cam = (g["cam_quat"][i].tolist(), g["cam_trans"][i].tolist(), g["buf_cam"][i * B, 0].tolist())
+        r = M.video.video_gan_iteration(args, d, g["real3d"][i], g["cam_param"], g["real2d"][i], ["S1"], s, w,
+                                        do_g_step=last, camera=cam, draws=draws)
+        assert not any(draws.q.values()), "recorded draws left over"
+        p3.append(r["pos_3d_cam"]); p2.append(r["pos_2d"])
+        s.train_iter_num += 1
+    assert maxabs(torch.cat(p3), g["buf_p3"]) <= 2e-5 and maxabs(torch.cat(p2), g["buf_p2"]) <= 2e-5
+    scalars_close(w, g, 3e-4)
+    grads_close(d["model_G"], g, 3e-3)
+    worst = {t: weights_close(d[names[t]], g, "final_%s__" % t, 1 if t == "G" else (10 if t in ("d3", "d2") else 20))
+             for t in names}
+    print("video loop: worst weight errors", {k: "%.2e" % v for k, v in worst.items()})
+
+
+@pytest.mark.parametrize("tag", ["m3", "m2"])
+def test_motion_critic_step_vs_reference(M, golden, tag):
+    """one critic step of each motion critic in the mode the video loop uses for it (M3: penalty over B clips;
+    M2: penalty over B*R frames) -- scalars, gradients before Adam, weights after it"""
+    from dhaug_amd.models_Fk_GAN import Fk_discriminator as dis
+    g = golden("motion_step_%s_D32" % tag)
+    B, R = 8, 9
+    args = _args(batch_size=B, single_or_multi_train_mode="multi", architecture="3,3")
+    cls = dis.Video_motion_Fk_3D_Discriminator if tag == "m3" else dis.Video_motion_Fk_2D_Discriminator
+    net = cls("cuda", args, R)
+    net.load_state_dict(GU.seeded_state_dict(LU.motion_shapes(32, R)[0 if tag == "m3" else 1], int(g["weight_seed"])))
+    net.precision = "bf16x6"
+    net = net.cuda()
+    opt = M.train.FusedAdam(net.parameters(), lr=1e-4, betas=(0.5, 0.9))
+    W, C = M.train.train_Fk_discriminator(net, g["real"].cuda(), g["fake"].cuda(), Summary(), None, "motion_" + tag, opt,
+                                          args, dis_mode="motion" if tag == "m3" else "single", alpha=g["alpha"].cuda())
+    assert torch.isfinite(W).item() and torch.isfinite(C).item()
+    assert abs(W.item() - g["Wasserstein_D"].item()) <= 2e-5
+    assert abs(C.item() - g["D_cost"].item()) <= 2e-4 * max(1.0, abs(g["D_cost"].item()))
+    for k, p in net.named_parameters():
+        ref = g["grad__" + k]
+        assert maxabs(p.grad, ref) <= 2e-5 + 5e-4 * ref.abs().max().item(), (k, maxabs(p.grad, ref))
+        assert maxabs(p, g["new__" + k]) <= 1.05e-4, k
+        well = ref.abs() > max(1e-3 * ref.abs().max().item(), 1e-7)
+        if well.any():
+            assert maxabs(p.detach().cpu()[well], g["new__" + k][well]) <= 3e-6, k

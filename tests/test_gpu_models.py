@@ -466,3 +466,74 @@ def test_normal_mode_sampler_golden(M, golden):
     assert np.abs(np.asarray(blen) - g["bone_len"].numpy()).max() <= 1e-6
     assert np.abs(np.asarray(roots) - g["root"].numpy()).max() == 0.0
     assert pos.shape == (48, 32, 3) and np.abs(pos - g["pos"].numpy()).max() <= 1e-5
+
+
+# --------------------------------------------------------------------- fused forward vs the REFERENCE's logits
+def _fused_nets(M, D, B):
+    args = make_args(batch_size=B, Gen_DenseDim=D, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D)
+    fk = M.fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+    return args, M.gen.Fk_Generator(fk, args, "cuda"), M.dis.Fk_3D_Discriminator("cuda", args), M.dis.Fk_2D_Discriminator(args, 16)
+
+
+def test_fused_forward_vs_reference_golden(M, golden):
+    """The one-launch fused programs (the path bench.py times) on the REFERENCE's D=256 goldens with the golden seeded
+    weights, under no_grad: the parity mode ('f16x3', fp16 hi+lo operands, three MFMA terms) holds north_star's 1e-4
+    relative logit tolerance and the 1e-5-grade pose tolerance; the throughput mode ('bf16') is measured and bounded."""
+    from dhaug_amd import fused
+    gc, gg = golden("critics_D256"), golden("gen_D256")
+    B, D = gc["x3"].shape[0], 256
+    _, G, D3, D2 = _fused_nets(M, D, B)
+    sd3 = GU.seeded_state_dict(GU.shapes_d3(D), int(gc["weight_seed3"]))
+    sd2 = GU.seeded_state_dict(GU.shapes_d2(D), int(gc["weight_seed2"]))
+    sdG = GU.seeded_state_dict(GU.shapes_generator(D), int(gg["weight_seed"]))
+    x3, x2, z = gc["x3"].cuda(), gc["x2"].cuda(), gg["z"].cuda()
+    res = {}
+    for mode in ("f16x3", "bf16"):
+        D3 = load(D3, sd3, mode); D2 = load(D2, sd2, mode); G = load(G, sdG, mode)
+        with torch.no_grad():
+            l3, l2, head = D3(x3), D2(x2), G.trunk(z)                  # no graph -> fused.critic3d / critic2d / generator_head
+            assert torch.equal(l3, fused.critic3d(D3, x3.reshape(B, 48), mode=mode))
+            G.GAN_generator_get_bone_length(gg["real16"].cuda())
+            fake = G(z, bone_len_scaler=gg["scaler"])
+        res[mode] = dict(r3=relerr(l3, gc["logit3"]), r2=relerr(l2, gc["logit2"]),
+                         s3=maxabs(l3, gc["logit3"]) / gc["logit3"].abs().max().item(),
+                         s2=maxabs(l2, gc["logit2"]) / gc["logit2"].abs().max().item(),
+                         head=maxabs(head, gg["head"]), fake=maxabs(fake, gg["fake"]))
+        print("fused %-6s logits rel D3 %.2e D2 %.2e | of scale D3 %.2e D2 %.2e | head %.2e | fake %.2e m"
+              % (mode, res[mode]["r3"], res[mode]["r2"], res[mode]["s3"], res[mode]["s2"], res[mode]["head"], res[mode]["fake"]))
+    p = res["f16x3"]
+    assert p["r3"] <= 1e-4 and p["r2"] <= 1e-4                     # north_star: GAN forward logits within 1e-4 rel
+    assert p["head"] <= 5e-6 and p["fake"] <= 1e-5                 # north_star: FK joints within 1e-5 abs, through the trunk
+    b = res["bf16"]
+    assert b["s3"] <= 5e-2 and b["s2"] <= 5e-2 and b["head"] <= 5e-2 * gg["head"].abs().max().item()
+
+
+@pytest.mark.parametrize("D,B", [(64, 333), (128, 200), (256, 1000), (256, 65536)])
+def test_fused_parity_mode_ragged_and_full_size(M, D, B):
+    """f16x3 programs at ragged batch sizes (tail tiles) and at BASELINE's batch against the fp32 oracle on the same
+    random-init weights; at B = 65 536 the oracle checks a sample of rows from both ends and tile-independence is checked
+    by re-running a slice of the batch on its own."""
+    _, G, D3, D2 = _fused_nets(M, D, B)
+    torch.manual_seed(21)
+    for m in (G, D3, D2):
+        m.cuda()
+        m.precision = "f16x3"
+    g = torch.Generator().manual_seed(22)
+    z = torch.randn(B, 128, generator=g).cuda()
+    x3 = GU.synth_pose16(B, seed=23); x3 = (x3 - x3[:, :1]).cuda()
+    x2 = ((torch.rand(B, 16, 2, generator=g) - 0.5) * 1.6).cuda()
+    with torch.no_grad():
+        head, l3, l2 = G.trunk(z), D3(x3), D2(x2)
+        m3, m2 = M.dis.score_fake_pair(D3, D2, x3, torch.empty(B, 32, dtype=torch.bfloat16, device="cuda"), x2)
+    assert head.shape == (B, 35) and l3.shape == (B, 1) and l2.shape == (B, 1)
+    assert torch.equal(m3, l3) and torch.equal(m2, l2)              # both critics in one launch = the two launches
+    rows = torch.arange(B) if B <= 1000 else torch.cat((torch.arange(0, 300), torch.arange(B - 300, B)))
+    cpu = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    r3 = O.d3_forward(x3.cpu()[rows], cpu(D3)); r2 = O.d2_forward(x2.cpu()[rows], cpu(D2)); rh = O.gen_trunk(z.cpu()[rows], cpu(G))
+    assert relerr(l3[rows], r3) <= 1e-4 and relerr(l2[rows], r2) <= 1e-4
+    assert maxabs(head[rows], rh) <= 5e-6 * max(1.0, rh.abs().max().item())
+    if B > 1000:
+        lo, hi = 64 * 501 + 7, 64 * 640 + 13                        # not tile aligned
+        with torch.no_grad():
+            assert maxabs(D3(x3[lo:hi].contiguous()), l3[lo:hi].cpu()) <= 1e-6 * max(1.0, l3.abs().max().item())
+        assert torch.isfinite(l3).all() and torch.isfinite(l2).all() and torch.isfinite(head).all()

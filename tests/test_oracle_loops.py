@@ -1,0 +1,75 @@
+"""CPU: the oracle's restatement of the epoch loops (oracle.gan_iteration / video_gan_iteration / critic_step_net) against
+golden vectors captured from the REFERENCE's own GAN_solutions_FK_generator / video_mode_GAN_solutions_FK_generator runs
+(tests/golden/make_golden_loops.py, recorded random draws replayed).  Pins rows a16 / a18 of SURVEY.md section 8."""
+import pytest
+import torch
+
+import golden_util as GU
+import loop_util as LU
+from oracle import dhaug_oracle as O
+
+
+def maxabs(a, b):
+    return (a.double() - b.double()).abs().max().item()
+
+
+def test_single_frame_loop_golden(golden):
+    g = golden("gan_loop_D32")
+    r = LU.replay_single_oracle(g)
+    # the fake pairs of all five iterations (generator weights are the seeded ones until the G step of the 5th)
+    assert maxabs(r["buf_p3"], g["buf_p3"]) <= 2e-6 and maxabs(r["buf_p2"], g["buf_p2"]) <= 2e-6
+    # critic scalars of every step, in the reference's logging order
+    for name, ref in LU.scalar_series(g).items():
+        got = torch.tensor(r["scalars"][name], dtype=torch.float64)
+        assert got.shape == ref.shape, name
+        assert maxabs(got, ref) <= 2e-5 * max(1.0, ref.abs().max().item()), name
+    # the G step: critic weights at that moment, the generator's gradients, its weights after Adam
+    for k in LU.keys(g, "gstep_d3__"):
+        assert maxabs(r["gstep_d"]["d3"][k], g["gstep_d3__" + k]) <= 2e-6, k
+    for k in LU.keys(g, "gstep_grad__"):
+        ref = g["gstep_grad__" + k]
+        assert maxabs(r["g_grads"][k], ref) <= 1e-7 + 2e-4 * ref.abs().max().item(), k
+    for tag, net in (("final_G__", r["G"]), ("final_d3__", r["D3"]), ("final_d2__", r["D2"])):
+        for k in LU.keys(g, tag):
+            assert maxabs(net.state()[k], g[tag + k]) <= 5e-6, (tag, k)
+
+
+def test_video_loop_golden(golden):
+    g = golden("video_loop_D32")
+    r = LU.replay_video_oracle(g)
+    assert maxabs(r["buf_p3"], g["buf_p3"]) <= 2e-6 and maxabs(r["buf_p2"], g["buf_p2"]) <= 2e-6
+    for name, ref in LU.scalar_series(g).items():
+        got = torch.tensor(r["scalars"][name], dtype=torch.float64)
+        assert got.shape == ref.shape, name
+        assert maxabs(got, ref) <= 5e-5 * max(1.0, ref.abs().max().item()), name
+    for k in LU.keys(g, "gstep_grad__"):
+        ref = g["gstep_grad__" + k]
+        assert maxabs(r["g_grads"][k], ref) <= 1e-7 + 5e-4 * ref.abs().max().item(), k
+    for tag in ("G", "d3", "d2", "m3", "m2"):
+        for k in LU.keys(g, "final_%s__" % tag):
+            assert maxabs(r["nets"][tag].state()[k], g["final_%s__%s" % (tag, k)]) <= 1e-5, (tag, k)
+
+
+@pytest.mark.parametrize("tag", ["m3", "m2"])
+def test_motion_critic_step_golden(golden, tag):
+    """one train_Fk_discriminator call per motion critic in the mode the video loop uses for it: GP over B clips for the
+    3D motion critic (dis_mode='motion'), over B*R frames for the 2D one (default mode, R/...video_GAN_fun.py:341-346)"""
+    g = golden("motion_step_%s_D32" % tag)
+    B, R = 8, 9
+    sd = GU.seeded_state_dict(LU.motion_shapes(32, R)[0 if tag == "m3" else 1], int(g["weight_seed"]))
+    fwd = (lambda x, p: O.motion_d3_forward(x, p, R)) if tag == "m3" else (lambda x, p: O.motion_d2_forward(x, p, R))
+    net = O.Net(sd, fwd)
+    rows = B if tag == "m3" else B * R
+    assert g["alpha"].shape == (rows, 1)
+    W, C = O.critic_step_net(net, g["real"], g["fake"], g["alpha"], rows)
+    # grads are read after the step: recompute them on a fresh net
+    net2 = O.Net(sd, fwd)
+    net2.zero_grad()
+    gp = O.gradient_penalty(net2, g["real"].reshape(rows, -1), g["fake"].reshape(rows, -1), g["alpha"])
+    (net2(g["fake"]).mean() - net2(g["real"]).mean() + gp).backward()
+    assert abs(W.item() - g["Wasserstein_D"].item()) <= 1e-6 and abs(C.item() - g["D_cost"].item()) <= 1e-5
+    for k, gr in net2.grads().items():
+        ref = g["grad__" + k]
+        assert maxabs(gr, ref) <= 1e-7 + 1e-4 * ref.abs().max().item(), k
+    for k, v in net.state().items():
+        assert maxabs(v, g["new__" + k]) <= 2e-6, k

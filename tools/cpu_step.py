@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import dhaug_amd
 from dhaug_amd import ops
-from dhaug_amd.selfcheck import synth_args
+from dhaug_amd.function_aug.config import synth_args
 from dhaug_amd.models_Fk_GAN import model_fk_gan_train as T
 from dhaug_amd.models_Fk_GAN.forward_kinematics_DH_model import Forward_Kinematics_DH_Model
 from dhaug_amd.models_Fk_GAN.Fk_discriminator import score_fake_pair

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import dhaug_amd
 from dhaug_amd import fused
-from dhaug_amd.selfcheck import synth_args
+from dhaug_amd.function_aug.config import synth_args
 from dhaug_amd.models_Fk_GAN import Fk_discriminator
 from oracle import dhaug_oracle as O
 import golden_util as GU

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import dhaug_amd
 from dhaug_amd import fused
-from dhaug_amd.selfcheck import synth_args
+from dhaug_amd.function_aug.config import synth_args
 from dhaug_amd.models_Fk_GAN import Fk_discriminator
 B, D = 65536, 256
 args = synth_args(B, D)

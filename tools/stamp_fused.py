@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import dhaug_amd
 from dhaug_amd import fused, _lib
-from dhaug_amd.selfcheck import synth_args
+from dhaug_amd.function_aug.config import synth_args
 from dhaug_amd.models_Fk_GAN import Fk_discriminator, Fk_generator, forward_kinematics_DH_model as fkm
 B = int(os.environ.get("STAMP_B", "65536"))
 args = synth_args(B, 256)
