@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the DH-AUG hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fwd|fk_gen_fwd|gan_step|fk] [--batch 65536]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fwd|fk_gen_fwd|gan_step|video|fk] [--batch 65536]
 
 One "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
-    fwd        (default) FK + Gen + D3 + D2 forward, B = 65 536 poses per GPU, D = 256, bf16 dense layers, fp32 FK
-               (north_star's target workload; superset of BASELINE.json configs[1])
+    fwd        (default) FK + Gen + D3 + D2 forward, B = 65 536 poses per GPU, D = 256, fp32 FK
+               (north_star's target workload; superset of BASELINE.json configs[1]).  Timed in BOTH arithmetics of the dense
+               layers: `value` = bf16 (one MFMA pass), `value_parity` = f16x3 (fp16 hi+lo operands, three MFMA terms --
+               the mode that meets the 1e-4 logit tolerance against the fp32 reference, tests/test_gpu_models.py)
     fk_gen_fwd FK + Gen forward only (configs[1] exactly)
     gan_step   full single-frame GAN iteration (configs[2]/[3]): 2+2 WGAN-GP critic steps (flip copies), G step every
                5th iteration, fused Adam; with N > 1 one RCCL all-reduce per optimizer step
+    video      multi-frame GAN iteration (configs[4]): B = 512 clips x R = 9 frames, DenseDim 1000, four critics
     fk         the FK kernel alone on B poses
-N > 1: one process per GPU (torch.distributed.run), the batch shards across ranks (B per rank, weak scaling); the
-forward workloads have no exchange step, gan_step all-reduces the flat gradient bucket of the network being stepped.
-Rank 0 prints ONE JSON line.
+N > 1: one process per GPU.  Launched by torch.distributed.run (RANK / WORLD_SIZE in the environment) the process is a rank;
+launched plainly with --gpus N it starts the N ranks itself, before touching the GPU.  The batch shards across ranks
+(B per rank, weak scaling); the forward workloads have no exchange step, the training workloads all-reduce the flat
+gradient bucket of the network being stepped.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -20,27 +24,51 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, MI355X_MICROARCH.md
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 / fp16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0              # HBM3E spec, MI355X_MICROARCH.md (6.29 TB/s measured copy ceiling)
 FK_BYTES_PER_POSE = 412            # 37+15+3 fp32 in, 48 fp32 out
+WORKLOADS = {"fwd": "FK+Gen+D3+D2 forward", "fk_gen_fwd": "FK+Gen forward",
+             "gan_step": "full single-frame GAN iteration (WGAN-GP critics x4, G every 5th, Adam)",
+             "video": "multi-frame GAN iteration (B clips x R frames; D3, D2 + two motion critics, G every 5th, Adam)",
+             "fk": "FK kernel only"}
 
 
-def mac_per_pose(D):
-    gen = 128 * D + 6 * D * D + 35 * D
+# ------------------------------------------------------------------------------------------------ FLOP accounting
+def mac_per_pose(D, R=1):
+    """multiply-accumulates per pose of one forward pass, from the layer shapes"""
+    gen = (128 * D + 6 * D * D + 35 * R * D) / R
     d3 = 78 * D + 12 * D * D + 200 * D + 2 * 100 * 100 + 100
     d2 = 32 * D + 4 * D * D + D
     return gen, d3, d2
 
 
+def mac_motion(D, R):
+    """per CLIP: the two motion critics (R/models_Fk_GAN/Fk_discriminator.py:381-587)"""
+    blocks = 6 * D * D
+    m3 = (R * 15 + (R - 1) * 15 + R * 48 + (R - 1) * 48) * D + 4 * blocks + 4 * D * 100 + 2 * 100 * 100 + 100
+    m2 = (R * 32 + (R - 1) * 2) * D + 2 * blocks + 2 * D * 100 + 2 * 100 * 100 + 100
+    return m3, m2
+
+
+def critic_step_flops(mac, mac_first, mac_out, rows):
+    """the explicit critic step (dhaug_amd/critic_step.py): forward 3B rows, backward chain 3B (the input layers only on the
+    B interpolated rows), tangent sweep B rows (no logit layer), weight gradients 3B rows"""
+    return 2.0 * rows * (3 * mac + 3 * (mac - mac_first) + mac_first + (mac - mac_out) + 3 * mac)
+
+
+def autograd_critic_step_flops(mac, rows):
+    """a critic stepped through autograd: forward + backward (x2) on real and fake, penalty forward + input backward +
+    double backward (~6 forward equivalents): 12 forward equivalents"""
+    return 2.0 * rows * 12 * mac
+
+
 def event_time(fn, iters, warm, rewarm_s=0.3):
     """average duration of fn (seconds), HIP events on the stream the kernels are launched on; rewarm_s of fn first so
     that the kernel is timed at the clocks it runs at inside the loaded step, not at those left by the previous phase"""
+    import torch
     t_end = time.perf_counter() + rewarm_s
     while time.perf_counter() < t_end:
         for _ in range(warm):
@@ -56,200 +84,6 @@ def event_time(fn, iters, warm, rewarm_s=0.3):
     e.record()
     torch.cuda.synchronize()
     return s.elapsed_time(e) * 1e-3 / iters
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--prewarm", type=float, default=1.0,
-                    help="seconds of the workload run before the W warmup steps, untimed: MI355X clocks take a few hundred ms "
-                         "of load to leave their idle state (the same step measures 0.28 ms right after start-up, 0.25 ms warm)")
-    ap.add_argument("--workload", default="fwd", choices=["fwd", "fk_gen_fwd", "gan_step", "fk"])
-    ap.add_argument("--batch", type=int, default=65536, help="poses per GPU per step")
-    ap.add_argument("--dense", type=int, default=256)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel roofline timing loops (profiling runs)")
-    a = ap.parse_args()
-
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # plain `python bench.py --gpus N`: this process becomes the launcher.  It has not touched the GPU (importing
-        # torch does not initialise HIP) and never will: it starts N rank processes and relays rank 0's JSON line.
-        sys.exit(launch_ranks(a.gpus))
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d)" % (a.gpus, world, a.gpus))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" = RCCL over xGMI on ROCm.  DHAUG_DIST_BACKEND=gloo lets the multi-rank path be rehearsed with all
-        # ranks on one GPU (RCCL refuses duplicate devices).
-        dist.init_process_group(os.environ.get("DHAUG_DIST_BACKEND", "nccl"))
-    local = local % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
-    import dhaug_amd
-    from dhaug_amd import ops
-    from dhaug_amd.function_aug.config import synth_args
-    from dhaug_amd.models_Fk_GAN import model_fk_gan_train as T
-    from dhaug_amd.models_Fk_GAN.forward_kinematics_DH_model import Forward_Kinematics_DH_Model
-    from dhaug_amd.models_Fk_GAN.Fk_discriminator import score_fake_pair
-    from dhaug_amd.common.camera import camera_params9
-    from dhaug_amd.common.h36m_dataset import h36m_cameras_extrinsic_params, h36m_cameras_intrinsic_params
-    dhaug_amd._lib.lib()
-
-    B, D = a.batch, a.dense
-    args = synth_args(B, D)
-    torch.manual_seed(1234 + rank)
-    fk = Forward_Kinematics_DH_Model(args, ["S1"], None)
-    models = T.my_get_poseFk_model(args, None, fk)
-    G, D3, D2 = models["model_G"], models["model_d3d"], models["model_d2d"]
-    if world > 1:                                # data-parallel replicas start from rank 0's weights
-        for k in ("optimizer_G", "optimizer_d3d", "optimizer_d2d"):
-            dist.broadcast(models[k].flat_param, 0)
-
-    # synthetic inputs, resident in HBM (BASELINE.md section 4)
-    ext = h36m_cameras_extrinsic_params["S1"][0]
-    quat, trans = [float(v) for v in ext["orientation"]], [float(v) / 1000.0 for v in ext["translation"]]
-    cam9 = camera_params9(h36m_cameras_intrinsic_params[0])
-    ang = (torch.randn(B, 37, device=dev) * 40).clamp(-180, 180)
-    bl = torch.rand(B, 15, device=dev) * 0.4 + 0.1
-    real_world = ops.fk_forward(ang, bl, torch.randn(B, 3, device=dev).clamp(-10, 10) * 0.3)
-    real_cam, real_2d = ops.world_to_camera_project(real_world, quat, trans, cam9)
-    cam_param = torch.zeros(B, 16, device=dev)
-    cam_param[:, 9:13] = torch.tensor(quat, device=dev)
-    cam_param[:, 13:16] = torch.tensor(trans, device=dev)
-    G.GAN_generator_get_bone_length(real_cam)
-    z = torch.randn(B, 128, device=dev)
-    root = torch.randn(B, 3, device=dev)
-    it = [0]
-
-    def step_fk():
-        ops.fk_forward(ang, bl, root)
-
-    def step_fk_gen():
-        with torch.no_grad():
-            return G(z)
-
-    def step_fwd():
-        with torch.no_grad():
-            fw, xc, kcs, p2 = G.sample_for_critics(z, (quat, trans, cam9), inputs_bf16=True)   # FK tail + critic inputs, one launch
-            l3, l2 = score_fake_pair(D3, D2, xc, kcs, p2)                      # both critics, one launch
-        return l3, l2
-
-    def step_gan():
-        T.gan_iteration(args, models, real_cam, cam_param, real_2d, ["S1"], summary=None, writer=None,
-                        do_g_step=(it[0] % 5 == 4), camera=(quat, trans, cam9))
-        it[0] += 1
-
-    steps = {"fk": step_fk, "fk_gen_fwd": step_fk_gen, "fwd": step_fwd, "gan_step": step_gan}
-
-    def timed(fn, k, w):
-        for _ in range(w):
-            fn()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(k):
-            fn()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([t], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t = tt.item()
-        return t
-
-    if a.prewarm > 0:                                   # bring the clocks up (untimed; W warmup steps still follow)
-        if world > 1:
-            # a step of the training workload holds a collective: every rank must run the same number of them, so the
-            # pre-warm is a step count here (~prewarm seconds at the single-GPU rates), not a wall-clock loop
-            for _ in range(max(1, int(a.prewarm * (45 if a.workload == "gan_step" else 3500)))):
-                steps[a.workload]()
-            torch.cuda.synchronize()
-        else:
-            t_end = time.perf_counter() + a.prewarm
-            while time.perf_counter() < t_end:
-                for _ in range(20):
-                    steps[a.workload]()
-                torch.cuda.synchronize()
-    t = timed(steps[a.workload], a.steps, a.warmup)
-    value = B * world * a.steps / t
-
-    extra = {}
-    if not a.no_extra:
-        for name in ("fk_gen_fwd", "fwd", "gan_step"):
-            if name != a.workload:
-                k = max(5, min(a.steps, 50 if name != "gan_step" else 10))
-                try:
-                    te = timed(steps[name], k, 5 if name == "gan_step" else 3)
-                    extra[name + "_poses_per_s"] = B * world * k / te
-                    extra[name + "_ms_per_step"] = te / k * 1e3
-                except Exception as ex:              # never lose the headline line to an optional measurement
-                    extra[name + "_error"] = repr(ex)[:200]
-
-    if rank == 0:
-        gen_mac, d3_mac, d2_mac = mac_per_pose(D)
-        # dominant kernel of the default workload: the fused D3 forward (one launch, 1.755 MFLOP/pose at D=256)
-        from dhaug_amd import fused
-        x3 = torch.randn(B, 48, device=dev) * 0.3
-        with torch.no_grad():
-            tg = event_time(lambda: fused.critic3d(D3, x3), 100, 20)
-        kcs_t = event_time(lambda: ops.kcs_forward(x3, True, f32=False, bf16_ld=32), 100, 20)
-        tg = max(tg - kcs_t, 1e-9)                       # critic3d() = KCS kernel + fused kernel
-        roofline = {"kernel": "fused_mlp_kernel (Fk_3D_Discriminator forward, M=%d, D=%d, 17 layers in one launch)" % (B, D),
-                    "bound": "mfma", "achieved": 2.0 * d3_mac * B / tg / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": 2.0 * d3_mac * B / tg / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                    "traffic": pmc_traffic("fused_mlp_kernel", "d3_") if (B, D) == (65536, 256) else None,
-                    "avg_us": tg * 1e6, "algorithmic_flop_per_pose": 2 * d3_mac}
-        xb = torch.randn(B, D, device=dev).to(torch.bfloat16)
-        wb = (torch.randn(D, D, device=dev) / D ** 0.5).to(torch.bfloat16)
-        bias = torch.zeros(D, device=dev)
-        tl = event_time(lambda: ops.gemm_nt(xb, wb, D, D, bias=bias, res_bf16=xb, act=1, out_bf16=True), 50, 10)
-        roofline_layer = {"kernel": "gemm_nt256s_kernel<16,1> (training path: one M=%d, N=K=%d layer, bias+residual+ReLU)" % (B, D),
-                          "bound": "hbm", "achieved": (3 * B * D * 2 + D * D * 2) / tl / 1e9, "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "frac": (3 * B * D * 2 + D * D * 2) / tl / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                          "avg_us": tl * 1e6, "tflops": 2.0 * B * D * D / tl / 1e12}
-        nfk = 1 << 22
-        a4 = (torch.rand(nfk, 37, device=dev) * 2 - 1) * 180
-        b4 = torch.rand(nfk, 15, device=dev) * 0.4 + 0.1
-        r4 = torch.randn(nfk, 3, device=dev)
-        tf = event_time(lambda: ops.fk_forward(a4, b4, r4), 20, 5)
-        tf_b = event_time(step_fk, 50, 10)
-        roofline_fk = {"kernel": "fk_forward_kernel<0,16,true>", "bound": "hbm", "achieved": FK_BYTES_PER_POSE * nfk / tf / 1e9,
-                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": FK_BYTES_PER_POSE * nfk / tf / 1e9 / HBM_PEAK_GBS,
-                       "traffic": pmc_traffic("fk_forward_kernel<0; 16; true; false>"), "algorithmic_bytes": FK_BYTES_PER_POSE * nfk, "poses_per_launch": nfk, "avg_us": tf * 1e6,
-                       "at_batch": {"poses": B, "avg_us": tf_b * 1e6, "achieved": FK_BYTES_PER_POSE * B / tf_b / 1e9}}
-        del a4, b4, r4
-
-        cpu = None
-        if world == 1 and not a.no_cpu_baseline:
-            cpu = cpu_baseline(a.workload, D, {k: v.detach().cpu() for k, v in G.state_dict().items()},
-                               {k: v.detach().cpu() for k, v in D3.state_dict().items()},
-                               {k: v.detach().cpu() for k, v in D2.state_dict().items()}, quat, trans, cam9)
-        flops = {"fk": 2.5e3, "fk_gen_fwd": 2.0 * gen_mac, "fwd": 2.0 * (gen_mac + d3_mac + d2_mac)}.get(a.workload)
-        out = {"metric": "augmented poses/sec (FK+GAN step), 16-joint batch=65536", "value": value, "unit": "poses/s",
-               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "prewarm_s": a.prewarm, "ms_per_step": t / a.steps * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": {"fwd": "FK+Gen+D3+D2 forward", "fk_gen_fwd": "FK+Gen forward",
-                                       "gan_step": "full single-frame GAN iteration (WGAN-GP critics x4, G every 5th, Adam)",
-                                       "fk": "FK kernel only"}[a.workload],
-                          "batch_per_gpu": B, "global_batch": B * world, "dense_dim": D, "preAngle": True,
-                          "fk_dtype": "f32", "dense_dtype": "bf16 MFMA, fp32 accumulate"},
-               "roofline": roofline, "roofline_fk": roofline_fk, "roofline_layer": roofline_layer, "cpu_baseline": cpu, "extra": extra}
-        if flops:
-            out["algorithmic_tflops"] = flops * value / 1e12
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
 
 
 def launch_ranks(n):
@@ -273,8 +107,323 @@ def launch_ranks(n):
     return rc
 
 
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--prewarm", type=float, default=1.0,
+                    help="seconds of the workload run before the W warmup steps, untimed: MI355X clocks take a few hundred ms "
+                         "of load to leave their idle state (the same step measures 0.28 ms right after start-up, 0.25 ms warm)")
+    ap.add_argument("--workload", default="fwd", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="poses per GPU per step (video: clips per GPU); default 65536 (512)")
+    ap.add_argument("--dense", type=int, default=None, help="DenseDim (default 256; video 1000)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "parity"],
+                    help="arithmetic of the dense layers in the forward workloads that `value` is measured in; the other one "
+                         "is reported beside it (value_parity / value_bf16)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel roofline timing loops (profiling runs)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous only: every rank joins the process group, the timing exchange runs, rank 0 prints the line "
+                         "(no GPU work; with DHAUG_DIST_BACKEND=gloo this rehearses the N-rank launch path on a CPU box)")
+    return ap.parse_args(argv)
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  It has not touched the GPU (importing
+        # torch does not initialise HIP) and never will: it starts N rank processes and relays rank 0's JSON line.
+        sys.exit(launch_ranks(a.gpus))
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d)" % (a.gpus, world, a.gpus))
+    backend = os.environ.get("DHAUG_DIST_BACKEND", "nccl")        # "nccl" = RCCL over xGMI on ROCm; gloo: CPU rehearsal
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend)
+    if a.dry_run:
+        tt = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            dist.barrier()
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "augmented poses/sec (FK+GAN step), 16-joint batch=65536", "dry_run": True,
+                              "n_gpus": world, "max_over_ranks": tt.item(), "backend": backend if world > 1 else None}))
+        return
+    local = local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import dhaug_amd
+    from dhaug_amd import _lib, ops, parallel
+    from dhaug_amd.function_aug.config import synth_args
+    from dhaug_amd.models_Fk_GAN import model_fk_gan_train as T
+    from dhaug_amd.models_Fk_GAN import video_GAN_fun as V
+    from dhaug_amd.models_Fk_GAN.forward_kinematics_DH_model import Forward_Kinematics_DH_Model
+    from dhaug_amd.models_Fk_GAN.Fk_discriminator import score_fake_pair
+    from dhaug_amd.common.camera import camera_params9
+    from dhaug_amd.common.h36m_dataset import h36m_cameras_extrinsic_params, h36m_cameras_intrinsic_params
+    _lib.lib()
+
+    video = a.workload == "video"
+    B = a.batch if a.batch is not None else (512 if video else 65536)
+    D = a.dense if a.dense is not None else (1000 if video else 256)
+    R = 9 if video else 1
+    if video:
+        args = synth_args(B, D, single_or_multi_train_mode="multi", architecture="3,3", video_Dis_DenseDim_3D=D,
+                          video_Dis_DenseDim_2D=D, single_dis_warmup_epoch=0)
+    else:
+        args = synth_args(B, D)
+    torch.manual_seed(1234 + rank)
+    fk = Forward_Kinematics_DH_Model(args, ["S1"], None)
+    models = T.video_mode_my_get_poseFk_model(args, None, fk, R) if video else T.my_get_poseFk_model(args, None, fk)
+    G, D3, D2 = models["model_G"], models["model_d3d"], models["model_d2d"]
+    opts = [v for k, v in models.items() if k.startswith("optimizer")]
+    if world > 1:                                # data-parallel replicas start from rank 0's weights
+        parallel.broadcast_optimizers(opts, 0)
+    bucket_bytes = {k[len("optimizer_"):]: v.flat_grad.numel() * 4 for k, v in models.items() if k.startswith("optimizer")}
+
+    # synthetic inputs, resident in HBM (BASELINE.md section 4)
+    N = B * R
+    ext = h36m_cameras_extrinsic_params["S1"][0]
+    quat, trans = [float(v) for v in ext["orientation"]], [float(v) / 1000.0 for v in ext["translation"]]
+    cam9 = camera_params9(h36m_cameras_intrinsic_params[0])
+    ang = (torch.randn(N, 37, device=dev) * 40).clamp(-180, 180)
+    bl = torch.rand(N, 15, device=dev) * 0.4 + 0.1
+    real_world = ops.fk_forward(ang, bl, torch.randn(N, 3, device=dev).clamp(-10, 10) * 0.3)
+    real_cam, real_2d = ops.world_to_camera_project(real_world, quat, trans, cam9)
+    cam_param = torch.zeros(B, 16, device=dev)
+    cam_param[:, 9:13] = torch.tensor(quat, device=dev)
+    cam_param[:, 13:16] = torch.tensor(trans, device=dev)
+    G.GAN_generator_get_bone_length(real_cam)
+    z = torch.randn(B, 128, device=dev)
+    root = torch.randn(N, 3, device=dev)
+    it = [0]
+    summary = argparse.Namespace(epoch=10, train_iter_num=0)
+
+    def set_precision(p):
+        for m in (G, D3, D2):
+            m.precision = p
+
+    def step_fk():
+        ops.fk_forward(ang, bl, root)
+
+    def step_fk_gen():
+        with torch.no_grad():
+            return G(z)
+
+    def step_fwd():
+        with torch.no_grad():
+            bf = G.precision == "bf16"
+            fw, xc, kcs, p2 = G.sample_for_critics(z, (quat, trans, cam9), inputs_bf16=bf)   # FK tail + critic inputs, one launch
+            l3, l2 = score_fake_pair(D3, D2, xc, kcs, p2)                                    # both critics, one launch
+        return l3, l2
+
+    def step_gan():
+        T.gan_iteration(args, models, real_cam, cam_param, real_2d, ["S1"], summary=None, writer=None,
+                        do_g_step=(it[0] % 5 == 4), camera=(quat, trans, cam9))
+        it[0] += 1
+
+    def step_video():
+        V.video_gan_iteration(args, models, real_cam.reshape(B, R, 16, 3), cam_param, real_2d.reshape(B, R, 16, 2), ["S1"],
+                              summary, None, do_g_step=(it[0] % 5 == 4), camera=(quat, trans, cam9))
+        it[0] += 1
+
+    steps = {"fk": step_fk, "fk_gen_fwd": step_fk_gen, "fwd": step_fwd, "gan_step": step_gan, "video": step_video}
+
+    def timed(fn, k, w):
+        for _ in range(w):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        c0 = _lib.CALLS[0]
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t = time.perf_counter() - t0
+        calls = (_lib.CALLS[0] - c0) / k
+        if world > 1:
+            tt = torch.tensor([t], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = tt.item()
+        return t, calls
+
+    def prewarm(fn, training):
+        if a.prewarm <= 0:
+            return
+        if world > 1 and training:
+            # a training step holds a collective: every rank must run the same number of them, so the pre-warm is a step
+            # count here (~prewarm seconds at the single-GPU rates), not a wall-clock loop
+            for _ in range(max(1, int(a.prewarm * 80))):
+                fn()
+            torch.cuda.synchronize()
+            return
+        t_end = time.perf_counter() + a.prewarm
+        while time.perf_counter() < t_end:
+            for _ in range(20 if not training else 2):
+                fn()
+            torch.cuda.synchronize()
+
+    training = a.workload in ("gan_step", "video")
+    fwd_like = a.workload in ("fwd", "fk_gen_fwd")
+    main_prec = "f16x3" if (a.precision == "parity" and fwd_like) else "bf16"
+    set_precision(main_prec)
+    prewarm(steps[a.workload], training)
+    t, calls = timed(steps[a.workload], a.steps, a.warmup)
+    value = N * world * a.steps / t
+    out = {"metric": "augmented poses/sec (FK+GAN step), 16-joint batch=65536", "value": value, "unit": "poses/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "prewarm_s": a.prewarm, "ms_per_step": t / a.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16" if main_prec == "bf16" else "f16x3 (fp16 hi+lo operands, fp32 accumulate)", "data": "synthetic",
+           "config": {"workload": WORKLOADS[a.workload], "batch_per_gpu": B, "frames": R, "poses_per_gpu_per_step": N,
+                      "global_batch": N * world, "dense_dim": D, "preAngle": True, "fk_dtype": "f32",
+                      "dense_dtype": "bf16 MFMA, fp32 accumulate" if main_prec == "bf16" else "3 x fp16 MFMA (hi+lo operands), fp32 accumulate"},
+           "c_abi_calls_per_step": calls}
+
+    # the forward workload in the OTHER arithmetic, same inputs (bf16 <-> parity), with its own step time
+    if fwd_like:
+        other = "bf16" if main_prec == "f16x3" else "f16x3"
+        set_precision(other)
+        to, _ = timed(steps[a.workload], max(5, a.steps // 2), max(3, a.warmup // 2))
+        k = max(5, a.steps // 2)
+        key = "value_bf16" if other == "bf16" else "value_parity"
+        out[key] = N * world * k / to
+        out[("ms_per_step_bf16" if other == "bf16" else "ms_per_step_parity")] = to / k * 1e3
+        out["parity_mode"] = ("f16x3: logits <= 1e-4 rel / poses <= 1e-5 m vs the fp32 reference "
+                              "(tests/test_gpu_models.py::test_fused_forward_vs_reference_golden)")
+        set_precision(main_prec)
+    if training and world > 1:
+        out["allreduce_bytes_per_optimizer_step"] = bucket_bytes
+
+    extra = {}
+    if not a.no_extra and not video:
+        set_precision("bf16")
+        for name in ("fk_gen_fwd", "fwd", "gan_step"):
+            if name != a.workload:
+                k = max(5, min(a.steps, 50 if name != "gan_step" else 10))
+                try:
+                    te, ce = timed(steps[name], k, 5 if name == "gan_step" else 3)
+                    extra[name + "_poses_per_s"] = N * world * k / te
+                    extra[name + "_ms_per_step"] = te / k * 1e3
+                    extra[name + "_c_abi_calls_per_step"] = ce
+                except Exception as ex:              # never lose the headline line to an optional measurement
+                    extra[name + "_error"] = repr(ex)[:200]
+        set_precision(main_prec)
+    out["extra"] = extra
+
+    gen_mac, d3_mac, d2_mac = mac_per_pose(D, R)
+    # FLOPs of the timed workload from the layer shapes
+    if a.workload == "gan_step":
+        d3_first, d2_first = 78 * D, 32 * D
+        per_it = (2 * critic_step_flops(d3_mac, d3_first, 100, B) + 2 * critic_step_flops(d2_mac, d2_first, D, B)
+                  + 2.0 * gen_mac * B                                              # sampling pass
+                  + 0.2 * (3 * 2.0 * (gen_mac + d3_mac + d2_mac) * B + 2.0 * (d3_mac + d2_mac) * B))   # G step (+ flipped evaluations)
+        flops = per_it
+    elif a.workload == "video":
+        m3, m2 = mac_motion(D, R)
+        dd3, dd2 = mac_per_pose(args.Dis_DenseDim_3D)[1], mac_per_pose(args.Dis_DenseDim_2D)[2]
+        gmac = mac_per_pose(args.Gen_DenseDim, R)[0]
+        d3_first, d2_first = 78 * args.Dis_DenseDim_3D, 32 * args.Dis_DenseDim_2D
+        per_it = (2 * critic_step_flops(dd3, d3_first, 100, N) + 2 * critic_step_flops(dd2, d2_first, args.Dis_DenseDim_2D, N)
+                  + 4 * autograd_critic_step_flops(m3, B) + 4 * autograd_critic_step_flops(m2, B) + 2.0 * gmac * N
+                  + 0.2 * (3 * 2.0 * ((gmac + dd3 + dd2) * N + 2 * (m3 + m2) * B) + 2.0 * ((dd3 + dd2) * N + 2 * (m3 + m2) * B)))
+        flops = per_it
+    else:
+        flops = {"fk": 2.5e3 * N, "fk_gen_fwd": 2.0 * gen_mac * N, "fwd": 2.0 * (gen_mac + d3_mac + d2_mac) * N}[a.workload]
+    out["algorithmic_tflops"] = flops * world * a.steps / t / 1e12
+    out["algorithmic_flop_per_step_per_gpu"] = flops
+    if training:
+        out["roofline_step"] = {"bound": "mfma", "achieved": flops * a.steps / t / 1e12 if world == 1 else flops * a.steps / t / 1e12,
+                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": flops * a.steps / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                                "note": "whole iteration (per GPU), FLOPs from the layer shapes; layer-by-layer GEMMs are HBM-bound "
+                                        "(see roofline_layer), the iteration's floor is launch gaps + HBM, not the matrix pipe"}
+
+    if rank == 0 and not a.no_roofline and not video:
+        from dhaug_amd import fused
+        set_precision("bf16")
+        x3 = torch.randn(B, 48, device=dev) * 0.3
+        kcs_b = ops.kcs_forward(x3, True, f32=False, bf16_ld=32)[1]
+        kcs_f = ops.kcs_forward(x3, True, f32=True)[0]
+        with torch.no_grad():
+            tg = event_time(lambda: fused.critic3d(D3, x3, kcs=kcs_b), 100, 20)
+            tp = event_time(lambda: fused.critic3d(D3, x3, kcs=kcs_f, mode="f16x3"), 40, 8)
+        fl = 2.0 * d3_mac * B
+        out["roofline"] = {"kernel": "fused_mlp_kernel (Fk_3D_Discriminator forward, M=%d, D=%d, 17 layers in one launch)" % (B, D),
+                           "bound": "mfma", "achieved": fl / tg / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": fl / tg / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                           "traffic": pmc_traffic("fused_mlp_kernel", "d3_") if (B, D) == (65536, 256) else None,
+                           "traffic_source": pmc_stamp(), "avg_us": tg * 1e6, "algorithmic_flop_per_pose": 2 * d3_mac}
+        out["roofline_parity"] = {"kernel": "fused_mlp_x3_kernel (same program, fp16 hi+lo operands: 3 MFMA terms per product)",
+                                  "bound": "mfma", "achieved": fl / tp / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": fl / tp / 1e12 / MFMA_BF16_PEAK_TFLOPS, "executed_tflops": 3 * fl / tp / 1e12,
+                                  "executed_frac": 3 * fl / tp / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "avg_us": tp * 1e6,
+                                  "note": "achieved counts ALGORITHMIC flops (the reference's fp32 layers); the kernel executes 3x"}
+        xb = torch.randn(B, D, device=dev).to(torch.bfloat16)
+        wb = (torch.randn(D, D, device=dev) / D ** 0.5).to(torch.bfloat16)
+        bias = torch.zeros(D, device=dev)
+        tl = event_time(lambda: ops.gemm_nt(xb, wb, D, D, bias=bias, res_bf16=xb, act=1, out_bf16=True), 50, 10)
+        out["roofline_layer"] = {"kernel": "gemm_nt256s_kernel<16,1> (training path: one M=%d, N=K=%d layer, bias+residual+ReLU)" % (B, D),
+                                 "bound": "hbm", "achieved": (3 * B * D * 2 + D * D * 2) / tl / 1e9, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": (3 * B * D * 2 + D * D * 2) / tl / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                 "avg_us": tl * 1e6, "tflops": 2.0 * B * D * D / tl / 1e12}
+        nfk = 1 << 22
+        a4 = (torch.rand(nfk, 37, device=dev) * 2 - 1) * 180
+        b4 = torch.rand(nfk, 15, device=dev) * 0.4 + 0.1
+        r4 = torch.randn(nfk, 3, device=dev)
+        tf = event_time(lambda: ops.fk_forward(a4, b4, r4), 20, 5)
+        tf_b = event_time(step_fk, 50, 10)
+        out["roofline_fk"] = {"kernel": "fk_forward_kernel<0,16,true>", "bound": "hbm", "achieved": FK_BYTES_PER_POSE * nfk / tf / 1e9,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": FK_BYTES_PER_POSE * nfk / tf / 1e9 / HBM_PEAK_GBS,
+                              "traffic": pmc_traffic("fk_forward_kernel<0; 16; true; false>"), "traffic_source": pmc_stamp(),
+                              "algorithmic_bytes": FK_BYTES_PER_POSE * nfk, "poses_per_launch": nfk, "avg_us": tf * 1e6,
+                              "at_batch": {"poses": N, "avg_us": tf_b * 1e6, "achieved": FK_BYTES_PER_POSE * N / tf_b / 1e9}}
+        del a4, b4, r4
+        set_precision(main_prec)
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not a.no_cpu_baseline:
+            sd = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}
+            if video:
+                cpu = cpu_baseline_video(D, R, sd(G), sd(D3), sd(D2), sd(models["model_motion_d3d"]), sd(models["model_motion_d2d"]),
+                                         quat, trans, cam9)
+            else:
+                cpu = cpu_baseline(a.workload, D, sd(G), sd(D3), sd(D2), quat, trans, cam9)
+        out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+PROFILE_TAG = "r02"
+
+
+def pmc_stamp():
+    """which committed profile the `traffic` numbers were read from (they are NOT measured by this run)"""
+    path = os.path.join(ROOT, "profiles", "%s_pmc_fetch_summary.csv" % PROFILE_TAG)
+    stamp = os.path.join(ROOT, "profiles", "%s_STAMP.txt" % PROFILE_TAG)
+    if not os.path.exists(path):
+        return None
+    return {"file": "profiles/%s_pmc_*_summary.csv" % PROFILE_TAG,
+            "collected": open(stamp).read().strip() if os.path.exists(stamp) else "unknown",
+            "note": "rocprofv3 --pmc passes of tools/collect_profiles.sh, not this run"}
+
+
 def pmc_traffic(kernel_substr, prefix=""):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summaries (profiles/r01_pmc_*_summary.csv,
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summaries (profiles/<tag>_pmc_*_summary.csv,
     collected by tools/collect_profiles.sh with separate --pmc FETCH_SIZE / WRITE_SIZE passes).  The largest dispatch
     of the kernel is the one bench.py times; prefix "d3_" selects the passes that ran the 3D critic's launch alone (the
     three networks share one kernel name).  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts half of the
@@ -282,7 +431,7 @@ def pmc_traffic(kernel_substr, prefix=""):
     import csv
     tot = 0.0
     for tag, mult in ((prefix + "fetch", 2.0), (prefix + "write", 1.0)):
-        path = os.path.join(ROOT, "profiles", "r01_pmc_%s_summary.csv" % tag)
+        path = os.path.join(ROOT, "profiles", "%s_pmc_%s_summary.csv" % (PROFILE_TAG, tag))
         if not os.path.exists(path):
             return None
         hit = [float(r["max"]) for r in csv.DictReader(open(path)) if kernel_substr in r["kernel"]]
@@ -304,11 +453,24 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(workload, D, sdG, sd3, sd2, quat, trans, cam9):
-    """The oracle (CPU restatement, 'port') timed on this box's host cores on a bounded sample of the workload."""
-    from oracle import dhaug_oracle as O
+def _time_cpu(one, poses_per_call, seconds=12.0, note=""):
+    import torch
     cores = usable_cores()
     torch.set_num_threads(cores)
+    one()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds and n < 2000:
+        one()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": poses_per_call * n / dt, "unit": "poses/s", "cores": cores, "kind": "port",
+            "sample": "%d batches of %d poses, fp32 torch-CPU oracle, %.1f s %s" % (n, poses_per_call, dt, note)}
+
+
+def cpu_baseline(workload, D, sdG, sd3, sd2, quat, trans, cam9):
+    """The oracle (CPU restatement, 'port') timed on this box's host cores on a bounded sample of the workload."""
+    import torch
+    from oracle import dhaug_oracle as O
     Bs = 4096
     g = torch.Generator().manual_seed(0)
     z = torch.randn(Bs, 128, generator=g)
@@ -330,20 +492,33 @@ def cpu_baseline(workload, D, sdG, sd3, sd2, quat, trans, cam9):
             O.d3_forward(fw - fw[:, :1], sd3)
             O.d2_forward(O.project_to_2d(O.world_to_camera(fw, q, tr), c9), sd2)
 
+    note = ""
     if workload == "gan_step":
-        wl = "fwd"
         workload = "fwd"
         note = "forward part only (FK+Gen+D3+D2); the oracle's full step is timed in tests at small batch"
-    else:
-        note = ""
-    one()
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < 12.0 and n < 2000:
-        one()
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": Bs * n / dt, "unit": "poses/s", "cores": cores, "kind": "port",
-            "sample": "%d batches of %d poses, fp32 torch-CPU oracle, %.1f s %s" % (n, Bs, dt, note)}
+    return _time_cpu(one, Bs, note=note)
+
+
+def cpu_baseline_video(D, R, sdG, sd3, sd2, sdm3, sdm2, quat, trans, cam9):
+    import torch
+    from oracle import dhaug_oracle as O
+    Bs = 64
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(Bs, 128, generator=g)
+    bl = torch.rand(Bs * R, 15, generator=g) * 0.4 + 0.1
+    sc = torch.randint(-200, 200, (Bs, 8), generator=g) / 1000.0
+    q, tr, c9 = torch.tensor([quat]), torch.tensor([trans]), torch.tensor([cam9]).repeat(Bs * R, 1)
+
+    def one():
+        with torch.no_grad():
+            fake, _, _ = O.generator_forward(z, sdG, bl, sc, frames=R)
+            fw = fake.reshape(-1, 16, 3)
+            fc = fw - fw[:, :1]
+            p2 = O.project_to_2d(O.world_to_camera(fw, q, tr), c9)
+            O.d3_forward(fc, sd3); O.d2_forward(p2, sd2)
+            O.motion_d3_forward(fc.reshape(-1, 48), sdm3, R); O.motion_d2_forward(p2.reshape(-1, 32), sdm2, R)
+
+    return _time_cpu(one, Bs * R, note="forward part only (video Gen + D3 + D2 + both motion critics, DenseDim %d)" % D)
 
 
 if __name__ == "__main__":

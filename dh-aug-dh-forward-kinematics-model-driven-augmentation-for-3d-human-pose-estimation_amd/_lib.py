@@ -31,6 +31,7 @@ SIGNATURES = {
     "dhaug_gemm_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i32,
                         _f32, _vp],
     "dhaug_gemm_tn_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp],
+    "dhaug_gemm_tn_bf16_rows": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
     "dhaug_cast_pad_bf16": [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp],
     "dhaug_cast_transpose_bf16": [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp],
     "dhaug_split_bf16": [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp],
@@ -39,6 +40,11 @@ SIGNATURES = {
     "dhaug_act_backward_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i32, _f32, _vp],
     "dhaug_act_backward_f32": [_vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "dhaug_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp],
+    "dhaug_adam_step_dev": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _vp, _f32, _vp],
+    "dhaug_counter_add": [_vp, _i32, _vp],
+    "dhaug_gp_assemble": [_vp, _vp, _vp, _vp, _i64, _i64, _vp],
+    "dhaug_gp_penalty": [_vp, _vp, _vp, _i64, _i64, _f32, _vp],
+    "dhaug_critic_scalars": [_vp, _i64, _vp, _i64, _f32, _vp, _vp],
 }
 
 class MlpUnit(ctypes.Structure):
@@ -83,12 +89,14 @@ def check(rc, name):
 
 
 _fn = {}
+CALLS = [0]          # C-ABI calls made by this process (bench.py reports calls per step)
 
 
 def call(name, *args):
     f = _fn.get(name)
     if f is None:
         f = _fn[name] = getattr(lib(), name)
+    CALLS[0] += 1
     rc = f(*args)
     if rc != 0:
         check(rc, name)

@@ -157,8 +157,7 @@ def _raw_outer(g, x, N, K, prec, colsum=None, out=None):
     g3 = ops.split_bf16(g, 0, T, Np)          # activation-side layout: hi / mid / lo live in fixed segments
     x3 = ops.split_bf16(x, 0, T, Kp)
     M = g.shape[0]
-    out = None
-    for a, b in _PAIRS[T]:
+    for a, b in _PAIRS[T]:                     # (a given `out` is accumulated into from the first term on)
         ga = g3[:, _SEG[T][a] * Np:]
         xb = x3[:, _SEG[T][b] * Kp:]
         out = ops.gemm_tn(ga, xb, N, K, out=out, accumulate=out is not None, M=M, lda=T * Np, ldb=T * Kp)
@@ -197,9 +196,14 @@ class LinearFn(torch.autograd.Function):
                 # first-order pass under a FusedAdam bucket: the weight-gradient GEMM accumulates straight into the
                 # parameter's slot of the flat gradient (and the bias gradient, A^T * ones on the MFMA pipe, into the
                 # bias slot): no zero-fill of a temporary, no AccumulateGrad add.  autograd sees "no gradient" for W/b.
-                _raw_outer(gz, x, N, K, prec, colsum=bslot if want_b else None, out=wslot)
+                # (a logit layer's bias gradient goes through the column-sum kernel: it pairs the real and the fake half of
+                # the batch, whose cotangents cancel exactly -- see dhaug_colsum_*)
+                narrow = N < 16
+                _raw_outer(gz, x, N, K, prec, colsum=bslot if (want_b and not narrow) else None, out=wslot)
+                if want_b and narrow:
+                    ops.colsum(gz, N=N, out=bslot, accumulate=True)
                 want_b = False
-            elif want_b and prec == "bf16" and not torch.is_grad_enabled():
+            elif want_b and prec == "bf16" and not torch.is_grad_enabled() and N >= 16:
                 # first-order pass: the weight-gradient GEMM also emits the bias gradient (A^T * ones on the MFMA pipe)
                 gb = torch.empty((N,), dtype=torch.float32, device=gz.device)
                 gW = _raw_outer(gz, x, N, K, prec, colsum=gb)

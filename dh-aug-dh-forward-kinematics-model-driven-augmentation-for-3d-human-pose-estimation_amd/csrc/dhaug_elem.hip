@@ -77,21 +77,32 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ sr
     }
 }
 
-// column sums: block (x) covers 64 columns, (y) a slab of rows; 4 row-lanes per column, LDS combine, atomics out
+// column sums: block (x) covers 64 columns, (y) a slab of rows; 4 row-lanes per column, LDS combine, atomics out.
+// Summation order: with an even row count, rows r and r + M/2 are added FIRST.  The cotangent of a WGAN critic's logits
+// is -1/B on the real half of the batch and +1/B on the fake half; the reference accumulates the two halves in two
+// identical passes, so its output-bias gradient is exactly 0 and Adam (lr * g / (|g| + eps)) leaves that bias alone.
+// Pairing the halves keeps the zero exact for any B (with B = 72 an unpaired order left 1.2e-7, i.e. a full 1e-4 step).
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ src, long long ld, float* __restrict__ dst,
-                                                     long long M, long long N, long long rows_per_block) {
+                                                     long long M, long long N, long long rows_per_block, long long fold) {
     __shared__ float part[4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const long long col = (long long)blockIdx.x * 64 + cx;
     const long long r0 = (long long)blockIdx.y * rows_per_block;
     long long r1 = r0 + rows_per_block;
-    if (r1 > M) r1 = M;
+    if (r1 > M) r1 = M;                                       // M = rows walked (half the rows when folding)
     float s = 0.0f;
     if (col < N) {
         for (long long r = r0 + ry; r < r1; r += 4) {
-            if constexpr (sizeof(T) == 2) s += dhaug_bf16_to_f32((uint16_t)src[r * ld + col]);
-            else s += (float)src[r * ld + col];
+            if constexpr (sizeof(T) == 2) {
+                float a = dhaug_bf16_to_f32((uint16_t)src[r * ld + col]);
+                if (fold) a += dhaug_bf16_to_f32((uint16_t)src[(r + fold) * ld + col]);
+                s += a;
+            } else {
+                float a = (float)src[r * ld + col];
+                if (fold) a += (float)src[(r + fold) * ld + col];
+                s += a;
+            }
         }
     }
     part[ry][cx] = s;
@@ -147,6 +158,86 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// same step with the step count read from device memory (a hipGraph replays the launch; the count must not be baked in)
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, long long n, float lr,
+                                                       float b1, float b2, float eps, const int* __restrict__ step_dev,
+                                                       float gscale) {
+    const int step = *step_dev;
+    const float bc1 = (float)(1.0 - pow((double)b1, (double)step)), bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i] * gscale;
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+        const float vi = v[i] * b2 + gi * gi * (1.0f - b2);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - (lr / bc1) * (mi / denom);
+    }
+}
+__global__ void counter_add_kernel(int* p, int v) { *p += v; }
+
+// rows [0,B) = real, [B,2B) = fake, [2B,3B) = alpha*real + (1-alpha)*fake: the batch one critic step scores
+// (R/models_Fk_GAN/model_fk_gan_train.py:186-198, R/models_Fk_GAN/Fk_discriminator.py:210-216)
+__global__ __launch_bounds__(256) void gp_assemble_kernel(const float* __restrict__ real, const float* __restrict__ fake,
+                                                          const float* __restrict__ alpha, float* __restrict__ out,
+                                                          long long B, long long W) {
+    const long long total = B * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long b = i / W;
+        const float r = real[i], f = fake[i], a = alpha[b];
+        out[i] = r;
+        out[total + i] = f;
+        out[2 * total + i] = a * r + ((1.0f - a) * f);
+    }
+}
+
+// one wave per row: n = ||g_b||_2, pen[b] = (n - 1)^2, v_b = coef * (n - 1) / n * g_b  (= d/dg of coef/2 * (n-1)^2)
+__global__ __launch_bounds__(256) void gp_penalty_kernel(const float* __restrict__ g, float* __restrict__ v,
+                                                         float* __restrict__ pen, long long B, int W, float coef) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+    for (long long b = wave; b < B; b += nw) {
+        const float* row = g + b * W;
+        float ss = 0.0f;
+        for (int c = lane; c < W; c += 64) ss = fmaf(row[c], row[c], ss);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float n = sqrtf(ss), d = n - 1.0f;
+        if (lane == 0) pen[b] = d * d;
+        const float k = coef * d / n;
+        for (int c = lane; c < W; c += 64) v[b * W + c] = k * row[c];
+    }
+}
+
+// out[0..4] = D_real, D_fake, GP, Wasserstein_D = D_real - D_fake, D_cost = D_fake - D_real + GP
+// logits (3B) fp32: rows [0,B) real, [B,2B) fake; pen (B).  One workgroup.
+__global__ __launch_bounds__(1024) void critic_scalars_kernel(const float* __restrict__ logits, long long ld,
+                                                              const float* __restrict__ pen, long long B, float lambda,
+                                                              float* __restrict__ out) {
+    __shared__ float red[3][16];
+    float s[3] = {0.f, 0.f, 0.f};
+    for (long long i = threadIdx.x; i < B; i += 1024) {
+        s[0] += logits[i * ld];
+        s[1] += logits[(B + i) * ld];
+        s[2] += pen[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s[k] += __shfl_xor(s[k], o, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < 3; ++k)
+            for (int w = 0; w < 16; ++w) t[k] += red[k][w];
+        const float dr = t[0] / (float)B, df = t[1] / (float)B, gp = lambda * (t[2] / (float)B);
+        out[0] = dr; out[1] = df; out[2] = gp; out[3] = dr - df; out[4] = df - dr + gp;
+    }
+}
+
 }  // namespace
 
 template <typename T>
@@ -160,14 +251,15 @@ static int colsum_impl(const T* src, int64_t ld, float* dst, int64_t M, int64_t 
     }
     if (M == 0) return DHAUG_OK;
     DHAUG_CHECK_PTR(src);
+    const long long fold = (M % 2 == 0) ? M / 2 : 0, Mw = fold ? fold : M;           // rows walked
     const long long col_blocks = (N + 63) / 64;
     long long slabs = 1024 / col_blocks;
     if (slabs < 1) slabs = 1;
-    long long rpb = (M + slabs - 1) / slabs;
+    long long rpb = (Mw + slabs - 1) / slabs;
     if (rpb < 64) rpb = 64;
-    slabs = (M + rpb - 1) / rpb;
+    slabs = (Mw + rpb - 1) / rpb;
     hipLaunchKernelGGL(colsum_kernel<T>, dim3((unsigned)col_blocks, (unsigned)slabs), dim3(256), 0, s, src, (long long)ld,
-                       dst, (long long)M, (long long)N, rpb);
+                       dst, Mw, (long long)N, rpb, fold);
     return dhaug_launch_status();
 }
 
@@ -246,6 +338,48 @@ int dhaug_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, (long long)n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+    return dhaug_launch_status();
+}
+
+int dhaug_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                        float beta2, float eps, const int* step_dev, float grad_scale, void* stream) {
+    DHAUG_CHECK(n >= 0, DHAUG_EINVAL);
+    if (n == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(param); DHAUG_CHECK_PTR(grad); DHAUG_CHECK_PTR(exp_avg); DHAUG_CHECK_PTR(exp_avg_sq); DHAUG_CHECK_PTR(step_dev);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid1d(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, (long long)n, lr, beta1, beta2, eps, step_dev, grad_scale);
+    return dhaug_launch_status();
+}
+
+int dhaug_counter_add(int* counter, int value, void* stream) {
+    DHAUG_CHECK_PTR(counter);
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, value);
+    return dhaug_launch_status();
+}
+
+int dhaug_gp_assemble(const float* real, const float* fake, const float* alpha, float* out, int64_t B, int64_t W, void* stream) {
+    DHAUG_CHECK(B >= 0 && W >= 1, DHAUG_EINVAL);
+    if (B == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(real); DHAUG_CHECK_PTR(fake); DHAUG_CHECK_PTR(alpha); DHAUG_CHECK_PTR(out);
+    hipLaunchKernelGGL(gp_assemble_kernel, dim3(grid1d(B * W, 256)), dim3(256), 0, (hipStream_t)stream, real, fake, alpha, out,
+                       (long long)B, (long long)W);
+    return dhaug_launch_status();
+}
+
+int dhaug_gp_penalty(const float* grad, float* v, float* pen, int64_t B, int64_t W, float coef, void* stream) {
+    DHAUG_CHECK(B >= 0 && W >= 1 && W <= (1 << 20), DHAUG_EINVAL);
+    if (B == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(grad); DHAUG_CHECK_PTR(v); DHAUG_CHECK_PTR(pen);
+    hipLaunchKernelGGL(gp_penalty_kernel, dim3(grid1d((B + 3) / 4, 1)), dim3(256), 0, (hipStream_t)stream, grad, v, pen,
+                       (long long)B, (int)W, coef);
+    return dhaug_launch_status();
+}
+
+int dhaug_critic_scalars(const float* logits, int64_t ld, const float* pen, int64_t B, float lambda, float* out5, void* stream) {
+    DHAUG_CHECK(B >= 1 && ld >= 1, DHAUG_EINVAL);
+    DHAUG_CHECK_PTR(logits); DHAUG_CHECK_PTR(pen); DHAUG_CHECK_PTR(out5);
+    hipLaunchKernelGGL(critic_scalars_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, (long long)ld, pen,
+                       (long long)B, lambda, out5);
     return dhaug_launch_status();
 }
 

@@ -225,6 +225,7 @@ struct TnArgs {
     float* colsum;                 // optional [N1]: column sums of A (bias gradient), accumulated by the n2-tile-0 blocks
     long long M, N1, N2;
     long long rows_per_split, ntiles, nsplits;
+    long long cs_rows;             // the column sums cover rows [0, cs_rows) only (a multiple of the stage height)
 };
 
 constexpr int TN_BN = 64;           // output tile edge: small tiles keep the split-K partial sums (fp32 atomics, the
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
             const bf16x8 fa = tr_frag(bufA, kbase, w1 * 32 + 16 * (grp & 1), lane);
             const bf16x8 fb = tr_frag(bufB, kbase, w2 * 32 + 16 * (grp & 1), lane);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
-            if (do_cs) accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, ones, accs, 0, 0, 0);
+            if (do_cs && ms + (long long)kt * BK < p.cs_rows) accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, ones, accs, 0, 0, 0);
         }
         if (kt + 1 < nkt) lstore((kt + 1) & 1);
         __syncthreads();
@@ -431,6 +432,7 @@ __global__ __launch_bounds__(256, TM == 64 ? 2 : 1) void gemm_tn64_kernel(TnArgs
         f_lds_barrier();
         const unsigned char* sa = tsm + buf * (SA + SB);
         const unsigned char* sb = sa + SA;
+        const bool cs_stage = do_cs && ms + (long long)st * TF_ROWS < p.cs_rows;       // wave-uniform
 #pragma unroll
         for (int ks = 0; ks < TF_ROWS / 16; ++ks) {
             const int kbase = 16 * ks + 8 * (grp >> 1);
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(256, TM == 64 ? 2 : 1) void gemm_tn64_kernel(TnArgs
             for (int t = 0; t < RT; ++t) {
                 const bf16x8 fa = tf_frag<CHA>(sa, kbase, (w1 * RT + t) * 32 + 16 * (grp & 1), lane);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
-                if (do_cs) accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, ones, accs[t], 0, 0, 0);
+                if (cs_stage) accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, ones, accs[t], 0, 0, 0);
             }
         }
         f_lds_barrier();                                        // every wave is done with this stage
@@ -838,20 +840,26 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmArgs p) {
 // K = 256) but no bias seeds.  Tile j lives in operand image j % NX (NX = 4 without a second operand, 3 with one).
 // LDS: NX (x2 with a second operand) images of 16 KB + two output images + bias 1 KB = 97 / 129 KB.
 // ---------------------------------------------------------------------------------------------------------------
+// MODE bit 0: residual, bit 1: activation-backward mask; both (3): (A B^T + res) * act'(mask), the input-gradient step of a
+// residual block (gz1 W1 + gz2) * relu'(x) and its tangent twin -- three operand streams, so the ring holds 2 tiles
 template <int KS, int MODE>
 __global__ __launch_bounds__(512, 1) void gemm_nt256s_kernel(GemmArgs p) {
-    constexpr bool RES = MODE == 1, MASK = MODE == 2, SECOND = MODE != 0;
+    constexpr bool RES = (MODE & 1) != 0, MASK = (MODE & 2) != 0;
+    constexpr int NSEC = (RES ? 1 : 0) + (MASK ? 1 : 0);
+    constexpr bool SECOND = NSEC != 0;
     static_assert(KS == 8 || KS == 16, "K = 128 or 256");
     constexpr int BM = 32;
-    constexpr int NX = SECOND ? 3 : 4;                                       // operand images in the ring: NX - 1 tiles ahead
+    constexpr int NX = 4 - NSEC;                                             // operand images in the ring: NX - 1 tiles ahead
     constexpr int S = 2 * KS, XP = S * 16;                                   // chunks per operand row, operand pitch (bytes)
     constexpr int IMG = BM * F_PITCH;                                        // bytes per image (operand images use XP <= 512)
-    constexpr int NCX = BM * S / 256, NCR = SECOND ? BM * 32 / 256 : 0;      // copies per mover lane: operand / second operand
+    constexpr int NCR1 = BM * 32 / 256;                                      // copies per mover lane of ONE second operand
+    constexpr int NCX = BM * S / 256, NCR = NSEC * NCR1;                     // copies per mover lane: operand / second operands
     constexpr int RCH = BM * 32 / 256;                                       // output chunks per mover lane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sX = smem;                                                // [NX][IMG]
-    unsigned char* sR = smem + NX * IMG;                                     // [NX][IMG]  (MODE 1/2)
-    unsigned char* sO = smem + (SECOND ? 2 : 1) * NX * IMG;                  // [2][IMG]
+    unsigned char* sR = smem + NX * IMG;                                     // [NX][IMG]  residual (or the mask when there is no residual)
+    unsigned char* sM = RES && MASK ? smem + 2 * NX * IMG : sR;              // [NX][IMG]  mask
+    unsigned char* sO = smem + (1 + NSEC) * NX * IMG;                        // [2][IMG]
     float* sBias = reinterpret_cast<float*>(sO + 2 * IMG);                   // [256]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -872,13 +880,18 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256s_kernel(GemmArgs p) {
                 const int row0 = (cw * NCX + q) * RW, row = row0 + lane / S, c = (lane % S) ^ (row & 15);
                 f_copy16(p.A + (m0 + row) * p.lda + c * 8, sX + buf * IMG + row0 * XP);
             }
-            if (SECOND) {
-                const uint16_t* src = RES ? p.res : p.dmask;
-                const long long ld = RES ? p.ld_res : p.ld_dmask;
+            if (RES) {
 #pragma unroll
-                for (int q = 0; q < NCR; ++q) {
-                    const int row0 = (cw * NCR + q) * 2, row = row0 + (lane >> 5), c = (lane & 31) ^ (row & 15);
-                    f_copy16(src + (m0 + row) * ld + c * 8, sR + buf * IMG + row0 * F_PITCH);
+                for (int q = 0; q < NCR1; ++q) {
+                    const int row0 = (cw * NCR1 + q) * 2, row = row0 + (lane >> 5), c = (lane & 31) ^ (row & 15);
+                    f_copy16(p.res + (m0 + row) * p.ld_res + c * 8, sR + buf * IMG + row0 * F_PITCH);
+                }
+            }
+            if (MASK) {
+#pragma unroll
+                for (int q = 0; q < NCR1; ++q) {
+                    const int row0 = (cw * NCR1 + q) * 2, row = row0 + (lane >> 5), c = (lane & 31) ^ (row & 15);
+                    f_copy16(p.dmask + (m0 + row) * p.ld_dmask + c * 8, sM + buf * IMG + row0 * F_PITCH);
                 }
             }
         };
@@ -917,10 +930,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256s_kernel(GemmArgs p) {
             // tile i+1 must be in LDS when the compute waves leave the barrier.  vmcnt retires in issue order; younger
             // than tile i+1's copies are the copies of tiles i+2 .. i+NX-1 and min(i, NX-1) sets of row stores.  Near the
             // end, where some of those tiles do not exist, everything is drained instead.
+            const int ks = i < NX - 1 ? i : NX - 1;                          // sets of row stores younger than tile i+1's copies
             if (i + NX - 1 >= nt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (i == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NX - 2) * (NCX + NCR)) : "memory");
-            else if (i == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NX - 2) * (NCX + NCR) + RCH) : "memory");
-            else if (i == 2 || NX == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NX - 2) * (NCX + NCR) + 2 * RCH) : "memory");
+            else if (ks == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NX - 2) * (NCX + NCR)) : "memory");
+            else if (ks == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NX - 2) * (NCX + NCR) + RCH) : "memory");
+            else if (ks == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NX - 2) * (NCX + NCR) + 2 * RCH) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NX - 2) * (NCX + NCR) + 3 * RCH) : "memory");
             f_lds_barrier();
         }
@@ -957,6 +971,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256s_kernel(GemmArgs p) {
     for (int i = 0; i < nt; ++i) {
         const unsigned char* X = sX + (i % NX) * IMG;
         const unsigned char* R = sR + (i % NX) * IMG;
+        const unsigned char* Mk = sM + (i % NX) * IMG;
         unsigned char* O = sO + (i & 1) * IMG;
         f32x16 acc[2];
         bf16x8 fx[4];
@@ -996,7 +1011,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256s_kernel(GemmArgs p) {
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * neg);
                 }
                 if (MASK) {                                                  // this lane's 4 mask-source values (bf16)
-                    const uint2 y = *reinterpret_cast<const uint2*>(R + (lep ^ ((16 * t + gq) << 4)));
+                    const uint2 y = *reinterpret_cast<const uint2*>(Mk + (lep ^ ((16 * t + gq) << 4)));
                     const short y0 = (short)(y.x & 0xffffu), y1 = (short)(y.x >> 16), y2 = (short)(y.y & 0xffffu), y3 = (short)(y.y >> 16);
                     v[0] = y0 > 0 ? v[0] : v[0] * p.dneg;                    // a positive bf16 is a positive int16
                     v[1] = y1 > 0 ? v[1] : v[1] * p.dneg;
@@ -1018,8 +1033,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256s_kernel(GemmArgs p) {
 
 template <int KS, int MODE>
 int launch_nt256s_mode(hipStream_t s, const GemmArgs& p) {
-    constexpr int BM = 32, NX = MODE == 0 ? 4 : 3;
-    constexpr int LDS = ((MODE == 0 ? 1 : 2) * NX + 2) * BM * F_PITCH + 1024;
+    constexpr int NSEC = (MODE & 1) + ((MODE >> 1) & 1);
+    constexpr int BM = 32, NX = 4 - NSEC;
+    constexpr int LDS = ((1 + NSEC) * NX + 2) * BM * F_PITCH + 1024;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256s_kernel<KS, MODE>),
@@ -1035,6 +1051,7 @@ int launch_nt256s_mode(hipStream_t s, const GemmArgs& p) {
 
 template <int KS>
 int launch_nt256s(hipStream_t s, const GemmArgs& p) {
+    if (p.dmask != nullptr && p.res != nullptr) return launch_nt256s_mode<KS, 3>(s, p);
     if (p.dmask != nullptr) return launch_nt256s_mode<KS, 2>(s, p);
     if (p.res != nullptr) return launch_nt256s_mode<KS, 1>(s, p);
     return launch_nt256s_mode<KS, 0>(s, p);
@@ -1121,7 +1138,7 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
     // the training path's 256-wide layers
     if (N == 256 && width == 256 && K <= 256 && M % F_BM == 0 && c_bf16 != nullptr && c_f32 == nullptr && residual_f32 == nullptr &&
         (bias == nullptr || dhaug_aligned16(bias)) && getenv("DHAUG_GEMM_GENERIC") == nullptr && getenv("DHAUG_GEMM_NO256") == nullptr) {
-        if (dmask != nullptr && residual == nullptr && (K == 128 || K == 256)) {   // mask in the epilogue (second LDS image)
+        if (dmask != nullptr && (K == 128 || K == 256) && getenv("DHAUG_NT256_SINGLE") == nullptr) {   // mask in the epilogue (its own LDS image)
             p.dmask = dmask; p.ld_dmask = ld_dmask; p.dneg = dneg;
             *mask_done = true;
         }
@@ -1189,8 +1206,18 @@ int dhaug_gemm_bf16_dmask(const uint16_t* A, int64_t lda, const uint16_t* B, int
     return dhaug_act_backward_bf16(c_bf16, ldc_bf16, dmask, ld_dmask, c_bf16, ldc_bf16, M, N, dmask_act, dmask_slope, stream);
 }
 
+int dhaug_gemm_tn_bf16_rows(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,
+                            float* colsum_a, int64_t colsum_rows, int64_t M, int64_t N1, int64_t N2, int accumulate, void* stream);
+
 int dhaug_gemm_tn_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,
                        float* colsum_a, int64_t M, int64_t N1, int64_t N2, int accumulate, void* stream) {
+    return dhaug_gemm_tn_bf16_rows(A, lda, B, ldb, C, ldc, colsum_a, M, M, N1, N2, accumulate, stream);
+}
+
+int dhaug_gemm_tn_bf16_rows(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,
+                            float* colsum_a, int64_t colsum_rows, int64_t M, int64_t N1, int64_t N2, int accumulate, void* stream) {
+    DHAUG_CHECK(colsum_rows >= 0 && colsum_rows <= M && (colsum_rows == M || colsum_rows % TF_ROWS == 0), DHAUG_EUNSUPPORTED);
+    const long long cs_rows = colsum_rows == M ? (1LL << 62) : colsum_rows;
     DHAUG_CHECK(M >= 0 && N1 >= 1 && N2 >= 1, DHAUG_EINVAL);
     DHAUG_CHECK_PTR(C);
     DHAUG_CHECK(ldc >= N2, DHAUG_EINVAL);
@@ -1239,12 +1266,12 @@ int dhaug_gemm_tn_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
             if (e != hipSuccess) return (int)e;
             configured = true;
         }
-        TnArgs pf{A, lda, B, ldb, C, ldc, colsum_a, M, N1, N2, r2, tl, sp};
+        TnArgs pf{A, lda, B, ldb, C, ldc, colsum_a, M, N1, N2, r2, tl, sp, cs_rows};
         if (wide) hipLaunchKernelGGL(gemm_tn64_kernel<128>, dim3((unsigned)(tl * sp)), dim3(256), lds, s, pf);
         else hipLaunchKernelGGL(gemm_tn64_kernel<64>, dim3((unsigned)(tl * sp)), dim3(256), lds, s, pf);
         return dhaug_launch_status();
     }
-    TnArgs p{A, lda, B, ldb, C, ldc, colsum_a, M, N1, N2, rows, tiles, splits};
+    TnArgs p{A, lda, B, ldb, C, ldc, colsum_a, M, N1, N2, rows, tiles, splits, cs_rows};
     hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, p);
     return dhaug_launch_status();
 }

@@ -35,6 +35,21 @@ def _branch(x, first, blocks, prec):
     return h
 
 
+def _cat(outs, widths, prec):
+    """concatenation of branch outputs along the feature axis.  bf16 activations are zero-padded to a multiple of 16 columns
+    (1000 -> 1008): the pads are cut out, and the result is padded once (the consumer reads ceil16(sum) columns)."""
+    if prec != "bf16":
+        return torch.cat(outs, dim=-1)
+    total = sum(widths)
+    if all(w % 16 == 0 for w in widths):
+        return torch.cat(outs, dim=-1)
+    parts = [o[:, :w] for o, w in zip(outs, widths)]
+    pad = A.ceil16(total) - total
+    if pad:
+        parts.append(torch.zeros((outs[0].shape[0], pad), dtype=outs[0].dtype, device=outs[0].device))
+    return torch.cat(parts, dim=-1)
+
+
 def _frame_diff(x, frames, width):
     x = x.reshape(-1, frames, width)
     return (x[:, 1:] - x[:, :-1]).reshape(-1, (frames - 1) * width)
@@ -67,7 +82,8 @@ class Fk_3D_Discriminator(nn.Module):
         k = _branch(A.KcsFn.apply(x, True), self.special_KCS_previous[0],
                     (self.special_KCS_block1, self.special_KCS_block2, self.special_KCS_block3), p)
         q = _branch(x, self.previous[0], (self.block1, self.block2, self.block3), p)
-        m = torch.cat((k, q), dim=-1)
+        Dw = self.args.Dis_DenseDim_3D
+        m = _cat((k, q), (Dw, Dw), p)
         m = A.linear(m, self.merge_previous[0].weight, self.merge_previous[0].bias, None, A.ACT_RELU, 0.0, p)
         m = self.merge_block1(m, p)
         return A.linear(m, self.output.weight, self.output.bias, None, A.ACT_NONE, 0.0, p, out_f32=True)
@@ -149,7 +165,7 @@ class Video_motion_Fk_3D_Discriminator(nn.Module):
             outs.append(self._b(x.reshape(-1, R * 48), "pos_3d"))
         if self.use_diff:
             outs.append(self._b(_frame_diff(x, R, 48), "diff_pos_3d"))
-        m = torch.cat(outs, dim=-1)
+        m = _cat(outs, [self.args.video_Dis_DenseDim_3D] * len(outs), p)
         m = A.linear(m, self.kcs_merge_previous[0].weight, self.kcs_merge_previous[0].bias, None, A.ACT_RELU, 0.0, p)
         m = self.kcs_merge_block1(m, p)
         return A.linear(m, self.kcs_output.weight, self.kcs_output.bias, None, A.ACT_NONE, 0.0, p, out_f32=True)
@@ -178,7 +194,8 @@ class Video_motion_Fk_2D_Discriminator(nn.Module):
         x = input.reshape(-1, 32)
         a = self._b(x.reshape(-1, R * 32), "pos_2d")
         b = self._b(_frame_diff(x.reshape(-1, 16, 2)[:, 0, :], R, 2), "root_diff_2d")
-        m = torch.cat((a, b), dim=-1)
+        Dw = self.args.video_Dis_DenseDim_2D
+        m = _cat((a, b), (Dw, Dw), p)
         m = A.linear(m, self.merge_previous[0].weight, self.merge_previous[0].bias, None, A.ACT_RELU, 0.0, p)
         m = self.merge_block1(m, p)
         return A.linear(m, self.merge_output.weight, self.merge_output.bias, None, A.ACT_NONE, 0.0, p, out_f32=True)

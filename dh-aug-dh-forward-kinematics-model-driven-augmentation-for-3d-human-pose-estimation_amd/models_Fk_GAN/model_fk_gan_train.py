@@ -7,10 +7,13 @@ Differences that are deliberate (documented in DESIGN.md):
   * RNG draws (noise, GP alpha, bone jitter, camera choice) happen on the device / are injectable.
   * the three backward calls of the critic step are one backward of -D(real).mean() + D(fake).mean() + GP
     (same gradients; fewer passes over the weights)."""
+import os
+
 import numpy as np
 import torch
 
 from .. import autograd_ops as A
+from .. import critic_step
 from .. import ops
 from ..common import camera as cam
 from ..common.h36m_dataset import h36m_cameras_extrinsic_params, h36m_cameras_intrinsic_params
@@ -103,33 +106,49 @@ class MeanFn(torch.autograd.Function):
         return (g / n).expand(ctx.shape).contiguous()
 
 
+ANALYTIC_CRITIC_STEP = os.environ.get("DHAUG_NO_ANALYTIC_STEP") is None
+
+
 def train_Fk_discriminator(model_dis, data_real, data_fake, summary, writer, writer_name, optimizerD, args,
                            one=None, mone=None, dis_mode='single', alpha=None):
-    """One WGAN-GP critic step; returns (Wasserstein_D, D_cost) as 0-dim device tensors."""
+    """One WGAN-GP critic step; returns (Wasserstein_D, D_cost) as 0-dim device tensors.
+
+    The two single-frame critics take the explicit four-sweep schedule of critic_step.py (forward, backward chain, tangent
+    sweep, weight gradients over one 3B-row batch; no autograd graph).  Every other critic (the video motion critics) runs
+    the same step through autograd: -D(real).mean() + D(fake).mean() + GP in one backward."""
     device = _device()
-    model_dis.zero_grad()
-    optimizerD.zero_grad()
     data_real = data_real.to(device)
     data_fake = data_fake.to(device)
-    # real and fake rows go through the critic as ONE batch (rows are independent; the two means are taken over its halves):
-    # every layer GEMM, weight-gradient GEMM and activation pass of the two passes of the reference
-    # (R/models_Fk_GAN/model_fk_gan_train.py:251-262) runs once over 2B rows instead of twice over B
-    # (the split is on the LOGIT count: a motion critic folds R input rows into one logit)
-    if data_fake.shape == data_real.shape:
-        logits = model_dis(torch.cat((data_real, data_fake), 0))
-        h = logits.shape[0] // 2
-        assert logits.shape[0] == 2 * h and h > 0, "critic returned %d logits for a real+fake batch" % logits.shape[0]
-        D_real, D_fake = MeanFn.apply(logits[:h]), MeanFn.apply(logits[h:])
-    else:
-        D_real = MeanFn.apply(model_dis(data_real))
-        D_fake = MeanFn.apply(model_dis(data_fake))
     real_used_num = frames_from_args(args) if dis_mode != 'motion' else 1
-    gradient_penalty = calc_gradient_penalty(model_dis, data_real.detach(), data_fake.detach(),
-                                             args.batch_size * real_used_num, args.GAN_LAMBDA, device, alpha=alpha)
-    (D_fake - D_real + gradient_penalty).backward()      # == backward(mone) + backward(one) + GP.backward()
-    D_cost = (D_fake - D_real + gradient_penalty).detach()
-    Wasserstein_D = (D_real - D_fake).detach()
-    optimizerD.step()
+    rows = args.batch_size * real_used_num                       # BATCH_SIZE of calc_gradient_penalty (:210)
+    if (ANALYTIC_CRITIC_STEP and critic_step.supported(model_dis, optimizerD, data_real, data_fake)
+            and data_real.numel() == rows * (48 if isinstance(model_dis, Fk_3D_Discriminator) else 32)):
+        if alpha is None:
+            alpha = torch.rand(rows, 1, device=device)
+        sc = critic_step.critic_step(model_dis, optimizerD, data_real.reshape(rows, -1), data_fake.reshape(rows, -1),
+                                     alpha.to(device).reshape(rows, 1), args.GAN_LAMBDA)
+        D_real, D_fake, Wasserstein_D, D_cost = sc[0], sc[1], sc[3], sc[4]
+    else:
+        model_dis.zero_grad()
+        optimizerD.zero_grad()
+        # real and fake rows go through the critic as ONE batch (rows are independent; the two means are taken over its
+        # halves): every layer GEMM, weight-gradient GEMM and activation pass of the two passes of the reference
+        # (R/models_Fk_GAN/model_fk_gan_train.py:251-262) runs once over 2B rows instead of twice over B
+        # (the split is on the LOGIT count: a motion critic folds R input rows into one logit)
+        if data_fake.shape == data_real.shape:
+            logits = model_dis(torch.cat((data_real, data_fake), 0))
+            h = logits.shape[0] // 2
+            assert logits.shape[0] == 2 * h and h > 0, "critic returned %d logits for a real+fake batch" % logits.shape[0]
+            D_real, D_fake = MeanFn.apply(logits[:h]), MeanFn.apply(logits[h:])
+        else:
+            D_real = MeanFn.apply(model_dis(data_real))
+            D_fake = MeanFn.apply(model_dis(data_fake))
+        gradient_penalty = calc_gradient_penalty(model_dis, data_real.detach(), data_fake.detach(), rows, args.GAN_LAMBDA,
+                                                 device, alpha=alpha)
+        (D_fake - D_real + gradient_penalty).backward()      # == backward(mone) + backward(one) + GP.backward()
+        D_cost = (D_fake - D_real + gradient_penalty).detach()
+        Wasserstein_D = (D_real - D_fake).detach()
+        optimizerD.step()
     if writer is not None:
         it = getattr(summary, "train_iter_num", 0)
         writer.add_scalar('train_G_iter_PoseFk/{}_D_real'.format(writer_name), D_real.detach(), it)

@@ -254,49 +254,58 @@ def split_bf16(src, mode, terms, pad_cols=None):
 
 
 def gemm_nt(A, B, N, K, bias=None, res_bf16=None, res_f32=None, act=0, slope=0.0, out_bf16=False, n_pad=0,
-            out_f32=False, lda=None, ldb=None):
+            out_f32=False, lda=None, ldb=None, c_bf16=None, c_f32=None):
     """C[M,N] = act(A[M,K] B[N,K]^T + bias + residual).  A, B bf16 (row strides lda/ldb default to their widths).
-    Returns (c_bf16 (M, max(n_pad, ceil8(N))) | None, c_f32 (M,N) | None)."""
+    Returns (c_bf16 (M, max(n_pad, ceil8(N))) | None, c_f32 (M,N) | None).  c_bf16 / c_f32: write into these (row-strided
+    views allowed: a column block of a wider buffer) instead of allocating; columns [N, n_pad) of c_bf16 are zeroed."""
     assert A.dtype == BF16 and B.dtype == BF16 and A.is_cuda and B.is_cuda
     M = A.shape[0]
     lda = A.stride(0) if lda is None else lda
     ldb = B.stride(0) if ldb is None else ldb
-    cb = cf = None
+    cb, cf = c_bf16, c_f32
     ldcb = 0
-    if out_bf16:
+    if cb is not None:
+        assert cb.dtype == BF16 and cb.stride(1) == 1 and cb.shape[0] == M
+        ldcb, n_pad = cb.stride(0), min(max(n_pad, N), cb.shape[1])       # never past the view's own columns
+    elif out_bf16:
         ldcb = max(n_pad, ceil_to(N, 8))
         cb = torch.empty((M, ldcb), dtype=BF16, device=A.device)
         n_pad = ldcb
-    if out_f32:
+    if cf is not None:
+        assert cf.dtype == torch.float32 and cf.stride(1) == 1 and cf.shape[0] == M
+    elif out_f32:
         cf = torch.empty((M, N), dtype=torch.float32, device=A.device)
     if bias is not None:
         bias = _dev(bias, torch.float32, "gemm_nt")
     _lib.call("dhaug_gemm_bf16", _p(A), lda, _p(B), ldb, _p(bias), _p(res_bf16),
               0 if res_bf16 is None else res_bf16.stride(0), _p(res_f32), 0 if res_f32 is None else res_f32.stride(0),
-              _p(cb), ldcb, n_pad, _p(cf), N, M, N, K, act, float(slope), _stream())
+              _p(cb), ldcb, n_pad, _p(cf), N if cf is None else cf.stride(0), M, N, K, act, float(slope), _stream())
     return cb, cf
 
 
-def gemm_nt_dmask(A, B, N, K, dmask, dmask_act, dmask_slope=0.0, res_bf16=None):
+def gemm_nt_dmask(A, B, N, K, dmask, dmask_act, dmask_slope=0.0, res_bf16=None, out=None):
     """(A[M,K] B[N,K]^T + res) * act'(dmask): input gradient of a layer + activation backward of its producer, bf16 (M,N)"""
     assert A.dtype == BF16 and B.dtype == BF16 and dmask.dtype == BF16 and N % 8 == 0
     M = A.shape[0]
-    out = torch.empty((M, N), dtype=BF16, device=A.device)
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=A.device)
+    assert out.dtype == BF16 and out.stride(1) == 1 and out.shape[0] == M
     _lib.call("dhaug_gemm_bf16_dmask", _p(A), A.stride(0), _p(B), B.stride(0), _p(res_bf16),
               0 if res_bf16 is None else res_bf16.stride(0), _p(dmask), dmask.stride(0), dmask_act, float(dmask_slope),
-              _p(out), N, M, N, K, _stream())
+              _p(out), out.stride(0), M, N, K, _stream())
     return out
 
 
-def gemm_tn(A, B, N1, N2, out=None, accumulate=False, M=None, lda=None, ldb=None, colsum=None):
-    """C[N1,N2] (+)= A[M,N1]^T B[M,N2], bf16 operands, fp32 result; colsum (fp32 [N1], optional) (+)= column sums of A."""
+def gemm_tn(A, B, N1, N2, out=None, accumulate=False, M=None, lda=None, ldb=None, colsum=None, colsum_rows=None):
+    """C[N1,N2] (+)= A[M,N1]^T B[M,N2], bf16 operands, fp32 result; colsum (fp32 [N1], optional) (+)= column sums of A
+    (over rows [0, colsum_rows) only when given: a multiple of 128)."""
     assert A.dtype == BF16 and B.dtype == BF16
     M = A.shape[0] if M is None else M
     if out is None:
         out = torch.empty((N1, N2), dtype=torch.float32, device=A.device)
         accumulate = False
-    _lib.call("dhaug_gemm_tn_bf16", _p(A), A.stride(0) if lda is None else lda, _p(B), B.stride(0) if ldb is None else ldb,
-              _p(out), out.stride(0), _p(colsum), M, N1, N2, int(accumulate), _stream())
+    _lib.call("dhaug_gemm_tn_bf16_rows", _p(A), A.stride(0) if lda is None else lda, _p(B), B.stride(0) if ldb is None else ldb,
+              _p(out), out.stride(0), _p(colsum), M if colsum_rows is None else colsum_rows, M, N1, N2, int(accumulate), _stream())
     return out
 
 
@@ -310,14 +319,17 @@ def colsum(src, N=None, out=None, accumulate=False):
     return out
 
 
-def act_backward(g, y, act, slope=0.0):
-    """g * act'(y), same dtype/shape as g (bf16: widths multiple of 8; fp32: any)."""
+def act_backward(g, y, act, slope=0.0, out=None):
+    """g * act'(y), same dtype/shape as g (bf16: widths multiple of 8, row-strided views allowed; fp32: contiguous).
+    out: write there (may be g itself)."""
     assert g.dtype == y.dtype and g.shape == y.shape
-    out = torch.empty_like(g)
+    if out is None:
+        out = torch.empty_like(g) if g.is_contiguous() else torch.empty(g.shape, dtype=g.dtype, device=g.device)
     if g.dtype == BF16:
         _lib.call("dhaug_act_backward_bf16", _p(g), g.stride(0), _p(y), y.stride(0), _p(out), out.stride(0), g.shape[0],
                   g.shape[1], act, float(slope), _stream())
     else:
+        assert g.is_contiguous() and y.is_contiguous() and out.is_contiguous()
         _lib.call("dhaug_act_backward_f32", _p(g), _p(y), _p(out), g.numel(), act, float(slope), _stream())
     return out
 
@@ -327,3 +339,44 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-4, betas=(0.5, 0.9),
     assert param.is_contiguous() and grad.is_contiguous() and grad.numel() == n
     _lib.call("dhaug_adam_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, lr, betas[0], betas[1], eps,
               int(step), float(grad_scale), _stream())
+
+
+def adam_step_dev(param, grad, exp_avg, exp_avg_sq, step_dev, lr=1e-4, betas=(0.5, 0.9), eps=1e-8, grad_scale=1.0):
+    """Adam step whose count lives on the device (int32 tensor, advanced here): replayable inside a captured graph"""
+    n = param.numel()
+    assert param.is_contiguous() and grad.is_contiguous() and grad.numel() == n and step_dev.dtype == torch.int32
+    _lib.call("dhaug_counter_add", _p(step_dev), 1, _stream())
+    _lib.call("dhaug_adam_step_dev", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, lr, betas[0], betas[1], eps,
+              _p(step_dev), float(grad_scale), _stream())
+
+
+# --------------------------------------------------------------------------------------- WGAN-GP arithmetic
+def gp_assemble(real, fake, alpha, out=None):
+    """(3B, W) fp32 = [real; fake; alpha * real + (1 - alpha) * fake]"""
+    r = _dev(real, torch.float32, "gp_assemble")
+    r = r.reshape(r.shape[0], -1)
+    f = _dev(fake, torch.float32, "gp_assemble").reshape(r.shape)
+    a = _dev(alpha, torch.float32, "gp_assemble").reshape(-1)
+    B, W = r.shape
+    assert a.shape[0] == B
+    if out is None:
+        out = torch.empty((3 * B, W), dtype=torch.float32, device=r.device)
+    _lib.call("dhaug_gp_assemble", _p(r), _p(f), _p(a), _p(out), B, W, _stream())
+    return out
+
+
+def gp_penalty(grad, coef):
+    """per-row (||g|| - 1)^2 and the penalty's cotangent coef * (n - 1) / n * g"""
+    g = _dev(grad, torch.float32, "gp_penalty")
+    B, W = g.shape
+    v = torch.empty_like(g)
+    pen = torch.empty((B,), dtype=torch.float32, device=g.device)
+    _lib.call("dhaug_gp_penalty", _p(g), _p(v), _p(pen), B, W, float(coef), _stream())
+    return v, pen
+
+
+def critic_scalars(logits, pen, B, lam):
+    """(5,) fp32: D_real, D_fake, GP, Wasserstein_D, D_cost"""
+    out = torch.empty((5,), dtype=torch.float32, device=logits.device)
+    _lib.call("dhaug_critic_scalars", _p(logits), logits.stride(0), _p(pen), B, float(lam), _p(out), _stream())
+    return out

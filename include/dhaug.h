@@ -213,6 +213,12 @@ int dhaug_gemm_bf16_dmask(const uint16_t* A, int64_t lda, const uint16_t* B, int
 int dhaug_gemm_tn_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
                        float* C, int64_t ldc, float* colsum_a, int64_t M, int64_t N1, int64_t N2, int accumulate,
                        void* stream);
+/* Same, with the column sums restricted to rows [0, colsum_rows) of A (colsum_rows == M or a multiple of 128): the
+ * explicit critic step contracts real, fake AND interpolated rows in one launch, but only the real / fake rows carry a
+ * bias gradient (the gradient penalty has none). */
+int dhaug_gemm_tn_bf16_rows(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
+                            float* C, int64_t ldc, float* colsum_a, int64_t colsum_rows, int64_t M, int64_t N1, int64_t N2,
+                            int accumulate, void* stream);
 
 /* fp32 -> bf16 (round-to-nearest-even) with zero padding: src (rows, cols) ld_src -> dst (rows, ld_dst),
  * columns [cols, pad_cols) zero-filled.  Used to pack weights / inputs as GEMM operands. */
@@ -312,6 +318,28 @@ int dhaug_act_backward_f32(const float* g, const float* y, float* dst, int64_t n
  * grad_scale multiplies the gradient first (1/world_size after an all-reduce sum). */
 int dhaug_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                     float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+
+/* The same step with the step count in device memory (*step_dev >= 1, advanced with dhaug_counter_add before the call): a
+ * captured hipGraph replays the launch, so the bias corrections must not be baked into kernel arguments. */
+int dhaug_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                        float lr, float beta1, float beta2, float eps, const int* step_dev, float grad_scale, void* stream);
+int dhaug_counter_add(int* counter, int value, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * WGAN-GP critic step arithmetic (R/models_Fk_GAN/Fk_discriminator.py:205-231, model_fk_gan_train.py:186-221)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* out (3B, W) fp32: rows [0,B) = real, [B,2B) = fake, [2B,3B) = alpha_b * real + (1 - alpha_b) * fake -- the batch one
+ * critic step scores (the two critic passes and the penalty's interpolates as one batch). */
+int dhaug_gp_assemble(const float* real, const float* fake, const float* alpha, float* out, int64_t B, int64_t W, void* stream);
+
+/* Per row b of grad (B, W) = dD/dx_hat:  n = ||grad_b||_2;  pen[b] = (n - 1)^2;  v_b = coef * (n - 1) / n * grad_b, the
+ * cotangent of the penalty on grad (coef = 2 * LAMBDA / B gives d/dgrad of LAMBDA * mean((n - 1)^2)). */
+int dhaug_gp_penalty(const float* grad, float* v, float* pen, int64_t B, int64_t W, float coef, void* stream);
+
+/* out5 = { D_real, D_fake, GP = lambda * mean(pen), Wasserstein_D = D_real - D_fake, D_cost = D_fake - D_real + GP } from
+ * the logits (rows [0,B) real, [B,2B) fake, stride ld) and the per-row penalties. */
+int dhaug_critic_scalars(const float* logits, int64_t ld, const float* pen, int64_t B, float lambda, float* out5, void* stream);
 
 #ifdef __cplusplus
 }

@@ -81,3 +81,25 @@ def test_shard_range_partitions():
         assert spans[0][0] == 0 and spans[-1][1] == total
         assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
         assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
+
+
+def test_bench_gpus_flag_launches_ranks():
+    """`python bench.py --gpus 2` (no torchrun around it) must become two rank processes and report n_gpus = 2: the
+    launcher path rehearsed on CPU with gloo (--dry-run: rendezvous + the max-over-ranks exchange, no GPU work)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["DHAUG_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["max_over_ranks"] == 2.0 and line["backend"] == "gloo"
+    # a mismatch between --gpus and an externally set WORLD_SIZE is an error, never a silent n_gpus = 1
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env2,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r2.returncode != 0

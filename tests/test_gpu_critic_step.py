@@ -1,0 +1,127 @@
+"""GPU: the explicit four-sweep WGAN-GP critic step (dhaug_amd/critic_step.py) against (a) the autograd composite it
+replaces, same weights / batch / interpolation coefficients, in the fp32-grade arithmetic (tight) and in bf16 (direction),
+(b) the oracle's fp64 critic step.  (The goldens captured from the reference's own train_Fk_discriminator are checked
+through train_Fk_discriminator in tests/test_gpu_models.py and tests/test_gpu_loops.py -- that entry point takes this path.)"""
+import argparse
+
+import pytest
+import torch
+
+import golden_util as GU
+from oracle import dhaug_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import dhaug_amd
+    dhaug_amd._lib.lib()
+    from dhaug_amd import critic_step
+    from dhaug_amd.models_Fk_GAN import Fk_discriminator, model_fk_gan_train
+    return argparse.Namespace(dis=Fk_discriminator, train=model_fk_gan_train, cs=critic_step)
+
+
+def _args(B, D):
+    from test_gpu_models import make_args
+    return make_args(batch_size=B, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D)
+
+
+def _data(tag, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    if tag == "d3":
+        r = GU.synth_pose16(B, seed=seed); r = r - r[:, :1]
+        f = r + 0.08 * torch.randn(B, 16, 3, generator=g); f = f - f[:, :1]
+    else:
+        r = (torch.rand(B, 16, 2, generator=g) - 0.5) * 1.6
+        f = r + 0.1 * torch.randn(B, 16, 2, generator=g)
+    return r, f, torch.rand(B, 1, generator=g)
+
+
+def _net(M, tag, args, sd, prec):
+    net = M.dis.Fk_3D_Discriminator("cuda", args) if tag == "d3" else M.dis.Fk_2D_Discriminator(args, 16)
+    net.load_state_dict(sd)
+    net.precision = prec
+    net = net.cuda()
+    return net, M.train.FusedAdam(net.parameters(), lr=1e-4, betas=(0.5, 0.9))
+
+
+def _run(M, tag, args, sd, prec, data, analytic):
+    net, opt = _net(M, tag, args, sd, prec)
+    old = M.train.ANALYTIC_CRITIC_STEP
+    M.train.ANALYTIC_CRITIC_STEP = analytic
+    try:
+        r, f, a = data
+        W, C = M.train.train_Fk_discriminator(net, r.cuda(), f.cuda(), argparse.Namespace(train_iter_num=0), None, tag, opt,
+                                              args, alpha=a.cuda())
+    finally:
+        M.train.ANALYTIC_CRITIC_STEP = old
+    return W.item(), C.item(), {k: p.grad.detach().float().cpu().clone() for k, p in net.named_parameters()}, \
+        {k: p.detach().cpu().clone() for k, p in net.named_parameters()}
+
+
+@pytest.mark.parametrize("tag,D,B", [("d3", 64, 72), ("d2", 64, 72), ("d3", 256, 300), ("d2", 256, 300)])
+def test_explicit_step_equals_autograd_and_oracle(M, tag, D, B):
+    args = _args(B, D)
+    shapes = GU.shapes_d3(D) if tag == "d3" else GU.shapes_d2(D)
+    sd = GU.seeded_state_dict(shapes, 900 + D)
+    data = _data(tag, B, 31 + D)
+    # fp32-grade arithmetic: explicit schedule == autograd composite == fp64 oracle
+    Wa, Ca, ga, pa = _run(M, tag, args, sd, "bf16x6", data, True)
+    Wc, Cc, gc, pc = _run(M, tag, args, sd, "bf16x6", data, False)
+    fwd = O.d3_forward if tag == "d3" else O.d2_forward
+    ref = O.critic_step(fwd, {k: v.double() for k, v in sd.items()}, data[0].double(), data[1].double(), data[2].double())
+    assert abs(Wa - ref["Wasserstein_D"].item()) <= 2e-6 and abs(Ca - ref["D_cost"].item()) <= 1e-5 * max(1.0, abs(Ca))
+    assert abs(Wa - Wc) <= 2e-6 and abs(Ca - Cc) <= 1e-5 * max(1.0, abs(Cc))
+    for k, r in ref["grads"].items():
+        scale = r.abs().max().item()
+        # fp64 vs fp32-grade arithmetic: a hidden unit within rounding of 0 flips its ReLU mask on ONE row, which moves the
+        # gradients it feeds by that row's O(1/B) term -- so: all but a few elements tight, every element within a row's worth
+        e = (ga[k].double() - r).abs().reshape(-1)
+        kth = max(1, int(e.numel() * 0.995))
+        assert e.kthvalue(kth).values.item() <= 1e-8 + 2e-5 * scale, (k, e.kthvalue(kth).values.item(), scale)
+        assert e.max().item() <= 2e-4 + 1e-3 * scale, (k, e.max().item(), scale)
+        assert (ga[k] - gc[k]).abs().max().item() <= 1e-8 + 2e-5 * scale, (k, (ga[k] - gc[k]).abs().max().item(), scale)
+    # the logit layer's bias sees -1/B on B rows and +1/B on B rows: exactly zero, so Adam leaves it alone (B is not a
+    # power of two here: an unpaired summation order leaves ~1e-7 and costs a full lr step)
+    last = "output.bias" if tag == "d3" else "layer_pred.bias"
+    assert ga[last].abs().max().item() == 0.0 and (pa[last] - sd[last]).abs().max().item() == 0.0
+    assert gc[last].abs().max().item() == 0.0
+    # bf16 (the throughput arithmetic): same step up to bf16 rounding
+    Wb, Cb, gb, _ = _run(M, tag, args, sd, "bf16", data, True)
+    Wd, Cd, gd, _ = _run(M, tag, args, sd, "bf16", data, False)
+    assert abs(Wb - Wa) <= 3e-2 * max(1.0, abs(Wa)) and abs(Cb - Ca) <= 5e-2 * max(1.0, abs(Ca))
+    cos_ref, cos_path = [], []
+    for k, r in ref["grads"].items():
+        if r.abs().max() > 0:
+            cs = torch.nn.functional.cosine_similarity
+            cos_ref.append(cs(gb[k].reshape(-1).double(), r.reshape(-1), dim=0).item())
+            cos_path.append(cs(gb[k].reshape(-1).double(), gd[k].reshape(-1).double(), dim=0).item())
+    # (a 72-row batch through bf16 layers: the weakest parameter's direction agrees to ~0.97 with fp64; the two bf16
+    # paths agree with each other at least as well)
+    assert min(cos_ref) > 0.95, cos_ref
+    assert min(cos_path) > 0.95, cos_path
+    assert gb[last].abs().max().item() == 0.0
+
+
+def test_explicit_step_full_batch_properties(M):
+    """BASELINE configs[2] size (B = 65 536, D = 256, bf16): finite, every parameter moves by at most ~lr, the step of a
+    2x replicated batch equals the step of the batch (means are batch-size independent), scalars match a bf16x6 subsample."""
+    B, D = 65536, 256
+    args = _args(B, D)
+    for tag in ("d3", "d2"):
+        shapes = GU.shapes_d3(D) if tag == "d3" else GU.shapes_d2(D)
+        sd = GU.seeded_state_dict(shapes, 1900)
+        r, f, a = _data(tag, 4096, 77)
+        rep = lambda t: t.repeat(B // 4096, *([1] * (t.dim() - 1)))
+        W, C, g, p = _run(M, tag, args, sd, "bf16", (rep(r), rep(f), rep(a)), True)
+        args_s = _args(4096, D)
+        Ws, Cs, gs, ps = _run(M, tag, args_s, sd, "bf16", (r, f, a), True)
+        assert all(torch.isfinite(v).all() for v in g.values())
+        assert abs(W - Ws) <= 1e-3 * max(1.0, abs(Ws)) and abs(C - Cs) <= 2e-3 * max(1.0, abs(Cs))
+        for k in g:
+            scale = gs[k].abs().max().item()
+            assert (g[k] - gs[k]).abs().max().item() <= 2e-2 * scale + 1e-9, (tag, k)
+            assert (p[k] - sd[k]).abs().max().item() <= 1.01e-4, (tag, k)
