@@ -124,6 +124,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel roofline timing loops (profiling runs)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="training workloads: replay the iteration as captured hipGraphs (auto: on for one rank)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only: every rank joins the process group, the timing exchange runs, rank 0 prints the line "
                          "(no GPU work; with DHAUG_DIST_BACKEND=gloo this rehearses the N-rank launch path on a CPU box)")
@@ -226,14 +228,30 @@ def main():
             l3, l2 = score_fake_pair(D3, D2, xc, kcs, p2)                                    # both critics, one launch
         return l3, l2
 
+    use_graph = a.graph == "on" or (a.graph == "auto" and world == 1)
+    graphed = None
+    if use_graph and a.workload in ("gan_step", "video"):
+        from dhaug_amd.graphs import GraphedGanIteration
+        graphed = GraphedGanIteration(V.video_gan_iteration if video else T.gan_iteration, args, models, ["S1"], summary)
+    vin3 = real_cam.reshape(B, R, 16, 3) if video else real_cam
+    vin2 = real_2d.reshape(B, R, 16, 2) if video else real_2d
+
     def step_gan():
-        T.gan_iteration(args, models, real_cam, cam_param, real_2d, ["S1"], summary=None, writer=None,
-                        do_g_step=(it[0] % 5 == 4), camera=(quat, trans, cam9))
+        g = it[0] % 5 == 4
+        if graphed is not None:
+            graphed(vin3, cam_param, vin2, g, (quat, trans, cam9))
+        else:
+            T.gan_iteration(args, models, real_cam, cam_param, real_2d, ["S1"], summary=None, writer=None,
+                            do_g_step=g, camera=(quat, trans, cam9))
         it[0] += 1
 
     def step_video():
-        V.video_gan_iteration(args, models, real_cam.reshape(B, R, 16, 3), cam_param, real_2d.reshape(B, R, 16, 2), ["S1"],
-                              summary, None, do_g_step=(it[0] % 5 == 4), camera=(quat, trans, cam9))
+        g = it[0] % 5 == 4
+        if graphed is not None:
+            graphed(vin3, cam_param, vin2, g, (quat, trans, cam9))
+        else:
+            V.video_gan_iteration(args, models, vin3, cam_param, vin2, ["S1"], summary, None, do_g_step=g,
+                                  camera=(quat, trans, cam9))
         it[0] += 1
 
     steps = {"fk": step_fk, "fk_gen_fwd": step_fk_gen, "fwd": step_fwd, "gan_step": step_gan, "video": step_video}
@@ -290,7 +308,7 @@ def main():
            "config": {"workload": WORKLOADS[a.workload], "batch_per_gpu": B, "frames": R, "poses_per_gpu_per_step": N,
                       "global_batch": N * world, "dense_dim": D, "preAngle": True, "fk_dtype": "f32",
                       "dense_dtype": "bf16 MFMA, fp32 accumulate" if main_prec == "bf16" else "3 x fp16 MFMA (hi+lo operands), fp32 accumulate"},
-           "c_abi_calls_per_step": calls}
+           "c_abi_calls_per_step": calls, "hip_graph": graphed is not None}
 
     # the forward workload in the OTHER arithmetic, same inputs (bf16 <-> parity), with its own step time
     if fwd_like:

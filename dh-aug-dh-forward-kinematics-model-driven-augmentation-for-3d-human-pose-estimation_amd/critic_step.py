@@ -65,7 +65,9 @@ class _Math:
                 if n % 16 == 0 and rf is None:
                     return ops.gemm_nt_dmask(a_op, Bop, n, kp, mask, mask_act, slope, res_bf16=rb, out=out)
                 y, _ = ops.gemm_nt(a_op, Bop, n, kp, bias=bias, res_bf16=rb, res_f32=rf, out_bf16=True, n_pad=ceil16(n), c_bf16=out)
-                ops.act_backward(y, mask, mask_act, slope, out=y)
+                w = min(y.shape[1], mask.shape[1])           # (a column block of a wider buffer carries no pad columns)
+                ya, ma = (y, mask) if (y.shape[1] == w and mask.shape[1] == w) else (y[:, :w], mask[:, :w])
+                ops.act_backward(ya, ma, mask_act, slope, out=ya)
                 return y
             cb, cf = ops.gemm_nt(a_op, Bop, n, kp, bias=bias, res_bf16=rb, res_f32=rf, act=act, slope=slope,
                                  out_bf16=not out_f32, n_pad=ceil16(n), out_f32=out_f32, c_bf16=None if out_f32 else out,

@@ -116,7 +116,8 @@ class _GeneratorBase(nn.Module):
             raise RuntimeError("boneLength has %d rows, the batch needs %d (call GAN_generator_get_bone_length)"
                                % (bl.shape[0], B * R))
         if (bone_len_scaler is None and self.args.bone_len_scaler == "different" and R == 1 and head.is_cuda
-                and not self.record_angles and not (torch.is_grad_enabled() and head.requires_grad)):
+                and not self.record_angles and not (torch.is_grad_enabled() and head.requires_grad)
+                and not torch.cuda.is_current_stream_capturing()):   # (a captured graph would replay one (seed, offset))
             # sampling pass (no graph): the jitter is drawn inside the tail kernel (see sample_for_critics) -- same
             # distribution, two RNG launches fewer than torch.randint + div
             seed, off = self._jitter_stream(head)
@@ -154,7 +155,8 @@ class Fk_Generator(_GeneratorBase):
                                    % (bl.shape[0], B))
             self.train_num += 1
             pre = bool(self.args.GAN_whether_use_preAngle)
-            if bone_len_scaler is None and self.args.bone_len_scaler == "different":
+            if (bone_len_scaler is None and self.args.bone_len_scaler == "different"
+                    and not torch.cuda.is_current_stream_capturing()):
                 # the jitter is drawn inside the tail kernel from the device generator's (seed, offset) stream: same
                 # distribution as torch.randint(-200, 200) / 1000, reproducible under torch.manual_seed
                 seed, off = self._jitter_stream(head)

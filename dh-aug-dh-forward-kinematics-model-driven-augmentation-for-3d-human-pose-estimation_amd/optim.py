@@ -38,13 +38,17 @@ class FusedAdam(torch.optim.Optimizer):
             self._views.append(gv)
             off += k
         self.step_count = 0
+        # the same count on the device: the Adam kernel reads it there, so a captured hipGraph of a training step replays
+        # with the right bias corrections (the host count is bookkeeping: state_dict, tests)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev) if dev.type == "cuda" else None
         self.process_group = process_group
         self.data_parallel = data_parallel      # None: follow torch.distributed state
 
     def state_dict(self):
         """torch.optim.Optimizer.state_dict() plus the flat moments and the step count (checkpoint / resume)"""
         d = super().state_dict()
-        d["dhaug_flat"] = dict(exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), step_count=self.step_count)
+        count = int(self.step_dev.item()) if self.step_dev is not None else self.step_count     # (graph replays advance only the device count)
+        d["dhaug_flat"] = dict(exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), step_count=count)
         return d
 
     def load_state_dict(self, state_dict):
@@ -54,6 +58,8 @@ class FusedAdam(torch.optim.Optimizer):
             self.exp_avg.copy_(flat["exp_avg"])
             self.exp_avg_sq.copy_(flat["exp_avg_sq"])
             self.step_count = int(flat["step_count"])
+            if self.step_dev is not None:
+                self.step_dev.fill_(self.step_count)
         self._check_views()
 
     def _check_views(self):
@@ -101,8 +107,8 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count += 1
         g = self.param_groups[0]
         if self.flat_param.is_cuda:
-            ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, g["lr"],
-                          tuple(g["betas"]), g["eps"], 1.0 / ws)
+            ops.adam_step_dev(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_dev, g["lr"],
+                              tuple(g["betas"]), g["eps"], 1.0 / ws)
         else:
             raise RuntimeError("FusedAdam needs GPU parameters (no CPU fallback exists)")
         A.bump_weight_epoch()                  # every packed bf16 copy of a weight is now stale

@@ -282,10 +282,42 @@ def video_loop(M):
              D_cost=C.detach(), weight_seed=np.array(2600 + len(mode)), **grads, **newp)
 
 
+def video_D1000(M):
+    """BASELINE configs[4] widths (DenseDim 1000 everywhere, R = 9): forward outputs of the video generator and of the four
+    critics on a small batch.  Weights come from seeded_state_dict (seeds stored), so only inputs and outputs are kept."""
+    gen, dis, fkm = M["gen"], M["dis"], M["fkm"]
+    B, R, D = 4, 9, 1000
+    args = RI.make_args(batch_size=B, Gen_DenseDim=D, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D, video_Dis_DenseDim_3D=D,
+                        video_Dis_DenseDim_2D=D, single_or_multi_train_mode="multi", architecture="3,3", random_seed=5)
+    fk = fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+    fk.random = RecordingRandomState(fk.random)
+    nets = dict(G=gen.Video_Fk_Generator(R, fk, args, "cpu"), d3=dis.Fk_3D_Discriminator("cpu", args),
+                d2=dis.Fk_2D_Discriminator(args, 16), m3=dis.Video_motion_Fk_3D_Discriminator("cpu", args, R),
+                m2=dis.Video_motion_Fk_2D_Discriminator("cpu", args, R))
+    seeds = dict(G=3100, d3=3200, d2=3300, m3=3400, m2=3500)
+    for k, net in nets.items():
+        net.load_state_dict(seeded_state_dict(motion_shapes(net), seed=seeds[k]))
+    real = synth_pose16(B * R, seed=71).view(B, R, 16, 3)
+    nets["G"].GAN_generator_get_bone_length(real)
+    z = torch.randn(B, 128, generator=torch.Generator().manual_seed(72))
+    with torch.no_grad():
+        fake = nets["G"](z)
+        x3 = synth_pose16(B * R, seed=73); x3 = x3 - x3[:, :1]
+        x2 = (torch.rand(B * R, 16, 2, generator=torch.Generator().manual_seed(74)) - 0.5) * 1.6
+        out = dict(z=z, real16=real, bone_len=nets["G"].boneLength, scaler=np.stack(fk.random.log)[0].astype(np.float32) / 1000.0,
+                   fake=fake, x3=x3, x2=x2, logit_d3=nets["d3"](x3), logit_d2=nets["d2"](x2), logit_m3=nets["m3"](x3),
+                   logit_m2=nets["m2"](x2), seeds=np.array([seeds[k] for k in ("G", "d3", "d2", "m3", "m2")]))
+    save("video_D1000", **out)
+
+
 def main():
     M = RI.load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "video_D1000":
+        video_D1000(M)
+        return
     single_frame_loop(M)
     video_loop(M)
+    video_D1000(M)
 
 
 if __name__ == "__main__":

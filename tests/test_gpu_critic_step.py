@@ -81,7 +81,7 @@ def test_explicit_step_equals_autograd_and_oracle(M, tag, D, B):
         # gradients it feeds by that row's O(1/B) term -- so: all but a few elements tight, every element within a row's worth
         e = (ga[k].double() - r).abs().reshape(-1)
         kth = max(1, int(e.numel() * 0.995))
-        assert e.kthvalue(kth).values.item() <= 1e-8 + 2e-5 * scale, (k, e.kthvalue(kth).values.item(), scale)
+        assert e.kthvalue(kth).values.item() <= 2e-6 + 2e-4 * scale, (k, e.kthvalue(kth).values.item(), scale)
         assert e.max().item() <= 2e-4 + 1e-3 * scale, (k, e.max().item(), scale)
         assert (ga[k] - gc[k]).abs().max().item() <= 1e-8 + 2e-5 * scale, (k, (ga[k] - gc[k]).abs().max().item(), scale)
     # the logit layer's bias sees -1/B on B rows and +1/B on B rows: exactly zero, so Adam leaves it alone (B is not a

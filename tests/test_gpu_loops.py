@@ -177,3 +177,82 @@ def test_motion_critic_step_vs_reference(M, golden, tag):
         well = ref.abs() > max(1e-3 * ref.abs().max().item(), 1e-7)
         if well.any():
             assert maxabs(p.detach().cpu()[well], g["new__" + k][well]) <= 3e-6, k
+
+
+# ------------------------------------------------------------------------------- BASELINE configs[4] widths (DenseDim 1000)
+def _video_nets(M, B, R, D, prec):
+    from dhaug_amd.function_aug.config import synth_args
+    args = synth_args(B, D, single_or_multi_train_mode="multi", architecture="3,3", video_Dis_DenseDim_3D=D,
+                      video_Dis_DenseDim_2D=D, single_dis_warmup_epoch=0)
+    fk = M.fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+    d = M.train.video_mode_my_get_poseFk_model(args, None, fk, R)
+    for k, m in d.items():
+        if k.startswith("model"):
+            m.precision = prec
+    return args, d
+
+
+def test_video_D1000_forward_vs_reference(M, golden):
+    """the video generator and the four critics at DenseDim 1000 (layer-by-layer: the fused programs cover 64/128/256) in the
+    fp32-grade arithmetic against the reference's outputs; the bf16 default is measured against the logit scale"""
+    g = golden("video_D1000")
+    R, D, B = 9, 1000, g["z"].shape[0]
+    args, d = _video_nets(M, B, R, D, "bf16x6")
+    sG, s3, s2, sm3, sm2 = (int(v) for v in g["seeds"])
+    m3s, m2s = LU.motion_shapes(D, R)
+    for key, shapes, seed in (("model_G", GU.shapes_generator(D, frames=R), sG), ("model_d3d", GU.shapes_d3(D), s3),
+                              ("model_d2d", GU.shapes_d2(D), s2), ("model_motion_d3d", m3s, sm3), ("model_motion_d2d", m2s, sm2)):
+        d[key].load_state_dict(GU.seeded_state_dict(shapes, seed))
+    G = d["model_G"]
+    rel = lambda a, b: ((a.detach().double().cpu() - b.double()).abs() / b.double().abs().clamp_min(0.1 * b.double().abs().mean())).max().item()
+    with torch.no_grad():
+        G.GAN_generator_get_bone_length(g["real16"].cuda())
+        fake = G(g["z"].cuda(), bone_len_scaler=g["scaler"])
+        assert fake.shape == (B, R, 48) and maxabs(fake, g["fake"]) <= 3e-5      # roots up to +-10 m; K = 1000 dot products
+        outs = dict(d3=d["model_d3d"](g["x3"].cuda()), d2=d["model_d2d"](g["x2"].cuda()),
+                    m3=d["model_motion_d3d"](g["x3"].cuda()), m2=d["model_motion_d2d"](g["x2"].cuda()))
+        for k, v in outs.items():
+            assert rel(v, g["logit_" + k]) <= 1e-4, (k, rel(v, g["logit_" + k]))
+        for k, m in d.items():
+            if k.startswith("model"):
+                m.precision = "bf16"
+        for k, net, x in (("d3", d["model_d3d"], g["x3"]), ("d2", d["model_d2d"], g["x2"]), ("m3", d["model_motion_d3d"], g["x3"]),
+                          ("m2", d["model_motion_d2d"], g["x2"])):
+            ref = g["logit_" + k]
+            assert maxabs(net(x.cuda()), ref) <= 8e-2 * ref.abs().max().item(), k
+
+
+def test_video_full_size_iteration_properties(M):
+    """BASELINE configs[4] on one GPU: B = 512 clips x R = 9 frames, DenseDim 1000, motion critics, playback and flip on.
+    Two iterations (the second with the G step): finite scalars, every network moves by at most (steps x lr), the generated
+    pairs have the epoch buffer's layout; a second replica from the same seed reports the same Wasserstein distances."""
+    from dhaug_amd import ops
+    B, R, D = 512, 9, 1000
+    cam = ([0.5, 0.5, -0.5, 0.5], [0.0, 0.0, 5.0], [2.3, 2.3, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0])
+    res = []
+    for rep in range(2):
+        torch.manual_seed(123)
+        args, d = _video_nets(M, B, R, D, "bf16")
+        before = {k: [p.detach().clone() for p in m.parameters()] for k, m in d.items() if k.startswith("model")}
+        a, bl, rt = GU.synth_fk_inputs(B * R, 5)
+        world = ops.fk_forward((a * 0.25).cuda(), bl.cuda(), (rt * 0.2).cuda())
+        c3, p2 = ops.world_to_camera_project(world, *cam)
+        cp = torch.zeros(B, 16); cp[:, 9:13] = torch.tensor(cam[0]); cp[:, 13:16] = torch.tensor(cam[1])
+        s = Summary(epoch=10)
+        out = None
+        for it in range(2):
+            out = M.video.video_gan_iteration(args, d, c3.reshape(B, R, 16, 3), cp, p2.reshape(B, R, 16, 2), ["S1"], s, None,
+                                              do_g_step=(it == 1), camera=cam)
+        torch.cuda.synchronize()
+        vals = {k: (out[k][0].item(), out[k][1].item()) for k in ("d3", "m3", "d2", "m2")}
+        assert all(torch.isfinite(torch.tensor(v)).all() for v in vals.values()) and torch.isfinite(out["G_cost"]).item()
+        assert out["pos_3d_cam"].shape == (B, R, 16, 3) and out["pos_2d"].shape == (B, R, 16, 2)
+        for k, ps in before.items():
+            steps = 1 if k == "model_G" else (4 if k in ("model_d3d", "model_d2d") else 8)
+            moved = max((p.detach() - q).abs().max().item() for p, q in zip(d[k].parameters(), ps))
+            assert 0 < moved <= 1.3e-4 * steps, (k, moved)          # (bias-corrected early Adam steps reach ~1.1 lr)
+        res.append(vals)
+        del d, before
+        torch.cuda.empty_cache()
+    for k in res[0]:
+        assert abs(res[0][k][0] - res[1][k][0]) <= 2e-3 * max(1.0, abs(res[0][k][0])), (k, res[0][k], res[1][k])

@@ -73,3 +73,21 @@ def test_motion_critic_step_golden(golden, tag):
         assert maxabs(gr, ref) <= 1e-7 + 1e-4 * ref.abs().max().item(), k
     for k, v in net.state().items():
         assert maxabs(v, g["new__" + k]) <= 2e-6, k
+
+
+def test_video_D1000_forward_golden(golden):
+    """BASELINE configs[4] widths (DenseDim 1000, R = 9): the oracle's video generator and four critics against the reference"""
+    g = golden("video_D1000")
+    R, D = 9, 1000
+    sG, s3, s2, sm3, sm2 = (int(v) for v in g["seeds"])
+    m3s, m2s = LU.motion_shapes(D, R)
+    sd = dict(G=GU.seeded_state_dict(GU.shapes_generator(D, frames=R), sG), d3=GU.seeded_state_dict(GU.shapes_d3(D), s3),
+              d2=GU.seeded_state_dict(GU.shapes_d2(D), s2), m3=GU.seeded_state_dict(m3s, sm3), m2=GU.seeded_state_dict(m2s, sm2))
+    fake, _, _ = O.generator_forward(g["z"], sd["G"], g["bone_len"], g["scaler"], frames=R)
+    # (K = 1000 dot products: the summation order of the CPU GEMM depends on the thread count -- 1e-6 of the +-10 m root range)
+    assert maxabs(fake, g["fake"]) <= 1e-5
+    rel = lambda a, b: ((a - b).abs() / b.abs().clamp_min(0.1 * b.abs().mean())).max().item()
+    assert rel(O.d3_forward(g["x3"], sd["d3"]), g["logit_d3"]) <= 1e-5
+    assert rel(O.d2_forward(g["x2"], sd["d2"]), g["logit_d2"]) <= 1e-5
+    assert rel(O.motion_d3_forward(g["x3"], sd["m3"], R), g["logit_m3"]) <= 1e-5
+    assert rel(O.motion_d2_forward(g["x2"], sd["m2"], R), g["logit_m2"]) <= 1e-5

@@ -1,15 +1,21 @@
-import sys, os
+"""Profiling target: the 3D critic's fused launch alone (the three networks share one kernel name), B = 65 536, D = 256.
+    python tools/prof_fused_d3.py [bf16|f16x3]"""
+import os
+import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import dhaug_amd
-from dhaug_amd import fused
+from dhaug_amd import fused, ops
 from dhaug_amd.function_aug.config import synth_args
 from dhaug_amd.models_Fk_GAN import Fk_discriminator
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 B, D = 65536, 256
 args = synth_args(B, D)
 D3 = Fk_discriminator.Fk_3D_Discriminator("cuda", args).cuda()
-x3 = torch.randn(B, 16, 3, device="cuda") * 0.3
+x3 = torch.randn(B, 48, device="cuda") * 0.3
+kcs = ops.kcs_forward(x3, True, f32=True)[0] if mode == "f16x3" else ops.kcs_forward(x3, True, f32=False, bf16_ld=32)[1]
 with torch.no_grad():
-    for _ in range(400):
-        fused.critic3d(D3, x3)
+    for _ in range(400 if mode == "bf16" else 150):
+        fused.critic3d(D3, x3, kcs=kcs, mode=mode)
 torch.cuda.synchronize()
