@@ -46,6 +46,74 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 
 constexpr int BK = 64;
 
+// coalesced epilogue of an fp32 C tile staged in LDS ([BM][BN + 4]): bias, residual, activation, bf16 / fp32 stores
+template <int BM, int BN>
+__device__ __forceinline__ void nt_store_tile(const GemmArgs& p, const float* sC, long long m0, long long n0, int tid) {
+    constexpr int CS = BN + 4;
+    constexpr int PIECES = BM * BN / 8;
+    for (int q = tid; q < PIECES; q += 256) {
+        const int row = q / (BN / 8), pc = q % (BN / 8);
+        const long long gm = m0 + row, n = n0 + pc * 8;
+        if (gm >= p.M) continue;
+        const bool any_out = n < p.N || (p.cb != nullptr && n < p.npad);
+        if (!any_out) continue;
+        float v[8];
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(sC + row * CS + pc * 8);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(sC + row * CS + pc * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = c0[e]; v[4 + e] = c1[e]; }
+        const bool full = n + 8 <= p.N;
+        if (p.bias != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (full || n + e < p.N) v[e] += p.bias[n + e];
+        }
+        if (p.resf != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (full || n + e < p.N) v[e] += p.resf[gm * p.ld_resf + n + e];
+        }
+        if (p.res != nullptr) {
+            if (full) {
+                const uint4 rr = *reinterpret_cast<const uint4*>(p.res + gm * p.ld_res + n);
+                const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += __builtin_bit_cast(float, w[e] << 16);
+                    v[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] += dhaug_bf16_to_f32(p.res[gm * p.ld_res + n + e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (full || n + e < p.N) ? apply_act(v[e], p.act, p.slope) : 0.0f;
+        if (p.cb != nullptr) {
+            if (n + 8 <= p.npad || full) {
+                uint4 o;
+                o.x = (uint32_t)dhaug_f32_to_bf16(v[0]) | ((uint32_t)dhaug_f32_to_bf16(v[1]) << 16);
+                o.y = (uint32_t)dhaug_f32_to_bf16(v[2]) | ((uint32_t)dhaug_f32_to_bf16(v[3]) << 16);
+                o.z = (uint32_t)dhaug_f32_to_bf16(v[4]) | ((uint32_t)dhaug_f32_to_bf16(v[5]) << 16);
+                o.w = (uint32_t)dhaug_f32_to_bf16(v[6]) | ((uint32_t)dhaug_f32_to_bf16(v[7]) << 16);
+                *reinterpret_cast<uint4*>(p.cb + gm * p.ldcb + n) = o;
+            } else {
+                const long long lim = p.npad > p.N ? p.npad : p.N;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (n + e < lim) p.cb[gm * p.ldcb + n + e] = dhaug_f32_to_bf16(v[e]);
+            }
+        }
+        if (p.cf != nullptr) {
+            if (full && (p.ldcf & 3) == 0) {
+                f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                *reinterpret_cast<f32x4*>(p.cf + gm * p.ldcf + n) = o0;
+                *reinterpret_cast<f32x4*>(p.cf + gm * p.ldcf + n + 4) = o1;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (n + e < p.N) p.cf[gm * p.ldcf + n + e] = v[e];
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -150,69 +218,108 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
         }
     __syncthreads();
 
-    // coalesced epilogue: each thread owns 8 consecutive features of one batch row
-    constexpr int PIECES = BM * BN / 8;
-    for (int q = tid; q < PIECES; q += 256) {
-        const int row = q / (BN / 8), pc = q % (BN / 8);
-        const long long gm = m0 + row, n = n0 + pc * 8;
-        if (gm >= p.M) continue;
-        const bool any_out = n < p.N || (p.cb != nullptr && n < p.npad);
-        if (!any_out) continue;
-        float v[8];
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(sC + row * CS + pc * 8);
-        const f32x4 c1 = *reinterpret_cast<const f32x4*>(sC + row * CS + pc * 8 + 4);
+    nt_store_tile<BM, BN>(p, sC, m0, n0, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same product for shapes the specialised kernels do not cover (DenseDim 1000 layers of the video configuration,
+// concatenation layers, 100-wide blocks), with the global loads FOUR K-stages ahead.  gemm_nt_kernel above keeps one
+// stage in flight and drains it at every __syncthreads(): 1.8 us per 64-wide K step whatever the tile does (29.7 us for
+// a 512 x 1000 x 1000 layer, rocprof r02_video).  Here: 64 x 64 tiles (a 512-row layer still gives 128 workgroups),
+// four register stages requested up front and refilled right after their LDS write, barriers that order LDS traffic
+// only (vmcnt keeps counting across them), several workgroups per CU.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void p_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void p_copy16(const void* g, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
+                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
+// Operand stages travel global -> LDS without registers (global_load_lds_dwordx4, counted in vmcnt): register-staged
+// loads behind control flow make hipcc wait with small vmcnt values right behind the requests (seen in the ISA of a
+// first version), which serialises the stages again.  A stage is [64 rows][64 k] bf16 per operand, rows contiguous (the
+// copy fixes a lane's LDS slot), 16-byte chunk c of row r at position c ^ ((r >> 1) & 7) (applied on the global side).
+// Rows beyond M / N read a valid row (their results are never stored); the K tail is cut in the k-step loop.
+__global__ __launch_bounds__(256, 2) void gemm_nt_pipe_kernel(GemmArgs p) {
+    constexpr int BM = 64, BN = 64, NSTG = 4;
+    constexpr int CS = BN + 4;
+    constexpr int STG = (BM + BN) * BK * 2;                                  // 16 384 bytes per stage
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[NSTG * STG];
+    float* sC = reinterpret_cast<float*>(smem_raw);             // [BM][CS], reuses the staging buffers
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                    // 2 x 2 waves, one 32 x 32 MFMA tile each
+    const long long ntn = (p.W + BN - 1) / BN;
+    const long long m0 = (long long)(blockIdx.x / ntn) * BM;
+    const long long n0 = (long long)(blockIdx.x % ntn) * BN;
+    const int nkt = (int)((p.K + BK - 1) / BK);
+
+    // this lane's two rows per operand and its swizzled chunk
+    const uint16_t* pa[2];
+    const uint16_t* pb[2];
+    int rowoff[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = c0[e]; v[4 + e] = c1[e]; }
-        const bool full = n + 8 <= p.N;
-        if (p.bias != nullptr) {
+    for (int i = 0; i < 2; ++i) {
+        const int row0 = (wave * 2 + i) * 8, row = row0 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+        const long long gm = m0 + row, gn = n0 + row;
+        pa[i] = p.A + (gm < p.M ? gm : p.M - 1) * p.lda + c * 8;
+        pb[i] = p.B + (gn < p.N ? gn : p.N - 1) * p.ldb + c * 8;
+        rowoff[i] = row0 * (BK * 2);
+    }
+    auto copy_stage = [&](int kt) {                             // 4 copies per lane
+        unsigned char* base = smem_raw + (kt % NSTG) * STG;
+        long long k0 = (long long)kt * BK;
+        if (k0 + BK > p.K) k0 = p.K - BK > 0 ? p.K - BK : 0;   // short last stage: re-read the last full window (K >= 64) ...
+        const long long shift = (long long)kt * BK - k0;       // ... and skip its first `shift` columns in the k-step loop
+        (void)shift;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) if (full || n + e < p.N) v[e] += p.bias[n + e];
+        for (int i = 0; i < 2; ++i) {
+            p_copy16(pa[i] + k0, base + rowoff[i]);
+            p_copy16(pb[i] + k0, base + BM * BK * 2 + rowoff[i]);
         }
-        if (p.resf != nullptr) {
+    };
+    f32x16 acc;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) if (full || n + e < p.N) v[e] += p.resf[gm * p.ld_resf + n + e];
-        }
-        if (p.res != nullptr) {
-            if (full) {
-                const uint4 rr = *reinterpret_cast<const uint4*>(p.res + gm * p.ld_res + n);
-                const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[2 * e] += __builtin_bit_cast(float, w[e] << 16);
-                    v[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] += dhaug_bf16_to_f32(p.res[gm * p.ld_res + n + e]);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (full || n + e < p.N) ? apply_act(v[e], p.act, p.slope) : 0.0f;
-        if (p.cb != nullptr) {
-            if (n + 8 <= p.npad || full) {
-                uint4 o;
-                o.x = (uint32_t)dhaug_f32_to_bf16(v[0]) | ((uint32_t)dhaug_f32_to_bf16(v[1]) << 16);
-                o.y = (uint32_t)dhaug_f32_to_bf16(v[2]) | ((uint32_t)dhaug_f32_to_bf16(v[3]) << 16);
-                o.z = (uint32_t)dhaug_f32_to_bf16(v[4]) | ((uint32_t)dhaug_f32_to_bf16(v[5]) << 16);
-                o.w = (uint32_t)dhaug_f32_to_bf16(v[6]) | ((uint32_t)dhaug_f32_to_bf16(v[7]) << 16);
-                *reinterpret_cast<uint4*>(p.cb + gm * p.ldcb + n) = o;
-            } else {
-                const long long lim = p.npad > p.N ? p.npad : p.N;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) if (n + e < lim) p.cb[gm * p.ldcb + n + e] = dhaug_f32_to_bf16(v[e]);
-            }
-        }
-        if (p.cf != nullptr) {
-            if (full && (p.ldcf & 3) == 0) {
-                f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                *reinterpret_cast<f32x4*>(p.cf + gm * p.ldcf + n) = o0;
-                *reinterpret_cast<f32x4*>(p.cf + gm * p.ldcf + n + 4) = o1;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) if (n + e < p.N) p.cf[gm * p.ldcf + n + e] = v[e];
-            }
+    for (int s = 0; s < NSTG - 1; ++s)
+        if (s < nkt) copy_stage(s);
+    const int rowb = wn * 32 + (lane & 31), rowa = wm * 32 + (lane & 31);
+    for (int kt = 0; kt < nkt; ++kt) {
+        // stage kt must have landed; younger: stages kt+1, kt+2 (4 copies each) where they exist
+        const int younger = nkt - 1 - kt;
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p_lds_barrier();                                        // everybody's copies of stage kt are in LDS, stage kt-1 is released
+        if (kt + NSTG - 1 < nkt) copy_stage(kt + NSTG - 1);
+        const unsigned char* bufA = smem_raw + (kt % NSTG) * STG;
+        const unsigned char* bufB = bufA + BM * BK * 2;
+        // k-steps of this stage: a short last stage was loaded as the last full 64-wide window, its first columns belong
+        // to the previous stage
+        const long long kbeg = (long long)kt * BK;
+        int ks0 = 0;
+        if (kbeg + BK > p.K && p.K >= BK) ks0 = (int)((kbeg - (p.K - BK)) >> 4);
+        const int ks1 = p.K >= BK ? 4 : (int)(p.K >> 4);
+        for (int ks = ks0; ks < ks1; ++ks) {
+            const int chunk = 2 * ks + (lane >> 5);
+            const bf16x8 fw = *reinterpret_cast<const bf16x8*>(bufB + rowb * (BK * 2) + ((chunk ^ ((rowb >> 1) & 7)) << 4));
+            const bf16x8 fx = *reinterpret_cast<const bf16x8*>(bufA + rowa * (BK * 2) + ((chunk ^ ((rowa >> 1) & 7)) << 4));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fx, acc, 0, 0, 0);
         }
     }
+    p_lds_barrier();                                            // the staging buffers become the C tile
+    {
+        const int m = wm * 32 + (lane & 31);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = wn * 32 + 8 * g + 4 * (lane >> 5);
+            f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            *reinterpret_cast<f32x4*>(sC + m * CS + n) = v;
+        }
+    }
+    p_lds_barrier();
+    nt_store_tile<BM, BN>(p, sC, m0, n0, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1163,6 +1270,11 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
             case 16: return launch_ws<16>(s, p);
             default: break;
         }
+    }
+    if (width > 64 && K >= 64 && lda >= 64 && ldb >= 64 && getenv("DHAUG_GEMM_NOPIPE") == nullptr) {
+        const long long grid = ((M + 63) / 64) * ((width + 63) / 64);
+        hipLaunchKernelGGL(gemm_nt_pipe_kernel, dim3((unsigned)grid), dim3(256), 0, s, p);
+        return dhaug_launch_status();
     }
     if (width > 64) {
         constexpr int BM = 128, BN = 128;

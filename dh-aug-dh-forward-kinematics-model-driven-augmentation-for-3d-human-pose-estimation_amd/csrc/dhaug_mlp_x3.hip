@@ -11,12 +11,19 @@
 // MFMA runs at the BF16 rate, so this mode costs 3 matrix instructions per k-step instead of 1 -- its roofline is a third
 // of the dense peak in ALGORITHMIC flops.  Range: |x| < 65 504 (fp16); values below 2^-14 keep an ABSOLUTE error of 2^-25.
 //
-// Structure (256 threads = 4 waves = one per SIMD; one persistent workgroup per CU walking 64-row batch tiles):
+// Structure (512 threads = 8 waves = TWO per SIMD, 256 registers each; one persistent workgroup per CU walking 64-row
+// batch tiles).  Measured on the first version of this kernel (4 waves, one per SIMD; ablation builds, D3 at B = 65 536:
+// 459 us as built, 411 without weight reloads, 352 without epilogue, 297 with MFMAs only against 145 us of pure MFMA issue):
+// what a single wave per SIMD cannot hide is (a) the epilogue -- the fp32 -> hi/lo split is ~6 VALU per element pair -- and
+// (b) the start of every layer, where the first weight fragments and the bias are requested and waited for.  Hence:
+//   * wave w owns feature slice w (32 features) for all 64 rows: while one wave of a SIMD runs its epilogue or waits at the
+//     layer boundary, the other one issues MFMAs;
+//   * the NEXT layer's first two weight chunks and its bias are requested before the current layer's epilogue (the unit
+//     program is scanned ahead; across tiles it wraps around to the first layer);
 //   * activations: fp16 hi / lo planes [64 rows][256] per buffer (two 64 KB buffers + one 32 KB [64][128] buffer = all
 //     160 KB of LDS), 16-byte chunks XOR-swizzled by (row & 15) -> conflict-free ds_read_b128 of MFMA B fragments;
 //   * weights: pre-split and pre-packed in A-fragment order (dhaug_pack_wfrag_f16x2): per (32-feature slice, k-step)
-//     two contiguous 1 KB blocks (hi, lo); wave w owns slices w and w + 4; fragments stream from L2 through a 3-slot
-//     register ring (4 k-steps per slot) -- 12 MFMAs per k-step per wave hide them;
+//     two contiguous 1 KB blocks (hi, lo), streamed from L2 through a 2-slot register ring (4 k-steps per slot);
 //   * MFMA issued swapped (A = weights, B = activations): a lane owns one batch row and 4 consecutive features per
 //     register quad; the epilogue (bias = accumulator seed, residual from the LDS planes, activation, hi/lo split) writes
 //     8 + 8 bytes per lane into the next layer's operand planes.  In-place residual layers are safe (own elements only).
@@ -33,7 +40,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int X3_BM = 64;                                            // batch rows per tile
 constexpr int X3_MT = X3_BM / 32;
-constexpr int X3_THREADS = 256;
+constexpr int X3_THREADS = 512;
+constexpr int X3_WAVES = X3_THREADS / 64;
 constexpr int X3_CH = 4;                                             // k-steps per ring slot (64 k)
 constexpr int X3_MAX_UNITS = 32;
 constexpr int X3_MAX_KSTEPS = 16;
@@ -58,7 +66,7 @@ struct Unit {
     const float* bias;
 };
 struct Program {
-    int nunits;
+    int nunits, first_gemm;
     Unit u[X3_MAX_UNITS];
 };
 typedef const Unit __attribute__((address_space(4))) * UnitPtr;      // units are read from the kernarg segment (s_load)
@@ -87,50 +95,71 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_
 
 __device__ __forceinline__ int chunks_of(int ksteps) { return (ksteps + X3_CH - 1) / X3_CH; }
 
-// global loads of chunk C (of the concatenated sources; the first has NCH1 chunks) into a ring slot [slice][k][piece]
-template <int C, int NCH, int NCH1, int NS>
-__device__ __forceinline__ void load_chunk(const _Float16* w1, const _Float16* w2, int wave, int lane, f16x8 (&slot)[NS][X3_CH][2]) {
+typedef f16x8 Ring[2][X3_CH][2];                  // [slot][k-step in chunk][piece]: chunk c lives in slot c & 1
+
+// global loads of chunk C (of the concatenated sources; the first has NCH1 chunks) of this wave's slice into a ring slot
+template <int C, int NCH, int NCH1>
+__device__ __forceinline__ void load_chunk(const _Float16* w1, const _Float16* w2, int wave, int lane, f16x8 (&slot)[X3_CH][2]) {
     constexpr bool second = C >= NCH1;
     constexpr int kpad = (second ? NCH - NCH1 : NCH1) * X3_CH;
     constexpr int k0 = (second ? C - NCH1 : C) * X3_CH;
-    const _Float16* w = second ? w2 : w1;
+    const _Float16* base = (second ? w2 : w1) + ((long long)wave * kpad * 2 * 64 + lane) * 8 + (long long)k0 * 2 * 512;
 #pragma unroll
-    for (int t = 0; t < NS; ++t) {
-        const _Float16* base = w + ((long long)(wave + 4 * t) * kpad * 2 * 64 + lane) * 8 + (long long)k0 * 2 * 512;
+    for (int q = 0; q < X3_CH; ++q)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) slot[q][p] = *reinterpret_cast<const f16x8*>(base + (2 * q + p) * 512);
+}
+
+// chunks 0 and 1 and the bias of GEMM unit `u` for this wave's slice (shape known only at run time): requested ahead of the
+// layer, i.e. before the previous layer's epilogue and barrier.  Slices beyond N are zero rows of the blob (it always holds
+// 8 slices), so every wave may load.
+__device__ __forceinline__ void prefetch_layer(UnitPtr u, int wave, int lane, Ring& ring, f32x16& seed) {
+    const int kp1 = chunks_of(u->ksteps) * X3_CH, ks2 = u->ksteps2;
+    const _Float16* b0 = u->w + ((long long)wave * kp1 * 2 * 64 + lane) * 8;
+#pragma unroll
+    for (int q = 0; q < X3_CH; ++q)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) ring[0][q][p] = *reinterpret_cast<const f16x8*>(b0 + (2 * q + p) * 512);
+    if (kp1 > X3_CH || ks2 > 0) {                                            // a second chunk exists (wave-uniform)
+        const _Float16* b1 = kp1 > X3_CH ? b0 + X3_CH * 2 * 512
+                                         : u->w2 + ((long long)wave * (chunks_of(ks2) * X3_CH) * 2 * 64 + lane) * 8;
 #pragma unroll
         for (int q = 0; q < X3_CH; ++q)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) slot[t][q][p] = *reinterpret_cast<const f16x8*>(base + (2 * q + p) * 512);
+            for (int p = 0; p < 2; ++p) ring[1][q][p] = *reinterpret_cast<const f16x8*>(b1 + (2 * q + p) * 512);
+    }
+    const int h = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(u->bias + 32 * wave + 4 * h + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) seed[4 * g + e] = b4[e];
     }
 }
 
-// dst = act(W src [+ W2 src2] + bias + res), one layer, self-contained.  NCH chunks of 64 k, the first NCH1 from source 1;
-// NS = feature slices this wave owns in this layer (2: wave and wave + 4; 1: only wave).
-template <int NCH, int NCH1, int NS>
-__device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int wave, int lane) {
+// dst = act(W src [+ W2 src2] + bias + res), one layer.  NCH chunks of 64 k, the first NCH1 from source 1.  On entry the
+// ring holds this layer's chunks 0 (and 1) and `seed` its bias; before the epilogue `next` (the GEMM unit that runs after
+// this one, possibly of the next tile; nullptr: none) is prefetched the same way.  Waves whose slice lies beyond N only
+// take part in the prefetch.
+template <int NCH, int NCH1>
+__device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned char* smem, int wave, int lane, Ring& ring, f32x16& seed) {
     asm volatile("" : "+v"(lane));                   // lane-derived constants are recomputed per unit, not parked across units
-    f16x8 ring[3][NS][X3_CH][2];
     const int r31 = lane & 31, h = lane >> 5;
+    const int nslices = (u->N + 31) >> 5;
+    if (wave >= nslices) {                           // wave-uniform
+        if (next != nullptr) prefetch_layer(next, wave, lane, ring, seed);
+        return;
+    }
     const _Float16* w1 = u->w;
     const _Float16* w2 = NCH1 < NCH ? u->w2 : u->w;
-    load_chunk<0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[0]);
-    if constexpr (NCH > 1) load_chunk<1, NCH, NCH1, NS>(w1, w2, wave, lane, ring[1]);
-    f32x16 acc[NS][X3_MT];
+    f32x16 acc[X3_MT];
     const unsigned char* src1 = buf_base(smem, u->src);
     const int pbs1 = buf_pitch_bytes(u->src), pl1 = buf_plane(u->src);
     const unsigned char* src2 = NCH1 < NCH ? buf_base(smem, u->src2) : src1;
     const int pbs2 = NCH1 < NCH ? buf_pitch_bytes(u->src2) : pbs1, pl2 = NCH1 < NCH ? buf_plane(u->src2) : pl1;
-    f32x16 seed[NS];                                 // the bias is the accumulators' start value
-#pragma unroll
-    for (int t = 0; t < NS; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(u->bias + 32 * (wave + 4 * t) + 4 * h + 8 * g);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) seed[t][4 * g + e] = b4[e];
-        }
     constexpr int KT = NCH * X3_CH;
-    f16x8 fx[3][X3_MT][2];                           // activation fragments (hi, lo), read two k-steps ahead
+    f16x8 fx[2][X3_MT][2];                           // activation fragments (hi, lo), read one k-step ahead (the SIMD's other
+                                                     // wave covers the LDS latency; three stages spill at 256 registers)
     auto read_frags = [&](int k, f16x8 (&f)[X3_MT][2]) {
         const bool second = k >= NCH1 * X3_CH;
         const unsigned char* src = second ? src2 : src1;
@@ -144,39 +173,40 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
         }
     };
     read_frags(0, fx[0]);
-    if (KT > 1) read_frags(1, fx[1]);
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
         const int c = k / X3_CH, q = k % X3_CH;
-        if (k + 2 < KT) read_frags(k + 2, fx[(k + 2) % 3]);
-        if (q == 0 && c + 2 < NCH) {
-            if (c + 2 == 2) load_chunk<2 < NCH ? 2 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[2]);
-            if (c + 2 == 3) load_chunk<3 < NCH ? 3 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[0]);
-            if (c + 2 == 4) load_chunk<4 < NCH ? 4 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[1]);
-            if (c + 2 == 5) load_chunk<5 < NCH ? 5 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[2]);
-            if (c + 2 == 6) load_chunk<6 < NCH ? 6 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[0]);
-            if (c + 2 == 7) load_chunk<7 < NCH ? 7 : 0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[1]);
+#ifndef X3_ABL_NOREAD
+        if (k + 1 < KT) read_frags(k + 1, fx[(k + 1) & 1]);
+#endif
+#ifdef X3_ABL_NOWLOAD
+        if (false) {
+#else
+        // chunk c+1 is requested when chunk c starts, into the slot chunk c-1 just left (chunk 1 came with the prefetch)
+        if (q == 0 && c >= 1 && c + 1 < NCH) {
+#endif
+            if (c + 1 == 2) load_chunk<2 < NCH ? 2 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[0]);
+            if (c + 1 == 3) load_chunk<3 < NCH ? 3 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[1]);
+            if (c + 1 == 4) load_chunk<4 < NCH ? 4 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[0]);
+            if (c + 1 == 5) load_chunk<5 < NCH ? 5 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[1]);
+            if (c + 1 == 6) load_chunk<6 < NCH ? 6 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[0]);
+            if (c + 1 == 7) load_chunk<7 < NCH ? 7 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[1]);
         }
         __builtin_amdgcn_sched_barrier(0);
         // small terms first, then hi * hi
 #pragma unroll
         for (int mt = 0; mt < X3_MT; ++mt)
-#pragma unroll
-            for (int t = 0; t < NS; ++t)
-                acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[c % 3][t][q][1], fx[k % 3][mt][0], k == 0 ? seed[t] : acc[t][mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[c & 1][q][1], fx[k & 1][mt][0], k == 0 ? seed : acc[mt], 0, 0, 0);
 #pragma unroll
         for (int mt = 0; mt < X3_MT; ++mt)
-#pragma unroll
-            for (int t = 0; t < NS; ++t)
-                acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[c % 3][t][q][0], fx[k % 3][mt][1], acc[t][mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[c & 1][q][0], fx[k & 1][mt][1], acc[mt], 0, 0, 0);
 #pragma unroll
         for (int mt = 0; mt < X3_MT; ++mt)
-#pragma unroll
-            for (int t = 0; t < NS; ++t)
-                acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[c % 3][t][q][0], fx[k % 3][mt][0], acc[t][mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[c & 1][q][0], fx[k & 1][mt][0], acc[mt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
-    const int nslices = (u->N + 31) >> 5;
+    // the ring and the seed are dead: the next layer's first fragments travel during the epilogue and the barrier
+    if (next != nullptr) prefetch_layer(next, wave, lane, ring, seed);
     const bool to_global = (u->flags & F_OUT_F32) != 0;
     unsigned char* dst = buf_base(smem, u->dst);
     const int pbd = buf_pitch_bytes(u->dst), pld = buf_plane(u->dst);
@@ -184,47 +214,46 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
     const unsigned char* res = buf_base(smem, resid >= 0 ? resid : 0);
     const int pbr = buf_pitch_bytes(resid >= 0 ? resid : 0), plr = buf_plane(resid >= 0 ? resid : 0);
     const float neg = act_neg(u->act, u->slope);
+    const int slice = wave;
     // epilogue: this lane owns row (32 mt + r31), features 32*slice + 8g + 4h .. +3
+    if (to_global) {
+        float* st = reinterpret_cast<float*>(dst);
 #pragma unroll
-    for (int t = 0; t < NS; ++t) {
-        const int slice = wave + 4 * t;
-        if (slice >= nslices) continue;                                      // wave-uniform
-        if (to_global) {
-            float* st = reinterpret_cast<float*>(dst);
-#pragma unroll
-            for (int mt = 0; mt < X3_MT; ++mt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[t][mt][4 * g + e], neg);
-                    *reinterpret_cast<f32x4*>(st + (32 * mt + r31) * OUT_PITCH + 32 * slice + 4 * h + 8 * g) = v;
-                }
-            continue;
-        }
-#pragma unroll
-        for (int mt = 0; mt < X3_MT; ++mt) {
-            const int row = 32 * mt + r31;
+        for (int mt = 0; mt < X3_MT; ++mt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float v[4];
+                f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[t][mt][4 * g + e];
-                if (resid >= 0) {
-                    const int ro = chunk_off(row, 4 * slice + g, pbr) + (h << 3);
-                    const f16x4 rh = *reinterpret_cast<const f16x4*>(res + ro), rl = *reinterpret_cast<const f16x4*>(res + plr + ro);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)rh[e] + (float)rl[e];
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_fn(v[e], neg);
-                uint2 oh, ol;
-                split2(v[0], v[1], oh.x, ol.x);
-                split2(v[2], v[3], oh.y, ol.y);
-                const int o = chunk_off(row, 4 * slice + g, pbd) + (h << 3);
-                *reinterpret_cast<uint2*>(dst + o) = oh;
-                *reinterpret_cast<uint2*>(dst + pld + o) = ol;
+                for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[mt][4 * g + e], neg);
+                *reinterpret_cast<f32x4*>(st + (32 * mt + r31) * OUT_PITCH + 32 * slice + 4 * h + 8 * g) = v;
             }
+        return;
+    }
+#ifdef X3_ABL_NOEPI
+    if (u->slope == 12345.f)
+#endif
+#pragma unroll
+    for (int mt = 0; mt < X3_MT; ++mt) {
+        const int row = 32 * mt + r31;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[mt][4 * g + e];
+            if (resid >= 0) {
+                const int ro = chunk_off(row, 4 * slice + g, pbr) + (h << 3);
+                const f16x4 rh = *reinterpret_cast<const f16x4*>(res + ro), rl = *reinterpret_cast<const f16x4*>(res + plr + ro);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)rh[e] + (float)rl[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_fn(v[e], neg);
+            uint2 oh, ol;
+            split2(v[0], v[1], oh.x, ol.x);
+            split2(v[2], v[3], oh.y, ol.y);
+            const int o = chunk_off(row, 4 * slice + g, pbd) + (h << 3);
+            *reinterpret_cast<uint2*>(dst + o) = oh;
+            *reinterpret_cast<uint2*>(dst + pld + o) = ol;
         }
     }
 }
@@ -284,8 +313,13 @@ __global__ __launch_bounds__(X3_THREADS, 1) void fused_mlp_x3_kernel(Program pro
         (const unsigned char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
     UnitPtr units = (UnitPtr)(ka + __builtin_offsetof(Program, u));
     const int nunits = *(const int __attribute__((address_space(4)))*)(ka + __builtin_offsetof(Program, nunits));
+    const int first_gemm = *(const int __attribute__((address_space(4)))*)(ka + __builtin_offsetof(Program, first_gemm));
+    Ring ring;
+    f32x16 seed;
+    if ((long long)blockIdx.x < ntiles) prefetch_layer(units + first_gemm, wave, lane, ring, seed);
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long m0 = tile * X3_BM;
+        const bool more = tile + gridDim.x < ntiles;
 #pragma unroll 1
         for (int i = 0; i < nunits; ++i) {
             UnitPtr u = units + i;
@@ -293,20 +327,19 @@ __global__ __launch_bounds__(X3_THREADS, 1) void fused_mlp_x3_kernel(Program pro
             if (kind == U_LOAD_F32) {
                 load_unit(u, smem, m0, M, tid);
             } else {
-                const int nslices = (plan >> 24) & 15;
-#define X3_SHAPES(NS)                                                                      \
-    switch ((plan >> 16) & 255) {                              /* validated on the host */ \
-        case 1 * 16 + 1: gemm_layer<1, 1, NS>(u, smem, wave, lane); break;                 \
-        case 2 * 16 + 2: gemm_layer<2, 2, NS>(u, smem, wave, lane); break;                 \
-        case 2 * 16 + 1: gemm_layer<2, 1, NS>(u, smem, wave, lane); break;                 \
-        case 4 * 16 + 4: gemm_layer<4, 4, NS>(u, smem, wave, lane); break;                 \
-        case 4 * 16 + 2: gemm_layer<4, 2, NS>(u, smem, wave, lane); break;                 \
-        case 8 * 16 + 4: gemm_layer<8, 4, NS>(u, smem, wave, lane); break;                 \
-        default: break;                                                                    \
-    }
-                if (wave + 4 < nslices) { X3_SHAPES(2) }
-                else if (wave < nslices) { X3_SHAPES(1) }
-#undef X3_SHAPES
+                // the GEMM unit that runs after this one: plan bits 0..7 hold its index + 1 (0: this is the program's last;
+                // the next tile then starts over at the first)
+                const int nx = plan & 255;
+                UnitPtr next = nx != 0 ? units + (nx - 1) : (more ? units + first_gemm : (UnitPtr) nullptr);
+                switch ((plan >> 16) & 255) {                          /* validated on the host */
+                    case 1 * 16 + 1: gemm_layer<1, 1>(u, next, smem, wave, lane, ring, seed); break;
+                    case 2 * 16 + 2: gemm_layer<2, 2>(u, next, smem, wave, lane, ring, seed); break;
+                    case 2 * 16 + 1: gemm_layer<2, 1>(u, next, smem, wave, lane, ring, seed); break;
+                    case 4 * 16 + 4: gemm_layer<4, 4>(u, next, smem, wave, lane, ring, seed); break;
+                    case 4 * 16 + 2: gemm_layer<4, 2>(u, next, smem, wave, lane, ring, seed); break;
+                    case 8 * 16 + 4: gemm_layer<8, 4>(u, next, smem, wave, lane, ring, seed); break;
+                    default: break;
+                }
                 if (u->flags & F_OUT_F32) {
                     lds_barrier();
                     store_output(u, smem, m0, M, tid);
@@ -392,12 +425,20 @@ int dhaug_mlp_forward_x3(const dhaug_mlp_unit* units, int nunits, int64_t M, voi
                 DHAUG_CHECK(u.res < 0 || (okbuf(u.res) && u.res != u.src && (u.ksteps2 == 0 || u.res != u.src2)), DHAUG_EINVAL);
                 DHAUG_CHECK(u.res < 0 || ((u.N + 31) / 32) * 32 <= pitch(u.res), DHAUG_EUNSUPPORTED);
             }
-            u.plan = (sh << 16) | (((u.N + 31) >> 5) << 24);
+            u.plan = (sh << 16) | (((u.N + 31) >> 5) << 24);                  // bits 0..7: index + 1 of the next GEMM unit (below)
         } else {
             DHAUG_CHECK(okbuf(u.dst) && u.g != nullptr && u.cols >= 2 && ((u.cols + 63) & ~63) <= pitch(u.dst), DHAUG_EINVAL);
             DHAUG_CHECK(u.cols % 2 == 0 && u.ld % 2 == 0 && u.ld >= u.cols && (reinterpret_cast<uintptr_t>(u.g) & 7u) == 0, DHAUG_EALIGN);
         }
     }
+    prog.first_gemm = -1;
+    for (int i = nunits - 1, nx = 0; i >= 0; --i)
+        if (prog.u[i].kind == U_GEMM) {
+            prog.u[i].plan |= nx;
+            nx = i + 1;
+            prog.first_gemm = i;
+        }
+    DHAUG_CHECK(prog.first_gemm >= 0, DHAUG_EINVAL);
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_x3_kernel),
