@@ -45,7 +45,11 @@ DHAUG_HD float div180(float x) {
 // sin/cos of an fp32 radian argument, ~1 ulp: 3-term Cody-Waite reduction by pi/2 in FMA, Cephes minimax
 // polynomials on [-pi/4, pi/4].  ~22 VALU instructions per pair (ocml sincosf is ~3x that and branches).
 DHAUG_HD void sincos_rad(float x, float& s, float& c) {
-    if (__builtin_expect(fabsf(x) > 131072.0f, 0)) {          // far outside any joint angle: library path
+    // far outside any joint angle, or not finite: library path.  The test is on the bit pattern (131072.0f = 0x48000000;
+    // inf / NaN compare greater): this file is built with -ffinite-math-only, under which a float comparison may be
+    // assumed false for NaN -- and the (int) conversion below is undefined for NaN (found by UBSan on the host build,
+    // tests/test_cpu_boundary.py).
+    if (__builtin_expect((__builtin_bit_cast(uint32_t, x) & 0x7fffffffu) > 0x48000000u, 0)) {
         sincosf(x, &s, &c);
         return;
     }

@@ -195,6 +195,37 @@ class FakePairBuffer:
             yield p3[j], p2[j], ['none'] * j.shape[0], c[j]
 
 
+def run_critic_steps(steps, optimizers, interleave):
+    """steps: [(key, fn)] in the reference's order, fn() -> (Wasserstein_D, D_cost).  Returns {index: result}.
+    interleave (multi-rank runs): the steps of different networks are independent given the fakes, so they are issued
+    round-robin over the networks -- per-network order kept -- with the optimizers in overlap mode: while one network's
+    gradient bucket is all-reduced, the next network's step computes.  Single-rank runs keep the reference's order."""
+    res = {}
+    if not interleave:
+        for i, (_, fn) in enumerate(steps):
+            res[i] = fn()
+        return res
+    for o in optimizers:
+        o.overlap = True
+    queues = {}
+    for i, (key, fn) in enumerate(steps):
+        queues.setdefault(key, []).append((i, fn))
+    while any(queues.values()):
+        for key in list(queues):
+            if queues[key]:
+                i, fn = queues[key].pop(0)
+                res[i] = fn()
+    for o in optimizers:
+        o.flush()
+        o.overlap = False
+    return res
+
+
+def _multi_rank():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 class Draws:
     """Replayable random draws of one iteration (parity tests): noise / scaler / alpha are lists consumed in the order the
     reference draws them (R/models_Fk_GAN/model_fk_gan_train.py:303, R/models_Fk_GAN/Fk_generator.py:197,
@@ -267,8 +298,6 @@ def gan_iteration(args, poseFk_dict, inputs_3d, cam_param, target_d2d, train_sub
     set_grad([D3, D2], True)
     set_grad([G], False)
     draws = draws or Draws()
-    step = lambda net, r, f, name, opt: train_Fk_discriminator(net, r, f, summary, writer, name, opt, args,
-                                                               alpha=draws.take("alpha", device))
     with torch.no_grad():
         noise = draws.take("noise", device)
         if noise is None:
@@ -276,17 +305,27 @@ def gan_iteration(args, poseFk_dict, inputs_3d, cam_param, target_d2d, train_sub
         fake_world = G(noise, bone_len_scaler=draws.take("scaler", device)).reshape(-1, 16, 3)   # :305-310 (.data: no graph)
     fake_c = ops.center_flip(fake_world, True, False)                        # :312
     out = {}
-    W3, C3 = step(D3, real_c, fake_c, 'Fk_d3d', o3)
     flip = bool(args.flip_GAN_model_input)
-    if flip:                                                                 # :319-341
-        W3f, C3f = step(D3, ops.center_flip(real_c, False, True), ops.center_flip(fake_c, False, True), 'Fk_d3d', o3)
-        W3, C3 = (W3 + W3f) / 2, (C3 + C3f) / 2
     quat, trans, cam9 = camera if camera is not None else pick_camera(train_subjects, rng)
     pos_3d_cam, pos_2d = ops.world_to_camera_project(fake_world, quat, trans, cam9)      # :374-376
-    W2, C2 = step(D2, target_d2d, pos_2d, 'd2d', o2)
-    if flip:                                                                 # :387-409
-        W2f, C2f = step(D2, ops.center_flip(target_d2d, False, True), ops.center_flip(pos_2d, False, True), 'd2d', o2)
-        W2, C2 = (W2 + W2f) / 2, (C2 + C2f) / 2
+    # the critic steps in the reference's order (D3, D3 flipped :319-341, D2, D2 flipped :387-409); their interpolation
+    # coefficients are taken in that order whatever order the steps are issued in
+    alphas = [draws.take("alpha", device) for _ in range(4 if flip else 2)]
+    mk = lambda net, r, f, name, opt, a: (lambda: train_Fk_discriminator(net, r, f, summary, writer, name, opt, args, alpha=a))
+    steps = [("d3", mk(D3, real_c, fake_c, 'Fk_d3d', o3, alphas[0]))]
+    if flip:
+        steps.append(("d3", mk(D3, ops.center_flip(real_c, False, True), ops.center_flip(fake_c, False, True), 'Fk_d3d', o3,
+                               alphas[1])))
+    steps.append(("d2", mk(D2, target_d2d, pos_2d, 'd2d', o2, alphas[2 if flip else 1])))
+    if flip:
+        steps.append(("d2", mk(D2, ops.center_flip(target_d2d, False, True), ops.center_flip(pos_2d, False, True), 'd2d', o2,
+                               alphas[3])))
+    res = run_critic_steps(steps, (o3, o2), _multi_rank())
+    if flip:
+        W3, C3 = (res[0][0] + res[1][0]) / 2, (res[0][1] + res[1][1]) / 2
+        W2, C2 = (res[2][0] + res[3][0]) / 2, (res[2][1] + res[3][1]) / 2
+    else:
+        (W3, C3), (W2, C2) = res[0], res[1]
     G_cost = None
     if do_g_step:                                                            # :415-484
         G_cost = generator_step(args, G, oG, (D3, D2), (args.GAN_3d_loss_weight, args.GAN_2d_loss_weight),

@@ -11,8 +11,8 @@ import torch
 
 from .. import ops
 from ..common import camera as cam
-from .model_fk_gan_train import (Draws, FakePairBuffer, generator_step, pick_camera, set_grad, train_Fk_discriminator,
-                                  _device)
+from .model_fk_gan_train import (Draws, FakePairBuffer, generator_step, pick_camera, run_critic_steps, set_grad,
+                                  train_Fk_discriminator, _device, _multi_rank)
 from .video_mode_operate import frames_from_args
 
 
@@ -50,43 +50,53 @@ def video_gan_iteration(args, poseFk_dict, inputs_3d, cam_param, inputs_2d, trai
             noise = torch.randn(B, 128, device=device)
         fake_world = G(noise, bone_len_scaler=draws.take("scaler", device)).reshape(-1, 16, 3)
     fake = ops.center_flip(fake_world, True, False)
-    avg = lambda a, b: tuple((x + y) / 2 for x, y in zip(a, b))
-
-    def critic_pair(net, opt, name, r, f, mode):
-        return train_Fk_discriminator(net, r, f, summary, writer, name, opt, args, dis_mode=mode,
-                                      alpha=draws.take("alpha", device))
-
-    def motion_steps(net, opt, name, back_name, r, f, width, mode):
-        """clip + (optionally) time-reversed clip"""
-        res = critic_pair(net, opt, name, r, f, mode)
-        if playback:
-            res = avg(res, critic_pair(net, opt, back_name, _rev(r, R, width), _rev(f, R, width), mode))
-        return res
-
-    out = {}
-    out['d3'] = critic_pair(D3, o3, 'Fk_d3d', real, fake, 'single')
-    if motion_on:
-        out['m3'] = motion_steps(M3, om3, 'motion_Fk_d3d', 'back_motion_Fk_d3d', real.reshape(-1, 48), fake.reshape(-1, 48),
-                                 48, 'motion')
-    if flip:
-        rf, ff = ops.center_flip(real, False, True), ops.center_flip(fake, False, True)
-        out['d3'] = avg(out['d3'], critic_pair(D3, o3, 'Fk_d3d', rf, ff, 'single'))
-        if motion_on:
-            out['m3'] = avg(out['m3'], motion_steps(M3, om3, 'motion_Fk_d3d', 'back_flip_motion_Fk_d3d', rf.reshape(-1, 48),
-                                                    ff.reshape(-1, 48), 48, 'motion'))
     quat, trans, cam9 = camera if camera is not None else pick_camera(train_subjects, rng)
     pos_3d_cam, pos_2d = ops.world_to_camera_project(fake_world, quat, trans, cam9)
     real2d = inputs_2d.reshape(-1, 16, 2)
-    out['d2'] = critic_pair(D2, o2, 'd2d', real2d, pos_2d, 'single')
-    if motion_on:
-        out['m2'] = motion_steps(M2, om2, 'motion_d2d', 'back_motion_d2d', real2d.reshape(-1, 32), pos_2d.reshape(-1, 32),
-                                 32, 'single')
+
+    # every critic step of the iteration, in the reference's order (the recorded interpolation coefficients follow it):
+    # 3D: D3, M3, M3 reversed [:208-232], the same on L/R-flipped copies [:237-289]; 2D likewise [:335-418]
+    steps, slots = [], {}
+
+    def add(key, net, opt, name, r, f, mode):
+        a = draws.take("alpha", device)
+        steps.append((key, lambda: train_Fk_discriminator(net, r, f, summary, writer, name, opt, args, dis_mode=mode, alpha=a)))
+        return len(steps) - 1
+
+    def group(tag, key_s, net_s, opt_s, name_s, key_m, net_m, opt_m, names_m, r, f, width, mode_m):
+        """one (single-frame critic, motion critic, motion critic on the reversed clip) triple"""
+        idx = dict(s=add(key_s, net_s, opt_s, name_s, r, f, 'single'))
+        if motion_on:
+            rr, ff = r.reshape(-1, width), f.reshape(-1, width)
+            idx['m'] = add(key_m, net_m, opt_m, names_m[0], rr, ff, mode_m)
+            if playback:
+                idx['b'] = add(key_m, net_m, opt_m, names_m[1], _rev(rr, R, width), _rev(ff, R, width), mode_m)
+        slots[tag] = idx
+
+    group('3', 'd3', D3, o3, 'Fk_d3d', 'm3', M3, om3, ('motion_Fk_d3d', 'back_motion_Fk_d3d'), real, fake, 48, 'motion')
     if flip:
-        r2f, f2f = ops.center_flip(real2d, False, True), ops.center_flip(pos_2d, False, True)
-        out['d2'] = avg(out['d2'], critic_pair(D2, o2, 'd2d', r2f, f2f, 'single'))
-        if motion_on:            # (the reference logs the flipped motion-2D step under 'd2d', :398-401)
-            out['m2'] = avg(out['m2'], motion_steps(M2, om2, 'd2d', 'back_flip_motion_d2d', r2f.reshape(-1, 32),
-                                                    f2f.reshape(-1, 32), 32, 'single'))
+        group('3f', 'd3', D3, o3, 'Fk_d3d', 'm3', M3, om3, ('motion_Fk_d3d', 'back_flip_motion_Fk_d3d'),
+              ops.center_flip(real, False, True), ops.center_flip(fake, False, True), 48, 'motion')
+    group('2', 'd2', D2, o2, 'd2d', 'm2', M2, om2, ('motion_d2d', 'back_motion_d2d'), real2d, pos_2d, 32, 'single')
+    if flip:            # (the reference logs the flipped motion-2D step under 'd2d', :398-401)
+        group('2f', 'd2', D2, o2, 'd2d', 'm2', M2, om2, ('d2d', 'back_flip_motion_d2d'),
+              ops.center_flip(real2d, False, True), ops.center_flip(pos_2d, False, True), 32, 'single')
+    res = run_critic_steps(steps, (o3, o2, om3, om2), _multi_rank())
+    avg = lambda a, b: tuple((x + y) / 2 for x, y in zip(a, b))
+
+    def motion(tag):
+        i = slots[tag]
+        return avg(res[i['m']], res[i['b']]) if 'b' in i else res[i['m']]
+
+    out = {}
+    for dim in ('3', '2'):
+        out['d' + dim] = res[slots[dim]['s']]
+        if motion_on:
+            out['m' + dim] = motion(dim)
+        if flip:
+            out['d' + dim] = avg(out['d' + dim], res[slots[dim + 'f']['s']])
+            if motion_on:
+                out['m' + dim] = avg(out['m' + dim], motion(dim + 'f'))
     out['G_cost'] = None
     if do_g_step:
         if motion_on:

@@ -43,6 +43,12 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev) if dev.type == "cuda" else None
         self.process_group = process_group
         self.data_parallel = data_parallel      # None: follow torch.distributed state
+        # overlap: step() only STARTS the gradient exchange (asynchronous all-reduce); the Adam launch waits for it in
+        # flush(), which zero_grad() calls -- i.e. right before this network is used again.  The epoch loops switch it on
+        # for multi-rank runs and interleave the steps of different networks, so that one network's all-reduce travels
+        # while the next network's step computes (25-100 MB buckets in the video configuration).
+        self.overlap = False
+        self._pending = None
 
     def state_dict(self):
         """torch.optim.Optimizer.state_dict() plus the flat moments and the step count (checkpoint / resume)"""
@@ -72,6 +78,7 @@ class FusedAdam(torch.optim.Optimizer):
                                    "re-allocated after the optimizer was built); rebuild the optimizer")
 
     def zero_grad(self, set_to_none=False):
+        self.flush()                            # never zero a bucket that is still being reduced
         self.flat_grad.zero_()
         for p, gv in zip(self._params, self._views):
             p.grad = gv
@@ -103,13 +110,32 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         self._check_views()
-        ws = self.exchange()
+        self._gather_grads()
+        ws = self.world_size()
         self.step_count += 1
-        g = self.param_groups[0]
-        if self.flat_param.is_cuda:
-            ops.adam_step_dev(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_dev, g["lr"],
-                              tuple(g["betas"]), g["eps"], 1.0 / ws)
-        else:
+        if not self.flat_param.is_cuda:
             raise RuntimeError("FusedAdam needs GPU parameters (no CPU fallback exists)")
-        A.bump_weight_epoch()                  # every packed bf16 copy of a weight is now stale
+        if ws > 1:
+            work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+            if self.overlap:
+                self._pending = (work, ws)
+                return None
+            work.wait()
+        self._apply(ws)
         return None
+
+    def _apply(self, ws):
+        g = self.param_groups[0]
+        ops.adam_step_dev(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_dev, g["lr"],
+                          tuple(g["betas"]), g["eps"], 1.0 / ws)
+        A.bump_weight_epoch()                  # every packed bf16 copy of a weight is now stale
+
+    @torch.no_grad()
+    def flush(self):
+        """finish a step whose exchange was started with overlap=True: wait for the all-reduce (on the stream, not the
+        host, with RCCL) and launch Adam.  A no-op otherwise."""
+        if self._pending is not None:
+            work, ws = self._pending
+            self._pending = None
+            work.wait()
+            self._apply(ws)

@@ -122,3 +122,36 @@ def test_hostcheck_fk_math_matches_oracle(built):
     lib.hostcheck_fk_backward(ptr(an), ptr(bn), ptr(gn), ptr(ga), ptr(gb), ptr(gr), ctypes.c_long(N))
     for got, ref in ((ga, ad.grad), (gb, bd.grad), (gr, rd.grad)):
         assert np.abs(got - ref.numpy()).max() <= 1e-4 * ref.abs().max().item()
+
+
+def test_hostcheck_under_address_and_ub_sanitizers(built, tmp_path):
+    """the same host build as an executable under -fsanitize=address,undefined (-fno-sanitize-recover): ordinary poses and
+    the degenerate ones of tests/test_gpu_edge.py (angles of +-1e4 and +-1e7 degrees -- the library path of the range
+    reduction --, zero bone lengths, inf / NaN angles) run clean, and the ordinary poses still match the oracle."""
+    import subprocess
+    import numpy as np
+    import golden_util as GU
+    from oracle import dhaug_oracle as O
+    import __graft_entry__ as ge
+    exe = ge.build_hostcheck_sanitized(verbose=False)
+    N = 512
+    a, bl, rt = GU.synth_fk_inputs(N, 17)
+    a, bl = a.clone(), bl.clone()
+    a[256:320] *= 55.0                      # +-1e4 deg
+    a[320:384] *= 5.0e4                     # +-1e7 deg: beyond the Cody-Waite window
+    bl[384:400] = 0.0
+    a[400, 3] = float("inf"); a[401, 12] = float("nan"); a[402, 36] = -float("inf")
+    g = torch.randn(N, 48, generator=torch.Generator().manual_seed(2))
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(np.int64(N).tobytes())
+        for t in (a, bl, rt, g):
+            f.write(t.numpy().astype(np.float32).tobytes())
+    r = subprocess.run([exe, str(fin), str(fout)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+    out = np.fromfile(fout, dtype=np.float32)[:N * 48].reshape(N, 48)
+    ref = O.fk_forward16(a, bl, rt).reshape(N, 48).numpy()
+    ok = np.r_[0:400]
+    assert np.abs(out[ok] - ref[ok]).max() <= 1e-5

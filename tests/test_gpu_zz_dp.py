@@ -123,3 +123,120 @@ def test_two_replica_critic_step_equals_full_batch(tag):
     for r in res:
         assert not r[1], r
     assert all(p.exitcode == 0 for p in procs)
+
+
+def _run_loop(rank, world, port, tag, q, gpu_ready):
+    """two replicas replay the reference's five-iteration loop (tests/golden/gan_loop_D32.npz), each on its half of every
+    batch: interleaved critic steps, asynchronous bucket exchange, deferred Adam (FusedAdam.overlap)"""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import numpy as np
+    import torch.distributed as dist
+    import loop_util as LU
+    import dhaug_amd
+    from dhaug_amd import parallel
+    from dhaug_amd.models_Fk_GAN import forward_kinematics_DH_model as fkm, model_fk_gan_train as train
+    from test_gpu_models import make_args
+    dist.init_process_group("gloo")
+    if rank > 0:
+        gpu_ready[rank - 1].wait(timeout=240)
+    torch.zeros(1, device="cuda").add_(1).item()
+    gpu_ready[rank].set()
+    parallel.init_from_env("gloo")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "gan_loop_D32.npz"))
+    g = {k: torch.from_numpy(z[k]) for k in z.files}
+    iters, B = g["real3d"].shape[0], g["real3d"].shape[1]
+    b, e = parallel.shard_range(B, rank, world)
+    args = make_args(batch_size=e - b, flip_GAN_model_input=True)
+    fk = fkm.Forward_Kinematics_DH_Model(args, ["S1", "S5"], None)
+    d = train.my_get_poseFk_model(args, None, fk)
+    for key, sd in zip(("model_G", "model_d3d", "model_d2d"), LU.single_state_dicts(g)):
+        d[key].load_state_dict(sd)
+        d[key].precision = "bf16x6"
+
+    class W:
+        def __init__(self):
+            self.s = {}
+
+        def add_scalar(self, name, value, step=None):
+            self.s.setdefault(name.split("/", 1)[1], []).append(float(value))
+
+    w, s = W(), argparse.Namespace(epoch=0, train_iter_num=0)
+    for i in range(iters):
+        last = i == iters - 1
+        draws = train.Draws(noise=[g["noise"][i][b:e]] + ([g["noise"][iters][b:e]] if last else []),
+                            scaler=[g["scaler"][i][b:e]] + ([g["scaler"][iters][b:e]] if last else []),
+                            alpha=[g["alpha"][4 * i + j][b:e] for j in range(4)])
+        cam = (g["cam_quat"][i].tolist(), g["cam_trans"][i].tolist(), g["buf_cam"][i * B].tolist())
+        train.gan_iteration(args, d, g["real3d"][i][b:e], g["cam_param"][b:e], g["real2d"][i][b:e], ["S1", "S5"], s, w,
+                            do_g_step=last, camera=cam, draws=draws)
+        s.train_iter_num += 1
+    bad = []
+    assert all(o._pending is None and not o.overlap for o in (d["optimizer_d3d"], d["optimizer_d2d"]))
+    # per-shard means average to the reference's values
+    ref = LU.scalar_series(g)
+    for name, r in ref.items():
+        t = torch.tensor(w.s[name], dtype=torch.float64)
+        dist.all_reduce(t)
+        t /= world
+        err = (t - r).abs().max().item()
+        if err > 2e-4 * max(1.0, r.abs().max().item()):
+            bad.append(("scalar", name, err))
+    for key, prefix, steps in (("model_d3d", "final_d3__", 10), ("model_d2d", "final_d2__", 10), ("model_G", "final_G__", 1)):
+        for k, p in d[key].named_parameters():
+            err = (p.detach().double().cpu() - g[prefix + k].double()).abs().reshape(-1)
+            if err.max().item() > 1.05e-4 * steps:
+                bad.append(("weights", key, k, err.max().item()))
+            if err.numel() >= 64 and torch.quantile(err, 0.98).item() > 2e-5:
+                bad.append(("weights q98", key, k, torch.quantile(err, 0.98).item()))
+    for key in ("optimizer_d3d", "optimizer_d2d", "optimizer_G"):
+        flat = d[key].flat_param.detach().cpu()
+        other = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(other, flat)
+        if not all(torch.equal(o, flat) for o in other):
+            bad.append(("replicas diverged", key))
+    q.put((rank, bad))
+    dist.destroy_process_group()
+
+
+def _worker_loop(rank, world, port, tag, q, gpu_ready):
+    try:
+        _run_loop(rank, world, port, tag, q, gpu_ready)
+    except BaseException as ex:
+        import traceback
+        q.put((rank, [("exception", repr(ex), traceback.format_exc())]))
+        raise
+
+
+def test_two_replica_loop_interleaved_overlap():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    ready = [ctx.Event() for _ in range(2)]
+    procs = [ctx.Process(target=_worker_loop, args=(r, 2, port, "loop", q, ready)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        import queue as _queue
+        import time
+        deadline = time.monotonic() + 300
+        while len(res) < len(procs) and time.monotonic() < deadline:
+            try:
+                res.append(q.get(timeout=2))
+            except _queue.Empty:
+                if [p for p in procs if p.exitcode not in (None, 0)]:
+                    break
+        res.sort()
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()                          # exact child only
+    assert [r[0] for r in res] == [0, 1], "replica exit codes %s, reported %s" % ([p.exitcode for p in procs], res)
+    for r in res:
+        assert not r[1], r
