@@ -28,6 +28,7 @@ SIGNATURES = {
     "dhaug_center_flip": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "dhaug_center_flip_backward": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "dhaug_gemm_bf16_dmask": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _f32, _vp, _i64, _i64, _i64, _i64, _vp],
+    "dhaug_gemm_bf16_dmask_pad": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _f32, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
     "dhaug_gemm_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i32,
                         _f32, _vp],
     "dhaug_gemm_tn_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp],
@@ -42,6 +43,7 @@ SIGNATURES = {
     "dhaug_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp],
     "dhaug_adam_step_dev": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _vp, _f32, _vp],
     "dhaug_counter_add": [_vp, _i32, _vp],
+    "dhaug_repack_weights": [_vp, _i32, _vp],
     "dhaug_gp_assemble": [_vp, _vp, _vp, _vp, _i64, _i64, _vp],
     "dhaug_gp_penalty": [_vp, _vp, _vp, _i64, _i64, _f32, _vp],
     "dhaug_critic_scalars": [_vp, _i64, _vp, _i64, _f32, _vp, _vp],
@@ -52,6 +54,11 @@ class MlpUnit(ctypes.Structure):
     _fields_ = [("kind", _i32), ("flags", _i32), ("src", _i32), ("dst", _i32), ("res", _i32), ("src2", _i32),
                 ("ksteps2", _i32), ("ksteps", _i32), ("n", _i32), ("act", _i32), ("slope", _f32), ("cols", _i32),
                 ("ld", _i64), ("g", _vp), ("w", _vp), ("w2", _vp), ("bias", _vp)]
+
+
+class RepackDesc(ctypes.Structure):
+    """struct dhaug_repack_desc (include/dhaug.h)"""
+    _fields_ = [("W", _vp), ("nt", _vp), ("nn", _vp), ("N", _i32), ("K", _i32), ("Kp", _i32), ("Np", _i32)]
 
 
 SIGNATURES["dhaug_pack_wfrag"] = [_vp, _i64, _vp, _i64, _i64, _i64, _vp]

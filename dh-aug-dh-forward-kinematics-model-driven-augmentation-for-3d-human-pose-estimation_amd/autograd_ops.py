@@ -58,14 +58,28 @@ WEIGHT_EPOCH = 0
 
 
 def bump_weight_epoch():
+    """every packed copy of every weight is stale (raw writes through .data: broadcasts, loads)"""
     global WEIGHT_EPOCH
     WEIGHT_EPOCH += 1
+
+
+def pack_key(W):
+    return (W.data_ptr(), W._version, tuple(W.shape), WEIGHT_EPOCH, getattr(W, "_dhaug_epoch", 0))
+
+
+def install_packed(W, nt, nn):
+    """the optimizer re-packed W itself (dhaug_repack_weights): register the fresh bf16 copies under the current key"""
+    ent = _Packed()
+    ent.key = pack_key(W)
+    ent.nt[(nt.shape[1], "bf16")] = nt
+    ent.nn = nn
+    W._dhaug_pack = ent
 
 
 def _pack(W):
     """cache entry for a weight-like fp32 (N,K) tensor.  The entry lives ON the parameter object (an id()-keyed dict
     would alias a freed parameter whose id / address get reused), and is valid for one (storage, version, epoch)."""
-    key = (W.data_ptr(), W._version, tuple(W.shape), WEIGHT_EPOCH)
+    key = (W.data_ptr(), W._version, tuple(W.shape), WEIGHT_EPOCH, getattr(W, "_dhaug_epoch", 0))
     if isinstance(W, torch.nn.Parameter):
         ent = getattr(W, "_dhaug_pack", None)
         if ent is not None and ent.key == key:

@@ -61,9 +61,9 @@ class _Math:
         if self.bf16:
             rb = res if (res is not None and res.dtype == BF16) else None
             rf = res if (res is not None and res.dtype != BF16) else None
+            if mask is not None and mask_act != NONE and not out_f32 and rf is None and bias is None:
+                return ops.gemm_nt_dmask(a_op, Bop, n, kp, mask, mask_act, slope, res_bf16=rb, out=out)
             if mask is not None and mask_act != NONE and not out_f32:
-                if n % 16 == 0 and rf is None:
-                    return ops.gemm_nt_dmask(a_op, Bop, n, kp, mask, mask_act, slope, res_bf16=rb, out=out)
                 y, _ = ops.gemm_nt(a_op, Bop, n, kp, bias=bias, res_bf16=rb, res_f32=rf, out_bf16=True, n_pad=ceil16(n), c_bf16=out)
                 w = min(y.shape[1], mask.shape[1])           # (a column block of a wider buffer carries no pad columns)
                 ya, ma = (y, mask) if (y.shape[1] == w and mask.shape[1] == w) else (y[:, :w], mask[:, :w])

@@ -158,6 +158,39 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// every weight of a network -> its two bf16 operand copies, two launches per optimizer step (blockIdx.y = parameter)
+__global__ __launch_bounds__(256) void repack_nt_kernel(const dhaug_repack_desc* __restrict__ descs) {
+    const dhaug_repack_desc d = descs[blockIdx.y];
+    const long long ppr = d.Kp >> 1, total = (long long)d.N * ppr;
+    uint16_t* dst = static_cast<uint16_t*>(d.nt);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / ppr, c = (i - r * ppr) * 2;
+        const float a = c < d.K ? d.W[r * d.K + c] : 0.0f;
+        const float b = c + 1 < d.K ? d.W[r * d.K + c + 1] : 0.0f;
+        *reinterpret_cast<uint32_t*>(dst + r * d.Kp + c) = (uint32_t)dhaug_f32_to_bf16(a) | ((uint32_t)dhaug_f32_to_bf16(b) << 16);
+    }
+}
+__global__ __launch_bounds__(256) void repack_nn_kernel(const dhaug_repack_desc* __restrict__ descs) {
+    __shared__ float t[32][33];
+    const dhaug_repack_desc d = descs[blockIdx.y];
+    uint16_t* dst = static_cast<uint16_t*>(d.nn);                // (K rows, Np columns) = W^T, zero beyond N
+    const long long tiles_r = (d.Np + 31) / 32, tiles_c = (d.K + 31) / 32;
+    for (long long tile = blockIdx.x; tile < tiles_r * tiles_c; tile += gridDim.x) {
+        const long long r0 = (tile / tiles_c) * 32, c0 = (tile % tiles_c) * 32;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int k = ty; k < 32; k += 8) {
+            const long long r = r0 + k, c = c0 + tx;
+            t[k][tx] = (r < d.N && c < d.K) ? d.W[r * d.K + c] : 0.0f;
+        }
+        __syncthreads();
+        for (int k = ty; k < 32; k += 8) {
+            const long long c = c0 + k, r = r0 + tx;
+            if (c < d.K && r < d.Np) dst[c * d.Np + r] = dhaug_f32_to_bf16(t[tx][k]);
+        }
+        __syncthreads();
+    }
+}
+
 // same step with the step count read from device memory (a hipGraph replays the launch; the count must not be baked in)
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v, long long n, float lr,
@@ -217,7 +250,19 @@ __global__ __launch_bounds__(1024) void critic_scalars_kernel(const float* __res
                                                               float* __restrict__ out) {
     __shared__ float red[3][16];
     float s[3] = {0.f, 0.f, 0.f};
-    for (long long i = threadIdx.x; i < B; i += 1024) {
+    long long i = threadIdx.x;
+    for (; i + 7 * 1024 < B; i += 8 * 1024) {                   // eight independent requests per array in flight
+        float a[8], b[8], c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a[j] = logits[(i + j * 1024) * ld];
+            b[j] = logits[(B + i + j * 1024) * ld];
+            c[j] = pen[i + j * 1024];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[0] += a[j]; s[1] += b[j]; s[2] += c[j]; }
+    }
+    for (; i < B; i += 1024) {
         s[0] += logits[i * ld];
         s[1] += logits[(B + i) * ld];
         s[2] += pen[i];
@@ -348,6 +393,15 @@ int dhaug_adam_step_dev(float* param, const float* grad, float* exp_avg, float* 
     DHAUG_CHECK_PTR(param); DHAUG_CHECK_PTR(grad); DHAUG_CHECK_PTR(exp_avg); DHAUG_CHECK_PTR(exp_avg_sq); DHAUG_CHECK_PTR(step_dev);
     hipLaunchKernelGGL(adam_dev_kernel, dim3(grid1d(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, (long long)n, lr, beta1, beta2, eps, step_dev, grad_scale);
+    return dhaug_launch_status();
+}
+
+int dhaug_repack_weights(const dhaug_repack_desc* descs_device, int nparams, void* stream) {
+    DHAUG_CHECK(nparams >= 0 && nparams <= 65535, DHAUG_EINVAL);
+    if (nparams == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(descs_device);
+    hipLaunchKernelGGL(repack_nt_kernel, dim3(32, (unsigned)nparams), dim3(256), 0, (hipStream_t)stream, descs_device);
+    hipLaunchKernelGGL(repack_nn_kernel, dim3(32, (unsigned)nparams), dim3(256), 0, (hipStream_t)stream, descs_device);
     return dhaug_launch_status();
 }
 

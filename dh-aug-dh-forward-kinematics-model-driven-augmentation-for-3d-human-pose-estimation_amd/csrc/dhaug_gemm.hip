@@ -87,6 +87,21 @@ __device__ __forceinline__ void nt_store_tile(const GemmArgs& p, const float* sC
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (full || n + e < p.N) ? apply_act(v[e], p.act, p.slope) : 0.0f;
+        if (p.dmask != nullptr) {                        // activation-backward mask of the producing layer
+            if (full && (p.ld_dmask & 7) == 0 && (reinterpret_cast<uintptr_t>(p.dmask) & 15) == 0) {
+                const uint4 mm = *reinterpret_cast<const uint4*>(p.dmask + gm * p.ld_dmask + n);
+                const uint32_t w[4] = {mm.x, mm.y, mm.z, mm.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {                // a positive bf16 is a positive int16
+                    v[2 * e] = (short)(w[e] & 0xffffu) > 0 ? v[2 * e] : v[2 * e] * p.dneg;
+                    v[2 * e + 1] = (short)(w[e] >> 16) > 0 ? v[2 * e + 1] : v[2 * e + 1] * p.dneg;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (full || n + e < p.N) v[e] = (short)p.dmask[gm * p.ld_dmask + n + e] > 0 ? v[e] : v[e] * p.dneg;
+            }
+        }
         if (p.cb != nullptr) {
             if (n + 8 <= p.npad || full) {
                 uint4 o;
@@ -729,6 +744,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ws_kernel(GemmArgs p) {
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (full || n + e < p.N) ? apply_act(v[e], p.act, p.slope) : 0.0f;
+            if (p.dmask != nullptr) {                        // activation-backward mask of the producing layer
+                if (full && (p.ld_dmask & 7) == 0 && (reinterpret_cast<uintptr_t>(p.dmask) & 15) == 0) {
+                    const uint4 mm = *reinterpret_cast<const uint4*>(p.dmask + gm * p.ld_dmask + n);
+                    const uint32_t w[4] = {mm.x, mm.y, mm.z, mm.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {            // a positive bf16 is a positive int16
+                        v[2 * e] = (short)(w[e] & 0xffffu) > 0 ? v[2 * e] : v[2 * e] * p.dneg;
+                        v[2 * e + 1] = (short)(w[e] >> 16) > 0 ? v[2 * e + 1] : v[2 * e + 1] * p.dneg;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (full || n + e < p.N) v[e] = (short)p.dmask[gm * p.ld_dmask + n + e] > 0 ? v[e] : v[e] * p.dneg;
+                }
+            }
             if (p.cb != nullptr) {
                 if (n + 8 <= p.npad || full) {
                     uint4 o;
@@ -1245,19 +1275,30 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
     // the training path's 256-wide layers
     if (N == 256 && width == 256 && K <= 256 && M % F_BM == 0 && c_bf16 != nullptr && c_f32 == nullptr && residual_f32 == nullptr &&
         (bias == nullptr || dhaug_aligned16(bias)) && getenv("DHAUG_GEMM_GENERIC") == nullptr && getenv("DHAUG_GEMM_NO256") == nullptr) {
-        if (dmask != nullptr && (K == 128 || K == 256) && getenv("DHAUG_NT256_SINGLE") == nullptr) {   // mask in the epilogue (its own LDS image)
-            p.dmask = dmask; p.ld_dmask = ld_dmask; p.dneg = dneg;
-            *mask_done = true;
-        }
-        if (getenv("DHAUG_NT256_SINGLE") == nullptr) {                        // two-role kernel (default)
+        if (getenv("DHAUG_NT256_SINGLE") == nullptr) {                        // two-role kernel (default): mask in its own LDS image
+            if (dmask != nullptr && (K == 128 || K == 256)) {
+                DHAUG_CHECK(ld_dmask % 8 == 0 && dhaug_aligned16(dmask), DHAUG_EALIGN);
+                p.dmask = dmask; p.ld_dmask = ld_dmask; p.dneg = dneg;
+                *mask_done = true;
+            }
             if (K == 128) return launch_nt256s<8>(s, p);
             if (K == 256) return launch_nt256s<16>(s, p);
+        } else if (dmask == nullptr || residual == nullptr) {                 // single-role kernel: mask OR residual
+            if (dmask != nullptr && (K == 128 || K == 256)) {
+                p.dmask = dmask; p.ld_dmask = ld_dmask; p.dneg = dneg;
+                *mask_done = true;
+            }
+            switch (K / 16) {
+                case 8: return launch_nt256<8>(s, p);
+                case 16: return launch_nt256<16>(s, p);
+                default: break;
+            }
         }
-        switch (K / 16) {
-            case 8: return launch_nt256<8>(s, p);
-            case 16: return launch_nt256<16>(s, p);
-            default: break;
-        }
+    }
+    // every other kernel applies the mask in its coalesced epilogue
+    if (dmask != nullptr && !*mask_done) {
+        p.dmask = dmask; p.ld_dmask = ld_dmask; p.dneg = dneg;
+        *mask_done = true;
     }
     if (width > 64 && K <= 256 && getenv("DHAUG_GEMM_GENERIC") == nullptr) {
         switch (K / 16) {
@@ -1303,19 +1344,24 @@ int dhaug_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t l
                           ldc_f32, M, N, K, act, slope, nullptr, 0, 1.0f, &done, stream);
 }
 
-int dhaug_gemm_bf16_dmask(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* residual,
-                          int64_t ld_res, const uint16_t* dmask, int64_t ld_dmask, int dmask_act, float dmask_slope,
-                          uint16_t* c_bf16, int64_t ldc_bf16, int64_t M, int64_t N, int64_t K, void* stream) {
+int dhaug_gemm_bf16_dmask_pad(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* residual,
+                              int64_t ld_res, const uint16_t* dmask, int64_t ld_dmask, int dmask_act, float dmask_slope,
+                              uint16_t* c_bf16, int64_t ldc_bf16, int64_t n_pad_zero, int64_t M, int64_t N, int64_t K, void* stream) {
     DHAUG_CHECK(dmask_act >= DHAUG_ACT_NONE && dmask_act <= DHAUG_ACT_LRELU, DHAUG_EINVAL);
     DHAUG_CHECK_PTR(c_bf16);
     if (dmask_act == DHAUG_ACT_NONE) dmask = nullptr;
-    if (dmask) DHAUG_CHECK(ld_dmask % 8 == 0 && ld_dmask >= N && dhaug_aligned16(dmask) && N % 8 == 0, DHAUG_EALIGN);
+    if (dmask) DHAUG_CHECK(ld_dmask >= N && (reinterpret_cast<uintptr_t>(dmask) & 1u) == 0, DHAUG_EALIGN);
     const float dneg = dmask_act == DHAUG_ACT_RELU ? 0.0f : dmask_slope;
     bool done = false;
-    int rc = gemm_bf16_impl(A, lda, B, ldb, nullptr, residual, ld_res, nullptr, 0, c_bf16, ldc_bf16, N, nullptr, 0, M, N, K,
-                            DHAUG_ACT_NONE, 0.0f, dmask, ld_dmask, dneg, &done, stream);
-    if (rc != DHAUG_OK || dmask == nullptr || done || M == 0) return rc;
-    return dhaug_act_backward_bf16(c_bf16, ldc_bf16, dmask, ld_dmask, c_bf16, ldc_bf16, M, N, dmask_act, dmask_slope, stream);
+    return gemm_bf16_impl(A, lda, B, ldb, nullptr, residual, ld_res, nullptr, 0, c_bf16, ldc_bf16, n_pad_zero > N ? n_pad_zero : N,
+                          nullptr, 0, M, N, K, DHAUG_ACT_NONE, 0.0f, dmask, ld_dmask, dneg, &done, stream);
+}
+
+int dhaug_gemm_bf16_dmask(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* residual,
+                          int64_t ld_res, const uint16_t* dmask, int64_t ld_dmask, int dmask_act, float dmask_slope,
+                          uint16_t* c_bf16, int64_t ldc_bf16, int64_t M, int64_t N, int64_t K, void* stream) {
+    return dhaug_gemm_bf16_dmask_pad(A, lda, B, ldb, residual, ld_res, dmask, ld_dmask, dmask_act, dmask_slope, c_bf16, ldc_bf16,
+                                     N, M, N, K, stream);
 }
 
 int dhaug_gemm_tn_bf16_rows(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,

@@ -284,15 +284,16 @@ def gemm_nt(A, B, N, K, bias=None, res_bf16=None, res_f32=None, act=0, slope=0.0
 
 
 def gemm_nt_dmask(A, B, N, K, dmask, dmask_act, dmask_slope=0.0, res_bf16=None, out=None):
-    """(A[M,K] B[N,K]^T + res) * act'(dmask): input gradient of a layer + activation backward of its producer, bf16 (M,N)"""
-    assert A.dtype == BF16 and B.dtype == BF16 and dmask.dtype == BF16 and N % 8 == 0
+    """(A[M,K] B[N,K]^T + res) * act'(dmask): input gradient of a layer + activation backward of its producer in one launch;
+    bf16 (M, ceil16 N) with zero pad columns, or `out` (a row-strided view: no columns beyond its own are touched)."""
+    assert A.dtype == BF16 and B.dtype == BF16 and dmask.dtype == BF16
     M = A.shape[0]
     if out is None:
-        out = torch.empty((M, N), dtype=BF16, device=A.device)
-    assert out.dtype == BF16 and out.stride(1) == 1 and out.shape[0] == M
-    _lib.call("dhaug_gemm_bf16_dmask", _p(A), A.stride(0), _p(B), B.stride(0), _p(res_bf16),
+        out = torch.empty((M, ceil_to(N, 16)), dtype=BF16, device=A.device)
+    assert out.dtype == BF16 and out.stride(1) == 1 and out.shape[0] == M and out.shape[1] >= N
+    _lib.call("dhaug_gemm_bf16_dmask_pad", _p(A), A.stride(0), _p(B), B.stride(0), _p(res_bf16),
               0 if res_bf16 is None else res_bf16.stride(0), _p(dmask), dmask.stride(0), dmask_act, float(dmask_slope),
-              _p(out), out.stride(0), M, N, K, _stream())
+              _p(out), out.stride(0), min(out.shape[1], ceil_to(N, 16)), M, N, K, _stream())
     return out
 
 

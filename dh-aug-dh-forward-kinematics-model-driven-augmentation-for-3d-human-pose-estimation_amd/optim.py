@@ -49,6 +49,7 @@ class FusedAdam(torch.optim.Optimizer):
         # while the next network's step computes (25-100 MB buckets in the video configuration).
         self.overlap = False
         self._pending = None
+        self._packs = None                      # (bf16 arena, device descriptors, [(param, nt view, nn view)])
 
     def state_dict(self):
         """torch.optim.Optimizer.state_dict() plus the flat moments and the step count (checkpoint / resume)"""
@@ -128,7 +129,38 @@ class FusedAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         ops.adam_step_dev(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_dev, g["lr"],
                           tuple(g["betas"]), g["eps"], 1.0 / ws)
-        A.bump_weight_epoch()                  # every packed bf16 copy of a weight is now stale
+        # the packed copies of THIS network's weights are stale (other networks keep theirs); the bf16 operand copies the
+        # training path reads are rebuilt right here, all layers in two launches
+        for p in self._params:
+            p._dhaug_epoch = getattr(p, "_dhaug_epoch", 0) + 1
+        self._repack()
+
+    def _repack(self):
+        import ctypes
+        from . import _lib
+        if self._packs is None:
+            ws2 = [p for p in self._params if p.dim() == 2]
+            c16 = A.ceil16
+            total = sum(p.shape[0] * c16(p.shape[1]) + p.shape[1] * c16(p.shape[0]) for p in ws2)
+            arena = torch.empty(total + 8 * len(ws2) * 2, dtype=torch.bfloat16, device=self.flat_param.device)
+            descs = (_lib.RepackDesc * max(1, len(ws2)))()
+            views, off = [], 0
+            for i, p in enumerate(ws2):
+                N, K = p.shape
+                Kp, Np = c16(K), c16(N)
+                nt = arena[off:off + N * Kp].view(N, Kp); off += (N * Kp + 7) // 8 * 8
+                nn = arena[off:off + K * Np].view(K, Np); off += (K * Np + 7) // 8 * 8
+                descs[i].W, descs[i].nt, descs[i].nn = p.data_ptr(), nt.data_ptr(), nn.data_ptr()
+                descs[i].N, descs[i].K, descs[i].Kp, descs[i].Np = N, K, Kp, Np
+                views.append((p, nt, nn))
+            raw = bytes(descs)
+            dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.flat_param.device)
+            self._packs = (arena, dev, views)
+        arena, dev, views = self._packs
+        if views:
+            _lib.call("dhaug_repack_weights", dev.data_ptr(), len(views), ops._stream())
+            for p, nt, nn in views:
+                A.install_packed(p, nt, nn)
 
     @torch.no_grad()
     def flush(self):

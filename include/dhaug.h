@@ -205,6 +205,13 @@ int dhaug_gemm_bf16_dmask(const uint16_t* A, int64_t lda, const uint16_t* B, int
                           int64_t ld_res, const uint16_t* dmask, int64_t ld_dmask, int dmask_act, float dmask_slope,
                           uint16_t* c_bf16, int64_t ldc_bf16, int64_t M, int64_t N, int64_t K, void* stream);
 
+/* Same with columns [N, n_pad_zero) of c_bf16 written as 0 (the result feeds the next GEMM as a zero-padded operand) and
+ * any N: every kernel applies the mask in its epilogue. */
+int dhaug_gemm_bf16_dmask_pad(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* residual,
+                              int64_t ld_res, const uint16_t* dmask, int64_t ld_dmask, int dmask_act, float dmask_slope,
+                              uint16_t* c_bf16, int64_t ldc_bf16, int64_t n_pad_zero, int64_t M, int64_t N, int64_t K,
+                              void* stream);
+
 /* Weight-gradient GEMM: C[N1,N2] (+)= A[M,N1]^T * B[M,N2], contraction over the batch dimension M
  * (split across workgroups, fp32 atomics into C).  bf16 operands, fp32 result.  `accumulate` != 0 adds
  * into C, otherwise C is overwritten (zeroed by the library on the stream first).  colsum_a (optional, fp32 [N1])
@@ -324,6 +331,17 @@ int dhaug_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
 int dhaug_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                         float lr, float beta1, float beta2, float eps, const int* step_dev, float grad_scale, void* stream);
 int dhaug_counter_add(int* counter, int value, void* stream);
+
+/* The bf16 operand copies of ALL weights of a network in two launches (after its Adam step): per weight W (N, K) fp32,
+ * contiguous: nt = bf16 (N, Kp) zero-padded along K (operand of x W^T), nn = bf16 (K, Np) = W^T zero-padded along N (operand
+ * of g W); Kp, Np multiples of 16.  descs_device: array of nparams descriptors in device memory. */
+typedef struct dhaug_repack_desc {
+    const float* W;
+    void* nt;
+    void* nn;
+    int N, K, Kp, Np;
+} dhaug_repack_desc;
+int dhaug_repack_weights(const dhaug_repack_desc* descs_device, int nparams, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * WGAN-GP critic step arithmetic (R/models_Fk_GAN/Fk_discriminator.py:205-231, model_fk_gan_train.py:186-221)

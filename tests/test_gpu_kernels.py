@@ -374,9 +374,15 @@ def test_gemm_nt_dmask(ops, M, N, K, act, slope, use_res):
     neg = 0.0 if act == 1 else slope
     ref = torch.where(y.float().cpu() > 0, z, z * neg)
     out = ops.gemm_nt_dmask(A, B, N, K, y, act, slope, res_bf16=res)
-    assert out.shape == (M, N)
+    Np = (N + 15) // 16 * 16                                     # zero-padded to the next GEMM's operand width
+    assert out.shape == (M, Np) and (Np == N or out[:, N:].float().abs().max().item() == 0.0)
+    out = out[:, :N]
     assert maxabs(out.float(), ref) <= 2.0 ** -7 * ref.abs().max().item()
     assert (out.float().cpu()[y.float().cpu() <= 0].abs().max().item() == 0.0) if act == 1 else True
+    # into a column block of a wider buffer: nothing beyond the block is touched
+    wide = torch.full((M, Np + 24), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt_dmask(A, B, N, K, y, act, slope, res_bf16=res, out=wide[:, 8:8 + N])
+    assert torch.equal(wide[:, 8:8 + N], out) and (wide[:, :8] == 7).all() and (wide[:, 8 + N:] == 7).all()
 
 
 @pytest.mark.parametrize("N,pre", [(1, True), (63, True), (1000, False), (65536, True)])
