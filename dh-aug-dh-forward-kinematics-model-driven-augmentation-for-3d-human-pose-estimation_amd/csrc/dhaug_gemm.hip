@@ -581,6 +581,112 @@ __global__ __launch_bounds__(256, TM == 64 ? 2 : 1) void gemm_tn64_kernel(TnArgs
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 128 x 128 output tiles for the long contractions of the explicit critic step (3B rows, N1 = N2 = 256).  With 64 x 64
+// tiles every row of both operands crosses L2 -> LDS four times (16 tiles x 128 B of 512 B each): 805 MB per layer at
+// 3B = 196 608 rows, and the measured 62 us per launch is 21 B/clk/CU of LDS-DMA -- the kernel is bound by the L2 -> CU
+// path, not by HBM (33 us) or the matrix pipe (10 us).  128 x 128 tiles halve that traffic.  64-row stages of 32 KB
+// (both operands), four in the ring (three in flight), one workgroup per CU; a wave owns a 64 x 64 quadrant.
+// RESULT (measured): correct (tests/test_gpu_kernels.py::test_gemm_tn) but slower -- the GAN iteration takes 12.5 ms with
+// it against 11.1 ms with the 64 x 64 tiles, with and without fragment reads one k-step ahead: one wave per SIMD hides
+// less than two workgroups per CU do, and the atomic traffic doubles (64 slices x 256 KB).  Not used by default
+// (DHAUG_TN_128=1 selects it).
+// ---------------------------------------------------------------------------------------------------
+constexpr int TB_ROWS = 64, TB_STG = 2 * TB_ROWS * 256, TB_NSTG = 4;           // 32 768 bytes per stage
+
+__global__ __launch_bounds__(256, 1) void gemm_tn128_kernel(TnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];       // [4 stages][A 16 KB | B 16 KB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w1 = wave >> 1, w2 = wave & 1;                    // quadrant: C rows [64 w1, +64), columns [64 w2, +64)
+    const long long nt2 = p.N2 / 128;
+    long long tile, split;
+    if ((p.nsplits & 7) == 0) {
+        const long long xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        tile = local % p.ntiles;
+        split = xcd + 8 * (local / p.ntiles);
+    } else {
+        tile = blockIdx.x % p.ntiles;
+        split = blockIdx.x / p.ntiles;
+    }
+    const long long n1_0 = (tile / nt2) * 128, n2_0 = (tile % nt2) * 128;
+    const long long ms = split * p.rows_per_split;
+    long long me = ms + p.rows_per_split;
+    if (me > p.M) me = p.M;
+    if (ms >= me) return;
+    const int nst = (int)((me - ms) / TB_ROWS);                 // whole stages (checked on the host)
+
+    auto copy_stage = [&](int st) {                             // 8 copies per lane, counted in vmcnt
+        const long long m0 = ms + (long long)st * TB_ROWS;
+        unsigned char* base = tsm + (st % TB_NSTG) * TB_STG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                           // 16 chunks per row: 4 rows per wave instruction
+            const int row0 = (wave * 4 + i) * 4, row = row0 + (lane >> 4), c = (lane & 15) ^ tf_sw<16>(row);
+            f_copy16(p.A + (m0 + row) * p.lda + n1_0 + c * 8, base + row0 * 256);
+            f_copy16(p.B + (m0 + row) * p.ldb + n2_0 + c * 8, base + TB_ROWS * 256 + row0 * 256);
+        }
+    };
+    f32x16 acc[2][2], accs[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[t][0][r] = 0.0f; acc[t][1][r] = 0.0f; accs[t][r] = 0.0f; }
+    }
+    const bool do_cs = p.colsum != nullptr && (tile % nt2) == 0 && w2 == 0;
+    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const int grp = lane >> 4;
+#pragma unroll
+    for (int st = 0; st < TB_NSTG - 1; ++st)
+        if (st < nst) copy_stage(st);
+    for (int st = 0; st < nst; ++st) {
+        const int younger = nst - 1 - st;                       // stages st+1, st+2 may still fly (8 copies each)
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        f_lds_barrier();                                        // stage st is in LDS, stage st-1 is released
+        if (st + TB_NSTG - 1 < nst) copy_stage(st + TB_NSTG - 1);
+        const unsigned char* sa = tsm + (st % TB_NSTG) * TB_STG;
+        const unsigned char* sb = sa + TB_ROWS * 256;
+        const bool cs_stage = do_cs && ms + (long long)st * TB_ROWS < p.cs_rows;
+        // fragments one k-step ahead of their MFMAs (one wave per SIMD: nobody else covers the LDS latency)
+        bf16x8 fa[2][2], fb[2][2];
+        auto frags = [&](int ks, bf16x8 (&a)[2], bf16x8 (&b)[2]) {
+            const int kbase = 16 * ks + 8 * (grp >> 1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = tf_frag<16>(sa, kbase, w1 * 64 + 32 * t + 16 * (grp & 1), lane);
+                b[t] = tf_frag<16>(sb, kbase, w2 * 64 + 32 * t + 16 * (grp & 1), lane);
+            }
+        };
+        frags(0, fa[0], fb[0]);
+#pragma unroll
+        for (int ks = 0; ks < TB_ROWS / 16; ++ks) {
+            if (ks + 1 < TB_ROWS / 16) frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][t], fb[ks & 1][u], acc[t][u], 0, 0, 0);
+                if (cs_stage) accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][t], ones, accs[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long n2 = n2_0 + w2 * 64 + 32 * u + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long n1 = n1_0 + w1 * 64 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                atomicAdd(p.C + n1 * p.ldc + n2, acc[t][u][r]);
+                if (u == 0 && do_cs && (lane & 31) == 0) atomicAdd(p.colsum + n1, accs[t][r]);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Weight-stationary NT kernel for the layer shapes of this path (M = batch, huge; N <= a few hundred; K <= 256).
 //
 // The first version above is bound by exposed global-load latency (its time is flat in K).  Here a workgroup
@@ -1402,6 +1508,26 @@ int dhaug_gemm_tn_bf16_rows(const uint16_t* A, int64_t lda, const uint16_t* B, i
     if (rows < 4 * BK) rows = 4 * BK;
     splits = (M + rows - 1) / rows;
     if (splits > 8) splits = (splits + 7) / 8 * 8;              // multiple of 8: XCD-local tile groups (empty slices exit)
+    if (N1 % 128 == 0 && N2 % 128 == 0 && M % TB_ROWS == 0 && M >= 64 * 1024 && getenv("DHAUG_GEMM_GENERIC") == nullptr &&
+        getenv("DHAUG_TN_128") != nullptr) {          // measured SLOWER than the 64 x 64 tiles (12.5 vs 11.1 ms per GAN iteration): kept selectable
+        const long long tl = (N1 / 128) * (N2 / 128);
+        long long sp = 256 / tl;                                 // one workgroup per CU
+        if (sp < 1) sp = 1;
+        long long r2 = ((M + sp - 1) / sp + TB_ROWS - 1) / TB_ROWS * TB_ROWS;
+        if (r2 < 4 * TB_ROWS) r2 = 4 * TB_ROWS;
+        sp = (M + r2 - 1) / r2;
+        if (sp > 8) sp = (sp + 7) / 8 * 8;
+        static bool configured128 = false;
+        if (!configured128) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, TB_NSTG * TB_STG);
+            if (e != hipSuccess) return (int)e;
+            configured128 = true;
+        }
+        TnArgs pb{A, lda, B, ldb, C, ldc, colsum_a, M, N1, N2, r2, tl, sp, cs_rows};
+        hipLaunchKernelGGL(gemm_tn128_kernel, dim3((unsigned)(tl * sp)), dim3(256), TB_NSTG * TB_STG, s, pb);
+        return dhaug_launch_status();
+    }
     if (N1 % TN_BN == 0 && N2 % TN_BN == 0 && M % TF_ROWS == 0 && M >= 4 * TF_ROWS && getenv("DHAUG_GEMM_GENERIC") == nullptr) {
         // 128 x 64 tiles (one workgroup per CU) re-read less from L2 but measured slower (35 vs 27 us at 65536 x 256 x 256):
         // the loop is bound by requests in flight, not by L2 bandwidth.  Kept selectable for experiments.

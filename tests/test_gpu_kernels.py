@@ -269,7 +269,8 @@ def test_gemm_split_terms(ops, terms, tol):
     assert maxabs(one, ref) > 10 * maxabs(cf, ref)                 # single-pass bf16 is visibly coarser
 
 
-@pytest.mark.parametrize("M,N1,N2", [(4096, 256, 256), (1000, 100, 512), (777, 32, 256), (65536, 256, 48), (130, 1, 100)])
+@pytest.mark.parametrize("M,N1,N2", [(4096, 256, 256), (1000, 100, 512), (777, 32, 256), (65536, 256, 48), (130, 1, 100),
+                                     (98304, 256, 256), (65536 + 192, 128, 384)])  # (the last two also run under DHAUG_TN_128=1 by hand)
 def test_gemm_tn(ops, M, N1, N2):
     gen = torch.Generator().manual_seed(M + N1)
     p1, p2 = (N1 + 7) // 8 * 8, (N2 + 7) // 8 * 8
@@ -288,6 +289,13 @@ def test_gemm_tn(ops, M, N1, N2):
     assert maxabs(C3, ref) <= tol
     csref = A[:, :N1].float().cpu().double().sum(0)
     assert maxabs(cs, csref) <= 1e-4 * max(1.0, csref.abs().max().item()) + 1e-3
+    # bias sums over a leading block of rows only (the explicit critic step: real / fake rows, not the interpolated ones)
+    if M % 3 == 0 and (2 * M // 3) % 128 == 0:
+        cs2 = torch.zeros(N1, device="cuda")
+        C4 = ops.gemm_tn(A, B, N1, N2, out=torch.zeros(N1, N2, device="cuda"), accumulate=True, colsum=cs2, colsum_rows=2 * M // 3)
+        assert maxabs(C4, ref) <= tol
+        cs2ref = A[:2 * M // 3, :N1].float().cpu().double().sum(0)
+        assert maxabs(cs2, cs2ref) <= 1e-4 * max(1.0, cs2ref.abs().max().item()) + 1e-3
 
 
 def test_pack_kernels(ops):
