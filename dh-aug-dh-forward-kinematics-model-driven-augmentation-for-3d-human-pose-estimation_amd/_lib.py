@@ -43,10 +43,12 @@ SIGNATURES = {
     "dhaug_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp],
     "dhaug_adam_step_dev": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _vp, _f32, _vp],
     "dhaug_counter_add": [_vp, _i32, _vp],
+    "dhaug_frame_diff": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     "dhaug_repack_weights": [_vp, _i32, _vp],
     "dhaug_gp_assemble": [_vp, _vp, _vp, _vp, _i64, _i64, _vp],
     "dhaug_gp_penalty": [_vp, _vp, _vp, _i64, _i64, _f32, _vp],
-    "dhaug_critic_scalars": [_vp, _i64, _vp, _i64, _f32, _vp, _vp],
+    "dhaug_critic_scalars": [_vp, _i64, _vp, _i64, _i64, _f32, _vp, _vp],
+    "dhaug_add_f32": [_vp, _vp, _vp, _i64, _vp],
 }
 
 class MlpUnit(ctypes.Structure):

@@ -55,6 +55,11 @@ class _Packed:
 # version counter does not see); every packed copy made under an older epoch is stale.
 DIRECT_WGRAD = True       # LinearFn.backward may accumulate weight/bias gradients straight into FusedAdam's flat bucket
 WEIGHT_EPOCH = 0
+# Non-zero while a hipGraph is being captured (graphs.GraphedCall): part of every cache key, so that a capture never
+# re-uses a packed copy made outside it.  A captured kernel holds the ADDRESS of its operands; a copy cached before the
+# capture would neither be refreshed by the replay (its pack kernel is not in the graph) nor stay alive (the cache drops it
+# the next time the weights change) -- the second case is a GPU memory fault on replay.
+CAPTURE_ID = 0
 
 
 def bump_weight_epoch():
@@ -64,7 +69,7 @@ def bump_weight_epoch():
 
 
 def pack_key(W):
-    return (W.data_ptr(), W._version, tuple(W.shape), WEIGHT_EPOCH, getattr(W, "_dhaug_epoch", 0))
+    return (W.data_ptr(), W._version, tuple(W.shape), WEIGHT_EPOCH, getattr(W, "_dhaug_epoch", 0), CAPTURE_ID)
 
 
 def install_packed(W, nt, nn):
@@ -79,7 +84,7 @@ def install_packed(W, nt, nn):
 def _pack(W):
     """cache entry for a weight-like fp32 (N,K) tensor.  The entry lives ON the parameter object (an id()-keyed dict
     would alias a freed parameter whose id / address get reused), and is valid for one (storage, version, epoch)."""
-    key = (W.data_ptr(), W._version, tuple(W.shape), WEIGHT_EPOCH, getattr(W, "_dhaug_epoch", 0))
+    key = pack_key(W)
     if isinstance(W, torch.nn.Parameter):
         ent = getattr(W, "_dhaug_pack", None)
         if ent is not None and ent.key == key:

@@ -188,8 +188,10 @@ def seeds(B, m, dev):
     return _SEED_CACHE[key]
 
 
-def _finish(optimizerD, logits, pen, B, lam):
-    sc = ops.critic_scalars(logits, pen, B, lam)
+def _finish(optimizerD, logits, pen, pen_rows, lam, rows=None):
+    """scalars (logit means over `rows` real / fake rows, penalty mean over the pen_rows = len(pen) penalty terms) and the
+    optimizer step"""
+    sc = ops.critic_scalars(logits, pen, pen_rows if rows is None else rows, lam)
     optimizerD.step()
     return sc
 
@@ -231,34 +233,34 @@ def step_d2(D, optimizerD, real, fake, alpha, lam, prec=None):
     return _finish(optimizerD, logits, pen, B, lam)
 
 
-def step_d3(D, optimizerD, real, fake, alpha, lam, prec=None):
-    """Fk_3D_Discriminator (R/models_Fk_GAN/Fk_discriminator.py:149-201).  real, fake (B,16,3)|(B,48) root-relative."""
-    m = _Math(prec or D.precision)
-    dev = real.device
-    Lk, Lp = _Lin(D.special_KCS_previous[0], RELU), _Lin(D.previous[0], RELU)
-    Kb = [_Block(b) for b in (D.special_KCS_block1, D.special_KCS_block2, D.special_KCS_block3)]
-    Pb = [_Block(b) for b in (D.block1, D.block2, D.block3)]
-    Lm, Mb, Lo = _Lin(D.merge_previous[0], RELU), _Block(D.merge_block1), _Lin(D.output, NONE)
-    Dw = Lk.N
-    optimizerD.zero_grad()
-    X = ops.gp_assemble(real, fake, alpha)                                   # (3B,48)
-    B = X.shape[0] // 3
+class _Branch:
+    """Linear + ReLU, three myResNet blocks (one input branch of the 3D critic / the motion critics)"""
+
+    def __init__(self, first, blocks):
+        self.first, self.blocks = _Lin(first, RELU), [_Block(b) for b in blocks]
+
+
+def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, input_grad, tangents, pen_view=None):
+    """The four sweeps for a critic of the form  cat_b(branch_b(feat_b(x))) -> Linear(100)+ReLU -> myResNet(100) -> Linear(1).
+    X (3*rows, W) fp32 = [real; fake; x_hat] (ops.gp_assemble); feats(X) -> one fp32 input per branch (3*rows each);
+    input_grad([g_b]) -> dD/dx_hat (rows, W) fp32 from the branches' input cotangents (x_hat rows); tangents(v) -> one fp32
+    tangent input per branch (rows each).  pen_view: shape the penalty sees g in (default (rows, W); the 2D motion critic is
+    stepped with one interpolation coefficient per FRAME)."""
+    dev = X.device
+    B = rows
     B2, M3 = 2 * B, 3 * B
-    Kf = ops.kcs_forward(X, True, f32=True)[0]                                # (3B,30) fp32
-    # ---- 1. forward (the two branch outputs land side by side: the concatenation is a buffer, not a copy)
-    cat = m.empty(M3, 2 * Dw, dev)
-    k = [Lk.fwd(m, Kf)]
-    kh = []
-    for i, b in enumerate(Kb):
-        h = b.fc1.fwd(m, k[-1])
-        kh.append(h)
-        k.append(b.fc2.fwd(m, h, res=k[-1], out=cat[:, :Dw] if i == 2 else None))
-    p = [Lp.fwd(m, X)]
-    ph = []
-    for i, b in enumerate(Pb):
-        h = b.fc1.fwd(m, p[-1])
-        ph.append(h)
-        p.append(b.fc2.fwd(m, h, res=p[-1], out=cat[:, Dw:] if i == 2 else None))
+    nb, Dw = len(branches), branches[0].first.N
+    F = feats(X)
+    # ---- 1. forward (the branch outputs land side by side: the concatenation is a buffer, not a copy)
+    cat = m.empty(M3, nb * Dw, dev)
+    y, h = [], []
+    for bi, br in enumerate(branches):
+        ys, hs = [br.first.fwd(m, F[bi])], []
+        for i, blk in enumerate(br.blocks):
+            hh = blk.fc1.fwd(m, ys[-1])
+            hs.append(hh)
+            ys.append(blk.fc2.fwd(m, hh, res=ys[-1], out=cat[:, bi * Dw:(bi + 1) * Dw] if i == len(br.blocks) - 1 else None))
+        y.append(ys); h.append(hs)
     m0 = Lm.fwd(m, cat)
     mh, m1 = Mb.fwd(m, m0)
     logits = Lo.fwd(m, m1, out_f32=True)
@@ -266,60 +268,165 @@ def step_d3(D, optimizerD, real, fake, alpha, lam, prec=None):
     gzo = seeds(B, m, dev)
     gz_m2 = Lo.bwd(m, gzo, m1, RELU, 0.0)
     gz_m1, gz_m0 = Mb.bwd(m, gz_m2, mh, m0)
-    gcat = Lm.bwd(m, gz_m0, cat, RELU, 0.0)                                  # (3B, 2D): cotangents at both branches' last fc2
-    gk2, gp2 = [None] * 3 + [gcat[:, :Dw]], [None] * 3 + [gcat[:, Dw:]]       # index i: cotangent at the pre-activation producing k[i]
-    gk1, gp1 = [None] * 3, [None] * 3
-    for i in (2, 1, 0):
-        gk1[i], gk2[i] = Kb[i].bwd(m, gk2[i + 1], kh[i], k[i])
-        gp1[i], gp2[i] = Pb[i].bwd(m, gp2[i + 1], ph[i], p[i])
-    xh = X[B2:]
-    g_feat = Lk.bwd(m, gk2[0][B2:], None, NONE, 0.0, out_f32=True)           # (B,30)
-    g_kcs = ops.kcs_backward(xh, g_feat, True)                               # (B,48): the KCS^T path
-    g = Lp.bwd(m, gp2[0][B2:], None, NONE, 0.0, skip=g_kcs, out_f32=True)    # dD/dx_hat = pose path + KCS^T path
+    gcat = Lm.bwd(m, gz_m0, cat, RELU, 0.0)                  # (3B, nb*D): cotangents at every branch's last fc2
+    g1, g2, gin = [], [], []
+    for bi, br in enumerate(branches):
+        n = len(br.blocks)
+        a2, a1 = [None] * n + [gcat[:, bi * Dw:(bi + 1) * Dw]], [None] * n    # a2[i]: cotangent at the pre-activation producing y[i]
+        for i in range(n - 1, -1, -1):
+            a1[i], a2[i] = br.blocks[i].bwd(m, a2[i + 1], h[bi][i], y[bi][i])
+        g1.append(a1); g2.append(a2)
+        gin.append(br.first.bwd(m, a2[0][B2:], None, NONE, 0.0, out_f32=True))   # (B, w_b) fp32, x_hat rows only
+    g = input_grad(gin)                                      # dD/dx_hat
     # ---- 3. penalty and tangent sweep (x_hat rows)
-    v, pen = ops.gp_penalty(g, 2.0 * lam / B)
-    tk = ops.kcs_jvp(xh, v, True)                                            # (B,30)
-    uk, up = [Lk.tan(m, tk, k[0][B2:])], [Lp.tan(m, v, p[0][B2:])]
-    ukh, uph = [], []
-    for i in range(3):
-        h, y = Kb[i].tan(m, uk[-1], kh[i][B2:], k[i + 1][B2:])
-        ukh.append(h); uk.append(y)
-        h, y = Pb[i].tan(m, up[-1], ph[i][B2:], p[i + 1][B2:])
-        uph.append(h); up.append(y)
-    if uk[3].data_ptr() == cat[B2:].data_ptr() and up[3].data_ptr() == cat[B2:, Dw:].data_ptr():
-        ucat = cat[B2:]                                                      # both branch tangents were written in place
+    gv = g if pen_view is None else g.reshape(pen_view)
+    v, pen = ops.gp_penalty(gv, 2.0 * lam / gv.shape[0])
+    T = tangents(v.reshape(g.shape))
+    u, uh = [], []
+    for bi, br in enumerate(branches):
+        us, uhs = [br.first.tan(m, T[bi], y[bi][0][B2:])], []
+        for i, blk in enumerate(br.blocks):
+            hh, yy = blk.tan(m, us[-1], h[bi][i][B2:], y[bi][i + 1][B2:])
+            uhs.append(hh); us.append(yy)
+        u.append(us); uh.append(uhs)
+    if all(u[bi][-1].data_ptr() == cat[B2:, bi * Dw:].data_ptr() for bi in range(nb)):
+        ucat = cat[B2:]                                      # every branch tangent was written in place
     else:
-        ucat = m.empty(B, 2 * Dw, dev)
-        ucat[:, :Dw].copy_(uk[3][:, :Dw]); ucat[:, Dw:2 * Dw].copy_(up[3][:, :Dw])
+        ucat = m.empty(B, nb * Dw, dev)
+        for bi in range(nb):
+            ucat[:, bi * Dw:(bi + 1) * Dw].copy_(u[bi][-1][:, :Dw])
     um0 = Lm.tan(m, ucat, m0[B2:])
     umh, um1 = Mb.tan(m, um0, mh[B2:], m1[B2:])
     # ---- 4. weight / bias gradients
-    Lk.grads(m, gk2[0], Kf, B2, tk)
-    Lp.grads(m, gp2[0], X, B2, v)
-    for i in range(3):
-        Kb[i].fc1.grads(m, gk1[i], k[i], B2, uk[i]); Kb[i].fc2.grads(m, gk2[i + 1], kh[i], B2, ukh[i])
-        Pb[i].fc1.grads(m, gp1[i], p[i], B2, up[i]); Pb[i].fc2.grads(m, gp2[i + 1], ph[i], B2, uph[i])
+    for bi, br in enumerate(branches):
+        br.first.grads(m, g2[bi][0], F[bi], B2, T[bi])
+        for i, blk in enumerate(br.blocks):
+            blk.fc1.grads(m, g1[bi][i], y[bi][i], B2, u[bi][i])
+            blk.fc2.grads(m, g2[bi][i + 1], h[bi][i], B2, uh[bi][i])
     Lm.grads(m, gz_m0, cat, B2, ucat)
     Mb.fc1.grads(m, gz_m1, m0, B2, um0); Mb.fc2.grads(m, gz_m2, mh, B2, umh)
     Lo.grads(m, gzo, m1, B2, um1)
-    return _finish(optimizerD, logits, pen, B, lam)
+    return _finish(optimizerD, logits, pen, gv.shape[0], lam, rows=B)
 
 
-def supported(model_dis, optimizerD, real, fake):
-    """the explicit schedule covers the two single-frame critics under a FusedAdam bucket on one real + fake batch"""
-    from .models_Fk_GAN.Fk_discriminator import Fk_2D_Discriminator, Fk_3D_Discriminator
+def step_d3(D, optimizerD, real, fake, alpha, lam, prec=None):
+    """Fk_3D_Discriminator (R/models_Fk_GAN/Fk_discriminator.py:149-201).  real, fake (B,16,3)|(B,48) root-relative."""
+    m = _Math(prec or D.precision)
+    br = [_Branch(D.special_KCS_previous[0], (D.special_KCS_block1, D.special_KCS_block2, D.special_KCS_block3)),
+          _Branch(D.previous[0], (D.block1, D.block2, D.block3))]
+    optimizerD.zero_grad()
+    X = ops.gp_assemble(real, fake, alpha)                                   # (3B,48)
+    B = X.shape[0] // 3
+    xh = X[2 * B:]
+    return step_branchnet(
+        m, optimizerD, br, _Lin(D.merge_previous[0], RELU), _Block(D.merge_block1), _Lin(D.output, NONE), X, B, lam,
+        feats=lambda X: [ops.kcs_forward(X, True, f32=True)[0], X],
+        input_grad=lambda gs: ops.add_f32(ops.kcs_backward(xh, gs[0], True), gs[1]),      # KCS^T path + pose path
+        tangents=lambda v: [ops.kcs_jvp(xh, v, True), v])
+
+
+def step_m3(D, optimizerD, real, fake, alpha, lam, prec=None):
+    """Video_motion_Fk_3D_Discriminator (R/models_Fk_GAN/Fk_discriminator.py:381-512), stepped with dis_mode='motion':
+    real, fake (B, R*48) clips, alpha (B,1), penalty over the B clips.  Branches: per-frame KCS cosines (R*15), their frame
+    differences ((R-1)*15), the poses (R*48), their frame differences ((R-1)*48)."""
+    m = _Math(prec or D.precision)
+    R = D.video_frame_num
+    names = ["special_KCS", "diff_special_KCS"] + (["pos_3d"] if D.use_pos else []) + (["diff_pos_3d"] if D.use_diff else [])
+    br = [_Branch(getattr(D, n + "_previous")[0], [getattr(D, "%s_block%d" % (n, i)) for i in (1, 2, 3)]) for n in names]
+    optimizerD.zero_grad()
+    X = ops.gp_assemble(real, fake, alpha)                                   # (3B, R*48)
+    B = X.shape[0] // 3
+    xh = X[2 * B:].reshape(B * R, 48)
+
+    def feats(X):
+        kc = ops.kcs_forward(X.reshape(-1, 48), False, f32=True)[0].reshape(-1, R * 15)
+        out = [kc, ops.frame_diff(kc, R, 15)]
+        if D.use_pos:
+            out.append(X)
+        if D.use_diff:
+            out.append(ops.frame_diff(X, R, 48))
+        return out
+
+    def input_grad(gs):
+        gk = ops.add_f32(gs[0], ops.frame_diff(gs[1], R, 15, adjoint=True))   # cotangent of the per-frame cosines
+        g = ops.kcs_backward(xh, gk.reshape(B * R, 15), False).reshape(B, R * 48)
+        i = 2
+        if D.use_pos:
+            g = ops.add_f32(g, gs[i]); i += 1
+        if D.use_diff:
+            g = ops.add_f32(g, ops.frame_diff(gs[i], R, 48, adjoint=True))
+        return g
+
+    def tangents(v):
+        tk = ops.kcs_jvp(xh, v.reshape(B * R, 48), False).reshape(B, R * 15)
+        out = [tk, ops.frame_diff(tk, R, 15)]
+        if D.use_pos:
+            out.append(v)
+        if D.use_diff:
+            out.append(ops.frame_diff(v, R, 48))
+        return out
+
+    return step_branchnet(m, optimizerD, br, _Lin(D.kcs_merge_previous[0], RELU), _Block(D.kcs_merge_block1),
+                          _Lin(D.kcs_output, NONE), X, B, lam, feats, input_grad, tangents)
+
+
+def step_m2(D, optimizerD, real, fake, alpha, lam, prec=None):
+    """Video_motion_Fk_2D_Discriminator (R/models_Fk_GAN/Fk_discriminator.py:516-587) as the video loop steps it: the DEFAULT
+    mode of train_Fk_discriminator, i.e. real, fake (B*R, 32) frames, alpha (B*R, 1) -- one interpolation coefficient per
+    frame -- and the penalty over the B*R per-frame gradient norms (R/models_Fk_GAN/video_GAN_fun.py:341-346).  Branches: the
+    clip's 2D poses (R*32) and the frame differences of its root joint ((R-1)*2)."""
+    m = _Math(prec or D.precision)
+    R = D.video_frame_num
+    br = [_Branch(getattr(D, n + "_previous")[0], [getattr(D, "%s_block%d" % (n, i)) for i in (1, 2, 3)])
+          for n in ("pos_2d", "root_diff_2d")]
+    optimizerD.zero_grad()
+    Xf = ops.gp_assemble(real, fake, alpha)                                  # (3*B*R, 32): interpolated per frame
+    B = Xf.shape[0] // (3 * R)
+    X = Xf.reshape(3 * B, R * 32)                                            # clips (real, fake and interpolated frames stay together)
+    return step_branchnet(
+        m, optimizerD, br, _Lin(D.merge_previous[0], RELU), _Block(D.merge_block1), _Lin(D.merge_output, NONE), X, B, lam,
+        feats=lambda X: [X, ops.frame_diff(X, R, 32, 2)],
+        input_grad=lambda gs: ops.add_f32(gs[0], ops.frame_diff(gs[1], R, 32, 2, adjoint=True)),
+        tangents=lambda v: [v, ops.frame_diff(v, R, 32, 2)],
+        pen_view=(B * R, 32))
+
+
+def supported(model_dis, optimizerD, real, fake, rows):
+    """The explicit schedule covers the four critics under a FusedAdam bucket on one real + fake batch, with `rows` =
+    BATCH_SIZE of calc_gradient_penalty: (rows,48) / (rows,32) for the single-frame critics, (rows, R*48) clips for the 3D
+    motion critic (dis_mode='motion'), (rows,32) FRAMES with rows a multiple of R for the 2D motion critic (default mode)."""
+    from .models_Fk_GAN.Fk_discriminator import (Fk_2D_Discriminator, Fk_3D_Discriminator, Video_motion_Fk_2D_Discriminator,
+                                                 Video_motion_Fk_3D_Discriminator)
     from .optim import FusedAdam
-    if not isinstance(optimizerD, FusedAdam) or real.shape != fake.shape or not real.is_cuda:
+    if not isinstance(optimizerD, FusedAdam) or real.shape != fake.shape or not real.is_cuda or rows < 1:
         return False
-    if type(model_dis) not in (Fk_2D_Discriminator, Fk_3D_Discriminator):
+    if real.numel() % rows:
         return False
-    return model_dis.precision in ("bf16", "bf16x3", "bf16x6", "f16x3") and all(p.requires_grad for p in model_dis.parameters())
+    w = real.numel() // rows
+    t = type(model_dis)
+    if t is Fk_3D_Discriminator:
+        ok = w == 48
+    elif t is Fk_2D_Discriminator:
+        ok = w == 32
+    elif t is Video_motion_Fk_3D_Discriminator:
+        ok = w == 48 * model_dis.video_frame_num
+    elif t is Video_motion_Fk_2D_Discriminator:
+        ok = w == 32 and rows % model_dis.video_frame_num == 0
+    else:
+        ok = False
+    return ok and model_dis.precision in ("bf16", "bf16x3", "bf16x6", "f16x3") and all(p.requires_grad for p in model_dis.parameters())
 
 
 def critic_step(model_dis, optimizerD, real, fake, alpha, lam):
-    from .models_Fk_GAN.Fk_discriminator import Fk_3D_Discriminator
+    """real, fake: (rows, W) with rows = the BATCH_SIZE calc_gradient_penalty is called with (one row per penalty term)"""
+    from .models_Fk_GAN.Fk_discriminator import (Fk_3D_Discriminator, Video_motion_Fk_2D_Discriminator,
+                                                 Video_motion_Fk_3D_Discriminator)
     from .models_Fk_GAN.Fk_generator import graph_precision
     prec = graph_precision(model_dis.precision)
+    if isinstance(model_dis, Video_motion_Fk_3D_Discriminator):
+        return step_m3(model_dis, optimizerD, real, fake, alpha, lam, prec)
+    if isinstance(model_dis, Video_motion_Fk_2D_Discriminator):
+        return step_m2(model_dis, optimizerD, real, fake, alpha, lam, prec)
     if isinstance(model_dis, Fk_3D_Discriminator):
         return step_d3(model_dis, optimizerD, real.reshape(-1, 48), fake.reshape(-1, 48), alpha, lam, prec)
     return step_d2(model_dis, optimizerD, real.reshape(-1, 32), fake.reshape(-1, 32), alpha, lam, prec)

@@ -191,6 +191,35 @@ __global__ __launch_bounds__(256) void repack_nn_kernel(const dhaug_repack_desc*
     }
 }
 
+// frame differences of clips: x (rows, R * in_w) -> out (rows, (R-1) * w), out[r][f][c] = x[r][f+1][c] - x[r][f][c] for the first
+// w columns of every frame (the motion critics' diff branches, R/models_Fk_GAN/Fk_discriminator.py:458-460,489-492,570-573);
+// adjoint: g (rows, (R-1) * w) -> out (rows, R * in_w), out[r][f][c] = g[r][f-1][c] - g[r][f][c] (0 outside, 0 for c >= w)
+__global__ __launch_bounds__(256) void frame_diff_kernel(const float* __restrict__ x, float* __restrict__ out, long long rows,
+                                                         int R, int in_w, int w, int adjoint) {
+    if (!adjoint) {
+        const long long per = (long long)(R - 1) * w, total = rows * per;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+            const long long r = i / per, j = i - r * per;
+            const int f = (int)(j / w), c = (int)(j - (long long)f * w);
+            const float* row = x + r * (long long)R * in_w;
+            out[i] = row[(f + 1) * in_w + c] - row[f * in_w + c];
+        }
+    } else {
+        const long long per = (long long)R * in_w, total = rows * per;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+            const long long r = i / per, j = i - r * per;
+            const int f = (int)(j / in_w), c = (int)(j - (long long)f * in_w);
+            float v = 0.0f;
+            if (c < w) {
+                const float* row = x + r * (long long)(R - 1) * w;
+                if (f > 0) v += row[(f - 1) * w + c];
+                if (f < R - 1) v -= row[f * w + c];
+            }
+            out[i] = v;
+        }
+    }
+}
+
 // same step with the step count read from device memory (a hipGraph replays the launch; the count must not be baked in)
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v, long long n, float lr,
@@ -245,28 +274,39 @@ __global__ __launch_bounds__(256) void gp_penalty_kernel(const float* __restrict
 
 // out[0..4] = D_real, D_fake, GP, Wasserstein_D = D_real - D_fake, D_cost = D_fake - D_real + GP
 // logits (3B) fp32: rows [0,B) real, [B,2B) fake; pen (B).  One workgroup.
+__global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                      long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = a[i] + b[i];
+}
+
 __global__ __launch_bounds__(1024) void critic_scalars_kernel(const float* __restrict__ logits, long long ld,
-                                                              const float* __restrict__ pen, long long B, float lambda,
+                                                              const float* __restrict__ pen, long long B, long long P, float lambda,
                                                               float* __restrict__ out) {
     __shared__ float red[3][16];
     float s[3] = {0.f, 0.f, 0.f};
     long long i = threadIdx.x;
     for (; i + 7 * 1024 < B; i += 8 * 1024) {                   // eight independent requests per array in flight
-        float a[8], b[8], c[8];
+        float a[8], b[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             a[j] = logits[(i + j * 1024) * ld];
             b[j] = logits[(B + i + j * 1024) * ld];
-            c[j] = pen[i + j * 1024];
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { s[0] += a[j]; s[1] += b[j]; s[2] += c[j]; }
+        for (int j = 0; j < 8; ++j) { s[0] += a[j]; s[1] += b[j]; }
     }
     for (; i < B; i += 1024) {
         s[0] += logits[i * ld];
         s[1] += logits[(B + i) * ld];
-        s[2] += pen[i];
     }
+    for (i = threadIdx.x; i + 7 * 1024 < P; i += 8 * 1024) {
+        float c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = pen[i + j * 1024];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[2] += c[j];
+    }
+    for (; i < P; i += 1024) s[2] += pen[i];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
 #pragma unroll
@@ -278,7 +318,7 @@ __global__ __launch_bounds__(1024) void critic_scalars_kernel(const float* __res
         float t[3] = {0.f, 0.f, 0.f};
         for (int k = 0; k < 3; ++k)
             for (int w = 0; w < 16; ++w) t[k] += red[k][w];
-        const float dr = t[0] / (float)B, df = t[1] / (float)B, gp = lambda * (t[2] / (float)B);
+        const float dr = t[0] / (float)B, df = t[1] / (float)B, gp = lambda * (t[2] / (float)P);
         out[0] = dr; out[1] = df; out[2] = gp; out[3] = dr - df; out[4] = df - dr + gp;
     }
 }
@@ -405,6 +445,16 @@ int dhaug_repack_weights(const dhaug_repack_desc* descs_device, int nparams, voi
     return dhaug_launch_status();
 }
 
+int dhaug_frame_diff(const float* x, float* out, int64_t rows, int R, int in_w, int w, int adjoint, void* stream) {
+    DHAUG_CHECK(rows >= 0 && R >= 2 && w >= 1 && in_w >= w, DHAUG_EINVAL);
+    if (rows == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(x); DHAUG_CHECK_PTR(out);
+    const long long total = adjoint ? rows * (long long)R * in_w : rows * (long long)(R - 1) * w;
+    hipLaunchKernelGGL(frame_diff_kernel, dim3(grid1d(total, 256)), dim3(256), 0, (hipStream_t)stream, x, out, (long long)rows, R,
+                       in_w, w, adjoint);
+    return dhaug_launch_status();
+}
+
 int dhaug_counter_add(int* counter, int value, void* stream) {
     DHAUG_CHECK_PTR(counter);
     hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, value);
@@ -429,11 +479,20 @@ int dhaug_gp_penalty(const float* grad, float* v, float* pen, int64_t B, int64_t
     return dhaug_launch_status();
 }
 
-int dhaug_critic_scalars(const float* logits, int64_t ld, const float* pen, int64_t B, float lambda, float* out5, void* stream) {
-    DHAUG_CHECK(B >= 1 && ld >= 1, DHAUG_EINVAL);
+int dhaug_critic_scalars(const float* logits, int64_t ld, const float* pen, int64_t B, int64_t P, float lambda, float* out5,
+                         void* stream) {
+    DHAUG_CHECK(B >= 1 && P >= 1 && ld >= 1, DHAUG_EINVAL);
     DHAUG_CHECK_PTR(logits); DHAUG_CHECK_PTR(pen); DHAUG_CHECK_PTR(out5);
     hipLaunchKernelGGL(critic_scalars_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, (long long)ld, pen,
-                       (long long)B, lambda, out5);
+                       (long long)B, (long long)P, lambda, out5);
+    return dhaug_launch_status();
+}
+
+int dhaug_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    DHAUG_CHECK(n >= 0, DHAUG_EINVAL);
+    if (n == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(a); DHAUG_CHECK_PTR(b); DHAUG_CHECK_PTR(out);
+    hipLaunchKernelGGL(add_f32_kernel, dim3(grid1d(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long long)n);
     return dhaug_launch_status();
 }
 

@@ -88,7 +88,7 @@ class FusedNet:
         from . import autograd_ops as A
         if self.params is None:                                # (walking the module tree costs more than the launch)
             self.params = list(self.module.parameters())
-        key = (A.WEIGHT_EPOCH,) + tuple((p.data_ptr(), p._version, getattr(p, "_dhaug_epoch", 0)) for p in self.params)
+        key = (A.WEIGHT_EPOCH, A.CAPTURE_ID) + tuple((p.data_ptr(), p._version, getattr(p, "_dhaug_epoch", 0)) for p in self.params)
         if key != self.key:
             self.layers = {name: _Layer(lin, splits, self.mode) for name, lin, splits in self.build["layers"](self.module)}
             self.key = key

@@ -7,16 +7,23 @@ hipGraphLaunch on the host.  What makes the step replayable:
   * every kernel of libdhaug.so is enqueued on the caller's stream with no host synchronisation and no allocation;
   * the Adam step count lives on the device (dhaug_adam_step_dev) -- the bias corrections are not baked into arguments;
   * random draws come from torch's graph-safe device generator (noise, GP coefficients, bone-length jitter);
-  * the weights' bf16 re-packing after every optimizer step happens inside the captured region;
+  * the weights' bf16 re-packing happens inside the captured region: before their first use (no packed copy made outside
+    the capture is ever read by a captured kernel) and after every optimizer step;
   * inputs are copied into static buffers before each replay; the camera is a launch argument, so a graph is keyed by it.
 Not captured: the data-parallel all-reduce (multi-rank runs stay eager)."""
+import itertools
+
 import torch
+
+from . import autograd_ops as A
+
+_capture_ids = itertools.count(1)
 
 
 class GraphedCall:
     """capture fn(*static_inputs) once (after warm-up calls that populate caches / one-time kernel configuration) and replay it"""
 
-    def __init__(self, fn, example_inputs, warmup=2):
+    def __init__(self, fn, example_inputs, warmup=2, prologue=None):
         self.static_in = [t.clone() if torch.is_tensor(t) else t for t in example_inputs]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -26,8 +33,16 @@ class GraphedCall:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = fn(*self.static_in)
+        # every cached bf16 / fragment copy of a weight is re-made INSIDE the capture (see autograd_ops.CAPTURE_ID): the
+        # graph then owns the memory its kernels read and refreshes it on every replay
+        A.CAPTURE_ID = next(_capture_ids)
+        try:
+            with torch.cuda.graph(self.graph):
+                if prologue is not None:
+                    prologue()
+                self.out = fn(*self.static_in)
+        finally:
+            A.CAPTURE_ID = 0
 
     def __call__(self, *inputs):
         for dst, src in zip(self.static_in, inputs):
@@ -51,5 +66,8 @@ class GraphedGanIteration:
         if g is None:
             def run(x3, cp, x2):
                 return self.fn(self.args, self.d, x3, cp, x2, self.subj, self.summary, None, do_g_step=do_g_step, camera=camera)
-            g = self.graphs[key] = GraphedCall(run, (inputs_3d, cam_param, inputs_2d))
+            # first thing in the graph: every network's bf16 operand copies, two launches per network (the lazy per-layer
+            # packing would put ~50 small kernels there)
+            opts = [v for k, v in self.d.items() if k.startswith("optimizer")]
+            g = self.graphs[key] = GraphedCall(run, (inputs_3d, cam_param, inputs_2d), prologue=lambda: [o._repack() for o in opts])
         return g(inputs_3d, cam_param, inputs_2d)

@@ -113,16 +113,15 @@ def train_Fk_discriminator(model_dis, data_real, data_fake, summary, writer, wri
                            one=None, mone=None, dis_mode='single', alpha=None):
     """One WGAN-GP critic step; returns (Wasserstein_D, D_cost) as 0-dim device tensors.
 
-    The two single-frame critics take the explicit four-sweep schedule of critic_step.py (forward, backward chain, tangent
-    sweep, weight gradients over one 3B-row batch; no autograd graph).  Every other critic (the video motion critics) runs
-    the same step through autograd: -D(real).mean() + D(fake).mean() + GP in one backward."""
+    The four critics take the explicit four-sweep schedule of critic_step.py (forward, backward chain, tangent sweep, weight
+    gradients over one 3B-row batch; no autograd graph).  Anything else (other modules, unusual shapes) runs the same step
+    through autograd: -D(real).mean() + D(fake).mean() + GP in one backward."""
     device = _device()
     data_real = data_real.to(device)
     data_fake = data_fake.to(device)
     real_used_num = frames_from_args(args) if dis_mode != 'motion' else 1
     rows = args.batch_size * real_used_num                       # BATCH_SIZE of calc_gradient_penalty (:210)
-    if (ANALYTIC_CRITIC_STEP and critic_step.supported(model_dis, optimizerD, data_real, data_fake)
-            and data_real.numel() == rows * (48 if isinstance(model_dis, Fk_3D_Discriminator) else 32)):
+    if ANALYTIC_CRITIC_STEP and critic_step.supported(model_dis, optimizerD, data_real, data_fake, rows):
         if alpha is None:
             alpha = torch.rand(rows, 1, device=device)
         sc = critic_step.critic_step(model_dis, optimizerD, data_real.reshape(rows, -1), data_fake.reshape(rows, -1),

@@ -377,7 +377,27 @@ def gp_penalty(grad, coef):
 
 
 def critic_scalars(logits, pen, B, lam):
-    """(5,) fp32: D_real, D_fake, GP, Wasserstein_D, D_cost"""
+    """(5,) fp32: D_real, D_fake, GP, Wasserstein_D, D_cost (logit means over B rows per half, penalty mean over len(pen))"""
     out = torch.empty((5,), dtype=torch.float32, device=logits.device)
-    _lib.call("dhaug_critic_scalars", _p(logits), logits.stride(0), _p(pen), B, float(lam), _p(out), _stream())
+    _lib.call("dhaug_critic_scalars", _p(logits), logits.stride(0), _p(pen), B, pen.numel(), float(lam), _p(out), _stream())
+    return out
+
+
+def add_f32(a, b):
+    """a + b (fp32, same shape)"""
+    a, b = _dev(a, torch.float32, "add_f32"), _dev(b, torch.float32, "add_f32")
+    assert a.shape == b.shape
+    out = torch.empty_like(a)
+    _lib.call("dhaug_add_f32", _p(a), _p(b), _p(out), a.numel(), _stream())
+    return out
+
+
+def frame_diff(x, R, in_w, w=None, adjoint=False):
+    """clips (rows, R*in_w) -> adjacent-frame differences (rows, (R-1)*w) over the first w columns of every frame; adjoint:
+    (rows, (R-1)*w) -> (rows, R*in_w), the transposed map"""
+    w = in_w if w is None else w
+    v = _dev(x, torch.float32, "frame_diff")
+    rows = v.shape[0]
+    out = torch.empty((rows, R * in_w if adjoint else (R - 1) * w), dtype=torch.float32, device=v.device)
+    _lib.call("dhaug_frame_diff", _p(v), _p(out), rows, R, in_w, w, int(bool(adjoint)), _stream())
     return out

@@ -355,9 +355,19 @@ int dhaug_gp_assemble(const float* real, const float* fake, const float* alpha, 
  * cotangent of the penalty on grad (coef = 2 * LAMBDA / B gives d/dgrad of LAMBDA * mean((n - 1)^2)). */
 int dhaug_gp_penalty(const float* grad, float* v, float* pen, int64_t B, int64_t W, float coef, void* stream);
 
+/* Frame differences of clips (the motion critics' diff branches, R/models_Fk_GAN/Fk_discriminator.py:458-460,489-492,570-573):
+ * x (rows, R*in_w) -> out (rows, (R-1)*w), out[r][f][c] = x[r][f+1][c] - x[r][f][c] over the first w columns of every frame;
+ * adjoint != 0: the transposed map, x (rows, (R-1)*w) -> out (rows, R*in_w) (zero for columns >= w). */
+int dhaug_frame_diff(const float* x, float* out, int64_t rows, int R, int in_w, int w, int adjoint, void* stream);
+
 /* out5 = { D_real, D_fake, GP = lambda * mean(pen), Wasserstein_D = D_real - D_fake, D_cost = D_fake - D_real + GP } from
- * the logits (rows [0,B) real, [B,2B) fake, stride ld) and the per-row penalties. */
-int dhaug_critic_scalars(const float* logits, int64_t ld, const float* pen, int64_t B, float lambda, float* out5, void* stream);
+ * the logits (rows [0,B) real, [B,2B) fake, stride ld) and the P per-row penalties (P = B, or B * frames for the 2D motion
+ * critic, whose penalty is taken per frame). */
+int dhaug_critic_scalars(const float* logits, int64_t ld, const float* pen, int64_t B, int64_t P, float lambda, float* out5,
+                         void* stream);
+
+/* out = a + b over n fp32 values (the branch contributions to dD/dx_hat of a multi-branch critic). */
+int dhaug_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }
