@@ -69,5 +69,7 @@ class GraphedGanIteration:
             # first thing in the graph: every network's bf16 operand copies, two launches per network (the lazy per-layer
             # packing would put ~50 small kernels there)
             opts = [v for k, v in self.d.items() if k.startswith("optimizer")]
+            for o in opts:
+                o._ensure_packs()                              # (allocation + descriptor upload must not happen in a capture)
             g = self.graphs[key] = GraphedCall(run, (inputs_3d, cam_param, inputs_2d), prologue=lambda: [o._repack() for o in opts])
         return g(inputs_3d, cam_param, inputs_2d)

@@ -135,8 +135,9 @@ class FusedAdam(torch.optim.Optimizer):
             p._dhaug_epoch = getattr(p, "_dhaug_epoch", 0) + 1
         self._repack()
 
-    def _repack(self):
-        import ctypes
+    def _ensure_packs(self):
+        """bf16 arena + device descriptors of this network's weights (allocated once, outside any graph capture)"""
+        import ctypes  # noqa: F401
         from . import _lib
         if self._packs is None:
             ws2 = [p for p in self._params if p.dim() == 2]
@@ -153,10 +154,13 @@ class FusedAdam(torch.optim.Optimizer):
                 descs[i].W, descs[i].nt, descs[i].nn = p.data_ptr(), nt.data_ptr(), nn.data_ptr()
                 descs[i].N, descs[i].K, descs[i].Kp, descs[i].Np = N, K, Kp, Np
                 views.append((p, nt, nn))
-            raw = bytes(descs)
-            dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.flat_param.device)
+            dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.flat_param.device)
             self._packs = (arena, dev, views)
-        arena, dev, views = self._packs
+        return self._packs
+
+    def _repack(self):
+        from . import _lib
+        arena, dev, views = self._ensure_packs()
         if views:
             _lib.call("dhaug_repack_weights", dev.data_ptr(), len(views), ops._stream())
             for p, nt, nn in views:
