@@ -88,8 +88,9 @@ class _Math:
         return cf
 
     def fusable(self, n, k, rows):
-        """shapes whose mask (and skip) ride the GEMM epilogue (gemm_nt256s_kernel): the output may then overwrite the mask"""
-        return self.bf16 and n == 256 and k in (128, 256) and rows % 64 == 0
+        """the mask (and skip) ride the GEMM epilogue of every bf16 kernel (an element's mask value is read by the thread
+        that then writes that element), so the output may overwrite the mask"""
+        return self.bf16
 
     def outer(self, g, x, N, K, wslot, bslot=None, colsum_rows=None):
         """wslot (N,K) += g^T x;  bslot (N) += column sums of g over rows [0, colsum_rows) (all rows by default; through the
@@ -144,6 +145,13 @@ class _Lin:
                 and u.stride(0) == x.stride(0)):
             # the tangent was written over the interpolated rows of x: one launch contracts all 3B rows
             m.outer(gz, x, self.N, self.K, _slot(self.W), _slot(self.b), colsum_rows=B2)
+            return
+        if m.bf16 and x.dtype != BF16 and u.dtype != BF16 and B2 % 128 == 0 and x.shape[0] == B2 + u.shape[0]:
+            # a network input layer: [x(real, fake); tangent seed] cast into one bf16 operand, one contraction
+            xb = torch.empty((x.shape[0], ceil16(self.K)), dtype=BF16, device=x.device)
+            ops.cast_pad_bf16(x[:B2], ceil16(self.K), out=xb[:B2])
+            ops.cast_pad_bf16(u, ceil16(self.K), out=xb[B2:])
+            m.outer(gz, xb, self.N, self.K, _slot(self.W), _slot(self.b), colsum_rows=B2)
             return
         m.outer(gz[:B2], x[:B2], self.N, self.K, _slot(self.W), _slot(self.b))
         m.outer(gz[B2:], u, self.N, self.K, _slot(self.W))
@@ -222,7 +230,7 @@ def step_d2(D, optimizerD, real, fake, alpha, lam, prec=None):
     gz1 = L[1].bwd(m, gz2, d1, LRELU, s, skip=gz3)
     g = L[0].bwd(m, gz1[B2:], None, NONE, 0.0, out_f32=True)                 # (B,32) fp32: dD/dx_hat
     v, pen = ops.gp_penalty(g, 2.0 * lam / B)
-    u1 = L[0].tan(m, v, d1[B2:])
+    u1 = L[0].tan(m, v, d1[B2:], inplace=True)
     u2 = L[1].tan(m, u1, d2[B2:], inplace=True)
     u3 = L[2].tan(m, u2, d3[B2:], skip=u1, inplace=True)
     u4 = L[3].tan(m, u3, d4[B2:], inplace=True)
@@ -284,7 +292,7 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
     T = tangents(v.reshape(g.shape))
     u, uh = [], []
     for bi, br in enumerate(branches):
-        us, uhs = [br.first.tan(m, T[bi], y[bi][0][B2:])], []
+        us, uhs = [br.first.tan(m, T[bi], y[bi][0][B2:], inplace=True)], []
         for i, blk in enumerate(br.blocks):
             hh, yy = blk.tan(m, us[-1], h[bi][i][B2:], y[bi][i + 1][B2:])
             uhs.append(hh); us.append(yy)
@@ -295,7 +303,7 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
         ucat = m.empty(B, nb * Dw, dev)
         for bi in range(nb):
             ucat[:, bi * Dw:(bi + 1) * Dw].copy_(u[bi][-1][:, :Dw])
-    um0 = Lm.tan(m, ucat, m0[B2:])
+    um0 = Lm.tan(m, ucat, m0[B2:], inplace=True)
     umh, um1 = Mb.tan(m, um0, mh[B2:], m1[B2:])
     # ---- 4. weight / bias gradients
     for bi, br in enumerate(branches):

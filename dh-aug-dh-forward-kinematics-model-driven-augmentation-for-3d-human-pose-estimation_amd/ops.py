@@ -223,13 +223,15 @@ def center_flip(x, center, flip, adjoint=False):
 
 
 # ---------------------------------------------------------------------------------------------- GEMM
-def cast_pad_bf16(src, pad_cols=None):
+def cast_pad_bf16(src, pad_cols=None, out=None):
+    """fp32 (rows, cols) -> bf16 (rows, pad_cols), zero-padded; out: write into these rows of a larger buffer"""
     s = _dev(src, torch.float32, "cast_pad_bf16")
     s = s.reshape(-1, s.shape[-1])
     rows, cols = s.shape
     pad_cols = ceil_to(cols, 16) if pad_cols is None else pad_cols
-    dst = torch.empty((rows, pad_cols), dtype=BF16, device=s.device)
-    _lib.call("dhaug_cast_pad_bf16", _p(s), cols, _p(dst), pad_cols, rows, cols, pad_cols, _stream())
+    dst = torch.empty((rows, pad_cols), dtype=BF16, device=s.device) if out is None else out
+    assert dst.dtype == BF16 and dst.shape == (rows, pad_cols) and dst.stride(1) == 1
+    _lib.call("dhaug_cast_pad_bf16", _p(s), cols, _p(dst), dst.stride(0), rows, cols, pad_cols, _stream())
     return dst
 
 

@@ -90,15 +90,11 @@ def _run(rank, world, port, tag, q, gpu_ready):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tag", ["d3", "d2"])
-def test_two_replica_critic_step_equals_full_batch(tag):
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU")
+def _launch_once(target, tag, port):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + (7 if tag == "d2" else 0)
     ready = [ctx.Event() for _ in range(2)]
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, tag, q, ready)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, 2, port, tag, q, ready)) for r in range(2)]
     for p in procs:
         p.start()
     res = []
@@ -110,19 +106,40 @@ def test_two_replica_critic_step_equals_full_batch(tag):
             try:
                 res.append(q.get(timeout=2))
             except _queue.Empty:
-                dead = [p for p in procs if p.exitcode not in (None, 0)]
-                if dead:                                  # a replica died without reporting: do not wait for the timeout
-                    break
+                if [p for p in procs if p.exitcode not in (None, 0)]:   # a replica died without reporting: do not
+                    break                                                 # wait for the timeout
         res.sort()
     finally:
         for p in procs:
             p.join(timeout=60)
             if p.is_alive():
                 p.kill()                          # exact child only
-    assert [r[0] for r in res] == [0, 1], "replica exit codes %s, reported %s" % ([p.exitcode for p in procs], res)
+    return res, [p.exitcode for p in procs]
+
+
+def _launch(target, tag, port):
+    """two replica processes on the one card.  The parent has run the whole GPU suite by now: drop what it caches first
+    (three torch processes share the box's memory).  A replica that the host kills from outside (SIGKILL before it
+    reported anything -- seen once, during the parameter broadcast, before any kernel of ours ran) is started once more
+    and the event printed; a replica that raises or reports a mismatch fails the test at once."""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    res, codes = _launch_once(target, tag, port)
+    if not res and any(c is not None and c < 0 for c in codes):
+        print("replicas %s ended by signal %s before reporting: starting them once more" % (tag, codes))
+        res, codes = _launch_once(target, tag, port + 11)
+    assert [r[0] for r in res] == [0, 1], "replica exit codes %s, reported %s" % (codes, res)
     for r in res:
         assert not r[1], r
-    assert all(p.exitcode == 0 for p in procs)
+    assert all(c == 0 for c in codes), codes
+
+
+@pytest.mark.parametrize("tag", ["d3", "d2"])
+def test_two_replica_critic_step_equals_full_batch(tag):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _launch(_worker, tag, 29500 + (os.getpid() % 2000) + (7 if tag == "d2" else 0))
 
 
 def _run_loop(rank, world, port, tag, q, gpu_ready):
@@ -213,30 +230,4 @@ def _worker_loop(rank, world, port, tag, q, gpu_ready):
 def test_two_replica_loop_interleaved_overlap():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
-    ready = [ctx.Event() for _ in range(2)]
-    procs = [ctx.Process(target=_worker_loop, args=(r, 2, port, "loop", q, ready)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = []
-    try:
-        import queue as _queue
-        import time
-        deadline = time.monotonic() + 300
-        while len(res) < len(procs) and time.monotonic() < deadline:
-            try:
-                res.append(q.get(timeout=2))
-            except _queue.Empty:
-                if [p for p in procs if p.exitcode not in (None, 0)]:
-                    break
-        res.sort()
-    finally:
-        for p in procs:
-            p.join(timeout=60)
-            if p.is_alive():
-                p.kill()                          # exact child only
-    assert [r[0] for r in res] == [0, 1], "replica exit codes %s, reported %s" % ([p.exitcode for p in procs], res)
-    for r in res:
-        assert not r[1], r
+    _launch(_worker_loop, "loop", 31500 + (os.getpid() % 2000))
