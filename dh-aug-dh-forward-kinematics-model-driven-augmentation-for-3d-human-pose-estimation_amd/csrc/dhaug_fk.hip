@@ -128,7 +128,15 @@ __device__ __forceinline__ void stage_in_strided(const float* __restrict__ g, fl
     }
 }
 
-__device__ __forceinline__ float tanh_acc(float x) { return tanhf(x); }
+// tanh = 1 - 2 / (exp(2|x|) + 1) on the hardware exp2 / rcp: |error| <= 1.2e-7 absolute (the quantity that matters: the
+// result is scaled to degrees / metres), 7 instructions where the library routine takes ~30 and branches.  Forward and
+// reverse mode use the same function.
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float e = __builtin_amdgcn_exp2f(fabsf(x) * 2.8853900817779268f);        // exp(2|x|); inf beyond 44: 1 - 0
+    const float t = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+    return copysignf(t, x);
+}
+__device__ __forceinline__ float tanh_acc(float x) { return tanh_fast(x); }
 
 // MODE 0: in0 = angles (N,37), in2 = root (N,3).      MODE 1: in0 = head (N,35), in2 = scaler (N,8) or null.
 template <int MODE> struct InLayout;
@@ -264,12 +272,12 @@ __device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2
     r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
 }
 
-template <int MODE, int OUTJ, bool PREANGLE, bool EXTRA = false>
+template <int MODE, int OUTJ, bool PREANGLE>
 __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu((MODE == 0 && OUTJ == 16) ? 3 : 1))) void fk_forward_kernel(const float* __restrict__ in0,
                                                           const float* __restrict__ bone_len,
                                                           const float* __restrict__ in2,
                                                           float* __restrict__ out, float* __restrict__ angles_out,
-                                                          TailExtra ex, long long N) {
+                                                          long long N) {
     using L = InLayout<MODE>;
     constexpr int OW = OUTJ * 3, OS = OW + 1;                  // output row width / odd LDS stride
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -291,19 +299,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu((MODE == 0
         }
 #pragma unroll
         for (int j = 0; j < L::W2; ++j) v2[j] = 0.0f;
-        if (EXTRA && MODE == 1 && ex.draw) {
-            // s = randint(-200, 200) / 1000 per pose and jitter column (R/models_Fk_GAN/Fk_generator.py:196-203)
-            const unsigned long long idx = (unsigned long long)(base + lane);
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                unsigned r[4];
-                philox4x32((unsigned)idx, (unsigned)(idx >> 32), (unsigned)ex.offset + half, (unsigned)(ex.offset >> 32),
-                           (unsigned)ex.seed, (unsigned)(ex.seed >> 32), r);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v2[(4 * half + j) < L::W2 ? 4 * half + j : 0] = (float)((int)(r[j] % 400u) - 200) / 1000.0f;
-            }
-            if (ex.scaler_out != nullptr) lanes_to_rows<8, 9>(v2, smem, ex.scaler_out + base * 8, rows, lane);
-        } else if (has2) rows_to_lanes<L::W2>(in2 + base * L::W2, smem, rows, lane, v2);
+        if (has2) rows_to_lanes<L::W2>(in2 + base * L::W2, smem, rows, lane, v2);
 
         float ang[37];
         V3 root, p[16];
@@ -321,7 +317,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu((MODE == 0
             for (int j = 0; j < 15; ++j)
                 bl[j] = kJitterCol[j] < 0 ? bl[j] : bl[j] * (1.0f + v2[kJitterCol[j] < 0 ? 0 : (kJitterCol[j] < L::W2 ? kJitterCol[j] : 0)]);
         }
-        fk_pose(ang, bl, p);
+        fk_pose<MODE == 0>(ang, bl, p);                        // (MODE 1: the angles are bounded, no large-argument guard)
 
         float o[OW];
         if (OUTJ == 16) {
@@ -340,49 +336,347 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu((MODE == 0
         }
         lanes_to_rows<OW, OS>(o, smem, out + base * OW, rows, lane);
         if (MODE == 1 && angles_out != nullptr) lanes_to_rows<37, 37>(ang, smem, angles_out + base * 37, rows, lane);
-        if (EXTRA && MODE == 1 && OUTJ == 16) {
-            if (ex.centered != nullptr) {
-                float cc[48];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Generator tail for the critics, FOUR waves per tile of 64 poses.
+//
+// One lane per pose and one wave per tile leaves a single wave on every SIMD at B = 65 536 (1 024 tiles, 1 024 SIMDs):
+// nothing hides a load, an LDS round trip or a transcendental, and the whole skeleton (31 joint transforms, 35 tanh) is
+// one dependency chain per lane.  Here a tile is a workgroup of four waves and the SKELETON is what is split: lane l of
+// every wave works on pose l, wave role r on one group of kinematic chains (compile-time DH constants stay: the roles are
+// wave-uniform code paths, not lane-divergent ones):
+//     role 0  both legs                       role 2  right arm (starts at body frame 8)
+//     role 1  body frames 0..8, then the head   role 3  left arm  (starts at body frame 8)
+// Role 1 hands frame 8 to the arm waves through LDS (they have their sines / cosines ready by then); every role
+// rebuilds the global rotation and the root it needs (3 + 3 tanh, 3 sincos: cheaper than a second hand-over).  The joints
+// meet in an LDS pose image; the critics' operands are then dealt out again by role (KCS features | centred pose | camera
+// projection of joints 0..7 | of joints 8..15) and everything leaves through coalesced 16-byte stores issued by all 256
+// threads.  Roles rotate with the tile index so that a SIMD does not collect four waves of the heaviest role.
+// tanh is 1 - 2 / (exp(2|x|) + 1) on the hardware exp2 / rcp (|error| <= 1.2e-7 absolute, 7 instructions; the library
+// routine is ~30 and branches); the joint angles are bounded by construction, so sincos skips the large-argument guard.
+// ---------------------------------------------------------------------------------------------------
+constexpr int T4_THREADS = 256;
+constexpr int T4_HEAD = 0, T4_BONE = TILE * 35, T4_FRAME = T4_BONE + TILE * 15;      // phase A: inputs, body frame 8 (stride 13)
+constexpr int T4_CEN = 0, T4_KCS = TILE * 49;                                        // phase B (aliases phase A's region)
+constexpr int T4_X = T4_KCS + TILE * 17;
+constexpr int T4_POSE = T4_X;                                                        // 64 x 49
+constexpr int T4_PROJ = T4_POSE + TILE * 49;                                         // 64 x 33 (fp32) or 64 x 17 (bf16 pairs)
+constexpr int T4_RG = T4_PROJ;                                                       // phase A: global rotation + root, 64 x 13
+constexpr int T4_SCAL = T4_PROJ + TILE * 33;                                         // 64 x 9
+constexpr int T4_FLOATS = T4_SCAL + TILE * 9;                                        // 10 048 floats = 39.25 KB: four tiles per CU
+static_assert(T4_FRAME + TILE * 13 <= T4_X, "phase A region");
+
+__device__ __forceinline__ void t4_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// k / 1000 correctly rounded for the integers of the jitter draw (checked exhaustively on the host, tests/test_cpu_boundary.py)
+__device__ __forceinline__ float div1000(float k) {
+    const float q = k * 0.001f;
+    return fmaf(fmaf(-q, 1000.0f, k), 0.001f, q);
+}
+// a / b within an ulp: reciprocal + one correction step each (the IEEE sequence is ~11 instructions)
+__device__ __forceinline__ float rcp_nr(float b) {
+    const float r = __builtin_amdgcn_rcpf(b);
+    return fmaf(fmaf(-b, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float div_nr(float a, float rb, float b) {              // rb = rcp_nr(b)
+    const float q = a * rb;
+    return fmaf(fmaf(-b, q, a), rb, q);
+}
+__device__ __forceinline__ float pack2(float a, float b) {                          // two bf16 (RNE) in one dword
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 f = {a, b};
+    return __builtin_bit_cast(float, __builtin_convertvector(f, bf2));
+}
+
+// the H36M projection of a camera-space point (second half of w2c_project, dhaug_fk_math.h), the two perspective
+// divisions taken through one corrected reciprocal
+__device__ __forceinline__ void project_nr(V3 xc, const float* __restrict__ c, float& ox, float& oy) {
+    const float rz = rcp_nr(xc.z);
+    const float u = fminf(fmaxf(div_nr(xc.x, rz, xc.z), -1.0f), 1.0f), v = fminf(fmaxf(div_nr(xc.y, rz, xc.z), -1.0f), 1.0f);
+    const float r2 = u * u + v * v;
+    const float radial = 1.0f + (c[4] * r2 + c[5] * (r2 * r2) + c[6] * (r2 * r2 * r2));
+    const float tan = c[7] * u + c[8] * v;
+    ox = c[0] * (u * (radial + tan) + c[7] * r2) + c[2];
+    oy = c[1] * (v * (radial + tan) + c[8] * r2) + c[3];
+}
+// theta0 (degrees) of leg slot i (0..3 right, 5..8 left) and of body frame i (0..8)
+__device__ __forceinline__ constexpr float leg_theta0(int i) {
+    constexpr float t[9] = {0.0f, -90.0f, 180.0f, 0.0f, 0.0f, 180.0f, -90.0f, 0.0f, 0.0f};
+    return t[i];
+}
+__device__ __forceinline__ constexpr float body_theta0(int i) { return i == 0 ? 90.0f : -90.0f; }
+
+// angle slot i of the pose whose head row is `h` (R/models_Fk_GAN/Fk_generator.py:121-168)
+template <bool PREANGLE>
+__device__ __forceinline__ float slot_angle(int i, const float* __restrict__ h) {
+    const int col = kSlotCol[i];
+    if (col < 0) return 0.0f;
+    const float t = tanh_fast(h[col]);
+    return PREANGLE ? (t * (kAngHi[i] - kAngLo[i])) * 0.5f + (kAngHi[i] + kAngLo[i]) * 0.5f : t * 180.0f;
+}
+
+// rows of W floats: LDS image with row stride S (odd) -> global, 16 bytes per thread and request
+template <int W, int S>
+__device__ __forceinline__ void t4_store_rows(const float* __restrict__ l, float* __restrict__ g, int rows, int tid) {
+    static_assert(W % 4 == 0, "row width");
+    constexpr int Q = W / 4, K = (TILE * Q + T4_THREADS - 1) / T4_THREADS;
+    asm volatile("" : "+v"(tid));                              // (addresses are derived here, not hoisted out of the tile loop and spilled)
+    float4 t[K];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) { cc[3 * j] = o[3 * j] - o[0]; cc[3 * j + 1] = o[3 * j + 1] - o[1]; cc[3 * j + 2] = o[3 * j + 2] - o[2]; }
-                if (ex.in_bf16) {
-                    float pk[24];                               // bf16 pairs travel as dwords
+    for (int k = 0; k < K; ++k) {
+        const int e = tid + T4_THREADS * k, r = e / Q, j = (e - r * Q) * 4;
+        const float* src = l + (r < TILE ? r : 0) * S + j;
+        t[k] = make_float4(src[0], src[1], src[2], src[3]);
+    }
 #pragma unroll
-                    for (int i = 0; i < 24; ++i)
-                        pk[i] = __builtin_bit_cast(float, (uint32_t)dhaug_f32_to_bf16(cc[2 * i]) | ((uint32_t)dhaug_f32_to_bf16(cc[2 * i + 1]) << 16));
-                    lanes_to_rows<24, 25>(pk, smem, static_cast<float*>(ex.centered) + base * 24, rows, lane);
-                } else {
-                    lanes_to_rows<48, 49>(cc, smem, static_cast<float*>(ex.centered) + base * 48, rows, lane);
-                }
+    for (int k = 0; k < K; ++k) {
+        const int e = tid + T4_THREADS * k, r = e / Q;
+#ifdef T4_ABL_NOSTORE
+        asm volatile("" :: "v"(t[k].x), "v"(t[k].y), "v"(t[k].z), "v"(t[k].w), "v"(g));
+#else
+        if (r < rows) reinterpret_cast<float4*>(g)[e] = t[k];
+#endif
+    }
+}
+
+template <bool PREANGLE>
+__global__ __launch_bounds__(T4_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void gen_tail4_kernel(const float* __restrict__ head, const float* __restrict__ bone_len,
+                                                               const float* __restrict__ scaler, float* __restrict__ out,
+                                                               TailExtra ex, long long N) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long ntiles = (N + TILE - 1) / TILE;
+    const bool has2 = scaler != nullptr;
+    float* pose = smem + T4_POSE;
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long base = tile * TILE;
+        const int rows = (int)((N - base) < TILE ? (N - base) : TILE);
+        const int role = (wave + (int)tile) & 3;
+        {   // inputs of the tile -> LDS (linear images; row strides 35 / 15 are odd), all requests in flight together
+            const float* gh = head + base * 35;
+            const float* gb = bone_len + base * 15;
+            const int n4h = (rows * 35) >> 2, n4b = (rows * 15) >> 2;
+            float4 th[3], tb, ts = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int i = tid + T4_THREADS * k;
+                th[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < n4h) th[k] = reinterpret_cast<const float4*>(gh)[i];
             }
+            tb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tid < n4b) tb = reinterpret_cast<const float4*>(gb)[tid];
+            const bool rd_s = has2 && !ex.draw && tid < rows * 2;
+            if (rd_s) ts = reinterpret_cast<const float4*>(scaler + base * 8)[tid];
+            float remh = 0.f, remb = 0.f;
+            const int rh = (rows * 35) & 3, rb = (rows * 15) & 3;
+            if (tid < rh) remh = gh[4 * n4h + tid];
+            if (tid < rb) remb = gb[4 * n4b + tid];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int i = tid + T4_THREADS * k;
+                if (i < n4h) reinterpret_cast<float4*>(smem + T4_HEAD)[i] = th[k];
+            }
+            if (tid < n4b) reinterpret_cast<float4*>(smem + T4_BONE)[tid] = tb;
+            if (tid < rh) smem[T4_HEAD + 4 * n4h + tid] = remh;
+            if (tid < rb) smem[T4_BONE + 4 * n4b + tid] = remb;
+            if (rd_s) {
+                float* d = smem + T4_SCAL + (tid >> 1) * 9 + (tid & 1) * 4;
+                d[0] = ts.x; d[1] = ts.y; d[2] = ts.z; d[3] = ts.w;
+            }
+        }
+        t4_barrier();
+
+#ifndef T4_ABL_NOCOMPUTE
+        const int src = lane < rows ? lane : 0;                // idle lanes of a ragged tile recompute pose 0 (never stored)
+        const float* hrow = smem + T4_HEAD + src * 35;
+        const float* brow = smem + T4_BONE + src * 15;
+        float* prow = pose + lane * 49;
+        float* jrow = smem + T4_SCAL + lane * 9;               // the pose's jitter (8) ...
+        float* grow = smem + T4_RG + lane * 13;                // ... and its global rotation (9) + root (3)
+        float ang[37], bl[15];
+        V3 p[16];
+        ArmSC arm;
+        // ---- before hand-over 0: sines / cosines of the role's chains; role 2 also builds the global rotation and the root,
+        // roles 2 / 3 draw the bone-length jitter (Philox4x32-10, R/models_Fk_GAN/Fk_generator.py:196-203): columns 4..7 / 0..3
+        auto draw_half = [&](int half) {
+            const unsigned long long idx = (unsigned long long)(base + lane);
+            unsigned r[4];
+            philox4x32((unsigned)idx, (unsigned)(idx >> 32), (unsigned)ex.offset + half, (unsigned)(ex.offset >> 32),
+                       (unsigned)ex.seed, (unsigned)(ex.seed >> 32), r);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) jrow[4 * half + q] = div1000((float)((int)(r[q] % 400u) - 200));
+        };
+        // legs and body: sincos of slot i sits in sc[2i], sc[2i+1] once computed; the chains run after the hand-over
+        float ssc[13], csc[13];
+        if (role == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sincos_deg_t<false>(leg_theta0(i) + slot_angle<PREANGLE>(i, hrow), ssc[i], csc[i]);
+                sincos_deg_t<false>(leg_theta0(5 + i) + slot_angle<PREANGLE>(5 + i, hrow), ssc[4 + i], csc[4 + i]);
+            }
+        } else if (role == 1) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) sincos_deg_t<false>(body_theta0(i) + slot_angle<PREANGLE>(10 + i, hrow), ssc[i], csc[i]);
+        } else if (role == 2) {
+            if (ex.draw) draw_half(1);
+#pragma unroll
+            for (int i = 34; i < 37; ++i) ang[i] = slot_angle<PREANGLE>(i, hrow);
+            float sgx, cgx;
+            const Rot R = fk_global<false>(ang, sgx, cgx);
+            grow[0] = R.r0.x; grow[1] = R.r0.y; grow[2] = R.r0.z; grow[3] = R.r1.x; grow[4] = R.r1.y; grow[5] = R.r1.z;
+            grow[6] = R.r2.x; grow[7] = R.r2.y; grow[8] = R.r2.z;
+            grow[9] = tanh_fast(hrow[32]) * 10.0f; grow[10] = tanh_fast(hrow[33]) * 10.0f; grow[11] = tanh_fast(hrow[34]) * 10.0f;
+#pragma unroll
+            for (int i = 23; i < 27; ++i) ang[i] = slot_angle<PREANGLE>(i, hrow);
+            arm = fk_right_arm_sc<false>(ang);
+        } else {
+            if (ex.draw) draw_half(0);
+#pragma unroll
+            for (int i = 28; i < 32; ++i) ang[i] = slot_angle<PREANGLE>(i, hrow);
+            arm = fk_left_arm_sc<false>(ang);
+        }
+        t4_barrier();                                          // hand-over 0: jitter, global rotation, root
+        Rot Rg;
+        Rg.r0 = mk(grow[0], grow[1], grow[2]); Rg.r1 = mk(grow[3], grow[4], grow[5]); Rg.r2 = mk(grow[6], grow[7], grow[8]);
+        const V3 root = mk(grow[9], grow[10], grow[11]);
+        const bool jittered = ex.draw || has2;
+        auto bone = [&](int b) -> float {
+            const float len = brow[b];
+            if (kJitterCol[b] < 0) return len;
+            const float* jr = smem + T4_SCAL + (ex.draw ? lane : src) * 9;
+            return len * (1.0f + (jittered ? jr[kJitterCol[b] < 0 ? 0 : kJitterCol[b]] : 0.0f));
+        };
+        auto put = [&](int q) {
+            prow[3 * q] = p[q].x + root.x; prow[3 * q + 1] = p[q].y + root.y; prow[3 * q + 2] = p[q].z + root.z;
+        };
+        Frame B;
+        if (role == 0) {
+#pragma unroll
+            for (int b = 0; b < 6; ++b) bl[b] = bone(b);
+            p[0] = mk(0.0f, 0.0f, 0.0f);
+            fk_right_leg_sc(ssc, csc, bl, Rg, p);
+            fk_left_leg_sc(ssc + 4, csc + 4, bl, Rg, p);
+#pragma unroll
+            for (int q = 0; q < 7; ++q) put(q);
+        } else if (role == 1) {
+            bl[6] = bone(6); bl[7] = bone(7);
+            B = fk_body_sc(ssc, csc, bl, Rg, p);
+            float* f = smem + T4_FRAME + lane * 13;
+            f[0] = B.c0.x; f[1] = B.c0.y; f[2] = B.c0.z; f[3] = B.c1.x; f[4] = B.c1.y; f[5] = B.c1.z;
+            f[6] = B.c2.x; f[7] = B.c2.y; f[8] = B.c2.z; f[9] = B.t.x; f[10] = B.t.y; f[11] = B.t.z;
+            put(7); put(8);
+        }
+        t4_barrier();                                          // hand-over 1: body frame 8
+        if (role == 1) {
+#pragma unroll
+            for (int i = 19; i < 22; ++i) ang[i] = slot_angle<PREANGLE>(i, hrow);
+            bl[14] = bone(14);
+            fk_head<false>(ang, bl, Rg, B, p);
+            put(9);
+        } else if (role >= 2) {
+            const float* f = smem + T4_FRAME + lane * 13;
+            B.c0 = mk(f[0], f[1], f[2]); B.c1 = mk(f[3], f[4], f[5]); B.c2 = mk(f[6], f[7], f[8]); B.t = mk(f[9], f[10], f[11]);
+            if (role == 2) {
+                bl[9] = bone(9); bl[11] = bone(11); bl[13] = bone(13);
+                fk_right_arm(arm, bl, Rg, B, p);
+                put(13); put(14); put(15);
+            } else {
+                bl[8] = bone(8); bl[10] = bone(10); bl[12] = bone(12);
+                fk_left_arm(arm, bl, Rg, B, p);
+                put(10); put(11); put(12);
+            }
+        }
+        t4_barrier();                                          // the pose image is complete; phase A's inputs are dead
+        // the poses leave now: these stores are in flight while the critics' operands are computed
+        t4_store_rows<48, 49>(pose, out + base * 48, rows, tid);
+
+        if (role == 0) {
             if (ex.kcs != nullptr) {
                 V3 pw[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) pw[j] = mk(o[3 * j], o[3 * j + 1], o[3 * j + 2]);
+                for (int q = 0; q < 16; ++q) pw[q] = mk(prow[3 * q], prow[3 * q + 1], prow[3 * q + 2]);
+                // 15 cosines between adjacent bones, 15 lengths (kcs_features), on the hardware sqrt / rcp: the operand
+                // is rounded to bf16 (2^-9 relative) right below
+                V3 b[15];
+                float len[15];
+#pragma unroll
+                for (int i = 0; i < 15; ++i) { b[i] = pw[kcs_bone_c(i)] - pw[kcs_bone_p(i)]; len[i] = __builtin_amdgcn_sqrtf(dot(b[i], b[i])); }
                 float f[32];
-                kcs_features(pw, f);
+#pragma unroll
+                for (int k = 0; k < 15; ++k) {
+                    const float den = len[kcs_i(k)] * len[kcs_j(k)];
+                    f[k] = div_nr(dot(b[kcs_i(k)], b[kcs_j(k)]), rcp_nr(den), den);
+                }
+#pragma unroll
+                for (int i = 0; i < 15; ++i) f[15 + i] = len[i];
                 f[30] = 0.0f; f[31] = 0.0f;
-                float pk[16];                                   // bf16 pairs travel as dwords
+                float* d = smem + T4_KCS + lane * 17;
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    pk[i] = __builtin_bit_cast(float, (uint32_t)dhaug_f32_to_bf16(f[2 * i]) | ((uint32_t)dhaug_f32_to_bf16(f[2 * i + 1]) << 16));
-                lanes_to_rows<16, 17>(pk, smem, reinterpret_cast<float*>(ex.kcs) + base * 16, rows, lane);
+                for (int i = 0; i < 16; ++i) d[i] = pack2(f[2 * i], f[2 * i + 1]);
             }
-            if (ex.proj2d != nullptr) {
-                float pr[32];
+        } else if (role == 1) {
+            if (ex.centered != nullptr) {
+                float o[48];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) w2c_project(mk(o[3 * j], o[3 * j + 1], o[3 * j + 2]), ex.q, ex.t, ex.c, pr[2 * j], pr[2 * j + 1]);
+                for (int i = 0; i < 48; ++i) o[i] = prow[i];
                 if (ex.in_bf16) {
-                    float pk[16];
+                    float* d = smem + T4_CEN + lane * 25;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        pk[i] = __builtin_bit_cast(float, (uint32_t)dhaug_f32_to_bf16(pr[2 * i]) | ((uint32_t)dhaug_f32_to_bf16(pr[2 * i + 1]) << 16));
-                    lanes_to_rows<16, 17>(pk, smem, static_cast<float*>(ex.proj2d) + base * 16, rows, lane);
+                    for (int i = 0; i < 24; ++i) d[i] = pack2(o[2 * i] - o[(2 * i) % 3], o[2 * i + 1] - o[(2 * i + 1) % 3]);
                 } else {
-                    lanes_to_rows<32, 33>(pr, smem, static_cast<float*>(ex.proj2d) + base * 32, rows, lane);
+                    float* d = smem + T4_CEN + lane * 49;
+#pragma unroll
+                    for (int i = 0; i < 48; ++i) d[i] = o[i] - o[i % 3];
                 }
             }
+        } else if (ex.proj2d != nullptr) {
+            const int j0 = role == 2 ? 0 : 8;
+            // the camera's rotation as a matrix (columns = the quaternion formula applied to the unit vectors: wave-uniform,
+            // once per tile), then 9 multiply-adds per joint instead of two cross products
+            const V3 qv = mk(-ex.q[1], -ex.q[2], -ex.q[3]);
+            V3 mc[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const V3 e = mk(a == 0 ? 1.0f : 0.0f, a == 1 ? 1.0f : 0.0f, a == 2 ? 1.0f : 0.0f);
+                const V3 uv = cross(qv, e);
+                mc[a] = e + 2.0f * (ex.q[0] * uv + cross(qv, uv));
+            }
+            float pr[16];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float* w = prow + 3 * (j0 + q);
+                const V3 x = mk(w[0] - ex.t[0], w[1] - ex.t[1], w[2] - ex.t[2]);
+                const V3 xc = axpy(x.z, mc[2], axpy(x.y, mc[1], x.x * mc[0]));
+                project_nr(xc, ex.c, pr[2 * q], pr[2 * q + 1]);
+            }
+            if (ex.in_bf16) {
+                float* d = smem + T4_PROJ + lane * 17 + j0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) d[i] = pack2(pr[2 * i], pr[2 * i + 1]);
+            } else {
+                float* d = smem + T4_PROJ + lane * 33 + 2 * j0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) d[i] = pr[i];
+            }
         }
+#endif
+        t4_barrier();
+
+        if (ex.centered != nullptr) {
+            if (ex.in_bf16) t4_store_rows<24, 25>(smem + T4_CEN, static_cast<float*>(ex.centered) + base * 24, rows, tid);
+            else t4_store_rows<48, 49>(smem + T4_CEN, static_cast<float*>(ex.centered) + base * 48, rows, tid);
+        }
+        if (ex.kcs != nullptr) t4_store_rows<16, 17>(smem + T4_KCS, reinterpret_cast<float*>(ex.kcs) + base * 16, rows, tid);
+        if (ex.proj2d != nullptr) {
+            if (ex.in_bf16) t4_store_rows<16, 17>(smem + T4_PROJ, static_cast<float*>(ex.proj2d) + base * 16, rows, tid);
+            else t4_store_rows<32, 33>(smem + T4_PROJ, static_cast<float*>(ex.proj2d) + base * 32, rows, tid);
+        }
+        if (ex.draw && ex.scaler_out != nullptr) t4_store_rows<8, 9>(smem + T4_SCAL, ex.scaler_out + base * 8, rows, tid);
+        t4_barrier();                                          // (a workgroup that takes another tile overwrites the images)
     }
 }
 
@@ -499,9 +793,9 @@ int dhaug_fk_forward(const float* angles, const float* bone_len, const float* ro
                 DHAUG_EALIGN);
     if (out_joints == 16)
         return launch_tiles(fk_forward_kernel<0, 16, true>, fwd_lds(37, 48), N, stream, angles, bone_len, root, out,
-                            (float*)nullptr, TailExtra{});
+                            (float*)nullptr);
     return launch_tiles(fk_forward_kernel<0, 32, true>, fwd_lds(37, 96), N, stream, angles, bone_len, root, out,
-                        (float*)nullptr, TailExtra{});
+                        (float*)nullptr);
 }
 
 int dhaug_fk_backward(const float* angles, const float* bone_len, const float* grad_out16, float* grad_angles,
@@ -523,9 +817,9 @@ int dhaug_gen_tail_forward(const float* head, const float* bone_len, const float
     DHAUG_CHECK(dhaug_aligned16(head) && dhaug_aligned16(bone_len) && dhaug_aligned16(scaler), DHAUG_EALIGN);
     if (use_preangle)
         return launch_tiles(fk_forward_kernel<1, 16, true>, fwd_lds(37, 48), N, stream, head, bone_len, scaler, fake16,
-                            angles_out, TailExtra{});
+                            angles_out);
     return launch_tiles(fk_forward_kernel<1, 16, false>, fwd_lds(37, 48), N, stream, head, bone_len, scaler, fake16,
-                        angles_out, TailExtra{});
+                        angles_out);
 }
 
 int dhaug_gen_tail_forward_critics(const float* head, const float* bone_len, const float* scaler, float* fake16,
@@ -547,11 +841,15 @@ int dhaug_gen_tail_forward_critics(const float* head, const float* bone_len, con
         for (int i = 0; i < 3; ++i) ex.t[i] = trans[i];
         for (int i = 0; i < 9; ++i) ex.c[i] = cam9[i];
     }
+    const long long ntiles = (N + TILE - 1) / TILE;
+    const int grid = dhaug_stream_grid(ntiles, 1, 256 * 4 * 4);
     if (use_preangle)
-        return launch_tiles(fk_forward_kernel<1, 16, true, true>, fwd_lds(37, 48), N, stream, head, bone_len, scaler, fake16,
-                            (float*)nullptr, ex);
-    return launch_tiles(fk_forward_kernel<1, 16, false, true>, fwd_lds(37, 48), N, stream, head, bone_len, scaler, fake16,
-                        (float*)nullptr, ex);
+        hipLaunchKernelGGL(gen_tail4_kernel<true>, dim3(grid), dim3(T4_THREADS), T4_FLOATS * sizeof(float), (hipStream_t)stream,
+                           head, bone_len, scaler, fake16, ex, (long long)N);
+    else
+        hipLaunchKernelGGL(gen_tail4_kernel<false>, dim3(grid), dim3(T4_THREADS), T4_FLOATS * sizeof(float), (hipStream_t)stream,
+                           head, bone_len, scaler, fake16, ex, (long long)N);
+    return dhaug_launch_status();
 }
 
 int dhaug_gen_tail_backward(const float* head, const float* bone_len, const float* scaler, const float* grad_fake16,

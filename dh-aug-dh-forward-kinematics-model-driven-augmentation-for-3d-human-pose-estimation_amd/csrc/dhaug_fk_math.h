@@ -44,15 +44,7 @@ DHAUG_HD float div180(float x) {
 
 // sin/cos of an fp32 radian argument, ~1 ulp: 3-term Cody-Waite reduction by pi/2 in FMA, Cephes minimax
 // polynomials on [-pi/4, pi/4].  ~22 VALU instructions per pair (ocml sincosf is ~3x that and branches).
-DHAUG_HD void sincos_rad(float x, float& s, float& c) {
-    // far outside any joint angle, or not finite: library path.  The test is on the bit pattern (131072.0f = 0x48000000;
-    // inf / NaN compare greater): this file is built with -ffinite-math-only, under which a float comparison may be
-    // assumed false for NaN -- and the (int) conversion below is undefined for NaN (found by UBSan on the host build,
-    // tests/test_cpu_boundary.py).
-    if (__builtin_expect((__builtin_bit_cast(uint32_t, x) & 0x7fffffffu) > 0x48000000u, 0)) {
-        sincosf(x, &s, &c);
-        return;
-    }
+DHAUG_HD void sincos_rad_bounded(float x, float& s, float& c) {
     float kf = rintf(x * 0.6366197466850281f);
     float r = fmaf(-kf, 1.5707963705062866f, x);
     r = fmaf(-kf, -4.371138828673793e-08f, r);
@@ -66,6 +58,17 @@ DHAUG_HD void sincos_rad(float x, float& s, float& c) {
     float cc = (k & 1) ? sp : cp;
     s = (k & 2) ? -ss : ss;
     c = ((k + 1) & 2) ? -cc : cc;
+}
+DHAUG_HD void sincos_rad(float x, float& s, float& c) {
+    // far outside any joint angle, or not finite: library path.  The test is on the bit pattern (131072.0f = 0x48000000;
+    // inf / NaN compare greater): this file is built with -ffinite-math-only, under which a float comparison may be
+    // assumed false for NaN -- and the (int) conversion below is undefined for NaN (found by UBSan on the host build,
+    // tests/test_cpu_boundary.py).
+    if (__builtin_expect((__builtin_bit_cast(uint32_t, x) & 0x7fffffffu) > 0x48000000u, 0)) {
+        sincosf(x, &s, &c);
+        return;
+    }
+    sincos_rad_bounded(x, s, c);
 }
 
 // sin/cos of an angle given in degrees, with the reference's fp32 conversion.
@@ -118,9 +121,7 @@ DHAUG_HD void dh_apply(Frame& F, float a, float d, float st, float ct) {
 
 // Rg = Rx(ax) * Ry(ay) * Rz(az), rows r0,r1,r2.   R/models_Fk_GAN/forward_kinematics_DH_model.py:141-191
 struct Rot { V3 r0, r1, r2; };
-DHAUG_HD Rot global_rot(float ax, float ay, float az, float& sx, float& cx) {
-    float sy, cy, sz, cz;
-    sincos_deg(ax, sx, cx); sincos_deg(ay, sy, cy); sincos_deg(az, sz, cz);
+DHAUG_HD Rot global_rot_sc(float sx, float cx, float sy, float cy, float sz, float cz) {
     // M = Rx*Ry
     V3 m0 = mk(cy, 0.0f, sy);
     V3 m1 = mk(sx * sy, cx, -sx * cy);
@@ -130,6 +131,11 @@ DHAUG_HD Rot global_rot(float ax, float ay, float az, float& sx, float& cx) {
     R.r1 = mk(fmaf(m1.y, sz, m1.x * cz), fmaf(m1.y, cz, -m1.x * sz), m1.z);
     R.r2 = mk(fmaf(m2.y, sz, m2.x * cz), fmaf(m2.y, cz, -m2.x * sz), m2.z);
     return R;
+}
+DHAUG_HD Rot global_rot(float ax, float ay, float az, float& sx, float& cx) {
+    float sy, cy, sz, cz;
+    sincos_deg(ax, sx, cx); sincos_deg(ay, sy, cy); sincos_deg(az, sz, cz);
+    return global_rot_sc(sx, cx, sy, cy, sz, cz);
 }
 DHAUG_HD V3 rot_apply(const Rot& R, V3 p) { return mk(dot(R.r0, p), dot(R.r1, p), dot(R.r2, p)); }
 DHAUG_HD V3 rot_apply_t(const Rot& R, V3 g) {      // R^T * g
@@ -184,84 +190,137 @@ DHAUG_HD void w2c_project(V3 xw, const float* __restrict__ q, const float* __res
 // 16-joint output order: 0 Hip 1 RHip 2 RKnee 3 RAnkle 4 LHip 5 LKnee 6 LAnkle 7 Spine 8 Thorax 9 Head
 //   10 LShoulder 11 LElbow 12 LWrist 13 RShoulder 14 RElbow 15 RWrist
 
-#define DHAUG_SC(idx, theta0) float s##idx, c##idx; sincos_deg((theta0) + ang[idx], s##idx, c##idx)
+// GUARD = false: the caller bounds the angle (the generator tail's angles are tanh * range), no library path
+template <bool GUARD> DHAUG_HD void sincos_deg_t(float deg, float& s, float& c) {
+    if (GUARD) sincos_deg(deg, s, c);
+    else sincos_rad_bounded(div180(deg) * kPiF, s, c);
+}
+#define DHAUG_SC(idx, theta0) float s##idx, c##idx; sincos_deg_t<GUARD>((theta0) + ang[idx], s##idx, c##idx)
+
+// The skeleton chain by chain (one wave per chain in the generator-tail kernel, all of them in fk_pose): joints are written
+// root-free, globally rotated.  Each piece reads only its own slots of ang[37] / bl[15].
+template <bool GUARD = true>
+DHAUG_HD Rot fk_global(const float* __restrict__ ang, float& sgx, float& cgx) {
+    float sy, cy, sz, cz;
+    sincos_deg_t<GUARD>(ang[34], sgx, cgx); sincos_deg_t<GUARD>(ang[35], sy, cy); sincos_deg_t<GUARD>(ang[36], sz, cz);
+    return global_rot_sc(sgx, cgx, sy, cy, sz, cz);
+}
+// (the *_sc forms take the sines / cosines of the chain's angles: the generator-tail kernel computes them before the bone
+// lengths and the global rotation arrive)
+DHAUG_HD void fk_right_leg_sc(const float* __restrict__ s, const float* __restrict__ c, const float* __restrict__ bl, const Rot& Rg,
+                              V3* __restrict__ p) {
+    Frame F = dh_first<0>(bl[5], 0.0f, s[0], c[0]);
+    p[1] = rot_apply(Rg, F.t);
+    dh_apply<-1, false, false, true>(F, 0.0f, 0.0f, s[1], c[1]);
+    dh_apply<-1, false, false, true>(F, 0.0f, 0.0f, s[2], c[2]);
+    dh_apply<0, true, false, true>(F, bl[3], 0.0f, s[3], c[3]);
+    p[2] = rot_apply(Rg, F.t);
+    dh_apply<0, true, false, false>(F, bl[1], 0.0f, 0.0f, 1.0f);
+    p[3] = rot_apply(Rg, F.t);
+}
+DHAUG_HD void fk_left_leg_sc(const float* __restrict__ s, const float* __restrict__ c, const float* __restrict__ bl, const Rot& Rg,
+                             V3* __restrict__ p) {
+    Frame F = dh_first<0>(-bl[4], 0.0f, s[0], c[0]);
+    p[4] = rot_apply(Rg, F.t);
+    dh_apply<1, false, false, true>(F, 0.0f, 0.0f, s[1], c[1]);
+    dh_apply<1, false, false, true>(F, 0.0f, 0.0f, s[2], c[2]);
+    dh_apply<0, true, false, true>(F, bl[2], 0.0f, s[3], c[3]);
+    p[5] = rot_apply(Rg, F.t);
+    dh_apply<0, true, false, false>(F, bl[0], 0.0f, 0.0f, 1.0f);
+    p[6] = rot_apply(Rg, F.t);
+}
+// body frames 0..8 (angles 10..18): Spine = frame 3, Thorax = frame 6; returns frame 8, where the head and the arms start
+DHAUG_HD Frame fk_body_sc(const float* __restrict__ s, const float* __restrict__ c, const float* __restrict__ bl, const Rot& Rg,
+                          V3* __restrict__ p) {
+    Frame B = dh_first<0>(0.0f, 0.0f, s[0], c[0]);
+    dh_apply<-1, false, false, true>(B, 0.0f, 0.0f, s[1], c[1]);
+    dh_apply<-1, false, false, true>(B, 0.0f, 0.0f, s[2], c[2]);
+    dh_apply<-1, false, true, true>(B, 0.0f, bl[6], s[3], c[3]);
+    p[7] = rot_apply(Rg, B.t);
+    dh_apply<-1, false, false, true>(B, 0.0f, 0.0f, s[4], c[4]);
+    dh_apply<-1, false, false, true>(B, 0.0f, 0.0f, s[5], c[5]);
+    dh_apply<-1, false, true, true>(B, 0.0f, bl[7], s[6], c[6]);
+    p[8] = rot_apply(Rg, B.t);
+    dh_apply<-1, false, false, true>(B, 0.0f, 0.0f, s[7], c[7]);
+    dh_apply<-1, false, false, true>(B, 0.0f, 0.0f, s[8], c[8]);
+    return B;
+}
+template <bool GUARD = true>
+DHAUG_HD void fk_right_leg(const float* __restrict__ ang, const float* __restrict__ bl, const Rot& Rg, V3* __restrict__ p) {
+    DHAUG_SC(0, 0.0f); DHAUG_SC(1, -90.0f); DHAUG_SC(2, 180.0f); DHAUG_SC(3, 0.0f);
+    const float s[4] = {s0, s1, s2, s3}, c[4] = {c0, c1, c2, c3};
+    fk_right_leg_sc(s, c, bl, Rg, p);
+}
+template <bool GUARD = true>
+DHAUG_HD void fk_left_leg(const float* __restrict__ ang, const float* __restrict__ bl, const Rot& Rg, V3* __restrict__ p) {
+    DHAUG_SC(5, 180.0f); DHAUG_SC(6, -90.0f); DHAUG_SC(7, 0.0f); DHAUG_SC(8, 0.0f);
+    const float s[4] = {s5, s6, s7, s8}, c[4] = {c5, c6, c7, c8};
+    fk_left_leg_sc(s, c, bl, Rg, p);
+}
+template <bool GUARD = true>
+DHAUG_HD Frame fk_body(const float* __restrict__ ang, const float* __restrict__ bl, const Rot& Rg, V3* __restrict__ p) {
+    DHAUG_SC(10, 90.0f); DHAUG_SC(11, -90.0f); DHAUG_SC(12, -90.0f); DHAUG_SC(13, -90.0f); DHAUG_SC(14, -90.0f);
+    DHAUG_SC(15, -90.0f); DHAUG_SC(16, -90.0f); DHAUG_SC(17, -90.0f); DHAUG_SC(18, -90.0f);
+    const float s[9] = {s10, s11, s12, s13, s14, s15, s16, s17, s18}, c[9] = {c10, c11, c12, c13, c14, c15, c16, c17, c18};
+    return fk_body_sc(s, c, bl, Rg, p);
+}
+// head: body frames 9..12 (angles 19..21)
+template <bool GUARD = true>
+DHAUG_HD void fk_head(const float* __restrict__ ang, const float* __restrict__ bl, const Rot& Rg, Frame F, V3* __restrict__ p) {
+    DHAUG_SC(19, -90.0f); DHAUG_SC(20, -90.0f); DHAUG_SC(21, 0.0f);
+    dh_apply<-1, false, false, true>(F, 0.0f, 0.0f, s19, c19);
+    dh_apply<-1, false, false, true>(F, 0.0f, 0.0f, s20, c20);
+    dh_apply<-1, false, false, true>(F, 0.0f, 0.0f, s21, c21);
+    dh_apply<1, true, false, false>(F, bl[14], 0.0f, 0.0f, 1.0f);
+    p[9] = rot_apply(Rg, F.t);
+}
+// the sines / cosines of an arm do not depend on the body frame: ArmSC lets a wave compute them before frame 8 arrives
+struct ArmSC { float s[4], c[4]; };
+template <bool GUARD = true>
+DHAUG_HD ArmSC fk_right_arm_sc(const float* __restrict__ ang) {
+    DHAUG_SC(23, -180.0f); DHAUG_SC(24, -90.0f); DHAUG_SC(25, 180.0f); DHAUG_SC(26, 0.0f);
+    ArmSC a; a.s[0] = s23; a.c[0] = c23; a.s[1] = s24; a.c[1] = c24; a.s[2] = s25; a.c[2] = c25; a.s[3] = s26; a.c[3] = c26;
+    return a;
+}
+template <bool GUARD = true>
+DHAUG_HD ArmSC fk_left_arm_sc(const float* __restrict__ ang) {
+    DHAUG_SC(28, 0.0f); DHAUG_SC(29, -90.0f); DHAUG_SC(30, 0.0f); DHAUG_SC(31, 0.0f);
+    ArmSC a; a.s[0] = s28; a.c[0] = c28; a.s[1] = s29; a.c[1] = c29; a.s[2] = s30; a.c[2] = c30; a.s[3] = s31; a.c[3] = c31;
+    return a;
+}
+DHAUG_HD void fk_right_arm(const ArmSC& a, const float* __restrict__ bl, const Rot& Rg, Frame F, V3* __restrict__ p) {
+    dh_apply<-1, true, false, true>(F, -bl[9], 0.0f, a.s[0], a.c[0]);
+    p[13] = rot_apply(Rg, F.t);
+    dh_apply<-1, false, false, true>(F, 0.0f, 0.0f, a.s[1], a.c[1]);
+    dh_apply<-1, false, false, true>(F, 0.0f, 0.0f, a.s[2], a.c[2]);
+    dh_apply<0, true, false, true>(F, bl[11], 0.0f, a.s[3], a.c[3]);
+    p[14] = rot_apply(Rg, F.t);
+    dh_apply<0, true, false, false>(F, bl[13], 0.0f, 0.0f, 1.0f);
+    p[15] = rot_apply(Rg, F.t);
+}
+DHAUG_HD void fk_left_arm(const ArmSC& a, const float* __restrict__ bl, const Rot& Rg, Frame F, V3* __restrict__ p) {
+    dh_apply<-1, true, false, true>(F, bl[8], 0.0f, a.s[0], a.c[0]);
+    p[10] = rot_apply(Rg, F.t);
+    dh_apply<1, false, false, true>(F, 0.0f, 0.0f, a.s[1], a.c[1]);
+    dh_apply<1, false, false, true>(F, 0.0f, 0.0f, a.s[2], a.c[2]);
+    dh_apply<0, true, false, true>(F, bl[10], 0.0f, a.s[3], a.c[3]);
+    p[11] = rot_apply(Rg, F.t);
+    dh_apply<0, true, false, false>(F, bl[12], 0.0f, 0.0f, 1.0f);
+    p[12] = rot_apply(Rg, F.t);
+}
 
 // Forward kinematics of one pose.  ang[37] degrees, bl[15] metres -> p[16] root-free, globally rotated.
+template <bool GUARD = true>
 DHAUG_HD void fk_pose(const float* __restrict__ ang, const float* __restrict__ bl, V3* __restrict__ p) {
     float sgx, cgx;
-    Rot Rg = global_rot(ang[34], ang[35], ang[36], sgx, cgx);
+    const Rot Rg = fk_global<GUARD>(ang, sgx, cgx);
     p[0] = mk(0.0f, 0.0f, 0.0f);                        // Hip: body frame 0 has a = d = 0
-    {   // right leg: angles 0..4
-        DHAUG_SC(0, 0.0f); DHAUG_SC(1, -90.0f); DHAUG_SC(2, 180.0f); DHAUG_SC(3, 0.0f);
-        Frame F = dh_first<0>(bl[5], 0.0f, s0, c0);
-        p[1] = rot_apply(Rg, F.t);
-        dh_apply<-1, false, false, true>(F, 0.0f, 0.0f, s1, c1);
-        dh_apply<-1, false, false, true>(F, 0.0f, 0.0f, s2, c2);
-        dh_apply<0, true, false, true>(F, bl[3], 0.0f, s3, c3);
-        p[2] = rot_apply(Rg, F.t);
-        dh_apply<0, true, false, false>(F, bl[1], 0.0f, 0.0f, 1.0f);
-        p[3] = rot_apply(Rg, F.t);
-    }
-    {   // left leg: angles 5..9
-        DHAUG_SC(5, 180.0f); DHAUG_SC(6, -90.0f); DHAUG_SC(7, 0.0f); DHAUG_SC(8, 0.0f);
-        Frame F = dh_first<0>(-bl[4], 0.0f, s5, c5);
-        p[4] = rot_apply(Rg, F.t);
-        dh_apply<1, false, false, true>(F, 0.0f, 0.0f, s6, c6);
-        dh_apply<1, false, false, true>(F, 0.0f, 0.0f, s7, c7);
-        dh_apply<0, true, false, true>(F, bl[2], 0.0f, s8, c8);
-        p[5] = rot_apply(Rg, F.t);
-        dh_apply<0, true, false, false>(F, bl[0], 0.0f, 0.0f, 1.0f);
-        p[6] = rot_apply(Rg, F.t);
-    }
-    Frame B;
-    {   // body: angles 10..22 (frames 0..8 here; 9..12 after the arms branch off)
-        DHAUG_SC(10, 90.0f); DHAUG_SC(11, -90.0f); DHAUG_SC(12, -90.0f); DHAUG_SC(13, -90.0f); DHAUG_SC(14, -90.0f);
-        DHAUG_SC(15, -90.0f); DHAUG_SC(16, -90.0f); DHAUG_SC(17, -90.0f); DHAUG_SC(18, -90.0f);
-        B = dh_first<0>(0.0f, 0.0f, s10, c10);
-        dh_apply<-1, false, false, true>(B, 0.0f, 0.0f, s11, c11);
-        dh_apply<-1, false, false, true>(B, 0.0f, 0.0f, s12, c12);
-        dh_apply<-1, false, true, true>(B, 0.0f, bl[6], s13, c13);
-        p[7] = rot_apply(Rg, B.t);                      // Spine = body frame 3
-        dh_apply<-1, false, false, true>(B, 0.0f, 0.0f, s14, c14);
-        dh_apply<-1, false, false, true>(B, 0.0f, 0.0f, s15, c15);
-        dh_apply<-1, false, true, true>(B, 0.0f, bl[7], s16, c16);
-        p[8] = rot_apply(Rg, B.t);                      // Thorax = body frame 6
-        dh_apply<-1, false, false, true>(B, 0.0f, 0.0f, s17, c17);
-        dh_apply<-1, false, false, true>(B, 0.0f, 0.0f, s18, c18);
-    }
-    {   // head: body frames 9..12
-        DHAUG_SC(19, -90.0f); DHAUG_SC(20, -90.0f); DHAUG_SC(21, 0.0f);
-        Frame F = B;
-        dh_apply<-1, false, false, true>(F, 0.0f, 0.0f, s19, c19);
-        dh_apply<-1, false, false, true>(F, 0.0f, 0.0f, s20, c20);
-        dh_apply<-1, false, false, true>(F, 0.0f, 0.0f, s21, c21);
-        dh_apply<1, true, false, false>(F, bl[14], 0.0f, 0.0f, 1.0f);
-        p[9] = rot_apply(Rg, F.t);
-    }
-    {   // right arm: angles 23..27
-        DHAUG_SC(23, -180.0f); DHAUG_SC(24, -90.0f); DHAUG_SC(25, 180.0f); DHAUG_SC(26, 0.0f);
-        Frame F = B;
-        dh_apply<-1, true, false, true>(F, -bl[9], 0.0f, s23, c23);
-        p[13] = rot_apply(Rg, F.t);
-        dh_apply<-1, false, false, true>(F, 0.0f, 0.0f, s24, c24);
-        dh_apply<-1, false, false, true>(F, 0.0f, 0.0f, s25, c25);
-        dh_apply<0, true, false, true>(F, bl[11], 0.0f, s26, c26);
-        p[14] = rot_apply(Rg, F.t);
-        dh_apply<0, true, false, false>(F, bl[13], 0.0f, 0.0f, 1.0f);
-        p[15] = rot_apply(Rg, F.t);
-    }
-    {   // left arm: angles 28..32
-        DHAUG_SC(28, 0.0f); DHAUG_SC(29, -90.0f); DHAUG_SC(30, 0.0f); DHAUG_SC(31, 0.0f);
-        Frame F = B;
-        dh_apply<-1, true, false, true>(F, bl[8], 0.0f, s28, c28);
-        p[10] = rot_apply(Rg, F.t);
-        dh_apply<1, false, false, true>(F, 0.0f, 0.0f, s29, c29);
-        dh_apply<1, false, false, true>(F, 0.0f, 0.0f, s30, c30);
-        dh_apply<0, true, false, true>(F, bl[10], 0.0f, s31, c31);
-        p[11] = rot_apply(Rg, F.t);
-        dh_apply<0, true, false, false>(F, bl[12], 0.0f, 0.0f, 1.0f);
-        p[12] = rot_apply(Rg, F.t);
-    }
+    fk_right_leg<GUARD>(ang, bl, Rg, p);
+    fk_left_leg<GUARD>(ang, bl, Rg, p);
+    const Frame B = fk_body<GUARD>(ang, bl, Rg, p);
+    fk_head<GUARD>(ang, bl, Rg, B, p);
+    fk_right_arm(fk_right_arm_sc<GUARD>(ang), bl, Rg, B, p);
+    fk_left_arm(fk_left_arm_sc<GUARD>(ang), bl, Rg, B, p);
 }
 
 
@@ -308,6 +367,7 @@ DHAUG_HD void bw_leaf(Frame& F, const GM& s, float a, float& g_a) {
 template <typename GLoad>
 DHAUG_HD void fk_pose_backward(const float* __restrict__ ang, const float* __restrict__ bl, GLoad gload,
                                float* __restrict__ gang, float* __restrict__ gbl, V3& groot) {
+    constexpr bool GUARD = true;
     float sgx, cgx, du;
     Rot Rg = global_rot(ang[34], ang[35], ang[36], sgx, cgx);
     groot = mk(0.f, 0.f, 0.f);
