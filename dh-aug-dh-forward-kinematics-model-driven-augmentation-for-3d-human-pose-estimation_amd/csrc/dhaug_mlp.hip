@@ -63,7 +63,8 @@ struct Unit {
 };
 // plan of a GEMM unit.  Stack: bits 0-3 lead k-steps, 4-9 run.  Single layer: bits 16-23 shape (chunks * 16 + chunks of
 // source 1), 24-27 feature slices
-enum { PLAN_STACK = 1 << 13, PLAN_LEAKY = 1 << 10, PLAN_ALT = 1 << 11, PLAN_TAIL = 1 << 12, PLAN_OUT = 1 << 28, PLAN_DOT = 1 << 29 };
+enum { PLAN_STACK = 1 << 13, PLAN_LEAKY = 1 << 10, PLAN_ALT = 1 << 11, PLAN_TAIL = 1 << 12, PLAN_TAIL_BF16 = 1 << 14, PLAN_OUT = 1 << 28,
+       PLAN_DOT = 1 << 29 };
 
 struct Program {
     int nunits;
@@ -394,11 +395,13 @@ struct StackDesc {
     const float* bias;
     const uint16_t* w;
     int narrow;                 // 1: the network's output layer (N <= 64): every wave holds slices 0 and 1
+    int nslices;                // feature slices of the unit (tail_gemm: waves beyond them skip the layer)
 };
 __device__ __forceinline__ StackDesc stack_desc(UnitPtr u) {
     StackDesc d;
     d.src = u->src; d.dst = u->dst; d.res = u->res; d.act = u->act; d.slope = u->slope; d.bias = u->bias; d.w = u->w;
     d.narrow = (u->flags & F_OUT_F32) ? 1 : 0;
+    d.nslices = (u->N + 31) >> 5;
     return d;
 }
 
@@ -656,11 +659,88 @@ __device__ __forceinline__ void tail_layer(const StackDesc& d, unsigned char* sm
         }
 }
 
+// A layer of at most 128 features with K = 256 right behind a stack (the 3D critic's merge halves): the last stack layer
+// requested its fragments like a next stack layer's (slices wave and wave + 4; only `wave` is used), so the unit starts
+// with its weights and bias in registers instead of an L2 round trip.  dst = act(W src + bias [+ res]) as bf16 into any
+// buffer; wave w computes slice w for the four 32-row tiles.
+__device__ __forceinline__ void tail_gemm(const StackDesc& d, unsigned char* smem, int wave, int lane, const WHalf& wlo,
+                                          const WHalf& whi, const f32x16 (&seed)[MLP_NS]) {
+    if (wave >= d.nslices) return;
+    const int r31 = lane & 31, h = lane >> 5;
+    const unsigned char* src = buf_base(smem, d.src);
+    const int pbs = buf_pitch_bytes(d.src);
+    bf16x8 fx[3][MLP_MT];
+    auto read_frags = [&](int k, bf16x8 (&f)[MLP_MT]) {
+#pragma unroll
+        for (int mt = 0; mt < MLP_MT; ++mt)
+            f[mt] = *reinterpret_cast<const bf16x8*>(src + chunk_off(32 * mt + r31, 2 * k + h, pbs));
+    };
+    read_frags(0, fx[0]);
+    read_frags(1, fx[1]);
+    f32x16 acc[MLP_MT];
+#pragma unroll
+    for (int k = 0; k < MLP_MAX_KSTEPS; ++k) {
+        if (k + 2 < MLP_MAX_KSTEPS) read_frags(k + 2, fx[(k + 2) % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MLP_MT; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k < 8 ? wlo[0][k & 7] : whi[0][k & 7], fx[k % 3][mt],
+                                                              k == 0 ? seed[0] : acc[mt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    unsigned char* dst = buf_base(smem, d.dst);
+    const int pbd = buf_pitch_bytes(d.dst);
+    if (d.res >= 0) {                                       // residual: two k-steps against identity fragments (see gemm_layer)
+        const unsigned char* res = buf_base(smem, d.res);
+        const int pbr = buf_pitch_bytes(d.res);
+        bf16x8 rf[MLP_MT][2];
+#pragma unroll
+        for (int mt = 0; mt < MLP_MT; ++mt)
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2)
+                rf[mt][ks2] = *reinterpret_cast<const bf16x8*>(res + chunk_off(32 * mt + r31, 4 * wave + 2 * ks2 + h, pbr));
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+            const int dd = r31 - 16 * ks2 - 8 * h;
+            u32x4_t v;
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) v[p2] = (dd == 2 * p2 ? 0x3F80u : 0u) | (dd == 2 * p2 + 1 ? 0x3F800000u : 0u);
+            const bf16x8 idf = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+            for (int mt = 0; mt < MLP_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(idf, rf[mt][ks2], acc[mt], 0, 0, 0);
+        }
+    }
+    if (d.act != DHAUG_ACT_LRELU) {
+        const uint32_t lb = d.act == DHAUG_ACT_RELU ? 0u : 0x80008000u;
+#pragma unroll
+        for (int mt = 0; mt < MLP_MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 o;
+                o.x = pk_relu(pack_bf16x2(acc[mt][4 * g + 0], acc[mt][4 * g + 1]), lb);
+                o.y = pk_relu(pack_bf16x2(acc[mt][4 * g + 2], acc[mt][4 * g + 3]), lb);
+                *reinterpret_cast<uint2*>(dst + chunk_off(32 * mt + r31, 4 * wave + g, pbd) + (h << 3)) = o;
+            }
+    } else {
+        const float neg = d.slope;
+#pragma unroll
+        for (int mt = 0; mt < MLP_MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 o;
+                o.x = pack_bf16x2(act_fn(acc[mt][4 * g + 0], neg), act_fn(acc[mt][4 * g + 1], neg));
+                o.y = pack_bf16x2(act_fn(acc[mt][4 * g + 2], neg), act_fn(acc[mt][4 * g + 3], neg));
+                *reinterpret_cast<uint2*>(dst + chunk_off(32 * mt + r31, 4 * wave + g, pbd) + (h << 3)) = o;
+            }
+    }
+}
+
 // A run of n full-width layers, optionally fed by one narrow layer (lead_ks = 4 or 8 k-steps, 0: none) and optionally
 // followed by the network's output layer (`tail`).
 // ALT: the layers alternate (no residual, residual) -- the myResNet blocks -- and n is even
+// tail: 0 none, 1 the network's fp32 output layer (tail_layer), 2 a bf16 layer of <= 128 features (tail_gemm)
 template <bool LEAKY, bool ALT>
-__device__ __forceinline__ void gemm_stack(UnitPtr lead, int lead_ks, UnitPtr first, int n, bool tail, unsigned char* smem,
+__device__ __forceinline__ void gemm_stack(UnitPtr lead, int lead_ks, UnitPtr first, int n, int tail, unsigned char* smem,
                                            int wave, int lane) {
     // units first[0 .. nt): the n full-width layers and, if `tail`, the output layer behind them
     const int nt = n + (tail ? 1 : 0);
@@ -737,7 +817,8 @@ __device__ __forceinline__ void gemm_stack(UnitPtr lead, int lead_ks, UnitPtr fi
 #pragma unroll
                 for (int k = 0; k < MLP_MAX_KSTEPS / 2; ++k) loA[t][k] = loB[t][k];
         }
-        tail_layer(cur, smem, wave, lane, loA, hi, seed);
+        if (tail == 1) tail_layer(cur, smem, wave, lane, loA, hi, seed);
+        else tail_gemm(cur, smem, wave, lane, loA, hi, seed);
     }
 }
 
@@ -939,7 +1020,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void fused_mlp_kernel(Program prog,
             const int kind = hk, plan = hp;
             // where the program continues, and that unit's header: requested now, used after this unit
             int ni = i + 1;
-            if (kind == U_GEMM && (plan & PLAN_STACK)) ni = i + ((plan & 15) != 0) + ((plan >> 4) & 63) + ((plan & PLAN_TAIL) ? 1 : 0);
+            if (kind == U_GEMM && (plan & PLAN_STACK)) ni = i + ((plan & 15) != 0) + ((plan >> 4) & 63) + ((plan & (PLAN_TAIL | PLAN_TAIL_BF16)) ? 1 : 0);
             {
                 UnitPtr nu = units + (ni < nunits ? ni : 0);
                 hk = nu->kind;
@@ -964,16 +1045,17 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void fused_mlp_kernel(Program prog,
                     // a run of consecutive plain 256 -> 256 layers, possibly fed by this (narrow) layer and followed by
                     // the output layer
                     const int lead_ks = plan & 15, run = (plan >> 4) & 63;
-                    const bool tail = (plan & PLAN_TAIL) != 0;
+                    const int tail = (plan & PLAN_TAIL) ? 1 : ((plan & PLAN_TAIL_BF16) ? 2 : 0);
                     UnitPtr f0 = u + (lead_ks != 0), tu = f0 + run;
                     if (plan & PLAN_LEAKY) gemm_stack<true, false>(u, lead_ks, f0, run, tail, smem, wave, lane);
                     else if (plan & PLAN_ALT) gemm_stack<false, true>(u, lead_ks, f0, run, tail, smem, wave, lane);
                     else gemm_stack<false, false>(u, lead_ks, f0, run, tail, smem, wave, lane);
                     lds_barrier();
-                    if (tail) {
+                    if (tail == 1) {
                         store_output(tu, smem, m0, M, tid);
                         lds_barrier();                       // (not __syncthreads: nobody waits for the stores to be acknowledged)
                     }
+
                     continue;                                                // (stamps of the run's inner layers stay 0)
                 }
                 const int nslices = (plan >> 24) & 15, dbg = MLP_MAX_UNITS + 64 + 4 * ui;
@@ -1052,8 +1134,12 @@ int plan_unit(const Program& p, int i) {
     const Unit* tu = U + i0 + run;
     const bool tail = i0 + run < p.nunits && tu->kind == U_GEMM && (tu->flags & F_OUT_F32) && tu->ksteps == 16 &&
                       tu->ksteps2 == 0 && tu->N <= 64 && tu->src < 2 && tu->dst < 2 && tu->res < 0;
+    // a bf16 layer of at most 128 features with K = 256 behind the run starts with its weights in registers (tail_gemm)
+    const bool tail2 = !tail && i0 + run < p.nunits && tu->kind == U_GEMM && !(tu->flags & (F_OUT_F32 | F_DOT_OUT)) &&
+                       tu->ksteps == 16 && tu->ksteps2 == 0 && tu->N <= 128 && tu->src < 2 && tu->res != tu->src &&
+                       !getenv("DHAUG_MLP_NOTAIL2");
     return PLAN_STACK | lead_ks | (run << 4) | (leaky ? PLAN_LEAKY : 0) | ((!leaky && alt && !(run & 1)) ? PLAN_ALT : 0) |
-           (tail ? PLAN_TAIL : 0);
+           (tail ? PLAN_TAIL : 0) | (tail2 ? PLAN_TAIL_BF16 : 0);
 }
 
 }  // namespace
