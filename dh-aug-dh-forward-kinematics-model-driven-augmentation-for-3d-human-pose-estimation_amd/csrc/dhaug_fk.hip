@@ -317,7 +317,10 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu((MODE == 0
             for (int j = 0; j < 15; ++j)
                 bl[j] = kJitterCol[j] < 0 ? bl[j] : bl[j] * (1.0f + v2[kJitterCol[j] < 0 ? 0 : (kJitterCol[j] < L::W2 ? kJitterCol[j] : 0)]);
         }
-        fk_pose<MODE == 0>(ang, bl, p);                        // (MODE 1: the angles are bounded, no large-argument guard)
+        // MODE 0 keeps the range guard in front of every sincos (user angles).  (tried: one test per pose on max|angle| and an
+        // unguarded body -- without the 37 branches the scheduler interleaves all the polynomials, the kernel spills at its
+        // three-waves-per-SIMD register budget and N = 4 Mi takes 481 us instead of 349.)  The tail's angles are bounded.
+        fk_pose<MODE == 0>(ang, bl, p);
 
         float o[OW];
         if (OUTJ == 16) {

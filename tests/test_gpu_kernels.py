@@ -364,6 +364,9 @@ def test_center_kcs_forward(ops, N):
     assert maxabs(xc, ref_c) == 0.0
     assert torch.equal(kb.view(torch.int16), ref_k.view(torch.int16))
     assert maxabs(xc.reshape(N, 16, 3), (x - x[:, :1]).cpu()) == 0.0
+    # the oracle's KCS features of the same poses (bf16 operand: half an ulp of the value)
+    o_k = O.kcs_features(x.cpu().double())
+    assert maxabs(kb.float()[:, :30], o_k) <= 2.0 ** -8 * 1.01 * max(1.0, o_k.abs().max().item())
 
 
 @pytest.mark.parametrize("M,N,K,act,slope,use_res", [(4096, 256, 256, 1, 0.0, False), (4096, 256, 256, 2, 0.01, False),
@@ -416,6 +419,19 @@ def test_gen_tail_forward_critics(ops, N, pre):
     assert maxabs(p2, ref_p) <= 1e-2                                  # and stays bounded everywhere (both clamp x/z to +-1)
     f2, x2, k2, none = ops.gen_tail_forward_critics(head, bl, None, pre, None)
     assert none is None and f2.shape == (N, 16, 3)
+    if N <= 1000:
+        # ... and the oracle's restatement of the reference (fp64 inputs: the arithmetic the fp32 reference approximates)
+        o_fake, _ = O.gen_tail(head.cpu().double(), bl.cpu().double(), sc.cpu().double(), use_preangle=pre)
+        o_fake = o_fake.reshape(N, 16, 3)
+        assert maxabs(fake, o_fake) <= 1e-5
+        o_c = (o_fake - o_fake[:, :1]).reshape(N, 48)
+        assert maxabs(xc, o_c) <= 1e-5
+        o_k = O.kcs_features(o_fake)
+        assert maxabs(kcs.float()[:, :30], o_k) <= 2.0 ** -8 * 1.01 + 1e-5             # bf16 operand: half an ulp of <= 1 (cosines), of <= 2 (lengths: 2^-7)
+        o_cam = O.world_to_camera(o_fake, torch.tensor([quat], dtype=torch.float64), torch.tensor([trans], dtype=torch.float64))
+        o_p = O.project_to_2d(o_cam, torch.tensor([cam9], dtype=torch.float64))
+        zc = o_cam[..., 2].abs().clamp_min(1e-3).unsqueeze(-1)
+        assert ((p2.cpu().double() - o_p).abs() * zc).max().item() <= 1e-4
 
 
 def test_gen_tail_in_kernel_jitter(ops):

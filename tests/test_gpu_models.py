@@ -9,6 +9,7 @@ Tolerances
   * relative logit error = |a-b| / max(|b|, 0.1 * mean|b|)."""
 import argparse
 
+import numpy as np
 import pytest
 import torch
 
@@ -79,6 +80,16 @@ def test_fk_class_api(M, golden):
     t = fk.init_Fk_DH_angle()
     gt = golden("fk_numpy_branch")
     assert t.shape == (32, 3) and abs(t - gt["tpose32"].numpy()).max() <= 1e-6
+    # the four random poses of the reference's scalar (numpy) branch, through the class's scalar branch on the GPU
+    for i in range(4):
+        a1, b1, r1 = gt["angles"][i].numpy(), gt["bone_len"][i].numpy(), gt["root"][i].numpy()
+        skw = dict(right_leg_joints_angle=a1[0:5], left_leg_joints_angle=a1[5:10], body_joints_angle=a1[10:23],
+                   right_hand_joints_angle=a1[23:28], left_hand_joints_angle=a1[28:33],
+                   generator_global_rot_3d_pos_angle=a1[34:37], root_3d_pos=r1)
+        skw.update({n: float(b1[j]) for j, n in enumerate(names)})
+        o = fk.change_3d_joint_angle(**skw)
+        assert isinstance(o, np.ndarray) and o.shape == (32, 3) and o.dtype == np.float32
+        assert abs(o - gt["out32"][i].numpy()).max() <= 1e-5
 
 
 # ------------------------------------------------------------------------------------------ generator
@@ -260,6 +271,23 @@ def test_gradient_penalty_fused_chain_matches_composite(M):
         if scale > 0:
             cos = torch.nn.functional.cosine_similarity(g1[k].reshape(-1).double(), g0[k].reshape(-1).double(), dim=0).item()
             assert cos > 0.999, (k, cos)
+    # ... and both against fp64 autograd on the oracle's restatement of the reference critic with the same weights: a bf16 pass
+    # through 17 layers and back twice -- a few per cent on the penalty, direction of every sizeable gradient kept
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in net.state_dict().items()}
+    gp_o = O.gradient_penalty(lambda x: O.d3_forward(x, sd), real.cpu().double().reshape(256, -1), fake.cpu().double().reshape(256, -1),
+                              alpha.cpu().double())
+    gp_o.backward()
+    assert abs(gp1 - gp_o.item()) <= 0.1 * max(1.0, abs(gp_o.item())), (gp1, gp_o.item())
+    big = max(v.grad.abs().max().item() for v in sd.values() if v.grad is not None)
+    checked = 0
+    for k in g1:
+        go = sd[k].grad
+        if go is None or go.abs().max().item() < 1e-2 * big or go.numel() < 64:
+            continue
+        cos = torch.nn.functional.cosine_similarity(g1[k].reshape(-1).double().cpu(), go.reshape(-1), dim=0).item()
+        assert cos > 0.97, (k, cos)
+        checked += 1
+    assert checked >= 8
 
 
 # ------------------------------------------------------------------------------------------- G step
