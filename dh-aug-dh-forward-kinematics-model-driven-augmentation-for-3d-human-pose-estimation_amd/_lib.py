@@ -55,7 +55,13 @@ class MlpUnit(ctypes.Structure):
     """struct dhaug_mlp_unit (include/dhaug.h)"""
     _fields_ = [("kind", _i32), ("flags", _i32), ("src", _i32), ("dst", _i32), ("res", _i32), ("src2", _i32),
                 ("ksteps2", _i32), ("ksteps", _i32), ("n", _i32), ("act", _i32), ("slope", _f32), ("cols", _i32),
-                ("ld", _i64), ("g", _vp), ("w", _vp), ("w2", _vp), ("bias", _vp)]
+                ("ld", _i64), ("g", _vp), ("w", _vp), ("w2", _vp), ("bias", _vp), ("save", _vp), ("save_ld", _i64)]
+
+
+class WfragDesc(ctypes.Structure):
+    """struct dhaug_wfrag_desc (include/dhaug.h)"""
+    _fields_ = [("W", _vp), ("ldw", _i64), ("dst", _vp), ("bias", _vp), ("bias_dst", _vp), ("dot_dst", _vp), ("N", _i32),
+                ("K", _i32), ("k0", _i32), ("ksteps", _i32)]
 
 
 class RepackDesc(ctypes.Structure):
@@ -64,6 +70,7 @@ class RepackDesc(ctypes.Structure):
 
 
 SIGNATURES["dhaug_pack_wfrag"] = [_vp, _i64, _vp, _i64, _i64, _i64, _vp]
+SIGNATURES["dhaug_pack_wfrag_batch"] = [_vp, _i32, _vp]
 SIGNATURES["dhaug_mlp_forward"] = [ctypes.POINTER(MlpUnit), _i32, _i64, _vp]
 SIGNATURES["dhaug_pack_wfrag_f16x2"] = [_vp, _i64, _vp, _i64, _i64, _i64, _vp]
 SIGNATURES["dhaug_mlp_forward_x3"] = [ctypes.POINTER(MlpUnit), _i32, _i64, _vp]

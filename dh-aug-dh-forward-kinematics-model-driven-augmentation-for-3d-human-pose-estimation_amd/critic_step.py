@@ -22,10 +22,16 @@ captured from the reference in the fp32-grade arithmetic, and the autograd path 
 instead of ~13, nothing but HIP kernels of libdhaug.so on the path.
 
 `prec`: 'bf16' (the throughput arithmetic) or 'bf16x3' / 'bf16x6' (split operands, fp32 activations: parity tests)."""
+import os
+
 import torch
 
 from . import autograd_ops as A
 from . import ops
+
+# sweep 1 (forward) of the single-frame critics as ONE fused launch that also saves every layer's output
+# (fused.critic3d_forward_save / critic2d_forward_save) instead of one GEMM launch per layer; bf16 arithmetic only
+FUSED_STEP_FORWARD = os.environ.get("DHAUG_NO_FUSED_STEP_FORWARD") is None
 
 BF16 = torch.bfloat16
 NONE, RELU, LRELU = A.ACT_NONE, A.ACT_RELU, A.ACT_LRELU
@@ -216,12 +222,17 @@ def step_d2(D, optimizerD, real, fake, alpha, lam, prec=None):
     X = ops.gp_assemble(real, fake, alpha)
     B = X.shape[0] // 3
     B2 = 2 * B
-    d1 = L[0].fwd(m, X)
-    d2 = L[1].fwd(m, d1)
-    d3 = L[2].fwd(m, d2, res=d1)
-    d4 = L[3].fwd(m, d3)
-    dl = L[4].fwd(m, d4)
-    logits = L[5].fwd(m, dl, out_f32=True)
+    from . import fused
+    if m.bf16 and FUSED_STEP_FORWARD and fused.step_forward_supported(D):
+        r = fused.critic2d_forward_save(D, X)
+        (d1, d2, d3, d4, dl), logits = r["d"], r["logits"]
+    else:
+        d1 = L[0].fwd(m, X)
+        d2 = L[1].fwd(m, d1)
+        d3 = L[2].fwd(m, d2, res=d1)
+        d4 = L[3].fwd(m, d3)
+        dl = L[4].fwd(m, d4)
+        logits = L[5].fwd(m, dl, out_f32=True)
     gzp = seeds(B, m, X.device)
     gzl = L[5].bwd(m, gzp, dl, LRELU, s)
     gz4 = L[4].bwd(m, gzl, d4, NONE, 0.0)
@@ -248,7 +259,7 @@ class _Branch:
         self.first, self.blocks = _Lin(first, RELU), [_Block(b) for b in blocks]
 
 
-def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, input_grad, tangents, pen_view=None):
+def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, input_grad, tangents, pen_view=None, fwd=None):
     """The four sweeps for a critic of the form  cat_b(branch_b(feat_b(x))) -> Linear(100)+ReLU -> myResNet(100) -> Linear(1).
     X (3*rows, W) fp32 = [real; fake; x_hat] (ops.gp_assemble); feats(X) -> one fp32 input per branch (3*rows each);
     input_grad([g_b]) -> dD/dx_hat (rows, W) fp32 from the branches' input cotangents (x_hat rows); tangents(v) -> one fp32
@@ -260,18 +271,22 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
     nb, Dw = len(branches), branches[0].first.N
     F = feats(X)
     # ---- 1. forward (the branch outputs land side by side: the concatenation is a buffer, not a copy)
-    cat = m.empty(M3, nb * Dw, dev)
-    y, h = [], []
-    for bi, br in enumerate(branches):
-        ys, hs = [br.first.fwd(m, F[bi])], []
-        for i, blk in enumerate(br.blocks):
-            hh = blk.fc1.fwd(m, ys[-1])
-            hs.append(hh)
-            ys.append(blk.fc2.fwd(m, hh, res=ys[-1], out=cat[:, bi * Dw:(bi + 1) * Dw] if i == len(br.blocks) - 1 else None))
-        y.append(ys); h.append(hs)
-    m0 = Lm.fwd(m, cat)
-    mh, m1 = Mb.fwd(m, m0)
-    logits = Lo.fwd(m, m1, out_f32=True)
+    if fwd is not None:                                      # one fused launch that saves every layer's output (same buffers)
+        r = fwd()
+        cat, y, h, m0, mh, m1, logits = r["cat"], r["y"], r["h"], r["m0"], r["mh"], r["m1"], r["logits"]
+    else:
+        cat = m.empty(M3, nb * Dw, dev)
+        y, h = [], []
+        for bi, br in enumerate(branches):
+            ys, hs = [br.first.fwd(m, F[bi])], []
+            for i, blk in enumerate(br.blocks):
+                hh = blk.fc1.fwd(m, ys[-1])
+                hs.append(hh)
+                ys.append(blk.fc2.fwd(m, hh, res=ys[-1], out=cat[:, bi * Dw:(bi + 1) * Dw] if i == len(br.blocks) - 1 else None))
+            y.append(ys); h.append(hs)
+        m0 = Lm.fwd(m, cat)
+        mh, m1 = Mb.fwd(m, m0)
+        logits = Lo.fwd(m, m1, out_f32=True)
     # ---- 2. backward chain
     gzo = seeds(B, m, dev)
     gz_m2 = Lo.bwd(m, gzo, m1, RELU, 0.0)
@@ -326,11 +341,15 @@ def step_d3(D, optimizerD, real, fake, alpha, lam, prec=None):
     X = ops.gp_assemble(real, fake, alpha)                                   # (3B,48)
     B = X.shape[0] // 3
     xh = X[2 * B:]
+    from . import fused
+    use = m.bf16 and FUSED_STEP_FORWARD and fused.step_forward_supported(D)
+    kf, kb = ops.kcs_forward(X, True, f32=True, bf16_ld=32 if use else 0)    # fp32 features (first layer's weight gradient) [+ bf16 operand]
     return step_branchnet(
         m, optimizerD, br, _Lin(D.merge_previous[0], RELU), _Block(D.merge_block1), _Lin(D.output, NONE), X, B, lam,
-        feats=lambda X: [ops.kcs_forward(X, True, f32=True)[0], X],
+        feats=lambda X: [kf, X],
         input_grad=lambda gs: ops.add_f32(ops.kcs_backward(xh, gs[0], True), gs[1]),      # KCS^T path + pose path
-        tangents=lambda v: [ops.kcs_jvp(xh, v, True), v])
+        tangents=lambda v: [ops.kcs_jvp(xh, v, True), v],
+        fwd=(lambda: fused.critic3d_forward_save(D, X, kb)) if use else None)
 
 
 def step_m3(D, optimizerD, real, fake, alpha, lam, prec=None):

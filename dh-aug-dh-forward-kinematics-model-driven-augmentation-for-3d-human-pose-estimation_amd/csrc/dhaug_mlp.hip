@@ -60,6 +60,8 @@ struct Unit {
     const uint16_t* w;          // GEMM: packed fragments [slice][kstep][64 lanes][8]
     const uint16_t* w2;         // fragments of the second source
     const float* bias;          // GEMM: fp32 [32 * nslices] (zero padded)
+    uint16_t* save;             // GEMM, optional: the layer's output image also goes to global memory (M, save_ld) bf16,
+    long long save_ld;          // columns [0, ceil16(N)) -- the training step's forward-with-save
 };
 // plan of a GEMM unit.  Stack: bits 0-3 lead k-steps, 4-9 run.  Single layer: bits 16-23 shape (chunks * 16 + chunks of
 // source 1), 24-27 feature slices
@@ -455,10 +457,17 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 // RESMODE 0: no residual, 1: residual, 2: decided at run time (the identity fragments are zeroed for a layer without).
 // KS < 16: the narrow layer that feeds a stack (K = 16 KS <= 128, no residual); its own fragments sit in `wlo`, and
 // BOTH halves of the following layer's are requested while it runs (tile 1: low, tile 2: high).
-template <bool LEAKY, int RESMODE, int KS = MLP_MAX_KSTEPS>
+// SAVE (forward-with-save): the layer also writes its INPUT image to global memory (`sv`: buffer resource of the 128-row
+// tile of the producer's save target, sv_ld bytes per row; zero records = nothing to save).  The activation fragments it reads
+// for the matrix pipe ARE the image, 16 bytes per lane: wave w stores the fragments of row tile w (one buffer store per
+// k-step behind a wave-uniform branch; rows beyond M fall outside the resource and are dropped by the range check) -- no
+// LDS read, no exposed copy loop between the layers.  (Issuing the stores from all four waves and letting the range check
+// drop three quarters of them cost more than the stores themselves: 448 us with every store nullified against 336 us
+// without the instructions, 3D critic at 3B = 196 608 rows.)
+template <bool LEAKY, int RESMODE, int KS = MLP_MAX_KSTEPS, bool SAVE = false>
 __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc& nd, unsigned char* smem, int wave, int lane,
                                             const WHalf& wlo, WHalf& nlo, WHalf& whi, f32x16 (&seed)[MLP_NS],
-                                            const bf16x8 (&idf)[2], int dbg) {
+                                            const bf16x8 (&idf)[2], int dbg, __amdgpu_buffer_rsrc_t sv, int sv_ld) {
     DHAUG_LSTAMP(dbg)
     static_assert(KS == 16 || ((KS == 4 || KS == 8) && RESMODE == 0), "layer shape");
     constexpr bool LEAD = KS < MLP_MAX_KSTEPS;
@@ -547,6 +556,11 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
     //   after (k odd,  t0)  activation fragment of k+3                       ~30
     //   after (k odd,  t1)  one fragment of the next layer's weights + pack/ReLU of two pairs of the previous tile ~32
     uint32_t st0 = 0, st1 = 0;                                               // packed pairs waiting for their store
+    int sv_off[MLP_MT];                                                      // byte offset of the lane's chunk 0 of row tile mt, or out of range
+    if (SAVE && !LEAD) {
+#pragma unroll
+        for (int mt = 0; mt < MLP_MT; ++mt) sv_off[mt] = (32 * mt + r31) * sv_ld + (h << 4);
+    }
 #pragma unroll
     for (int mt = 0; mt < MLP_MT; ++mt) {
 #pragma unroll
@@ -585,6 +599,12 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
                     }
                 }
 #endif
+#ifndef SAVE_ABL_NOSTORE
+                if (SAVE && !LEAD && t == 0 && mt == wave)               // chunk 2k+h of the lane's row: this k-step's fragment
+#else
+                if (false)
+#endif
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, fx[s & 3]), sv, sv_off[mt] + 32 * k, 0, 0);
                 if (t == 1) {
                     if (!LEAD) {                                             // pairs 2(k-1), 2k are packed at odd k, stored at k+1
                         if (mt > 0 && (k & 1)) {
@@ -735,13 +755,61 @@ __device__ __forceinline__ void tail_gemm(const StackDesc& d, unsigned char* sme
     }
 }
 
+// data-movement units.  LOAD zero-fills columns [cols, ceil64(cols)) so that the consuming GEMM may read whole chunks.
+// (row, col-group) walker for a workgroup-strided sweep of a [MLP_BM][q] grid: no division inside the loops
+struct Sweep {
+    int row, c, dr, dc, q;
+    __device__ __forceinline__ Sweep(int tid, int q_) : q(q_) {
+        row = tid / q_; c = tid - row * q_; dr = MLP_THREADS / q_; dc = MLP_THREADS - dr * q_;
+    }
+    __device__ __forceinline__ void next() {
+        row += dr; c += dc;
+        if (c >= q) { c -= q; ++row; }
+    }
+};
+
+// forward-with-save: the bf16 image a layer left in buffer `id` (columns [0, cols), cols a multiple of 16) also goes to
+// global memory, 16 bytes per thread and access.  Called behind the barrier that completes the image; the buffer is not
+// written again before the next barrier (buffers alternate), and nobody waits for the stores.
+__device__ __forceinline__ void save_image(int id, uint16_t* g, long long ld, int cols, unsigned char* smem, long long m0, long long M,
+                                           int tid) {
+    asm volatile("" : "+v"(tid));
+#if defined(SAVE_ABL_NOSTORE)
+    return;
+#endif
+    const unsigned char* img = buf_base(smem, id);
+    const int pb = buf_pitch_bytes(id);
+    // (tried: eight LDS reads in flight, then their stores -- slower inside the stack, 600 -> 830 us for the 3D critic at 3B
+    // rows: the 40 extra registers spill.  Inside a run the layers save their INPUT from the fragments they read anyway, see
+    // stack_layer; this copy is for the images no stack layer consumes.)
+    for (Sweep sw(tid, cols >> 3); sw.row < MLP_BM; sw.next())
+        if (m0 + sw.row < M)
+            *reinterpret_cast<uint4*>(g + (m0 + sw.row) * ld + sw.c * 8) = *reinterpret_cast<const uint4*>(img + chunk_off(sw.row, sw.c, pb));
+}
+
 // A run of n full-width layers, optionally fed by one narrow layer (lead_ks = 4 or 8 k-steps, 0: none) and optionally
 // followed by the network's output layer (`tail`).
 // ALT: the layers alternate (no residual, residual) -- the myResNet blocks -- and n is even
 // tail: 0 none, 1 the network's fp32 output layer (tail_layer), 2 a bf16 layer of <= 128 features (tail_gemm)
-template <bool LEAKY, bool ALT>
+// SAVE (forward-with-save): every run layer is followed by a barrier and the copy of its image to global memory
+template <bool LEAKY, bool ALT, bool SAVE>
 __device__ __forceinline__ void gemm_stack(UnitPtr lead, int lead_ks, UnitPtr first, int n, int tail, unsigned char* smem,
-                                           int wave, int lane) {
+                                           int wave, int lane, long long m0, long long M, int tid) {
+    // forward-with-save: layer j of the run writes the image of its producer `su` (the unit in front of it; none for the
+    // first layer behind a LOAD) to that unit's save target -- a buffer resource over the tile's rows; zero records: nothing.
+    // (The unit is read from the kernarg segment where it is needed, not carried in the layer descriptors.)
+    (void)tid;
+    auto save_of = [&](UnitPtr su, bool on, int& ld_bytes) -> __amdgpu_buffer_rsrc_t {
+        uint16_t* base = (SAVE && on) ? su->save : nullptr;
+        const long long ld = (SAVE && on) ? su->save_ld : 0;
+        const long long rows = M - m0 < MLP_BM ? M - m0 : MLP_BM;
+        ld_bytes = (int)(ld * 2);
+#if defined(SAVE_ABL_NOSTORE) || defined(SAVE_ABL_NULLSTORES)          /* timing only: every store of the run falls outside its resource */
+        base = nullptr;
+#endif
+        return __builtin_amdgcn_make_buffer_rsrc(base != nullptr ? base + m0 * ld : reinterpret_cast<uint16_t*>(smem), 0,
+                                                 base != nullptr ? (int)(rows * ld * 2) : 0, 0x27000);
+    };
     // units first[0 .. nt): the n full-width layers and, if `tail`, the output layer behind them
     const int nt = n + (tail ? 1 : 0);
     StackDesc cur = stack_desc(first), nxt = stack_desc(first + (nt > 1 ? 1 : 0));
@@ -757,6 +825,8 @@ __device__ __forceinline__ void gemm_stack(UnitPtr lead, int lead_ks, UnitPtr fi
         for (int p2 = 0; p2 < 4; ++p2) v[p2] = (dd == 2 * p2 ? 0x3F80u : 0u) | (dd == 2 * p2 + 1 ? 0x3F800000u : 0u);
         idf[ks2] = __builtin_bit_cast(bf16x8, v);
     }
+    int nold = 0;
+    const __amdgpu_buffer_rsrc_t nosv = save_of(first, false, nold);
     if (lead_ks != 0) {
         const StackDesc ld = stack_desc(lead);
         load_seed(ld.bias, wave, 4, lane, seed);
@@ -766,14 +836,14 @@ __device__ __forceinline__ void gemm_stack(UnitPtr lead, int lead_ks, UnitPtr fi
             for (int t = 0; t < MLP_NS; ++t)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) loB[t][k] = b.frag(t, k);
-            stack_layer<LEAKY, 0, 8>(ld, cur, smem, wave, lane, loB, loA, hi, seed, idf, MLP_MAX_UNITS + 50);
+            stack_layer<LEAKY, 0, 8, false>(ld, cur, smem, wave, lane, loB, loA, hi, seed, idf, MLP_MAX_UNITS + 50, nosv, 0);
         } else {
             const WBase<4> b(ld.w, wave, 4, lane);
 #pragma unroll
             for (int t = 0; t < MLP_NS; ++t)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) loB[t][k] = b.frag(t, k);
-            stack_layer<LEAKY, 0, 4>(ld, cur, smem, wave, lane, loB, loA, hi, seed, idf, MLP_MAX_UNITS + 50);
+            stack_layer<LEAKY, 0, 4, false>(ld, cur, smem, wave, lane, loB, loA, hi, seed, idf, MLP_MAX_UNITS + 50, nosv, 0);
         }
         lds_barrier();
         DHAUG_LSTAMP(MLP_MAX_UNITS + 56)
@@ -795,10 +865,13 @@ __device__ __forceinline__ void gemm_stack(UnitPtr lead, int lead_ks, UnitPtr fi
         const StackDesc n2 = stack_desc(first + (l + 2 < nt ? l + 2 : nt - 1));         // arrive during the layers
         const StackDesc n3 = stack_desc(first + (l + 3 < nt ? l + 3 : nt - 1));
         const int dbg = MLP_MAX_UNITS + 2 + 8 * (l < 4 ? l : 4);
-        stack_layer<LEAKY, ALT ? 0 : 2>(cur, nxt, smem, wave, lane, loA, loB, hi, seed, idf, dbg);
+        int ldb0, ldb1;
+        const __amdgpu_buffer_rsrc_t sv0 = save_of(l == 0 ? lead : first + (l - 1), l != 0 || lead_ks != 0, ldb0);
+        const __amdgpu_buffer_rsrc_t sv1 = save_of(first + l, true, ldb1);
+        stack_layer<LEAKY, ALT ? 0 : 2, MLP_MAX_KSTEPS, SAVE>(cur, nxt, smem, wave, lane, loA, loB, hi, seed, idf, dbg, sv0, ldb0);
         lds_barrier();
         DHAUG_LSTAMP(dbg + 6)
-        stack_layer<LEAKY, ALT ? 1 : 2>(nxt, n2, smem, wave, lane, loB, loA, hi, seed, idf, dbg + 8);
+        stack_layer<LEAKY, ALT ? 1 : 2, MLP_MAX_KSTEPS, SAVE>(nxt, n2, smem, wave, lane, loB, loA, hi, seed, idf, dbg + 8, sv1, ldb1);
         cur = n2;
         nxt = n3;
         if (l + 2 < nt) lds_barrier();
@@ -806,7 +879,9 @@ __device__ __forceinline__ void gemm_stack(UnitPtr lead, int lead_ks, UnitPtr fi
     }
     const bool odd = !ALT && l < n;
     if (odd) {
-        stack_layer<LEAKY, 2>(cur, nxt, smem, wave, lane, loA, loB, hi, seed, idf, MLP_MAX_UNITS + 2);
+        int ldb;
+        const __amdgpu_buffer_rsrc_t svo = save_of(l == 0 ? lead : first + (l - 1), l != 0 || lead_ks != 0, ldb);
+        stack_layer<LEAKY, 2, MLP_MAX_KSTEPS, SAVE>(cur, nxt, smem, wave, lane, loA, loB, hi, seed, idf, MLP_MAX_UNITS + 2, svo, ldb);
         cur = nxt;
         if (tail) lds_barrier();
     }
@@ -821,19 +896,6 @@ __device__ __forceinline__ void gemm_stack(UnitPtr lead, int lead_ks, UnitPtr fi
         else tail_gemm(cur, smem, wave, lane, loA, hi, seed);
     }
 }
-
-// data-movement units.  LOAD zero-fills columns [cols, ceil64(cols)) so that the consuming GEMM may read whole chunks.
-// (row, col-group) walker for a workgroup-strided sweep of a [MLP_BM][q] grid: no division inside the loops
-struct Sweep {
-    int row, c, dr, dc, q;
-    __device__ __forceinline__ Sweep(int tid, int q_) : q(q_) {
-        row = tid / q_; c = tid - row * q_; dr = MLP_THREADS / q_; dc = MLP_THREADS - dr * q_;
-    }
-    __device__ __forceinline__ void next() {
-        row += dr; c += dc;
-        if (c >= q) { c -= q; ++row; }
-    }
-};
 
 #ifdef MOVE_BATCH_OVERRIDE
 constexpr int MOVE_BATCH = MOVE_BATCH_OVERRIDE;
@@ -999,6 +1061,7 @@ __device__ __forceinline__ void store_output(UnitPtr u, unsigned char* smem, lon
         if (m0 + sw.row < M) out[(m0 + sw.row) * ld + sw.c] = st[sw.row * OUT_PITCH + sw.c];
 }
 
+template <bool SAVE>
 __global__ __launch_bounds__(MLP_THREADS, 1) void fused_mlp_kernel(Program prog, long long M) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1047,10 +1110,16 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void fused_mlp_kernel(Program prog,
                     const int lead_ks = plan & 15, run = (plan >> 4) & 63;
                     const int tail = (plan & PLAN_TAIL) ? 1 : ((plan & PLAN_TAIL_BF16) ? 2 : 0);
                     UnitPtr f0 = u + (lead_ks != 0), tu = f0 + run;
-                    if (plan & PLAN_LEAKY) gemm_stack<true, false>(u, lead_ks, f0, run, tail, smem, wave, lane);
-                    else if (plan & PLAN_ALT) gemm_stack<false, true>(u, lead_ks, f0, run, tail, smem, wave, lane);
-                    else gemm_stack<false, false>(u, lead_ks, f0, run, tail, smem, wave, lane);
+                    if (plan & PLAN_LEAKY) gemm_stack<true, false, SAVE>(u, lead_ks, f0, run, tail, smem, wave, lane, m0, M, tid);
+                    else if (plan & PLAN_ALT) gemm_stack<false, true, SAVE>(u, lead_ks, f0, run, tail, smem, wave, lane, m0, M, tid);
+                    else gemm_stack<false, false, SAVE>(u, lead_ks, f0, run, tail, smem, wave, lane, m0, M, tid);
                     lds_barrier();
+                    if (SAVE) {                                              // (inside the run every layer saved its input)
+                        UnitPtr lu = tu - 1;                                 // the run's last layer: nobody in the run read its image
+                        if (lu->save != nullptr) save_image(lu->dst, lu->save, lu->save_ld, (lu->N + 15) & ~15, smem, m0, M, tid);
+                        if (tail == 2 && tu->save != nullptr)
+                            save_image(tu->dst, tu->save, tu->save_ld, (tu->N + 15) & ~15, smem, m0, M, tid);
+                    }
                     if (tail == 1) {
                         store_output(tu, smem, m0, M, tid);
                         lds_barrier();                       // (not __syncthreads: nobody waits for the stores to be acknowledged)
@@ -1082,6 +1151,8 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void fused_mlp_kernel(Program prog,
                 }
             }
             lds_barrier();
+            if (SAVE && kind == U_GEMM && !(plan & (PLAN_OUT | PLAN_DOT)) && u->save != nullptr)
+                save_image(u->dst, u->save, u->save_ld, (u->N + 15) & ~15, smem, m0, M, tid);
             DHAUG_LSTAMP(MLP_MAX_UNITS + 64 + 4 * ui + 3)
         }
         DHAUG_STAMP(nunits)
@@ -1089,6 +1160,26 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void fused_mlp_kernel(Program prog,
     (void)prog;
 }
 
+#ifdef DHAUG_MLP_SAVE_TU
+}  // namespace
+
+// This translation unit (csrc/dhaug_mlp_save.hip) holds the forward-with-save instantiation only: the inference
+// instantiation's code (register allocation, schedule) does not depend on it.  (Build note: while the layer descriptors
+// carried the save pointers the instantiation spilled, and hipcc 7.2's "AMDGPU Rewrite AGPR-Copy-MFMA" pass crashes on
+// spilled MFMA code under -amdgpu-mfma-vgpr-form; reading them from the kernarg segment at the save removed both.)
+extern "C" __attribute__((visibility("hidden"))) int dhaug_mlp_launch_save_(const void* prog, long long M, unsigned grid, void* stream) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(fused_mlp_kernel<true>, dim3(grid), dim3(MLP_THREADS), MLP_LDS_BYTES, (hipStream_t)stream,
+                       *static_cast<const Program*>(prog), M);
+    return dhaug_launch_status();
+}
+#else
 // weights -> fragment order.  dst[((slice*ksteps + ks)*64 + lane)*8 + j] = W[32 slice + (lane&31)][k0 + 16 ks + 8 (lane>>5) + j]
 __global__ __launch_bounds__(256) void pack_wfrag_kernel(const float* __restrict__ W, long long ldw, uint16_t* __restrict__ dst,
                                                          int N, int K, int k0, int ksteps, int nslices) {
@@ -1099,6 +1190,29 @@ __global__ __launch_bounds__(256) void pack_wfrag_kernel(const float* __restrict
         const int ks = (int)(blk % ksteps), s = (int)(blk / ksteps);
         const int n = 32 * s + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
         dst[i] = (n < N && k < K) ? dhaug_f32_to_bf16(W[(long long)n * ldw + k0 + k]) : (uint16_t)0;
+    }
+}
+
+// the same for every layer of a network in ONE launch (after an optimizer step): blockIdx.y = descriptor.  Also refreshes the
+// zero-padded fp32 bias [256] and, for a logit layer folded into its producer, the DOT_OUT vector [257].
+__global__ __launch_bounds__(256) void pack_wfrag_batch_kernel(const dhaug_wfrag_desc* __restrict__ descs) {
+    const dhaug_wfrag_desc d = descs[blockIdx.y];
+    const long long total = (long long)8 * d.ksteps * 64 * 8;
+    uint16_t* dst = static_cast<uint16_t*>(d.dst);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const long long blk = i >> 9;
+        const int ks = (int)(blk % d.ksteps), sl = (int)(blk / d.ksteps);
+        const int n = 32 * sl + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+        dst[i] = (n < d.N && k < d.K) ? dhaug_f32_to_bf16(d.W[(long long)n * d.ldw + d.k0 + k]) : (uint16_t)0;
+    }
+    if (blockIdx.x == 0) {
+        const int t = threadIdx.x;
+        if (d.bias_dst != nullptr) d.bias_dst[t] = (d.bias != nullptr && t < d.N) ? d.bias[t] : 0.0f;
+        if (d.dot_dst != nullptr) {                                          // (N == 1: the layer's weights as bf16 values, bias at [256])
+            d.dot_dst[t] = t < d.K ? dhaug_bf16_to_f32(dhaug_f32_to_bf16(d.W[d.k0 + t])) : 0.0f;
+            if (t == 0) d.dot_dst[256] = d.bias != nullptr ? d.bias[0] : 0.0f;
+        }
     }
 }
 
@@ -1144,6 +1258,8 @@ int plan_unit(const Program& p, int i) {
 
 }  // namespace
 
+extern "C" __attribute__((visibility("hidden"))) int dhaug_mlp_launch_save_(const void* prog, long long M, unsigned grid, void* stream);
+
 extern "C" {
 
 /* see include/dhaug.h */
@@ -1162,6 +1278,14 @@ int dhaug_pack_wfrag(const float* W, int64_t ldw, uint16_t* dst, int64_t N, int6
     return dhaug_launch_status();
 }
 
+int dhaug_pack_wfrag_batch(const dhaug_wfrag_desc* descs_device, int n, void* stream) {
+    DHAUG_CHECK(n >= 0, DHAUG_EINVAL);
+    if (n == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(descs_device);
+    hipLaunchKernelGGL(pack_wfrag_batch_kernel, dim3(64, (unsigned)n), dim3(256), 0, (hipStream_t)stream, descs_device);
+    return dhaug_launch_status();
+}
+
 int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* stream) {
     DHAUG_CHECK(nunits >= 1 && nunits <= MLP_MAX_UNITS && M >= 0, DHAUG_EINVAL);
     DHAUG_CHECK_PTR(units);
@@ -1169,6 +1293,7 @@ int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* 
     Program prog;
     prog.nunits = nunits;
     prog.min_run = getenv("DHAUG_MLP_NOSTACK") ? 1 << 20 : 2;                // debugging aid: layer-at-a-time path only
+    bool any_save = false;
     for (int i = 0; i < nunits; ++i) {
         const dhaug_mlp_unit& s = units[i];
         Unit& u = prog.u[i];
@@ -1176,7 +1301,13 @@ int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* 
         u.src2 = s.src2; u.ksteps2 = s.ksteps2;
         u.ksteps = s.ksteps; u.N = s.n; u.act = s.act; u.slope = s.slope; u.cols = s.cols; u.ld = s.ld;
         u.g = s.g; u.w = static_cast<const uint16_t*>(s.w); u.w2 = static_cast<const uint16_t*>(s.w2); u.bias = s.bias;
+        u.save = static_cast<uint16_t*>(s.save); u.save_ld = s.save_ld;
         DHAUG_CHECK(u.kind >= U_LOAD_F32 && u.kind <= U_GEMM, DHAUG_EINVAL);
+        if (u.save != nullptr) {
+            DHAUG_CHECK(u.kind == U_GEMM && !(u.flags & (F_OUT_F32 | F_DOT_OUT)), DHAUG_EINVAL);
+            DHAUG_CHECK(dhaug_aligned16(u.save) && u.save_ld % 8 == 0 && u.save_ld >= ((u.N + 15) & ~15), DHAUG_EALIGN);
+            any_save = true;
+        }
         auto okbuf = [](int b) { return b >= 0 && b <= 2; };
         auto pitch = [](int b) { return b == 2 ? BUF2_PITCH : BUF01_PITCH; };
         if (u.kind == U_GEMM) {
@@ -1218,18 +1349,23 @@ int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* 
     for (int i = 0; i < prog.nunits; ++i) prog.u[i].plan = plan_unit(prog, i);
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
     const long long ntiles = (M + MLP_BM - 1) / MLP_BM;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);           // one persistent workgroup per CU
-    hipLaunchKernelGGL(fused_mlp_kernel, dim3(grid), dim3(MLP_THREADS), MLP_LDS_BYTES, (hipStream_t)stream, prog, (long long)M);
+    // forward-with-save (a unit asks for its image in global memory) is a second instantiation: the inference kernel's
+    // schedule is exactly what it was
+    if (any_save) return dhaug_mlp_launch_save_(&prog, (long long)M, grid, stream);        // (csrc/dhaug_mlp_save.hip)
+    hipLaunchKernelGGL(fused_mlp_kernel<false>, dim3(grid), dim3(MLP_THREADS), MLP_LDS_BYTES, (hipStream_t)stream, prog, (long long)M);
     return dhaug_launch_status();
 }
 
 }  // extern "C"
+
+#endif  // DHAUG_MLP_SAVE_TU
 
 #ifdef DHAUG_MLP_TIMING
 extern "C" int dhaug_debug_mlp_stamps(long long* out, int n) {

@@ -54,11 +54,28 @@ class _Layer:
             self.dot = torch.zeros(260, dtype=torch.float32, device=W.device)
             self.dot[:K] = W[0].to(torch.bfloat16).float()
             self.dot[256] = b[0]
+        self.lin, self.splits = lin, splits
+
+    def descs(self):
+        """dhaug_wfrag_desc entries that re-pack this layer in place from its (updated) parameters"""
+        W, b = self.lin.weight, self.lin.bias
+        out = []
+        for i, ((k0, k), blob, ks) in enumerate(zip(self.splits, self.w, self.ksteps)):
+            d = _lib.WfragDesc()
+            d.W, d.ldw, d.dst, d.N, d.K, d.k0, d.ksteps = W.data_ptr(), W.shape[1], blob.data_ptr(), self.N, k, k0, (k + 63) // 64 * 4
+            d.bias = b.data_ptr()
+            d.bias_dst = self.bias.data_ptr() if i == 0 else None
+            d.dot_dst = self.dot.data_ptr() if (i == 0 and hasattr(self, "dot")) else None
+            out.append(d)
+        return out
 
 
 def _unit(kind, flags=0, src=-1, dst=-1, res=-1, src2=-1, ksteps2=0, ksteps=0, n=0, act=0, slope=0.0, cols=0, ld=0,
-          g=None, w=None, w2=None, bias=None):
+          g=None, w=None, w2=None, bias=None, save=None):
     u = _lib.MlpUnit()
+    if save is not None:                                      # forward-with-save: the layer's image also goes to `save`
+        assert save.dtype == torch.bfloat16 and save.stride(1) == 1
+        u.save, u.save_ld = save.data_ptr(), save.stride(0)
     u.kind, u.flags, u.src, u.dst, u.res, u.src2, u.ksteps2 = kind, flags, src, dst, res, src2, ksteps2
     u.ksteps, u.n, u.act, u.slope, u.cols, u.ld = ksteps, n, act, float(slope), cols, ld
     u.g = None if g is None else g.data_ptr()
@@ -68,8 +85,8 @@ def _unit(kind, flags=0, src=-1, dst=-1, res=-1, src2=-1, ksteps2=0, ksteps=0, n
     return u
 
 
-def _gemm(layer, src, dst, act, slope=0.0, res=-1, out=None, src2=-1):
-    kw = dict(src=src, ksteps=layer.ksteps[0], n=layer.N, act=act, slope=slope, w=layer.w[0], bias=layer.bias, res=res)
+def _gemm(layer, src, dst, act, slope=0.0, res=-1, out=None, src2=-1, save=None):
+    kw = dict(src=src, ksteps=layer.ksteps[0], n=layer.N, act=act, slope=slope, w=layer.w[0], bias=layer.bias, res=res, save=save)
     if len(layer.w) == 2:
         kw.update(src2=src2, ksteps2=layer.ksteps[1], w2=layer.w[1])
     if out is not None:
@@ -83,6 +100,7 @@ class FusedNet:
     def __init__(self, module, build, mode="bf16"):
         assert mode in MODES
         self.module, self.build, self.key, self.layers, self.params, self.mode = module, build, None, None, None, mode
+        self.ptrs, self.descs_dev, self.ndescs = None, None, 0
 
     def _fresh(self):
         from . import autograd_ops as A
@@ -90,13 +108,27 @@ class FusedNet:
             self.params = list(self.module.parameters())
         key = (A.WEIGHT_EPOCH, A.CAPTURE_ID) + tuple((p.data_ptr(), p._version, getattr(p, "_dhaug_epoch", 0)) for p in self.params)
         if key != self.key:
-            self.layers = {name: _Layer(lin, splits, self.mode) for name, lin, splits in self.build["layers"](self.module)}
+            ptrs = tuple(p.data_ptr() for p in self.params)
+            if self.layers is not None and self.mode == "bf16" and ptrs == self.ptrs:
+                # the same tensors with new values (an optimizer step): every blob, bias and logit vector is re-packed in
+                # place by ONE launch (inside a hipGraph capture too: the graph replays the re-pack, and owns nothing new)
+                _lib.call("dhaug_pack_wfrag_batch", self.descs_dev.data_ptr(), self.ndescs, ops._stream())
+            else:
+                self.layers = {name: _Layer(lin, splits, self.mode) for name, lin, splits in self.build["layers"](self.module)}
+                if self.mode == "bf16":
+                    ds = [d for L in self.layers.values() for d in L.descs()]
+                    arr = (_lib.WfragDesc * len(ds))(*ds)
+                    dev = next(iter(self.layers.values())).bias.device
+                    self.descs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+                    self.ndescs = len(ds)
+                self.ptrs = ptrs
             self.key = key
         return self.layers
 
     def invalidate(self):
         self.key = None
         self.params = None
+        self.layers = None
 
     def run(self, inputs, M):
         L = self._fresh()
@@ -110,12 +142,12 @@ def launch(units, M, mode):
     _lib.call("dhaug_mlp_forward" if mode == "bf16" else "dhaug_mlp_forward_x3", arr, len(units), M, ops._stream())
 
 
-def _net(module, build, mode):
-    """the module's compiled program for `mode` (one per arithmetic, cached on the module)"""
+def _net(module, build, mode, tag=""):
+    """the module's compiled program for `mode` (one per arithmetic [and purpose: tag], cached on the module)"""
     d = module.__dict__.setdefault("_fused", {})
-    if mode not in d:
-        d[mode] = FusedNet(module, build, mode)
-    return d[mode]
+    if mode + tag not in d:
+        d[mode + tag] = FusedNet(module, build, mode)
+    return d[mode + tag]
 
 
 def _res_blocks(L, units, names, a=0, b=1, act=ACT_RELU):
@@ -212,6 +244,87 @@ def _d3_program(D, L, inputs, M):
 
 
 D3 = dict(layers=_d3_layers, program=_d3_program)
+
+
+# ---- forward-with-save: the explicit critic step's forward sweep as ONE launch -----------------------------------
+# (critic_step.py: sweep 1 of 4.  Every layer's output also goes to global memory -- the saved activations of the
+# reference's autograd graph, R/models_Fk_GAN/model_fk_gan_train.py:177-230 -- but no layer reads its input back from there.)
+def _empty16(M, n, dev):
+    return torch.empty((M, (n + 15) // 16 * 16), dtype=torch.bfloat16, device=dev)
+
+
+def _d3s_program(D, L, inputs, M):
+    x, kcs = inputs["x"], inputs["kcs"]                       # (M,48) fp32, (M,32) bf16 KCS operand
+    dev, Dw = x.device, D.previous[0].weight.shape[0]
+    mp = L["merge_previous.0"]
+    cat = torch.empty((M, 2 * Dw), dtype=torch.bfloat16, device=dev)
+    y = [[_empty16(M, Dw, dev) for _ in range(3)] + [cat[:, b * Dw:(b + 1) * Dw]] for b in range(2)]
+    h = [[_empty16(M, Dw, dev) for _ in range(3)] for _ in range(2)]
+    m0, mh, m1 = _empty16(M, mp.N, dev), _empty16(M, mp.N, dev), _empty16(M, mp.N, dev)
+    logits = torch.empty((M, 1), dtype=torch.float32, device=dev)
+
+    def branch(u, b, first, names):
+        u.append(_gemm(L[first], 1, 0, ACT_RELU, save=y[b][0]))
+        for i, n in enumerate(names):
+            u.append(_gemm(L[n + ".fc1"], 0, 1, ACT_RELU, save=h[b][i]))
+            u.append(_gemm(L[n + ".fc2"], 1, 0, ACT_RELU, res=0, save=y[b][i + 1]))
+
+    u = [_unit(LOAD_BF16, dst=1, cols=32, ld=kcs.stride(0), g=kcs)]
+    branch(u, 0, "special_KCS_previous.0", ("special_KCS_block1", "special_KCS_block2", "special_KCS_block3"))
+    u.append(_unit(GEMM, src=0, dst=2, ksteps=mp.ksteps[0], n=mp.N, act=ACT_NONE, w=mp.w[0], bias=mp.bias))      # (see _d3_program)
+    u.append(_unit(LOAD_F32, dst=1, cols=48, ld=x.stride(0), g=x))
+    branch(u, 1, "previous.0", ("block1", "block2", "block3"))
+    u.append(_unit(GEMM, src=0, dst=2, res=2, ksteps=mp.ksteps[1], n=mp.N, act=ACT_RELU, w=mp.w[1], bias=mp.zero, save=m0))
+    u.append(_gemm(L["merge_block1.fc1"], 2, 0, ACT_RELU, save=mh))
+    u.append(_gemm(L["merge_block1.fc2"], 0, 1, ACT_RELU, res=2, save=m1))
+    u.append(_gemm(L["output"], 1, 0, ACT_NONE, out=logits))
+    return u, dict(cat=cat, y=y, h=h, m0=m0, mh=mh, m1=m1, logits=logits)
+
+
+def _d3s_layers(D):
+    out = _d3_layers(D)
+    return out
+
+
+D3S = dict(layers=_d3s_layers, program=_d3s_program)
+
+
+def _d2s_program(D, L, inputs, M):
+    x = inputs["x"]                                           # (M,32) fp32
+    dev, Dw, s = x.device, D.pose_layer_1.weight.shape[0], D.slope
+    d = [_empty16(M, Dw, dev) for _ in range(5)]
+    logits = torch.empty((M, 1), dtype=torch.float32, device=dev)
+    u = [_unit(LOAD_F32, dst=1, cols=32, ld=x.stride(0), g=x),
+         _gemm(L["pose_layer_1"], 1, 0, ACT_LRELU, s, save=d[0]),
+         _gemm(L["pose_layer_2"], 0, 1, ACT_LRELU, s, save=d[1]),
+         _gemm(L["pose_layer_3"], 1, 0, ACT_LRELU, s, res=0, save=d[2]),
+         _gemm(L["pose_layer_4"], 0, 1, ACT_NONE, save=d[3]),
+         _gemm(L["layer_last"], 1, 0, ACT_LRELU, s, save=d[4]),
+         _gemm(L["layer_pred"], 0, 1, ACT_NONE, out=logits)]
+    return u, dict(d=d, logits=logits)
+
+
+D2S = dict(layers=_d2_layers, program=_d2s_program)
+
+
+def step_forward_supported(D):
+    """the critics whose explicit step can take its forward sweep from one fused launch: the single-frame critics at a
+    hidden width the kernel has shapes for"""
+    from .models_Fk_GAN.Fk_discriminator import Fk_2D_Discriminator, Fk_3D_Discriminator
+    if type(D) is Fk_3D_Discriminator:
+        return supported(D.previous[0].weight.shape[0]) and D.previous[0].weight.shape[0] == 256 and D.merge_previous[0].weight.shape[0] <= 128
+    if type(D) is Fk_2D_Discriminator:
+        return D.pose_layer_1.weight.shape[0] == 256
+    return False
+
+
+def critic3d_forward_save(D, x, kcs):
+    """x (M,48) fp32 root-relative poses, kcs (M,32) bf16 operand -> saved activations + logits (see _d3s_program)"""
+    return _net(D, D3S, "bf16", "+save").run(dict(x=x, kcs=kcs), x.shape[0])
+
+
+def critic2d_forward_save(D, x):
+    return _net(D, D2S, "bf16", "+save").run(dict(x=x), x.shape[0])
 
 
 def generator_head(G, z, mode="bf16"):

@@ -280,7 +280,27 @@ typedef struct dhaug_mlp_unit {
     const void* w;                /* GEMM: packed fragments of the first source's weight columns (dhaug_pack_wfrag)  */
     const void* w2;               /* fragments of the second source's weight columns                                 */
     const float* bias;            /* GEMM: fp32 [256], zero padded                                                   */
+    void* save;                   /* GEMM (dhaug_mlp_forward, not OUT_F32 / DOT_OUT), optional: the layer's output also   */
+    int64_t save_ld;              /* goes to global memory as bf16 (M, save_ld), columns [0, ceil16(n)) (zero beyond n):   */
+                                  /* forward-with-save of the training step (the saved activations of                     */
+                                  /* R/models_Fk_GAN/model_fk_gan_train.py:177-230's autograd graph)                      */
 } dhaug_mlp_unit;
+
+/* dhaug_pack_wfrag for every layer of a network in one launch (after each optimizer step of a training loop that runs the
+ * fused programs: R/models_Fk_GAN/model_fk_gan_train.py:177-230 steps the critics every iteration).  Per descriptor: the
+ * fragment blob of W[:, k0:k0+K] (ksteps = K padded to multiples of 64, in units of 16; always 8 slices), the zero-padded
+ * fp32 bias [256] (bias_dst, optional) and, for a 1-wide logit layer folded into its producer, the DOT_OUT vector [257]
+ * (dot_dst, optional).  descs_device: array of n descriptors in device memory. */
+typedef struct dhaug_wfrag_desc {
+    const float* W;
+    int64_t ldw;
+    void* dst;
+    const float* bias;
+    float* bias_dst;
+    float* dot_dst;
+    int32_t N, K, k0, ksteps;
+} dhaug_wfrag_desc;
+int dhaug_pack_wfrag_batch(const dhaug_wfrag_desc* descs_device, int n, void* stream);
 
 /* Runs the program on every 128-row tile of the batch: replaces the nn.Sequential / myResNet stacks of
  * R/models_Fk_GAN/Fk_generator.py:115-119, Fk_discriminator.py:180-201 and :253-266 (inference / sampling passes).
