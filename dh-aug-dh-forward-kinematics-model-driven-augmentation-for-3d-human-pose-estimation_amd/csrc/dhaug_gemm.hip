@@ -779,6 +779,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ws_kernel(GemmArgs p) {
                                                      : make_uint4(0, 0, 0, 0);
             }
         }
+        // ... and of the activation-backward mask (requested here, used in the epilogue: a load issued where its value is
+        // needed costs one exposed memory round trip per piece -- 65 -> 4x us for the 100-wide backward / tangent layers)
+        uint4 rmask[4];
+        const bool mask_vec = p.dmask != nullptr && (p.ld_dmask & 7) == 0 && (reinterpret_cast<uintptr_t>(p.dmask) & 15) == 0;
+        if (mask_vec) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = tid + 256 * i, row = q >> 4, pc = q & 15;
+                const long long gm = m0 + row, n = n0 + pc * 8;
+                rmask[i] = (gm < p.M && n + 8 <= p.N) ? *reinterpret_cast<const uint4*>(p.dmask + gm * p.ld_dmask + n)
+                                                      : make_uint4(0, 0, 0, 0);
+            }
+        }
         // compute
         const uint16_t* img = reinterpret_cast<const uint16_t*>(smem_raw + buf * WS_BUF_BYTES);
         f32x16 acc[2];
@@ -851,8 +864,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ws_kernel(GemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (full || n + e < p.N) ? apply_act(v[e], p.act, p.slope) : 0.0f;
             if (p.dmask != nullptr) {                        // activation-backward mask of the producing layer
-                if (full && (p.ld_dmask & 7) == 0 && (reinterpret_cast<uintptr_t>(p.dmask) & 15) == 0) {
-                    const uint4 mm = *reinterpret_cast<const uint4*>(p.dmask + gm * p.ld_dmask + n);
+                if (full && mask_vec) {
+                    const uint4 mm = rmask[i];
                     const uint32_t w[4] = {mm.x, mm.y, mm.z, mm.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {            // a positive bf16 is a positive int16
