@@ -324,6 +324,31 @@ def main():
         set_precision(main_prec)
     if training and world > 1:
         out["allreduce_bytes_per_optimizer_step"] = bucket_bytes
+    if world > 1:
+        # the exchange step of the training path, timed alone: all-reduce of the flat gradient buckets (D2 / G / D3 at D = 256,
+        # and a DenseDim-1000 motion critic's) over the job's backend ("nccl" = RCCL over xGMI).  Never fails the bench line.
+        try:
+            import time as _t
+            sizes = (1_090_000, 1_750_000, 3_530_000, 100_000_000)
+            res = []
+            for nb in sizes:
+                ar_buf = torch.zeros(nb // 4, dtype=torch.float32, device=dev if backend == "nccl" else "cpu")
+                for _ in range(3):
+                    dist.all_reduce(ar_buf)
+                if backend == "nccl":
+                    torch.cuda.synchronize()
+                dist.barrier()
+                t0 = _t.perf_counter()
+                ar_k = 10 if nb < 50_000_000 else 5
+                for _ in range(ar_k):
+                    dist.all_reduce(ar_buf)
+                if backend == "nccl":
+                    torch.cuda.synchronize()
+                dt = (_t.perf_counter() - t0) / ar_k
+                res.append({"bytes": nb // 4 * 4, "us": dt * 1e6, "busbw_GBps": 2.0 * (world - 1) / world * (nb // 4 * 4) / dt / 1e9})
+            out["allreduce_alone"] = {"backend": backend, "world": world, "sizes": res}
+        except Exception as ex:                                  # noqa: BLE001 (reported, not raised)
+            out["allreduce_alone"] = {"error": repr(ex)}
 
     extra = {}
     if not a.no_extra and not video:
