@@ -125,3 +125,67 @@ def test_explicit_step_full_batch_properties(M):
             scale = gs[k].abs().max().item()
             assert (g[k] - gs[k]).abs().max().item() <= 2e-2 * scale + 1e-9, (tag, k)
             assert (p[k] - sd[k]).abs().max().item() <= 1.01e-4, (tag, k)
+
+
+@pytest.mark.parametrize("tag", ["d3", "d2"])
+def test_forward_with_save_layer_by_layer(M, tag):
+    """The explicit step's sweep 1 as one fused launch (fused.critic3d_forward_save / critic2d_forward_save): every SAVED
+    activation must be the layer function of the saved activations in front of it -- act(W x + b [+ skip]) evaluated by
+    torch in fp32 on the bf16 values the kernel consumed -- to bf16 rounding (one ulp of the value + the partial-sum
+    rounding of the merge layer's two halves), on a ragged row count (900 = 7 tiles of 128 + 4 rows)."""
+    from dhaug_amd import fused, ops
+    D, rows = 256, 900
+    args = _args(300, D)
+    shapes = GU.shapes_d3(D) if tag == "d3" else GU.shapes_d2(D)
+    sd = GU.seeded_state_dict(shapes, 4242)
+    net = (M.dis.Fk_3D_Discriminator("cuda", args) if tag == "d3" else M.dis.Fk_2D_Discriminator(args, 16)).cuda()
+    net.load_state_dict(sd)
+    net.precision = "bf16"
+    gen = torch.Generator().manual_seed(5)
+    W = lambda k: sd[k + ".weight"].cuda().bfloat16().float()
+    b = lambda k: sd[k + ".bias"].cuda()
+    relu = torch.relu
+
+    def close(got, ref, n, extra=0.0):
+        got, ref = got[:, :n].float(), ref
+        tol = 2.0 ** -8 * ref.abs() + 2.0 ** -8 * extra + 1e-6              # bf16: half an ulp of the value (+ slack where a partial sum was rounded)
+        bad = ((got - ref).abs() > tol)
+        assert bad.float().mean().item() <= 2e-4, bad.float().mean().item()  # (fp32 summation order: a value within rounding of a bf16 tie)
+        assert (got - ref).abs().max().item() <= 2.0 ** -6 * max(1.0, ref.abs().max().item())
+
+    if tag == "d3":
+        x = (GU.synth_pose16(rows, seed=9) - GU.synth_pose16(rows, seed=9)[:, :1]).reshape(rows, 48).cuda()
+        kf, kb = ops.kcs_forward(x, True, f32=True, bf16_ld=32)
+        r = fused.critic3d_forward_save(net, x, kb)
+        lin = lambda k, v: v @ W(k).t() + b(k)
+        for bi, (first, blocks, inp) in enumerate((("special_KCS_previous.0", ("special_KCS_block1", "special_KCS_block2", "special_KCS_block3"), kb[:, :30].float()),
+                                                   ("previous.0", ("block1", "block2", "block3"), x.bfloat16().float()))):
+            close(r["y"][bi][0], relu(lin(first, inp)), D)
+            for i, blk in enumerate(blocks):
+                yin = r["y"][bi][i][:, :D].float()
+                close(r["h"][bi][i], relu(lin(blk + ".fc1", yin)), D)
+                close(r["y"][bi][i + 1], relu(lin(blk + ".fc2", r["h"][bi][i][:, :D].float()) + yin), D)
+        cat = r["cat"].float()
+        pre = cat @ W("merge_previous.0").t() + b("merge_previous.0")
+        half = (cat[:, :D] @ W("merge_previous.0")[:, :D].t()).abs()           # the KCS half waits in LDS as bf16
+        close(r["m0"], relu(pre), 100, extra=half.max().item())
+        m0 = r["m0"][:, :100].float()
+        close(r["mh"], relu(lin("merge_block1.fc1", m0)), 100)
+        close(r["m1"], relu(lin("merge_block1.fc2", r["mh"][:, :100].float()) + m0), 100)
+        assert (r["m0"][:, 100:] == 0).all() and (r["m1"][:, 100:] == 0).all()
+        logit = r["m1"][:, :100].float() @ W("output").t() + b("output")
+        assert (r["logits"] - logit).abs().max().item() <= 1e-4 * max(1.0, logit.abs().max().item())
+    else:
+        x = (torch.rand(rows, 32, generator=gen) - 0.5).cuda()
+        r = fused.critic2d_forward_save(net, x)
+        s = net.slope
+        lr = lambda v: torch.nn.functional.leaky_relu(v, s)
+        lin = lambda k, v: v @ W(k).t() + b(k)
+        d = [t[:, :D].float() for t in r["d"]]
+        close(r["d"][0], lr(lin("pose_layer_1", x.bfloat16().float())), D)
+        close(r["d"][1], lr(lin("pose_layer_2", d[0])), D)
+        close(r["d"][2], lr(lin("pose_layer_3", d[1]) + d[0]), D)
+        close(r["d"][3], lin("pose_layer_4", d[2]), D)
+        close(r["d"][4], lr(lin("layer_last", d[3])), D)
+        logit = lin("layer_pred", d[4])
+        assert (r["logits"] - logit).abs().max().item() <= 1e-4 * max(1.0, logit.abs().max().item())
