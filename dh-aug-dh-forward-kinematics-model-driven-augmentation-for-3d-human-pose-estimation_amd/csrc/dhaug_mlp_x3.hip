@@ -95,6 +95,15 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_
 
 __device__ __forceinline__ int chunks_of(int ksteps) { return (ksteps + X3_CH - 1) / X3_CH; }
 
+#ifdef X3_TIMING
+__device__ long long g_x3_stamps[4 * X3_MAX_UNITS + 4];
+#ifndef X3_STAMP_TID
+#define X3_STAMP_TID 0
+#endif
+#define X3_STAMP(i) if (blockIdx.x == 0 && threadIdx.x == X3_STAMP_TID) g_x3_stamps[i] = (long long)__builtin_readcyclecounter();
+#else
+#define X3_STAMP(i)
+#endif
 typedef f16x8 Ring[2][X3_CH][2];                  // [slot][k-step in chunk][piece]: chunk c lives in slot c & 1
 
 // global loads of chunk C (of the concatenated sources; the first has NCH1 chunks) of this wave's slice into a ring slot
@@ -142,7 +151,7 @@ __device__ __forceinline__ void prefetch_layer(UnitPtr u, int wave, int lane, Ri
 // this one, possibly of the next tile; nullptr: none) is prefetched the same way.  Waves whose slice lies beyond N only
 // take part in the prefetch.
 template <int NCH, int NCH1>
-__device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned char* smem, int wave, int lane, Ring& ring, f32x16& seed) {
+__device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned char* smem, int wave, int lane, Ring& ring, f32x16& seed, int ui = 0) {
     asm volatile("" : "+v"(lane));                   // lane-derived constants are recomputed per unit, not parked across units
     const int r31 = lane & 31, h = lane >> 5;
     const int nslices = (u->N + 31) >> 5;
@@ -205,6 +214,7 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned cha
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[c & 1][q][0], fx[k & 1][mt][0], acc[mt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (ui >= 0) { X3_STAMP(4 * ui + 1) }
     // the ring and the seed are dead: the next layer's first fragments travel during the epilogue and the barrier
     if (next != nullptr) prefetch_layer(next, wave, lane, ring, seed);
     const bool to_global = (u->flags & F_OUT_F32) != 0;
@@ -324,6 +334,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void fused_mlp_x3_kernel(Program pro
         for (int i = 0; i < nunits; ++i) {
             UnitPtr u = units + i;
             const int kind = u->kind, plan = u->plan;
+            if (tile == blockIdx.x) { X3_STAMP(4 * i) }
             if (kind == U_LOAD_F32) {
                 load_unit(u, smem, m0, M, tid);
             } else {
@@ -332,12 +343,12 @@ __global__ __launch_bounds__(X3_THREADS, 1) void fused_mlp_x3_kernel(Program pro
                 const int nx = plan & 255;
                 UnitPtr next = nx != 0 ? units + (nx - 1) : (more ? units + first_gemm : (UnitPtr) nullptr);
                 switch ((plan >> 16) & 255) {                          /* validated on the host */
-                    case 1 * 16 + 1: gemm_layer<1, 1>(u, next, smem, wave, lane, ring, seed); break;
-                    case 2 * 16 + 2: gemm_layer<2, 2>(u, next, smem, wave, lane, ring, seed); break;
-                    case 2 * 16 + 1: gemm_layer<2, 1>(u, next, smem, wave, lane, ring, seed); break;
-                    case 4 * 16 + 4: gemm_layer<4, 4>(u, next, smem, wave, lane, ring, seed); break;
-                    case 4 * 16 + 2: gemm_layer<4, 2>(u, next, smem, wave, lane, ring, seed); break;
-                    case 8 * 16 + 4: gemm_layer<8, 4>(u, next, smem, wave, lane, ring, seed); break;
+                    case 1 * 16 + 1: gemm_layer<1, 1>(u, next, smem, wave, lane, ring, seed, tile == blockIdx.x ? i : -1); break;
+                    case 2 * 16 + 2: gemm_layer<2, 2>(u, next, smem, wave, lane, ring, seed, tile == blockIdx.x ? i : -1); break;
+                    case 2 * 16 + 1: gemm_layer<2, 1>(u, next, smem, wave, lane, ring, seed, tile == blockIdx.x ? i : -1); break;
+                    case 4 * 16 + 4: gemm_layer<4, 4>(u, next, smem, wave, lane, ring, seed, tile == blockIdx.x ? i : -1); break;
+                    case 4 * 16 + 2: gemm_layer<4, 2>(u, next, smem, wave, lane, ring, seed, tile == blockIdx.x ? i : -1); break;
+                    case 8 * 16 + 4: gemm_layer<8, 4>(u, next, smem, wave, lane, ring, seed, tile == blockIdx.x ? i : -1); break;
                     default: break;
                 }
                 if (u->flags & F_OUT_F32) {
@@ -345,7 +356,9 @@ __global__ __launch_bounds__(X3_THREADS, 1) void fused_mlp_x3_kernel(Program pro
                     store_output(u, smem, m0, M, tid);
                 }
             }
+            if (tile == blockIdx.x) { X3_STAMP(4 * i + 2) }
             lds_barrier();
+            if (tile == blockIdx.x) { X3_STAMP(4 * i + 3) }
         }
     }
     (void)prog;
@@ -452,4 +465,9 @@ int dhaug_mlp_forward_x3(const dhaug_mlp_unit* units, int nunits, int64_t M, voi
     return dhaug_launch_status();
 }
 
+#ifdef X3_TIMING
+int dhaug_debug_mlp_stamps(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x3_stamps), sizeof(long long) * (n < 4 * X3_MAX_UNITS ? n : 4 * X3_MAX_UNITS));
+}
+#endif
 }  // extern "C"
