@@ -2,7 +2,7 @@
 # Run on the GPU box (gpurun -- 'bash tools/collect_profiles.sh r02'): rocprofv3 kernel-trace stats of the bench workloads
 # (timed steps only: --no-roofline, --prewarm 0) and separate PMC passes (FETCH_SIZE / WRITE_SIZE /
 # SQ_VALU_MFMA_BUSY_CYCLES), reduced to the small summaries that are committed under profiles/ (copy
-# gpurun_out/profiles/* there afterwards and stamp them: tools/stamp_profiles.sh).
+# gpurun_out/profiles/* there afterwards; <round>_STAMP.txt holds the collection time bench.py quotes as traffic_source).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT || exit 1
 R=${1:-r02}
 O=gpurun_out/profiles
