@@ -242,6 +242,20 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned cha
 #ifdef X3_ABL_NOEPI
     if (u->slope == 12345.f)
 #endif
+    // all residual values first (16 reads in flight, one LDS round trip): read where they are used, every group's loads sat
+    // behind the previous group's stores (dst may be res: they may alias, the compiler keeps the order) -- eight exposed LDS
+    // round trips per epilogue under the other wave's fragment traffic (phase stamps: 4 - 5.6 k clocks per epilogue)
+    f16x4 rhv[X3_MT][4], rlv[X3_MT][4];
+    if (resid >= 0) {
+#pragma unroll
+        for (int mt = 0; mt < X3_MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ro = chunk_off(32 * mt + r31, 4 * slice + g, pbr) + (h << 3);
+                rhv[mt][g] = *reinterpret_cast<const f16x4*>(res + ro);
+                rlv[mt][g] = *reinterpret_cast<const f16x4*>(res + plr + ro);
+            }
+    }
 #pragma unroll
     for (int mt = 0; mt < X3_MT; ++mt) {
         const int row = 32 * mt + r31;
@@ -251,8 +265,7 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned cha
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[mt][4 * g + e];
             if (resid >= 0) {
-                const int ro = chunk_off(row, 4 * slice + g, pbr) + (h << 3);
-                const f16x4 rh = *reinterpret_cast<const f16x4*>(res + ro), rl = *reinterpret_cast<const f16x4*>(res + plr + ro);
+                const f16x4 rh = rhv[mt][g], rl = rlv[mt][g];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += (float)rh[e] + (float)rl[e];
             }
