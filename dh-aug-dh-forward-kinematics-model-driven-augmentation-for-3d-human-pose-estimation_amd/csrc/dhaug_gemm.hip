@@ -490,6 +490,11 @@ __device__ __forceinline__ bf16x8 tf_frag(const unsigned char* stage, int kbase,
     return f;
 }
 
+// chunks beyond the operands' column counts (N1, N2 not multiples of the tile edge: the 100-wide and the input layers) are
+// copied from these 16 zero bytes: every lane of every copy instruction stays active, so the vmcnt arithmetic is the same in
+// every wave, and the tile's unused rows / columns contribute nothing
+__device__ uint4 g_tn_zero16 = {0u, 0u, 0u, 0u};
+
 // TM x 64 output tile (TM = 64 or 128 rows of C = columns of A), one batch slice.
 template <int TM>
 __global__ __launch_bounds__(256, TM == 64 ? 2 : 1) void gemm_tn64_kernel(TnArgs p) {
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(256, TM == 64 ? 2 : 1) void gemm_tn64_kernel(TnArgs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w1 = wave >> 1, w2 = wave & 1;                    // 2 x 2 waves: rows [RT*32*w1, ...), columns [32*w2, +32)
-    const long long nt2 = p.N2 / TN_BN;
+    const long long nt2 = (p.N2 + TN_BN - 1) / TN_BN;
     long long tile, split;
     if ((p.nsplits & 7) == 0) {
         const long long xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
@@ -516,6 +521,7 @@ __global__ __launch_bounds__(256, TM == 64 ? 2 : 1) void gemm_tn64_kernel(TnArgs
     if (me > p.M) me = p.M;
     if (ms >= me) return;
     const int nst = (int)((me - ms) / TF_ROWS);                 // whole stages (checked on the host)
+    const long long n1c = (p.N1 + 7) & ~7LL, n2c = (p.N2 + 7) & ~7LL;    // readable columns (the operands' rows are padded to 8)
 
     auto copy_stage = [&](int st, int buf) {                    // asynchronous: NCOPY copies per lane, counted in vmcnt
         const long long m0 = ms + (long long)st * TF_ROWS;
@@ -524,12 +530,16 @@ __global__ __launch_bounds__(256, TM == 64 ? 2 : 1) void gemm_tn64_kernel(TnArgs
         for (int i = 0; i < TF_ROWS * CHA / 256; ++i) {
             constexpr int RW = 64 / CHA;                        // rows per wave instruction
             const int row0 = (wave * (TF_ROWS * CHA / 256) + i) * RW, row = row0 + lane / CHA, c = (lane % CHA) ^ tf_sw<CHA>(row);
-            f_copy16(p.A + (m0 + row) * p.lda + n1_0 + c * 8, base + row0 * (CHA * 16));
+            const bool in = n1_0 + c * 8 < n1c;
+            f_copy16(in ? static_cast<const void*>(p.A + (m0 + row) * p.lda + n1_0 + c * 8) : static_cast<const void*>(&g_tn_zero16),
+                     base + row0 * (CHA * 16));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row0 = (wave * 4 + i) * 8, row = row0 + (lane >> 3), c = (lane & 7) ^ tf_sw<8>(row);
-            f_copy16(p.B + (m0 + row) * p.ldb + n2_0 + c * 8, base + SA + row0 * 128);
+            const bool in = n2_0 + c * 8 < n2c;
+            f_copy16(in ? static_cast<const void*>(p.B + (m0 + row) * p.ldb + n2_0 + c * 8) : static_cast<const void*>(&g_tn_zero16),
+                     base + SA + row0 * 128);
         }
     };
     f32x16 acc[RT], accs[RT];
@@ -575,8 +585,8 @@ __global__ __launch_bounds__(256, TM == 64 ? 2 : 1) void gemm_tn64_kernel(TnArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long long n1 = n1_0 + (w1 * RT + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            atomicAdd(p.C + n1 * p.ldc + n2, acc[t][r]);
-            if (do_cs && (lane & 31) == 0) atomicAdd(p.colsum + n1, accs[t][r]);
+            if (n1 < p.N1 && n2 < p.N2) atomicAdd(p.C + n1 * p.ldc + n2, acc[t][r]);
+            if (do_cs && (lane & 31) == 0 && n1 < p.N1) atomicAdd(p.colsum + n1, accs[t][r]);
         }
 }
 
@@ -1541,10 +1551,12 @@ int dhaug_gemm_tn_bf16_rows(const uint16_t* A, int64_t lda, const uint16_t* B, i
         hipLaunchKernelGGL(gemm_tn128_kernel, dim3((unsigned)(tl * sp)), dim3(256), TB_NSTG * TB_STG, s, pb);
         return dhaug_launch_status();
     }
-    if (N1 % TN_BN == 0 && N2 % TN_BN == 0 && M % TF_ROWS == 0 && M >= 4 * TF_ROWS && getenv("DHAUG_GEMM_GENERIC") == nullptr) {
+    static const bool tn_any = getenv("DHAUG_TN_NOPAD") == nullptr;     // (experiment switch: ragged N1 / N2 on the generic kernel)
+    const bool whole = N1 % TN_BN == 0 && N2 % TN_BN == 0;
+    if ((whole || (tn_any && M >= 16 * TF_ROWS)) && M % TF_ROWS == 0 && M >= 4 * TF_ROWS && getenv("DHAUG_GEMM_GENERIC") == nullptr) {
         // 128 x 64 tiles (one workgroup per CU) re-read less from L2 but measured slower (35 vs 27 us at 65536 x 256 x 256):
         // the loop is bound by requests in flight, not by L2 bandwidth.  Kept selectable for experiments.
-        const bool wide = N1 % 128 == 0 && getenv("DHAUG_TN_WIDE") != nullptr;
+        const bool wide = whole && N1 % 128 == 0 && getenv("DHAUG_TN_WIDE") != nullptr;
         const long long tl = wide ? tiles / 2 : tiles;
         long long sp = (wide ? 256 : 512) / tl;
         if (sp < 1) sp = 1;

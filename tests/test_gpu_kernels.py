@@ -270,7 +270,9 @@ def test_gemm_split_terms(ops, terms, tol):
 
 
 @pytest.mark.parametrize("M,N1,N2", [(4096, 256, 256), (1000, 100, 512), (777, 32, 256), (65536, 256, 48), (130, 1, 100),
-                                     (98304, 256, 256), (65536 + 192, 128, 384)])  # (the last two also run under DHAUG_TN_128=1 by hand)
+                                     (98304, 256, 256), (65536 + 192, 128, 384),  # (these two also run under DHAUG_TN_128=1 by hand)
+                                     # ragged feature counts on whole 128-row stages: the LDS-DMA kernel with zero-sourced chunks
+                                     (6144, 100, 100), (12288, 1, 100), (12288, 256, 30), (98304, 100, 512), (6144, 1, 256)])
 def test_gemm_tn(ops, M, N1, N2):
     gen = torch.Generator().manual_seed(M + N1)
     p1, p2 = (N1 + 7) // 8 * 8, (N2 + 7) // 8 * 8

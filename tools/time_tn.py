@@ -6,9 +6,12 @@ import dhaug_amd
 from dhaug_amd import ops
 
 M = int(os.environ.get("M", 196608))
-for N1, N2 in ((256, 256), (112, 512), (256, 64)):
-    g = (torch.randn(M, N1, device="cuda") * 0.1).bfloat16()
-    x = (torch.randn(M, N2, device="cuda") * 0.1).bfloat16()
+for N1, N2 in ((256, 256), (100, 512), (256, 64), (256, 32), (256, 48), (100, 100), (1, 100), (1, 256)):
+    c16 = lambda n: (n + 15) // 16 * 16
+    g = (torch.randn(M, c16(N1), device="cuda") * 0.1).bfloat16()
+    x = (torch.randn(M, c16(N2), device="cuda") * 0.1).bfloat16()
+    g[:, N1:] = 0
+    x[:, N2:] = 0
     out = torch.zeros(N1, N2, device="cuda")
     cs = torch.zeros(N1, device="cuda")
     fn = lambda: ops.gemm_tn(g, x, N1, N2, colsum=cs, out=out, accumulate=True, colsum_rows=M // 3 * 2)
