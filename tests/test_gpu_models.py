@@ -565,3 +565,35 @@ def test_fused_parity_mode_ragged_and_full_size(M, D, B):
         with torch.no_grad():
             assert maxabs(D3(x3[lo:hi].contiguous()), l3[lo:hi].cpu()) <= 1e-6 * max(1.0, l3.abs().max().item())
         assert torch.isfinite(l3).all() and torch.isfinite(l2).all() and torch.isfinite(head).all()
+
+
+def test_fused_weights_refresh_in_one_launch(M):
+    """After an in-place parameter update the fused programs re-pack every fragment blob, padded bias and folded logit vector
+    with ONE launch (dhaug_pack_wfrag_batch) instead of rebuilding their layers: the refreshed program must give exactly
+    the logits of a program built from scratch on the new weights."""
+    from dhaug_amd import fused, autograd_ops as A, _lib
+    dhaug_calls = lambda: _lib.CALLS[0]
+    B, D = 300, 256
+    _, G, D3, D2 = _fused_nets(M, D, B)
+    gen = torch.Generator().manual_seed(12)
+    x3 = (GU.synth_pose16(B, seed=3) - GU.synth_pose16(B, seed=3)[:, :1]).reshape(B, 48).cuda()
+    x2 = (torch.rand(B, 32, generator=gen) - 0.5).cuda()
+    z = torch.randn(B, 128, generator=gen).cuda()
+    nets = [(G.cuda(), lambda n: fused.generator_head(n, z)), (D3.cuda(), lambda n: fused.critic3d(n, x3)),
+            (D2.cuda(), lambda n: fused.critic2d(n, x2))]
+    with torch.no_grad():
+        for net, run in nets:
+            before = run(net).clone()
+            calls0 = dhaug_calls()
+            for p in net.parameters():                               # an optimizer step's effect: same tensors, new values
+                p.mul_(1.0 + 0.05 * torch.randn(p.shape, generator=gen).to(p.device))
+                p._dhaug_epoch = getattr(p, "_dhaug_epoch", 0) + 1
+            A.bump_weight_epoch()
+            calls1 = dhaug_calls()
+            refreshed = run(net).clone()
+            assert dhaug_calls() - calls1 <= 3                       # the batched re-pack + the fused launch (a rebuild packs layer by layer)
+            assert not torch.equal(refreshed, before)
+            net.__dict__.pop("_fused", None)                         # forget the compiled program: next call builds it from scratch
+            scratch = run(net)
+            assert torch.equal(refreshed, scratch)
+            del calls0
