@@ -108,3 +108,26 @@ def test_fk_nan_pose_does_not_leak_into_other_poses(ops):
     o0 = ops.fk_forward(a.cuda(), bl0.cuda(), rt.cuda()).cpu()
     assert (o0 - O.fk_forward16(a, bl0, rt)).abs().max().item() <= 1e-5
     assert (o0[:, 6] - o0[:, 5]).abs().max().item() <= 1e-6
+
+
+def test_empty_batches(ops):
+    """N = 0 through the entry points of the path: nothing is launched, shapes are kept, accumulating outputs are untouched"""
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    assert ops.fk_forward(z(0, 37), z(0, 15), z(0, 3)).shape == (0, 16, 3)
+    fake, ang = ops.gen_tail_forward(z(0, 35), z(0, 15), None, True)
+    assert fake.shape[0] == 0
+    out = ops.gen_tail_forward_critics(z(0, 35), z(0, 15), None, True, ([1.0, 0, 0, 0], [0.0, 0, 0], [1.0, 1, 0, 0, 0, 0, 0, 0, 0]))
+    assert all(t.shape[0] == 0 for t in out)
+    kf, kb = ops.kcs_forward(z(0, 48), True, f32=True, bf16_ld=32)
+    assert kf.shape == (0, 30) and kb.shape == (0, 32)
+    assert ops.bone_length(z(0, 16, 3)).shape[0] == 0
+    A = torch.zeros(0, 64, device="cuda", dtype=torch.bfloat16)
+    W = torch.zeros(32, 64, device="cuda", dtype=torch.bfloat16)
+    cb, _ = ops.gemm_nt(A, W, 32, 64, out_bf16=True)
+    assert cb.shape[0] == 0
+    acc = torch.full((32, 64), 3.0, device="cuda")
+    got = ops.gemm_tn(torch.zeros(0, 32, device="cuda", dtype=torch.bfloat16), A, 32, 64, out=acc, accumulate=True)
+    assert (got == 3.0).all()                                    # dW += 0 rows
+    fresh = ops.gemm_tn(torch.zeros(0, 32, device="cuda", dtype=torch.bfloat16), A, 32, 64)
+    assert fresh.shape == (32, 64) and (fresh == 0).all()
+    torch.cuda.synchronize()
