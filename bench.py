@@ -65,6 +65,24 @@ def autograd_critic_step_flops(mac, rows):
     return 2.0 * rows * 12 * mac
 
 
+def critic_step_bytes(widths, rows, in_cols):
+    """ALGORITHMIC HBM bytes of one explicit critic step: every layer output y (bf16) is written once by the forward sweep and
+    read once by its weight-gradient contraction, every cotangent gz (bf16) is written once by the backward sweep and read
+    once by the contraction, over the 3B rows [real; fake; x_hat] (the tangents replace y on the x_hat rows in place); the
+    fp32 inputs are read once.  widths = output widths of all layers.  What the sweeps move on top of this (masks, skips and
+    cotangents re-read layer by layer) is the traffic / algorithmic ratio of roofline_step."""
+    return 3.0 * rows * (8.0 * sum(widths) + 4.0 * in_cols)
+
+
+def step_algorithmic_bytes(D, B):
+    """one single-frame GAN iteration (2 + 2 critic steps; the sampling pass and the G step every fifth iteration are
+    compute-resident: their inputs / outputs only)"""
+    d3 = critic_step_bytes([D] * 14 + [100, 100, 100, 1], B, 48 + 30)
+    d2 = critic_step_bytes([D] * 5 + [1], B, 32)
+    gen = B * (128 * 4 + 48 * 4 + 15 * 4)
+    return 2 * d3 + 2 * d2 + 1.2 * gen
+
+
 def event_time(fn, iters, warm, rewarm_s=0.3):
     """average duration of fn (seconds), HIP events on the stream the kernels are launched on; rewarm_s of fn first so
     that the kernel is timed at the clocks it runs at inside the loaded step, not at those left by the previous phase"""
@@ -101,9 +119,26 @@ def launch_ranks(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    # poll all ranks: as soon as one exits non-zero the others (stuck in a collective by then) are terminated
+    rc, alive = 0, list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            c = p.poll()
+            if c is None:
+                continue
+            alive.remove(p)
+            rc = max(rc, abs(c))
+        if rc != 0 and alive:
+            for p in alive:
+                p.terminate()                    # (exact children only)
+            t_end = time.time() + 10
+            for p in alive:
+                try:
+                    p.wait(timeout=max(0.1, t_end - time.time()))
+                except Exception:
+                    p.kill()
+            break
     return rc
 
 

@@ -69,6 +69,15 @@ class RepackDesc(ctypes.Structure):
     _fields_ = [("W", _vp), ("nt", _vp), ("nn", _vp), ("N", _i32), ("K", _i32), ("Kp", _i32), ("Np", _i32)]
 
 
+class TnLayer(ctypes.Structure):
+    """struct dhaug_tn_layer (include/dhaug.h)"""
+    _fields_ = [("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("C", _vp), ("ldc", _i64), ("colsum_a", _vp),
+                ("colsum_rows", _i64), ("M", _i64), ("N1", _i32), ("N2", _i32), ("accumulate", _i32), ("reserved", _i32)]
+
+
+TN_GROUP_MAX = 24
+TN_GROUP_WORKSPACE_FLOATS = 256 * (256 * 256 + 256)
+SIGNATURES["dhaug_gemm_tn_group_bf16"] = [ctypes.POINTER(TnLayer), _i32, _vp, _vp]
 SIGNATURES["dhaug_pack_wfrag"] = [_vp, _i64, _vp, _i64, _i64, _i64, _vp]
 SIGNATURES["dhaug_pack_wfrag_batch"] = [_vp, _i32, _vp]
 SIGNATURES["dhaug_mlp_forward"] = [ctypes.POINTER(MlpUnit), _i32, _i64, _vp]

@@ -32,6 +32,9 @@ from . import ops
 # sweep 1 (forward) of the single-frame critics as ONE fused launch that also saves every layer's output
 # (fused.critic3d_forward_save / critic2d_forward_save) instead of one GEMM launch per layer; bf16 arithmetic only
 FUSED_STEP_FORWARD = os.environ.get("DHAUG_NO_FUSED_STEP_FORWARD") is None
+# sweep 4: the weight / bias gradients of all layers up to 256 wide in ONE grouped launch (ops.gemm_tn_group) instead of one
+# contraction launch per layer
+TN_GROUP = os.environ.get("DHAUG_NO_TN_GROUP") is None
 
 BF16 = torch.bfloat16
 NONE, RELU, LRELU = A.ACT_NONE, A.ACT_RELU, A.ACT_LRELU
@@ -44,6 +47,7 @@ class _Math:
     def __init__(self, prec):
         self.prec, self.bf16 = prec, prec == "bf16"
         self.T = 1 if self.bf16 else A.TERMS[prec]
+        self.tn = []                                 # weight-gradient contractions waiting for the grouped launch (flush)
 
     def width(self, n):
         return ceil16(n) if self.bf16 else n
@@ -93,6 +97,12 @@ class _Math:
             return out
         return cf
 
+    def flush(self):
+        """launch the collected weight-gradient contractions (before the optimizer step reads the gradient bucket)"""
+        if self.tn:
+            ops.gemm_tn_group(self.tn)
+            self.tn = []
+
     def fusable(self, n, k, rows):
         """the mask (and skip) ride the GEMM epilogue of every bf16 kernel (an element's mask value is read by the thread
         that then writes that element), so the output may overwrite the mask"""
@@ -105,8 +115,17 @@ class _Math:
             gb = g if g.dtype == BF16 else ops.cast_pad_bf16(g, ceil16(N))
             xb = x if x.dtype == BF16 else ops.cast_pad_bf16(x, ceil16(K))
             narrow = N < 16
-            ops.gemm_tn(gb, xb, N, K, colsum=bslot if (bslot is not None and not narrow) else None, out=wslot, accumulate=True,
-                        colsum_rows=colsum_rows)
+            M = gb.shape[0]
+            cr = M if colsum_rows is None else colsum_rows
+            if TN_GROUP and N <= 256 and ops.tn_group_ok(M, N, min(K, 256), cr):
+                # joins the step's grouped launch; a wider input (the merge layer behind a concatenation) as column blocks
+                for k0 in range(0, K, 256):
+                    kk = min(256, K - k0)
+                    cs = bslot if (bslot is not None and not narrow and k0 == 0) else None
+                    self.tn.append((gb, xb[:, k0:], N, kk, wslot[:, k0:], cs, cr if cs is not None else 0, True, M, None, None))
+            else:
+                ops.gemm_tn(gb, xb, N, K, colsum=bslot if (bslot is not None and not narrow) else None, out=wslot, accumulate=True,
+                            colsum_rows=colsum_rows)
             if bslot is not None and narrow:
                 ops.colsum(gb if colsum_rows is None else gb[:colsum_rows], N=N, out=bslot, accumulate=True)
             return
@@ -249,6 +268,7 @@ def step_d2(D, optimizerD, real, fake, alpha, lam, prec=None):
     for lay, gz, x, u in ((L[0], gz1, X, v), (L[1], gz2, d1, u1), (L[2], gz3, d2, u2), (L[3], gz4, d3, u3),
                           (L[4], gzl, d4, u4), (L[5], gzp, dl, ul)):
         lay.grads(m, gz, x, B2, u)
+    m.flush()
     return _finish(optimizerD, logits, pen, B, lam)
 
 
@@ -329,6 +349,7 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
     Lm.grads(m, gz_m0, cat, B2, ucat)
     Mb.fc1.grads(m, gz_m1, m0, B2, um0); Mb.fc2.grads(m, gz_m2, mh, B2, umh)
     Lo.grads(m, gzo, m1, B2, um1)
+    m.flush()
     return _finish(optimizerD, logits, pen, gv.shape[0], lam, rows=B)
 
 

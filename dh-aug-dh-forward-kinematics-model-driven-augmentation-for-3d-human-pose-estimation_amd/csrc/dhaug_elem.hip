@@ -267,7 +267,9 @@ __global__ __launch_bounds__(256) void gp_penalty_kernel(const float* __restrict
         for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
         const float n = sqrtf(ss), d = n - 1.0f;
         if (lane == 0) pen[b] = d * d;
-        const float k = coef * d / n;
+        // n == 0 (every unit of the critic dead on this row): torch's norm has subgradient 0 there (the reference's
+        // gradients.norm(2, dim=1) back-propagates 0, not -inf * 0 = NaN)
+        const float k = n > 0.0f ? coef * d / n : 0.0f;
         for (int c = lane; c < W; c += 64) v[b * W + c] = k * row[c];
     }
 }

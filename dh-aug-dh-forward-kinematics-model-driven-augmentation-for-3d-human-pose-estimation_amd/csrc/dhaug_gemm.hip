@@ -470,6 +470,16 @@ __device__ __forceinline__ void f_copy16(const void* g, unsigned char* lds_wave_
                                      (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
 }
 
+// The same copy for the TN kernels below, as inline assembly ON PURPOSE: their fragments are read with the hardware
+// transpose read (an intrinsic without memory operand), and hipcc's waitcnt pass -- which knows that the LDS-DMA builtin
+// writes LDS -- puts a full `s_waitcnt vmcnt(0)` in front of the first such read of every stage: right behind the explicit
+// vmcnt(N) that was meant to leave the younger stages in flight, so the ring was drained at every stage (visible in the ISA;
+// found in round 3).  The asm copy is invisible to that pass; completion is tracked by the explicit waits alone.
+typedef unsigned char __attribute__((address_space(3))) * tn_lds_ptr;
+__device__ __forceinline__ void tn_copy16(const void* g, unsigned char* lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"((tn_lds_ptr)lds_wave_base), "v"(g) : "memory");
+}
+
 constexpr int TF_ROWS = 128;                                    // contraction rows per stage
 
 // fragment of 8 contraction rows x 16 columns from a stage whose rows hold CH 16-byte chunks (CH = 8: 64 columns,
@@ -531,14 +541,14 @@ __global__ __launch_bounds__(256, TM == 64 ? 2 : 1) void gemm_tn64_kernel(TnArgs
             constexpr int RW = 64 / CHA;                        // rows per wave instruction
             const int row0 = (wave * (TF_ROWS * CHA / 256) + i) * RW, row = row0 + lane / CHA, c = (lane % CHA) ^ tf_sw<CHA>(row);
             const bool in = n1_0 + c * 8 < n1c;
-            f_copy16(in ? static_cast<const void*>(p.A + (m0 + row) * p.lda + n1_0 + c * 8) : static_cast<const void*>(&g_tn_zero16),
+            tn_copy16(in ? static_cast<const void*>(p.A + (m0 + row) * p.lda + n1_0 + c * 8) : static_cast<const void*>(&g_tn_zero16),
                      base + row0 * (CHA * 16));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row0 = (wave * 4 + i) * 8, row = row0 + (lane >> 3), c = (lane & 7) ^ tf_sw<8>(row);
             const bool in = n2_0 + c * 8 < n2c;
-            f_copy16(in ? static_cast<const void*>(p.B + (m0 + row) * p.ldb + n2_0 + c * 8) : static_cast<const void*>(&g_tn_zero16),
+            tn_copy16(in ? static_cast<const void*>(p.B + (m0 + row) * p.ldb + n2_0 + c * 8) : static_cast<const void*>(&g_tn_zero16),
                      base + SA + row0 * 128);
         }
     };
@@ -631,8 +641,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tn128_kernel(TnArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                           // 16 chunks per row: 4 rows per wave instruction
             const int row0 = (wave * 4 + i) * 4, row = row0 + (lane >> 4), c = (lane & 15) ^ tf_sw<16>(row);
-            f_copy16(p.A + (m0 + row) * p.lda + n1_0 + c * 8, base + row0 * 256);
-            f_copy16(p.B + (m0 + row) * p.ldb + n2_0 + c * 8, base + TB_ROWS * 256 + row0 * 256);
+            tn_copy16(p.A + (m0 + row) * p.lda + n1_0 + c * 8, base + row0 * 256);
+            tn_copy16(p.B + (m0 + row) * p.ldb + n2_0 + c * 8, base + TB_ROWS * 256 + row0 * 256);
         }
     };
     f32x16 acc[2][2], accs[2];

@@ -561,6 +561,9 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
 #pragma unroll
         for (int mt = 0; mt < MLP_MT; ++mt) sv_off[mt] = (32 * mt + r31) * sv_ld + (h << 4);
     }
+#if defined(SAVE_ABL_TILE0)
+    const int sv_rot = (32 * wave + r31) * sv_ld + (h << 4);
+#endif
 #pragma unroll
     for (int mt = 0; mt < MLP_MT; ++mt) {
 #pragma unroll
@@ -599,7 +602,11 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
                     }
                 }
 #endif
-#ifndef SAVE_ABL_NOSTORE
+#if defined(SAVE_ABL_TILE0)            /* timing only (wrong rows): every wave stores during tile 0, no branch in the MFMA stream */
+                if (SAVE && !LEAD && t == 0 && mt == 0)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, fx[s & 3]), sv, sv_rot + 32 * k, 0, 0);
+                if (false)
+#elif !defined(SAVE_ABL_NOSTORE)
                 if (SAVE && !LEAD && t == 0 && mt == wave)               // chunk 2k+h of the lane's row: this k-step's fragment
 #else
                 if (false)

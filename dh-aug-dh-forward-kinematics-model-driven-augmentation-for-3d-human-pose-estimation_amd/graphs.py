@@ -23,15 +23,22 @@ _capture_ids = itertools.count(1)
 class GraphedCall:
     """capture fn(*static_inputs) once (after warm-up calls that populate caches / one-time kernel configuration) and replay it"""
 
-    def __init__(self, fn, example_inputs, warmup=2, prologue=None):
+    def __init__(self, fn, example_inputs, warmup=2, prologue=None, state=()):
+        """state: tensors the warm-up calls modify in place (weights, Adam moments, step counts): they are put back before
+        the capture, so building a graph advances nothing -- the first replay is the first iteration."""
         self.static_in = [t.clone() if torch.is_tensor(t) else t for t in example_inputs]
+        saved = [t.clone() for t in state]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 fn(*self.static_in)
+            for t, s in zip(state, saved):
+                t.copy_(s)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if saved:
+            A.bump_weight_epoch()                                  # packed copies made from the warm-up's weights are stale
         self.graph = torch.cuda.CUDAGraph()
         # every cached bf16 / fragment copy of a weight is re-made INSIDE the capture (see autograd_ops.CAPTURE_ID): the
         # graph then owns the memory its kernels read and refreshes it on every replay
@@ -61,7 +68,8 @@ class GraphedGanIteration:
         self.graphs = {}
 
     def __call__(self, inputs_3d, cam_param, inputs_2d, do_g_step, camera):
-        key = (bool(do_g_step), tuple(camera[0]), tuple(camera[1]), tuple(camera[2]))
+        key = (bool(do_g_step), tuple(camera[0]), tuple(camera[1]), tuple(camera[2]),
+               tuple(inputs_3d.shape), tuple(cam_param.shape), tuple(inputs_2d.shape))
         g = self.graphs.get(key)
         if g is None:
             def run(x3, cp, x2):
@@ -71,5 +79,10 @@ class GraphedGanIteration:
             opts = [v for k, v in self.d.items() if k.startswith("optimizer")]
             for o in opts:
                 o._ensure_packs()                              # (allocation + descriptor upload must not happen in a capture)
-            g = self.graphs[key] = GraphedCall(run, (inputs_3d, cam_param, inputs_2d), prologue=lambda: [o._repack() for o in opts])
+            state = [t for o in opts for t in (o.flat_param, o.exp_avg, o.exp_avg_sq, o.step_dev)]
+            counts = [o.step_count for o in opts]
+            g = self.graphs[key] = GraphedCall(run, (inputs_3d, cam_param, inputs_2d), prologue=lambda: [o._repack() for o in opts],
+                                               state=state)
+            for o, c in zip(opts, counts):                     # (host-side bookkeeping of the warm-up calls)
+                o.step_count = c
         return g(inputs_3d, cam_param, inputs_2d)

@@ -1,6 +1,7 @@
 """Tensor-level wrappers of the C-ABI (no autograd here): allocate outputs with torch, pass raw device pointers and
 the current HIP stream to libdhaug.so.  Every function requires CUDA(HIP) tensors and raises otherwise."""
 import ctypes
+import os
 
 import torch
 
@@ -299,6 +300,38 @@ def gemm_nt_dmask(A, B, N, K, dmask, dmask_act, dmask_slope=0.0, res_bf16=None, 
     return out
 
 
+TN256 = os.environ.get("DHAUG_NO_TN256") is None
+_TN_WS = {}
+
+
+def _tn_group_workspace(dev):
+    """DHAUG_TN_GROUP_WORKSPACE_FLOATS fp32 values per device: the per-workgroup partial results of dhaug_gemm_tn_group_bf16
+    (any content; calls are ordered on the stream)"""
+    k = (dev.type, dev.index)
+    if k not in _TN_WS:
+        _TN_WS[k] = torch.empty(_lib.TN_GROUP_WORKSPACE_FLOATS, dtype=torch.float32, device=dev)
+    return _TN_WS[k]
+
+
+def tn_group_ok(M, N1, N2, colsum_rows):
+    """shapes dhaug_gemm_tn_group_bf16 takes (and where it pays: a long batch)"""
+    return M >= 2048 and M % 32 == 0 and colsum_rows % 32 == 0 and 1 <= N1 <= 256 and 1 <= N2 <= 256
+
+
+def gemm_tn_group(items):
+    """items: [(A, B, N1, N2, out, colsum | None, colsum_rows, accumulate, M | None, lda | None, ldb | None)] -- the weight
+    gradients C_i (+)= A_i^T B_i of several layers in one launch (+ one that sums the partial results)."""
+    for i0 in range(0, len(items), _lib.TN_GROUP_MAX):
+        chunk = items[i0:i0 + _lib.TN_GROUP_MAX]
+        arr = (_lib.TnLayer * len(chunk))()
+        for d, (A, B, N1, N2, out, cs, cr, accumulate, M, la, lb) in zip(arr, chunk):
+            assert A.dtype == BF16 and B.dtype == BF16 and out.dtype == torch.float32
+            d.A, d.lda, d.B, d.ldb = _p(A), A.stride(0) if la is None else la, _p(B), B.stride(0) if lb is None else lb
+            d.C, d.ldc, d.colsum_a, d.colsum_rows = _p(out), out.stride(0), _p(cs), cr
+            d.M, d.N1, d.N2, d.accumulate = A.shape[0] if M is None else M, N1, N2, int(bool(accumulate))
+        _lib.call("dhaug_gemm_tn_group_bf16", arr, len(chunk), _p(_tn_group_workspace(chunk[0][0].device)), _stream())
+
+
 def gemm_tn(A, B, N1, N2, out=None, accumulate=False, M=None, lda=None, ldb=None, colsum=None, colsum_rows=None):
     """C[N1,N2] (+)= A[M,N1]^T B[M,N2], bf16 operands, fp32 result; colsum (fp32 [N1], optional) (+)= column sums of A
     (over rows [0, colsum_rows) only when given: a multiple of 128)."""
@@ -307,6 +340,12 @@ def gemm_tn(A, B, N1, N2, out=None, accumulate=False, M=None, lda=None, ldb=None
     if out is None:
         out = torch.empty((N1, N2), dtype=torch.float32, device=A.device)
         accumulate = False
+    la, lb = A.stride(0) if lda is None else lda, B.stride(0) if ldb is None else ldb
+    cr = M if colsum_rows is None else colsum_rows
+    if TN256 and N1 == 256 and N2 == 256 and tn_group_ok(M, N1, N2, cr):
+        # a long 256 x 256 contraction alone: a group of one (whole-output tiles, dhaug_tn256.hip)
+        gemm_tn_group([(A, B, N1, N2, out, colsum, cr, accumulate, M, la, lb)])
+        return out
     _lib.call("dhaug_gemm_tn_bf16_rows", _p(A), A.stride(0) if lda is None else lda, _p(B), B.stride(0) if ldb is None else ldb,
               _p(out), out.stride(0), _p(colsum), M if colsum_rows is None else colsum_rows, M, N1, N2, int(accumulate), _stream())
     return out

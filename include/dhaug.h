@@ -227,6 +227,30 @@ int dhaug_gemm_tn_bf16_rows(const uint16_t* A, int64_t lda, const uint16_t* B, i
                             float* C, int64_t ldc, float* colsum_a, int64_t colsum_rows, int64_t M, int64_t N1, int64_t N2,
                             int accumulate, void* stream);
 
+/* The weight / bias gradients of ALL layers of a critic step in one launch (+ one small launch that sums the partial
+ * results): layer i computes C[N1,N2] (+)= A[M,N1]^T * B[M,N2] and colsum_a[N1] (+)= column sums of A over rows
+ * [0, colsum_rows), with N1, N2 <= 256, M and colsum_rows multiples of 32, operands bf16 with rows readable up to ceil8(N)
+ * columns.  One workgroup per CU owns a layer's WHOLE output over its slice of the batch (every operand byte crosses
+ * L2 -> LDS once; the 64 x 64-tile kernel behind dhaug_gemm_tn_bf16 re-reads each row four times); the workgroups are dealt
+ * out to the layers in proportion to their operand bytes, so a step leaves 256 partial results in total, not per layer.
+ * `layers`: host array (read during the call).  `workspace`: DHAUG_TN_GROUP_WORKSPACE_FLOATS fp32 values owned by the
+ * caller, any content (calls sharing it must be ordered on one stream).
+ * Replaces the parameter-gradient half of loss.backward() in R/models_Fk_GAN/model_fk_gan_train.py:191-214. */
+#define DHAUG_TN_GROUP_MAX 24
+#define DHAUG_TN_GROUP_WORKSPACE_FLOATS (256LL * (256 * 256 + 256))
+typedef struct dhaug_tn_layer {
+    const uint16_t* A; int64_t lda;
+    const uint16_t* B; int64_t ldb;
+    float* C; int64_t ldc;
+    float* colsum_a;            /* optional */
+    int64_t colsum_rows;
+    int64_t M;
+    int32_t N1, N2;
+    int32_t accumulate;         /* != 0: add into C / colsum_a, else overwrite */
+    int32_t reserved;
+} dhaug_tn_layer;
+int dhaug_gemm_tn_group_bf16(const dhaug_tn_layer* layers, int n, float* workspace, void* stream);
+
 /* fp32 -> bf16 (round-to-nearest-even) with zero padding: src (rows, cols) ld_src -> dst (rows, ld_dst),
  * columns [cols, pad_cols) zero-filled.  Used to pack weights / inputs as GEMM operands. */
 int dhaug_cast_pad_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst,

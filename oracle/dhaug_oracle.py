@@ -172,6 +172,69 @@ def fk_forward32(angles, bone_len, root):
     return out + root.reshape(-1, 1, 3)                                         # :819-820
 
 
+def _dh_matrix_slicewise(alpha, a, d, theta):
+    """One joint's modified-DH matrix the way the reference builds it: a float64 numpy zeros block turned into an fp32
+    tensor, then sixteen strided slice assignments with the sines / cosines re-evaluated per entry
+    (R/models_Fk_GAN/forward_kinematics_DH_model.py:89-116).  Same values as dh_matrix()."""
+    al = _deg2rad(alpha)
+    th = _deg2rad(theta)
+    m = torch.tensor(np.zeros((theta.shape[0], 4, 4)), dtype=torch.float32)
+    m[:, 0, 0] = torch.cos(th); m[:, 0, 1] = -torch.sin(th); m[:, 0, 2] = 0; m[:, 0, 3] = a
+    m[:, 1, 0] = torch.sin(th) * torch.cos(al); m[:, 1, 1] = torch.cos(th) * torch.cos(al)
+    m[:, 1, 2] = -torch.sin(al); m[:, 1, 3] = -torch.sin(al) * d
+    m[:, 2, 0] = torch.sin(th) * torch.sin(al); m[:, 2, 1] = torch.cos(th) * torch.sin(al)
+    m[:, 2, 2] = torch.cos(al); m[:, 2, 3] = torch.cos(al) * d
+    m[:, 3, 0] = 0; m[:, 3, 1] = 0; m[:, 3, 2] = 0; m[:, 3, 3] = 1
+    return m
+
+
+def fk_forward32_op_by_op(angles, bone_len, root):
+    """fk_forward32 at the REFERENCE'S OP GRANULARITY (bench.py's cpu_baseline_faithful: the same arithmetic issued as the
+    reference issues it, so that the CPU-vs-GPU ratio can be split into "fewer, fused ops" and "hardware"):
+    33 per-joint matrix builds (_dh_matrix_slicewise), the arm chains re-multiplying the body prefix, 46 sequential bmm on
+    cloned operands written back in place, cloned translation columns, one global-rotation bmm per chain and coordinate
+    block, one slice assignment per output coordinate (R/models_Fk_GAN/forward_kinematics_DH_model.py:592-822).
+    Bit-identical to fk_forward32 (tests/test_oracle_golden.py)."""
+    N = angles.shape[0]
+    rl, ll, bd, ra, la = _chain_tables(bone_len, angles.dtype)
+
+    def build(tab, ang, n, lead=None):
+        hm = torch.zeros((N, n, 4, 4), dtype=torch.float32)
+        off = 0
+        if lead is not None:
+            hm[:, 0:9] = torch.clone(lead[:, 0:9])
+            off = 9
+        for i in range(n - off):
+            hm[:, i + off] = _dh_matrix_slicewise(tab["alpha"][:, i], tab["a"][:, i], tab["d"][:, i], tab["theta"][:, i] + ang[:, i])
+        return hm
+
+    ll_hm = build(ll, angles[:, 5:10], 5)
+    rl_hm = build(rl, angles[:, 0:5], 5)
+    bd_hm = build(bd, angles[:, 10:23], 13)
+    ra_hm = build(ra, angles[:, 23:28], 14, lead=bd_hm)              # (the prefix is copied BEFORE the body chain is multiplied out)
+    la_hm = build(la, angles[:, 28:33], 14, lead=bd_hm)
+    for hm in (ll_hm, rl_hm, bd_hm, ra_hm, la_hm):
+        for i in range(hm.shape[1] - 1):
+            hm[:, i + 1] = torch.bmm(torch.clone(hm[:, i]), torch.clone(hm[:, i + 1]))
+    Rg = rotation_matrix(angles[:, 34], angles[:, 35], angles[:, 36])
+
+    def rotated(hm):
+        X, Y, Z = torch.clone(hm[:, :, 0, 3]), torch.clone(hm[:, :, 1, 3]), torch.clone(hm[:, :, 2, 3])
+        p = torch.zeros((N, 3, hm.shape[1]), dtype=torch.float32)
+        p[:, 0, :] = X; p[:, 1, :] = Y; p[:, 2, :] = Z
+        q = torch.bmm(Rg, p)
+        return torch.clone(q[:, 0, :]), torch.clone(q[:, 1, :]), torch.clone(q[:, 2, :])
+
+    out = torch.zeros((N, 32, 3), dtype=torch.float32)
+    slots = ((bd_hm, ((0, 0), (12, 3), (13, 6), (14, 12), (15, 12))), (rl_hm, ((1, 0), (2, 3), (3, 4))),
+             (ll_hm, ((6, 0), (7, 3), (8, 4))), (la_hm, ((17, 9), (18, 12), (19, 13))), (ra_hm, ((25, 9), (26, 12), (27, 13))))
+    for hm, pairs in slots:
+        X, Y, Z = rotated(hm)
+        for slot, j in pairs:
+            out[:, slot, 0] = X[:, j]; out[:, slot, 1] = Y[:, j]; out[:, slot, 2] = Z[:, j]
+    return out + root.reshape(-1, 1, 3)
+
+
 def fk_forward16(angles, bone_len, root):
     """FK followed by the 32->16 joint gather (R/models_Fk_GAN/Fk_generator.py:259)."""
     return fk_forward32(angles, bone_len, root)[:, H36M_32_TO_16]
@@ -318,14 +381,15 @@ def jitter_bone_len(bone_len, scaler):
     return torch.stack(cols, dim=1)
 
 
-def gen_tail(head, bone_len, scaler, use_preangle=True):
-    """head (N,35), bone_len (N,15), scaler (N,8) -> (fake (N,48), generator_angle (N,37))."""
+def gen_tail(head, bone_len, scaler, use_preangle=True, fk32=None):
+    """head (N,35), bone_len (N,15), scaler (N,8) -> (fake (N,48), generator_angle (N,37)).  fk32: the FK restatement to use
+    (default fk_forward32; bench.py's faithful CPU baseline passes fk_forward32_op_by_op)."""
     g, root = gen_tail_angles(head, use_preangle)
     bl = jitter_bone_len(bone_len, scaler)
-    return fk_forward16(g, bl, root).reshape(-1, 48), g
+    return (fk32 or fk_forward32)(g, bl, root)[:, H36M_32_TO_16].reshape(-1, 48), g
 
 
-def generator_forward(z, sd, bone_len, scaler, use_preangle=True, frames=1, precision="fp32"):
+def generator_forward(z, sd, bone_len, scaler, use_preangle=True, frames=1, precision="fp32", fk32=None):
     """Fk_Generator.forward (frames=1, R/models_Fk_GAN/Fk_generator.py:114-261) /
     Video_Fk_Generator.forward (frames=R, :302-458; scaler (B,8) repeated over frames).
     Returns fake (B,48) or (B,R,48), plus the head pre-activation and the 37-angle tensor."""
@@ -334,7 +398,7 @@ def generator_forward(z, sd, bone_len, scaler, use_preangle=True, frames=1, prec
     h = head.reshape(B * frames, 35)
     if frames > 1:
         scaler = scaler.reshape(B, 1, 8).repeat(1, frames, 1).reshape(B * frames, 8)
-    fake, g = gen_tail(h, bone_len, scaler, use_preangle)
+    fake, g = gen_tail(h, bone_len, scaler, use_preangle, fk32)
     if frames > 1:
         fake = fake.reshape(B, frames, 48)
     return fake, head, g

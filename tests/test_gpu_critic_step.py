@@ -106,6 +106,35 @@ def test_explicit_step_equals_autograd_and_oracle(M, tag, D, B):
     assert gb[last].abs().max().item() == 0.0
 
 
+def test_gradient_penalty_dead_rows(M):
+    """A row whose input gradient is exactly zero (every ReLU unit behind the merge layer dead): the reference's
+    gradients.norm(2, dim=1) back-propagates 0 there (torch's norm subgradient at 0), the penalty term is (0 - 1)^2.  The
+    explicit step must give the autograd path's finite gradients, not -inf * 0 = NaN (R/models_Fk_GAN/Fk_discriminator.py:229)."""
+    from dhaug_amd import ops
+    g = torch.randn(64, 48, device="cuda")
+    g[5] = 0.0
+    g[63] = 0.0
+    v, pen = ops.gp_penalty(g, 0.25)
+    n = g.norm(dim=1, keepdim=True)
+    ref = torch.where(n > 0, 0.25 * (n - 1) / n.clamp_min(1e-30) * g, torch.zeros_like(g))
+    assert torch.isfinite(v).all() and (v[5] == 0).all() and (v[63] == 0).all()
+    assert (v - ref).abs().max().item() <= 1e-5 and ((pen - (n[:, 0] - 1) ** 2).abs() / (1 + pen)).max().item() <= 1e-5
+    assert pen[5].item() == 1.0
+    # through the whole step: the 3D critic with its merge layer switched off by a large negative bias
+    B, D = 72, 64
+    args = _args(B, D)
+    sd = GU.seeded_state_dict(GU.shapes_d3(D), 123)
+    sd["merge_previous.0.bias"] = torch.full_like(sd["merge_previous.0.bias"], -1e3)
+    data = _data("d3", B, 8)
+    for prec in ("bf16x6", "bf16"):
+        Wa, Ca, ga, pa = _run(M, "d3", args, sd, prec, data, True)
+        Wc, Cc, gc, pc = _run(M, "d3", args, sd, prec, data, False)
+        assert all(torch.isfinite(t).all() for t in ga.values()) and all(torch.isfinite(t).all() for t in pa.values())
+        assert abs(Ca - Cc) <= 1e-5 * max(1.0, abs(Cc)) and abs(Ca - args.GAN_LAMBDA) <= 1e-4     # GP = lambda * mean(1)
+        for k in ga:
+            assert (ga[k] - gc[k]).abs().max().item() <= 1e-7, k
+
+
 def test_explicit_step_full_batch_properties(M):
     """BASELINE configs[2] size (B = 65 536, D = 256, bf16): finite, every parameter moves by at most ~lr, the step of a
     2x replicated batch equals the step of the batch (means are batch-size independent), scalars match a bf16x6 subsample."""

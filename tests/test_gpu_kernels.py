@@ -300,6 +300,67 @@ def test_gemm_tn(ops, M, N1, N2):
         assert maxabs(cs2, cs2ref) <= 1e-4 * max(1.0, cs2ref.abs().max().item()) + 1e-3
 
 
+@pytest.mark.parametrize("M,cs_rows", [(2048, 2048), (8224, 4096), (32 * 1000, 32 * 333), (196608, 131072)])
+def test_gemm_tn256(ops, M, cs_rows):
+    """the whole-output weight-gradient kernel (dhaug_gemm_tn_group_bf16, here a group of one): uneven batch slices, operands that are column blocks
+    of a wider buffer (the 3D critic's concatenation), row-limited bias sums, accumulate; against fp64
+    and against the 64 x 64-tile kernel it replaces for this shape."""
+    gen = torch.Generator().manual_seed(M)
+    wide = _bf(torch.randn(M, 512, generator=gen)).cuda()
+    A, B = wide[:, 256:], _bf(torch.randn(M, 256, generator=gen) * 0.5).cuda()
+    assert ops.TN256
+    ref = A.float().cpu().double().t() @ B.float().cpu().double()
+    csref = A[:cs_rows].float().cpu().double().sum(0)
+    tol = 1e-4 * max(1.0, ref.abs().max().item())
+    cs = torch.full((256,), 3.0, device="cuda")
+    C = ops.gemm_tn(A, B, 256, 256, colsum=cs, colsum_rows=cs_rows)
+    assert maxabs(C, ref) <= tol
+    assert maxabs(cs, csref) <= 1e-4 * max(1.0, csref.abs().max().item()) + 1e-3
+    C2 = ops.gemm_tn(A, B, 256, 256, out=C.clone(), accumulate=True, colsum=cs, colsum_rows=cs_rows)
+    assert maxabs(C2, 2 * ref) <= 2 * tol and maxabs(cs, 2 * csref) <= 2e-4 * max(1.0, csref.abs().max().item()) + 2e-3
+    if M % 128 == 0 and cs_rows % 128 == 0:
+        ops.TN256 = False
+        try:
+            cs_old = torch.zeros(256, device="cuda")
+            C_old = ops.gemm_tn(A, B, 256, 256, colsum=cs_old, colsum_rows=cs_rows)
+        finally:
+            ops.TN256 = True
+        assert maxabs(C, C_old) <= tol
+
+
+def test_gemm_tn_group(ops):
+    """one launch for the weight gradients of a whole step: layers of different widths and batch lengths (the 3D critic's
+    shapes: 256 x 256 blocks, the 100-wide merge block, the 1-wide logit layer, the 30 / 48-column input layers, a column
+    block of the concatenation), accumulate and overwrite mixed, bias sums over a leading block of rows."""
+    gen = torch.Generator().manual_seed(77)
+    M = 12288
+    c16 = lambda n: (n + 15) // 16 * 16
+    shapes = [(256, 256, M, 8192), (256, 256, M, 8192), (100, 256, M, 8192), (100, 100, M, 8192), (1, 100, M, 8192),
+              (256, 30, M, 8192), (256, 48, 4096, 4096), (100, 256, M, 0), (7, 9, 2048, 2048)]
+    wide = _bf(torch.randn(M, 512, generator=gen) * 0.5).cuda()
+    items, refs = [], []
+    for i, (N1, N2, m, cr) in enumerate(shapes):
+        A = torch.zeros(m, c16(N1)); A[:, :N1] = torch.randn(m, N1, generator=gen)
+        A = _bf(A).cuda()
+        if i == 7:
+            B = wide[:, 256:]                                       # a column block: ld 512
+        else:
+            B = torch.zeros(m, c16(N2)); B[:, :N2] = torch.randn(m, N2, generator=gen) * 0.5
+            B = _bf(B).cuda()
+        acc = i % 2 == 1
+        out = torch.full((N1, N2), 2.0, device="cuda")
+        cs = torch.full((N1,), -1.0, device="cuda") if cr else None
+        items.append((A, B, N1, N2, out, cs, cr, acc, None, None, None))
+        ref = A[:, :N1].float().cpu().double().t() @ B[:, :N2].float().cpu().double()
+        csr = A[:cr, :N1].float().cpu().double().sum(0)
+        refs.append((ref + (2.0 if acc else 0.0), csr + (-1.0 if acc else 0.0)))
+    ops.gemm_tn_group(items)
+    for (A, B, N1, N2, out, cs, cr, acc, _, _, _), (ref, csr) in zip(items, refs):
+        assert maxabs(out, ref) <= 1e-4 * max(1.0, ref.abs().max().item()), (N1, N2)
+        if cs is not None:
+            assert maxabs(cs, csr) <= 1e-4 * max(1.0, csr.abs().max().item()) + 1e-3, (N1, N2)
+
+
 def test_pack_kernels(ops):
     gen = torch.Generator().manual_seed(4)
     W = torch.randn(100, 30, generator=gen)

@@ -126,8 +126,11 @@ def _launch(target, tag, port):
     gc.collect()
     torch.cuda.empty_cache()
     res, codes = _launch_once(target, tag, port)
-    if not res and any(c is not None and c < 0 for c in codes):
-        print("replicas %s ended by signal %s before reporting: starting them once more" % (tag, codes))
+    import signal
+    # only an external SIGKILL is retried: SIGSEGV / SIGABRT (how a GPU memory fault ends a process) is a native crash of
+    # ours and must fail the test
+    if not res and any(c == -signal.SIGKILL for c in codes) and all(c in (None, 0, -signal.SIGKILL) for c in codes):
+        print("replicas %s ended by SIGKILL %s before reporting: starting them once more" % (tag, codes))
         res, codes = _launch_once(target, tag, port + 11)
     assert [r[0] for r in res] == [0, 1], "replica exit codes %s, reported %s" % (codes, res)
     for r in res:

@@ -181,3 +181,11 @@ def test_random_bl_aug(golden):
     out = O.random_bl_aug(g["x"], T[g["idx"].long()])
     assert maxabs(out, g["out"]) < 2e-6
     assert maxabs(O.project_to_2d(g["out"], g["cam"]), g["proj"]) < 1e-6
+
+
+def test_fk_op_by_op_variant_is_bit_identical(golden):
+    """the reference-granularity FK restatement (bench.py's cpu_baseline_faithful) gives exactly the batched restatement's
+    values -- and therefore the reference's (fk_N1024 golden)"""
+    g = golden("fk_N1024")
+    out = O.fk_forward32_op_by_op(g["angles"], g["bone_len"], g["root"].reshape(-1, 3))
+    assert maxabs(out, g["out32"]) == 0.0
