@@ -59,12 +59,6 @@ def critic_step_flops(mac, mac_first, mac_out, rows):
     return 2.0 * rows * (3 * mac + 3 * (mac - mac_first) + mac_first + (mac - mac_out) + 3 * mac)
 
 
-def autograd_critic_step_flops(mac, rows):
-    """a critic stepped through autograd: forward + backward (x2) on real and fake, penalty forward + input backward +
-    double backward (~6 forward equivalents): 12 forward equivalents"""
-    return 2.0 * rows * 12 * mac
-
-
 def critic_step_bytes(widths, rows, in_cols):
     """ALGORITHMIC HBM bytes of one explicit critic step: every layer output y (bf16) is written once by the forward sweep and
     read once by its weight-gradient contraction, every cotangent gz (bf16) is written once by the backward sweep and read
@@ -398,6 +392,19 @@ def main():
                     extra[name + "_c_abi_calls_per_step"] = ce
                 except Exception as ex:              # never lose the headline line to an optional measurement
                     extra[name + "_error"] = repr(ex)[:200]
+        if "gan_step_ms_per_step" in extra and world == 1:
+            # the training step in the arithmetic the loop goldens pass in (bf16x6: six MFMA terms per product, fp32
+            # activations, layer by layer; tests/test_gpu_loops.py), eager
+            try:
+                set_precision("bf16x6")
+                it6 = lambda: T.gan_iteration(args, models, real_cam, cam_param, real_2d, ["S1"], summary=None, writer=None,
+                                              do_g_step=False, camera=(quat, trans, cam9))
+                t6, _ = timed(it6, 3, 1)
+                extra["gan_step_parity_ms_per_step"] = t6 / 3 * 1e3
+                extra["gan_step_parity_note"] = "bf16x6 critics + generator, critic steps only (no G step in these 3 iterations)"
+            except Exception as ex:
+                extra["gan_step_parity_error"] = repr(ex)[:200]
+            set_precision("bf16")
         set_precision(main_prec)
     out["extra"] = extra
 
@@ -414,20 +421,52 @@ def main():
         dd3, dd2 = mac_per_pose(args.Dis_DenseDim_3D)[1], mac_per_pose(args.Dis_DenseDim_2D)[2]
         gmac = mac_per_pose(args.Gen_DenseDim, R)[0]
         d3_first, d2_first = 78 * args.Dis_DenseDim_3D, 32 * args.Dis_DenseDim_2D
+        # the motion critics take the explicit four-sweep schedule too (critic_step.step_m3 / step_m2): input layers only on
+        # the B interpolated clips in the backward chain
+        m3_first, m2_first = (R * 15 + (R - 1) * 15 + R * 48 + (R - 1) * 48) * D, (R * 32 + (R - 1) * 2) * D
         per_it = (2 * critic_step_flops(dd3, d3_first, 100, N) + 2 * critic_step_flops(dd2, d2_first, args.Dis_DenseDim_2D, N)
-                  + 4 * autograd_critic_step_flops(m3, B) + 4 * autograd_critic_step_flops(m2, B) + 2.0 * gmac * N
+                  + 4 * critic_step_flops(m3, m3_first, 100, B) + 4 * critic_step_flops(m2, m2_first, 100, B) + 2.0 * gmac * N
                   + 0.2 * (3 * 2.0 * ((gmac + dd3 + dd2) * N + 2 * (m3 + m2) * B) + 2.0 * ((dd3 + dd2) * N + 2 * (m3 + m2) * B)))
         flops = per_it
     else:
         flops = {"fk": 2.5e3 * N, "fk_gen_fwd": 2.0 * gen_mac * N, "fwd": 2.0 * (gen_mac + d3_mac + d2_mac) * N}[a.workload]
     out["algorithmic_tflops"] = flops * world * a.steps / t / 1e12
     out["algorithmic_flop_per_step_per_gpu"] = flops
-    if training:
-        out["roofline_step"] = {"bound": "mfma", "achieved": flops * a.steps / t / 1e12 if world == 1 else flops * a.steps / t / 1e12,
-                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": flops * a.steps / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                                "note": "whole iteration (per GPU), FLOPs from the layer shapes; layer-by-layer GEMMs are HBM-bound "
-                                        "(see roofline_layer), the iteration's floor is launch gaps + HBM, not the matrix pipe"}
+    if video:
+        out["roofline_step"] = {"bound": "mfma", "achieved": flops * a.steps / t / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": flops * a.steps / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_step_traffic("video"),
+                                "traffic_source": pmc_stamp(),
+                                "note": "whole video iteration (per GPU), FLOPs from the layer shapes (explicit schedule for all four critics)"}
+    else:
+        # the single-frame training step (configs[2]): HBM-bound layer sweeps.  From the timed workload if that is gan_step,
+        # else from the extra measurement of the same run.
+        ts = (t / a.steps) if a.workload == "gan_step" else (extra.get("gan_step_ms_per_step", 0.0) * 1e-3)
+        if ts > 0:
+            d3_first, d2_first = 78 * D, 32 * D
+            fl_it = (2 * critic_step_flops(d3_mac, d3_first, 100, B) + 2 * critic_step_flops(d2_mac, d2_first, D, B) + 2.0 * gen_mac * B
+                     + 0.2 * (3 * 2.0 * (gen_mac + d3_mac + d2_mac) * B + 2.0 * (d3_mac + d2_mac) * B))
+            by_it = step_algorithmic_bytes(D, B)
+            tr = pmc_step_traffic("step") if (B, D) == (65536, 256) else None
+            out["roofline_step"] = {"kernel": "one single-frame GAN iteration: 2 + 2 explicit critic steps, sampling pass, G step every 5th",
+                                    "bound": "hbm", "achieved": by_it / ts / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": by_it / ts / 1e9 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": pmc_stamp(),
+                                    "traffic_over_algorithmic": (tr / by_it) if tr else None,
+                                    "algorithmic_bytes_per_iteration": by_it, "ms_per_iteration": ts * 1e3,
+                                    "poses_per_s": N * world / ts, "tflops": fl_it / ts / 1e12,
+                                    "mfma_frac": fl_it / ts / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                    "note": "algorithmic bytes: every activation / cotangent written once and read once by its "
+                                            "weight-gradient contraction (critic_step_bytes); per GPU"}
+    if world > 1 and "gan_step_ms_per_step" in extra:
+        # N > 1: the forward workloads have no exchange step, so the scaled quantity with the all-reduce in it is printed too
+        out["value_gan_step"] = extra["gan_step_poses_per_s"]
+        out["gan_step_ms_per_step_max_over_ranks"] = extra["gan_step_ms_per_step"]
+        ar = {r["bytes"]: r["us"] for r in out.get("allreduce_alone", {}).get("sizes", [])} if isinstance(out.get("allreduce_alone"), dict) else {}
+        if ar:
+            near = lambda nb: ar[min(ar, key=lambda k: abs(k - nb))]
+            per_opt = {k: near(v) for k, v in bucket_bytes.items()}
+            out["allreduce_us_per_optimizer_step"] = per_opt
+            comm = 2 * per_opt.get("d3d", 0.0) + 2 * per_opt.get("d2d", 0.0) + 0.2 * per_opt.get("G", 0.0)
+            out["allreduce_share_of_gan_step_upper_bound"] = comm * 1e-3 / extra["gan_step_ms_per_step"]
 
     if rank == 0 and not a.no_roofline and not video:
         from dhaug_amd import fused
@@ -479,14 +518,16 @@ def main():
                 cpu = cpu_baseline_video(D, R, sd(G), sd(D3), sd(D2), sd(models["model_motion_d3d"]), sd(models["model_motion_d2d"]),
                                          quat, trans, cam9)
             else:
-                cpu = cpu_baseline(a.workload, D, sd(G), sd(D3), sd(D2), quat, trans, cam9)
+                cpu = cpu_baseline(a.workload, D, sd(G), sd(D3), sd(D2), quat, trans, cam9, Bs=B)
+                out["cpu_baseline_faithful"] = cpu_baseline(a.workload, D, sd(G), sd(D3), sd(D2), quat, trans, cam9, faithful=True,
+                                                            Bs=B, seconds=10.0)
         out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 
 def pmc_stamp():
@@ -498,6 +539,16 @@ def pmc_stamp():
     return {"file": "profiles/%s_pmc_*_summary.csv" % PROFILE_TAG,
             "collected": open(stamp).read().strip() if os.path.exists(stamp) else "unknown",
             "note": "rocprofv3 --pmc passes of tools/collect_profiles.sh, not this run"}
+
+
+def pmc_step_traffic(tag):
+    """HBM bytes per ITERATION of a training workload (tag 'step' / 'video'): sum over all kernels of the committed
+    FETCH_SIZE x 2 + WRITE_SIZE passes of tools/collect_profiles.sh (profiles/<tag>_pmc_<step|video>_totals.json)."""
+    path = os.path.join(ROOT, "profiles", "%s_pmc_%s_totals.json" % (PROFILE_TAG, tag))
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    return d.get("hbm_bytes_per_iteration")
 
 
 def pmc_traffic(kernel_substr, prefix=""):
@@ -531,7 +582,7 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def _time_cpu(one, poses_per_call, seconds=12.0, note=""):
+def _time_cpu(one, poses_per_call, seconds=12.0, note="", kind="port"):
     import torch
     cores = usable_cores()
     torch.set_num_threads(cores)
@@ -541,15 +592,18 @@ def _time_cpu(one, poses_per_call, seconds=12.0, note=""):
         one()
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": poses_per_call * n / dt, "unit": "poses/s", "cores": cores, "kind": "port",
+    return {"value": poses_per_call * n / dt, "unit": "poses/s", "cores": cores, "kind": kind,
             "sample": "%d batches of %d poses, fp32 torch-CPU oracle, %.1f s %s" % (n, poses_per_call, dt, note)}
 
 
-def cpu_baseline(workload, D, sdG, sd3, sd2, quat, trans, cam9):
-    """The oracle (CPU restatement, 'port') timed on this box's host cores on a bounded sample of the workload."""
+def cpu_baseline(workload, D, sdG, sd3, sd2, quat, trans, cam9, faithful=False, Bs=65536, seconds=12.0):
+    """The oracle (CPU restatement, 'port') timed on this box's host cores on a bounded sample of the workload, at the
+    benchmark's own batch size.  faithful=True: the same arithmetic with the FK issued at the reference's op granularity
+    (oracle.fk_forward32_op_by_op: 33 per-joint matrix builds with slice writes, 46 sequential bmm on cloned operands,
+    per-coordinate scatters -- SURVEY.md section 8d) instead of the batched restatement: the ratio of the two is what
+    op fusion alone buys on the CPU; the rest of the GPU / CPU ratio is hardware."""
     import torch
     from oracle import dhaug_oracle as O
-    Bs = 4096
     g = torch.Generator().manual_seed(0)
     z = torch.randn(Bs, 128, generator=g)
     bl = torch.rand(Bs, 15, generator=g) * 0.4 + 0.1
@@ -557,24 +611,25 @@ def cpu_baseline(workload, D, sdG, sd3, sd2, quat, trans, cam9):
     q, tr, c9 = torch.tensor([quat]), torch.tensor([trans]), torch.tensor([cam9]).repeat(Bs, 1)
     ang = (torch.rand(Bs, 37, generator=g) * 2 - 1) * 180
     rt = torch.randn(Bs, 3, generator=g)
+    fk32 = O.fk_forward32_op_by_op if faithful else None
 
     def one():
         with torch.no_grad():
             if workload == "fk":
-                O.fk_forward16(ang, bl, rt)
+                (fk32 or O.fk_forward32)(ang, bl, rt)[:, O.H36M_32_TO_16]
                 return
-            fake, _, _ = O.generator_forward(z, sdG, bl, sc)
+            fake, _, _ = O.generator_forward(z, sdG, bl, sc, fk32=fk32)
             if workload == "fk_gen_fwd":
                 return
             fw = fake.reshape(-1, 16, 3)
             O.d3_forward(fw - fw[:, :1], sd3)
             O.d2_forward(O.project_to_2d(O.world_to_camera(fw, q, tr), c9), sd2)
 
-    note = ""
+    note = "(reference-faithful op-by-op FK)" if faithful else "(batched restatement)"
     if workload == "gan_step":
         workload = "fwd"
-        note = "forward part only (FK+Gen+D3+D2); the oracle's full step is timed in tests at small batch"
-    return _time_cpu(one, Bs, note=note)
+        note += " forward part only (FK+Gen+D3+D2); the oracle's full step is timed in tests at small batch"
+    return _time_cpu(one, Bs, seconds=seconds, note=note)
 
 
 def cpu_baseline_video(D, R, sdG, sd3, sd2, sdm3, sdm2, quat, trans, cam9):

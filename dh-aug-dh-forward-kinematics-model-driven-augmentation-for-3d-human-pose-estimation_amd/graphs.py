@@ -67,13 +67,16 @@ class GraphedGanIteration:
         self.fn, self.args, self.d, self.subj, self.summary = iteration_fn, args, poseFk_dict, train_subjects, summary
         self.graphs = {}
 
-    def __call__(self, inputs_3d, cam_param, inputs_2d, do_g_step, camera):
+    def __call__(self, inputs_3d, cam_param, inputs_2d, do_g_step, camera, draws=None):
+        """draws: None (the iteration draws on the device: graph-safe generator), or a ConstDraws whose DEVICE tensors are
+        baked into the graph (it must outlive the graph and keep its values)."""
         key = (bool(do_g_step), tuple(camera[0]), tuple(camera[1]), tuple(camera[2]),
-               tuple(inputs_3d.shape), tuple(cam_param.shape), tuple(inputs_2d.shape))
+               tuple(inputs_3d.shape), tuple(cam_param.shape), tuple(inputs_2d.shape), id(draws))
         g = self.graphs.get(key)
         if g is None:
             def run(x3, cp, x2):
-                return self.fn(self.args, self.d, x3, cp, x2, self.subj, self.summary, None, do_g_step=do_g_step, camera=camera)
+                return self.fn(self.args, self.d, x3, cp, x2, self.subj, self.summary, None, do_g_step=do_g_step, camera=camera,
+                               draws=draws)
             # first thing in the graph: every network's bf16 operand copies, two launches per network (the lazy per-layer
             # packing would put ~50 small kernels there)
             opts = [v for k, v in self.d.items() if k.startswith("optimizer")]

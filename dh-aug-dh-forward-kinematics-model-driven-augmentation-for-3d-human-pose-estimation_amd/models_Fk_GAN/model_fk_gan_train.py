@@ -238,6 +238,15 @@ class Draws:
         return q.pop(0).to(device) if q else None
 
 
+class ConstDraws(Draws):
+    """the same device tensors at every take: a captured hipGraph bakes its draws in, so an eager run that is to be compared
+    with graph replays must see constant draws too (tests/test_gpu_graphs.py)"""
+
+    def take(self, kind, device):
+        q = self.q[kind]
+        return q[0].to(device) if q else None
+
+
 def generator_step(args, G, oG, critics, weights, camera, flip, noise=None, scaler=None, frames=1, playback=False):
     """The G step of both epoch loops (R/models_Fk_GAN/model_fk_gan_train.py:415-484, R/models_Fk_GAN/video_GAN_fun.py:421-566).
     critics = (D3, D2) or (D3, D2, M3, M2), weights the matching loss weights.  Flipped copies contribute their value

@@ -1,0 +1,101 @@
+"""GPU: the hipGraph path of the training iteration (dhaug_amd/graphs.py) against the eager path it replaces in bench.py.
+
+N iterations eager and N iterations as captured graphs, from identical weights, identical inputs and constant draws
+(ConstDraws: a graph bakes its draws in): same weights, same Adam state, same step counts, same scalars.  What differs
+between the two paths and is therefore under test: the in-capture weight re-pack (optimizer prologue + FusedNet in-place
+re-pack), the device-side Adam step count, the static input buffers, and that BUILDING a graph (two warm-up calls + the
+capture) advances nothing."""
+import argparse
+
+import pytest
+import torch
+
+import golden_util as GU
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import dhaug_amd
+    dhaug_amd._lib.lib()
+    from dhaug_amd import graphs
+    from dhaug_amd.common.camera import camera_params9
+    from dhaug_amd.common.h36m_dataset import h36m_cameras_extrinsic_params, h36m_cameras_intrinsic_params
+    from dhaug_amd.models_Fk_GAN import forward_kinematics_DH_model as fkm, model_fk_gan_train as train
+    ext = h36m_cameras_extrinsic_params["S1"][0]
+    cam = ([float(v) for v in ext["orientation"]], [float(v) / 1000.0 for v in ext["translation"]],
+           camera_params9(h36m_cameras_intrinsic_params[0]))
+    return argparse.Namespace(graphs=graphs, fkm=fkm, train=train, cam=cam)
+
+
+def _build(M, args, D):
+    fk = M.fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+    d = M.train.my_get_poseFk_model(args, None, fk)
+    for key, shapes, seed in (("model_G", GU.shapes_generator(D), 11), ("model_d3d", GU.shapes_d3(D), 12), ("model_d2d", GU.shapes_d2(D), 13)):
+        sd = GU.seeded_state_dict(shapes, seed)
+        with torch.no_grad():
+            for k, p in d[key].named_parameters():
+                p.copy_(sd[k].cuda())                       # in place: the parameters stay views of the optimizer's flat buffer
+    from dhaug_amd import autograd_ops as A
+    A.bump_weight_epoch()
+    return d
+
+
+@pytest.mark.parametrize("B,D", [(96, 64), (2048, 256)])
+def test_graphed_iterations_equal_eager(M, B, D):
+    from test_gpu_models import make_args
+    args = make_args(batch_size=B, Gen_DenseDim=D, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D)
+    gen = torch.Generator().manual_seed(5)
+    x3 = GU.synth_pose16(B, seed=3).cuda()
+    x3 = x3 + torch.tensor([0.0, 0.0, 4.5], device="cuda")                       # camera space: in front of the camera
+    x2 = ((torch.rand(B, 16, 2, generator=gen) - 0.5) * 1.2).cuda()
+    cp = torch.zeros(B, 16, device="cuda")
+    cp[:, 9:13] = torch.tensor(M.cam[0], device="cuda")
+    cp[:, 13:16] = torch.tensor(M.cam[1], device="cuda")
+    mk = lambda: M.train.ConstDraws(noise=[torch.randn(B, 128, generator=torch.Generator().manual_seed(1)).cuda()],
+                                    scaler=[(torch.randint(-200, 200, (B, 8), generator=torch.Generator().manual_seed(2)) / 1000.0).cuda()],
+                                    alpha=[torch.rand(B, 1, generator=torch.Generator().manual_seed(3)).cuda()])
+    # five iterations, the G step at the end of the fifth: the critics' ten steps each are deterministic kernels (graph and
+    # eager must agree to the last bit or two); the G step's short / ragged weight-gradient shapes still add with fp32 atomics,
+    # and Adam's g / (|g| + eps) turns a last-bit difference of a near-zero gradient into a visible one -- so nothing that
+    # DEPENDS on the stepped generator is compared (a sixth iteration would be)
+    N = 5
+    # ---- eager
+    de = _build(M, args, D)
+    dr = mk()
+    eager = []
+    for i in range(N):
+        r = M.train.gan_iteration(args, de, x3, cp, x2, ["S1"], None, None, do_g_step=(i % 5 == 4), camera=M.cam, draws=dr)
+        eager.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in r.items()})
+    # ---- graphs (two graphs: with / without the G step); building one must not advance anything
+    dg = _build(M, args, D)
+    dr2 = mk()
+    G = M.graphs.GraphedGanIteration(M.train.gan_iteration, args, dg, ["S1"], None)
+    for i in range(N):
+        r = G(x3, cp, x2, i % 5 == 4, M.cam, draws=dr2)
+        e = eager[i]
+        for k in ("Wasserstein_D_3D", "D_cost_3D", "Wasserstein_D_2D", "D_cost_2D", "G_cost"):
+            if e[k] is None:
+                assert r[k] is None
+                continue
+            assert abs(r[k].item() - e[k].item()) <= 1e-4 * max(1.0, abs(e[k].item())), (i, k, r[k].item(), e[k].item())
+        assert (r["pos_3d_cam"] - e["pos_3d_cam"]).abs().max().item() <= 1e-5
+    assert len(G.graphs) == 2
+    steps = {"optimizer_G": 1, "optimizer_d3d": 2 * N, "optimizer_d2d": 2 * N}
+    for ok, n in steps.items():
+        assert int(dg[ok].step_dev.item()) == n == int(de[ok].step_dev.item()), (ok, dg[ok].step_dev.item(), de[ok].step_dev.item())
+        assert dg[ok].state_dict()["dhaug_flat"]["step_count"] == n
+        for name in ("flat_param", "exp_avg", "exp_avg_sq"):
+            a, b = getattr(dg[ok], name), getattr(de[ok], name)
+            scale = b.abs().max().item()
+            tol = 2e-5 if (ok == "optimizer_G" or B < 2048) else 1e-7       # (B < 2048: the critics' short-batch contractions use atomics too)
+            assert (a - b).abs().max().item() <= tol * scale + 1e-12, (ok, name, (a - b).abs().max().item(), scale)
+    for mk_, mo in (("model_G", "optimizer_G"), ("model_d3d", "optimizer_d3d"), ("model_d2d", "optimizer_d2d")):
+        sg, se = dg[mk_].state_dict(), de[mk_].state_dict()
+        assert sg.keys() == se.keys()
+        for k in sg:
+            tol = 2e-5 if (mk_ == "model_G" or B < 2048) else 1e-7
+            assert (sg[k] - se[k]).abs().max().item() <= tol * se[k].abs().max().item() + 1e-12, (mk_, k)

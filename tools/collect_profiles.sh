@@ -4,7 +4,7 @@
 # SQ_VALU_MFMA_BUSY_CYCLES), reduced to the small summaries that are committed under profiles/ (copy
 # gpurun_out/profiles/* there afterwards; <round>_STAMP.txt holds the collection time bench.py quotes as traffic_source).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT || exit 1
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/profiles
 mkdir -p $O
 B="python bench.py --no-cpu-baseline --no-extra --no-roofline --prewarm 0"
@@ -31,12 +31,29 @@ for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   pmc d3p $c python tools/prof_fused_d3.py f16x3 || exit 1
 done
 for c in FETCH_SIZE WRITE_SIZE; do pmc fk $c python tools/prof_fk.py || exit 1; done
+# training workloads (configs[2] and configs[4]): 5 eager iterations each (3 timed + 2 warm-up: exactly one of them runs the
+# G step, the steady-state mix), every dispatch counted
+for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
+  pmc step $c $B --workload gan_step --steps 3 --warmup 2 --graph off || exit 1
+  pmc video $c $B --workload video --steps 3 --warmup 2 --graph off || exit 1
+done
 python - <<PY
 import csv, collections, glob
 def rows(tag, c):
     f = glob.glob("gpurun_out/pmc_%s_%s/**/*counter_collection.csv" % (tag, c), recursive=True)
     return [r for r in csv.DictReader(open(f[0])) if r["Counter_Name"] == c] if f else []
-for tag, name in (("fwd", ""), ("d3", "d3_"), ("d3p", "d3_parity_"), ("fk", "fk_")):
+import json
+for tag in ("step", "video"):
+    # whole-iteration totals: HBM bytes = FETCH_SIZE x 2 (gfx950: wide coalesced reads are tallied at half their bytes,
+    # MI355X_MICROARCH.md) + WRITE_SIZE, both in KiB; 5 iterations were run
+    f, w, m = rows(tag, "FETCH_SIZE"), rows(tag, "WRITE_SIZE"), rows(tag, "SQ_VALU_MFMA_BUSY_CYCLES")
+    if f and w:
+        fb, wb = sum(float(r["Counter_Value"]) for r in f) * 1024.0, sum(float(r["Counter_Value"]) for r in w) * 1024.0
+        json.dump({"iterations": 5, "dispatches": len(f), "fetch_bytes_per_iteration_x2": 2 * fb / 5, "write_bytes_per_iteration": wb / 5,
+                   "hbm_bytes_per_iteration": (2 * fb + wb) / 5,
+                   "mfma_busy_cycles_per_iteration": (sum(float(r["Counter_Value"]) for r in m) / 5) if m else None},
+                  open("$O/${R}_pmc_%s_totals.json" % tag, "w"), indent=1)
+for tag, name in (("fwd", ""), ("d3", "d3_"), ("d3p", "d3_parity_"), ("fk", "fk_"), ("step", "step_"), ("video", "video_")):
     for c, short in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write"), ("SQ_VALU_MFMA_BUSY_CYCLES", "mfma")):
         acc = collections.defaultdict(list)
         for r in rows(tag, c):
