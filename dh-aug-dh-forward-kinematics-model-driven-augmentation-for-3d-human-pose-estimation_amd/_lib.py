@@ -49,6 +49,8 @@ SIGNATURES = {
     "dhaug_gp_penalty": [_vp, _vp, _vp, _i64, _i64, _f32, _vp],
     "dhaug_critic_scalars": [_vp, _i64, _vp, _i64, _i64, _f32, _vp, _vp],
     "dhaug_add_f32": [_vp, _vp, _vp, _i64, _vp],
+    "dhaug_frame_reverse": [_vp, _vp, _i64, _i32, _i32, _vp],
+    "dhaug_weighted_means": [ctypes.POINTER(_vp), ctypes.POINTER(_i64), ctypes.POINTER(_f32), _i32, _vp, _vp],
 }
 
 class MlpUnit(ctypes.Structure):

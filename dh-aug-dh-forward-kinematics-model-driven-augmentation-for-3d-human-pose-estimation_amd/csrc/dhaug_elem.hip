@@ -325,6 +325,53 @@ __global__ __launch_bounds__(1024) void critic_scalars_kernel(const float* __res
     }
 }
 
+// out[r][f][:] = x[r][R-1-f][:] for clips (rows, R*w): its own inverse and its own transpose
+__global__ __launch_bounds__(256) void frame_reverse_kernel(const float* __restrict__ x, float* __restrict__ out, long long rows,
+                                                            int R, int w) {
+    const long long total = rows * (long long)R * w;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long row = i / ((long long)R * w);
+        const int rem = (int)(i - row * R * w), f = rem / w, c = rem - f * w;
+        out[i] = x[row * R * w + (long long)(R - 1 - f) * w + c];
+    }
+}
+
+// out[0] = sum_i weight_i * mean(x_i[0 .. n_i)): the generator loss from the critics' logits (one workgroup; the arrays are
+// read with several requests in flight per thread)
+struct WMeans {
+    int n;
+    const float* x[DHAUG_WEIGHTED_MEANS_MAX];
+    long long count[DHAUG_WEIGHTED_MEANS_MAX];
+    float weight[DHAUG_WEIGHTED_MEANS_MAX];
+};
+__global__ __launch_bounds__(1024) void weighted_means_kernel(WMeans a, float* __restrict__ out) {
+    __shared__ float red[16];
+    float total = 0.f;
+    for (int i = 0; i < a.n; ++i) {
+        const float* x = a.x[i];
+        const long long n = a.count[i];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        long long j = threadIdx.x;
+        for (; j + 3 * 1024 < n; j += 4 * 1024) {
+            const float v0 = x[j], v1 = x[j + 1024], v2 = x[j + 2048], v3 = x[j + 3072];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        }
+        for (; j < n; j += 1024) s0 += x[j];
+        float s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int w = 0; w < 16; ++w) t += red[w];
+            total += a.weight[i] * (t / (float)n);
+        }
+    }
+    if (threadIdx.x == 0) out[0] = total;
+}
+
 }  // namespace
 
 template <typename T>
@@ -454,6 +501,29 @@ int dhaug_frame_diff(const float* x, float* out, int64_t rows, int R, int in_w, 
     const long long total = adjoint ? rows * (long long)R * in_w : rows * (long long)(R - 1) * w;
     hipLaunchKernelGGL(frame_diff_kernel, dim3(grid1d(total, 256)), dim3(256), 0, (hipStream_t)stream, x, out, (long long)rows, R,
                        in_w, w, adjoint);
+    return dhaug_launch_status();
+}
+
+int dhaug_frame_reverse(const float* x, float* out, int64_t rows, int R, int w, void* stream) {
+    DHAUG_CHECK(rows >= 0 && R >= 1 && w >= 1, DHAUG_EINVAL);
+    if (rows == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(x); DHAUG_CHECK_PTR(out);
+    DHAUG_CHECK(x != out, DHAUG_EINVAL);
+    hipLaunchKernelGGL(frame_reverse_kernel, dim3(grid1d(rows * (long long)R * w, 256)), dim3(256), 0, (hipStream_t)stream, x, out,
+                       (long long)rows, R, w);
+    return dhaug_launch_status();
+}
+
+int dhaug_weighted_means(const float* const* arrays, const int64_t* counts, const float* weights, int n, float* out, void* stream) {
+    DHAUG_CHECK(n >= 1 && n <= DHAUG_WEIGHTED_MEANS_MAX, DHAUG_EINVAL);
+    DHAUG_CHECK_PTR(arrays); DHAUG_CHECK_PTR(counts); DHAUG_CHECK_PTR(weights); DHAUG_CHECK_PTR(out);
+    WMeans a;
+    a.n = n;
+    for (int i = 0; i < n; ++i) {
+        DHAUG_CHECK(arrays[i] != nullptr && counts[i] >= 1, DHAUG_EINVAL);
+        a.x[i] = arrays[i]; a.count[i] = counts[i]; a.weight[i] = weights[i];
+    }
+    hipLaunchKernelGGL(weighted_means_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, out);
     return dhaug_launch_status();
 }
 

@@ -14,6 +14,7 @@ import torch
 
 from .. import autograd_ops as A
 from .. import critic_step
+from .. import gen_step
 from .. import ops
 from ..common import camera as cam
 from ..common.h36m_dataset import h36m_cameras_extrinsic_params, h36m_cameras_intrinsic_params
@@ -107,6 +108,7 @@ class MeanFn(torch.autograd.Function):
 
 
 ANALYTIC_CRITIC_STEP = os.environ.get("DHAUG_NO_ANALYTIC_STEP") is None
+EXPLICIT_G_STEP = os.environ.get("DHAUG_NO_EXPLICIT_G_STEP") is None
 
 
 def train_Fk_discriminator(model_dis, data_real, data_fake, summary, writer, writer_name, optimizerD, args,
@@ -253,12 +255,17 @@ def generator_step(args, G, oG, critics, weights, camera, flip, noise=None, scal
     but no gradient (.detach().clone() in the reference).  Returns G_cost = -gen_loss (0-dim device tensor)."""
     device = _device()
     quat, trans, cam9 = camera
+    if noise is None:
+        noise = torch.randn(args.batch_size, 128, device=device)
+    if EXPLICIT_G_STEP and gen_step.supported(G, oG, critics):
+        # explicit schedule (gen_step.py): forward with kept activations, one input-gradient chain per critic, the FK tail's
+        # reverse mode, the trunk's backward chain + grouped weight-gradient launch -- no autograd graph
+        with torch.no_grad():
+            return gen_step.generator_step(args, G, oG, critics, weights, camera, flip, noise.to(device), scaler, frames, playback)
     set_grad(critics, False)
     set_grad([G], True)
     G.zero_grad()
     oG.zero_grad()
-    if noise is None:
-        noise = torch.randn(args.batch_size, 128, device=device)
     fw = G(noise, bone_len_scaler=scaler).reshape(-1, 16, 3)
     _, f2d = A.W2CProjectFn.apply(fw, tuple(quat), tuple(trans), tuple(cam9))
     fc = A.center_flip(fw, True, False)

@@ -442,3 +442,26 @@ def frame_diff(x, R, in_w, w=None, adjoint=False):
     out = torch.empty((rows, R * in_w if adjoint else (R - 1) * w), dtype=torch.float32, device=v.device)
     _lib.call("dhaug_frame_diff", _p(v), _p(out), rows, R, in_w, w, int(bool(adjoint)), _stream())
     return out
+
+
+def frame_reverse(x, R, w):
+    """clips (rows, R*w) -> the frames of every clip in reverse order (its own transpose: also the backward map)"""
+    v = _dev(x, torch.float32, "frame_reverse")
+    rows = v.shape[0]
+    assert v.shape[1] == R * w
+    out = torch.empty_like(v)
+    _lib.call("dhaug_frame_reverse", _p(v), _p(out), rows, R, w, _stream())
+    return out
+
+
+def weighted_means(arrays, weights):
+    """0-dim fp32 tensor sum_i weights[i] * mean(arrays[i]) (fp32 device tensors, contiguous), one launch"""
+    n = len(arrays)
+    assert 1 <= n <= 16 and len(weights) == n
+    arrs = [_dev(a, torch.float32, "weighted_means").reshape(-1) for a in arrays]
+    out = torch.empty((1,), dtype=torch.float32, device=arrs[0].device)
+    P = (_vp * n)(*[a.data_ptr() for a in arrs])
+    C = (ctypes.c_int64 * n)(*[a.numel() for a in arrs])
+    W = (ctypes.c_float * n)(*[float(w) for w in weights])
+    _lib.call("dhaug_weighted_means", P, C, W, n, _p(out), _stream())
+    return out.reshape(())

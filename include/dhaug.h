@@ -404,6 +404,16 @@ int dhaug_gp_penalty(const float* grad, float* v, float* pen, int64_t B, int64_t
  * adjoint != 0: the transposed map, x (rows, (R-1)*w) -> out (rows, R*in_w) (zero for columns >= w). */
 int dhaug_frame_diff(const float* x, float* out, int64_t rows, int R, int in_w, int w, int adjoint, void* stream);
 
+/* Frame reversal of clips, x (rows, R*w) -> out[r][f][:] = x[r][R-1-f][:] (torch.flip(dims=[1]) of the video loop's playback
+ * copies, R/models_Fk_GAN/video_GAN_fun.py:467,521); the map is its own transpose, so the same call back-propagates. */
+int dhaug_frame_reverse(const float* x, float* out, int64_t rows, int R, int w, void* stream);
+
+/* out[0] = sum_i weights[i] * mean(arrays[i][0 .. counts[i])): the generator loss gen_loss (or -gen_loss) from the critics'
+ * logit arrays in one launch (R/models_Fk_GAN/model_fk_gan_train.py:470-476).  arrays / counts / weights: HOST arrays of
+ * n <= DHAUG_WEIGHTED_MEANS_MAX entries (read during the call); the logit arrays and out are device memory. */
+#define DHAUG_WEIGHTED_MEANS_MAX 16
+int dhaug_weighted_means(const float* const* arrays, const int64_t* counts, const float* weights, int n, float* out, void* stream);
+
 /* out5 = { D_real, D_fake, GP = lambda * mean(pen), Wasserstein_D = D_real - D_fake, D_cost = D_fake - D_real + GP } from
  * the logits (rows [0,B) real, [B,2B) fake, stride ld) and the P per-row penalties (P = B, or B * frames for the 2D motion
  * critic, whose penalty is taken per frame). */
