@@ -64,3 +64,31 @@ def shapes_d2(D):
         s[n + ".weight"] = (D, D); s[n + ".bias"] = (D,)
     s["layer_pred.weight"] = (1, D); s["layer_pred.bias"] = (1,)
     return s
+
+
+# ---- compact fixtures of large tensors (critic_step_*_D256: 0.9 M parameters per critic) -----------------------------------
+def compact(t, seed, max_full=8192, samples=4096, nproj=32):
+    """what a fixture keeps of a large tensor: every (numel // samples)-th element and nproj seeded +-1 projections (a wrong
+    gradient moves them with overwhelming probability); small tensors are kept whole.  Deterministic in (shape, seed)."""
+    import torch
+    f = t.detach().double().reshape(-1).cpu()
+    if f.numel() <= max_full:
+        return dict(full=f.float())
+    stride = f.numel() // samples
+    g = torch.Generator().manual_seed(1000003 * seed + f.numel())
+    signs = torch.randint(0, 2, (nproj, f.numel()), generator=g, dtype=torch.int8).double() * 2 - 1
+    return dict(sample=f[::stride].float(), proj=(signs @ f))
+
+
+def compact_close(t, ref, seed, atol, rtol, name=""):
+    """t against the compact record `ref` of the reference's tensor: sampled elements within atol + rtol * max|ref|, projections
+    within the same per-element bound times sqrt(numel) (independent roundings add in quadrature; x4 margin)"""
+    got = compact(t, seed)
+    if "full" in ref:
+        scale = ref["full"].abs().max().item()
+        assert (got["full"].double() - ref["full"].double()).abs().max().item() <= atol + rtol * scale, name
+        return
+    scale = ref["sample"].abs().max().item()
+    assert (got["sample"].double() - ref["sample"].double()).abs().max().item() <= atol + rtol * scale, name
+    n = t.numel()
+    assert (got["proj"] - ref["proj"].double()).abs().max().item() <= 4.0 * (atol + rtol * scale) * n ** 0.5, name

@@ -106,6 +106,44 @@ def test_explicit_step_equals_autograd_and_oracle(M, tag, D, B):
     assert gb[last].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("tag", ["d3", "d2"])
+def test_explicit_step_vs_reference_at_dense_dim_256(M, golden, tag):
+    """ONE critic step at the benchmark's width against the reference's own train_Fk_discriminator (fixtures
+    critic_step_{d3,d2}_D256 captured by tests/golden/make_golden_d256.py: scalars, every gradient, the Adam update) -- the
+    explicit schedule in the fp32-grade arithmetic; then the throughput arithmetic (bf16) for direction."""
+    g = golden("critic_step_%s_D256" % tag)
+    B, D = g["real"].shape[0], 256
+    args = _args(B, D)
+    shapes = GU.shapes_d3(D) if tag == "d3" else GU.shapes_d2(D)
+    sd = GU.seeded_state_dict(shapes, int(g["weight_seed"]))
+    rec = lambda kind, k: {part: g["%s__%s__%s" % (kind, part, k)] for part in ("full", "sample", "proj")
+                           if "%s__%s__%s" % (kind, part, k) in g}
+    data = (g["real"], g["fake"], g["alpha"])
+    W, C, grads, params = _run(M, tag, args, sd, "bf16x6", data, True)
+    assert abs(W - g["Wasserstein_D"].item()) <= 1e-5 and abs(C - g["D_cost"].item()) <= 1e-4 * max(1.0, abs(g["D_cost"].item()))
+    for i, k in enumerate(sd):
+        GU.compact_close(grads[k], rec("grad", k), 100 + i, 2e-6, 3e-4, k)
+        ref = rec("delta", k)
+        got = GU.compact(params[k] - sd[k], 100 + i)
+        key = "full" if "full" in ref else "sample"
+        gref = rec("grad", k)[key]
+        # Adam's first step is lr * g / (|g| + eps): compared where |g| is not within rounding of zero
+        well = gref.abs() > max(1e-3 * gref.abs().max().item(), 1e-7)
+        if well.any():
+            assert (got[key].double() - ref[key].double())[well].abs().max().item() <= 2e-6, k
+        assert (got[key].double() - ref[key].double()).abs().max().item() <= 2.01e-4, k
+    Wb, Cb, gb, _ = _run(M, tag, args, sd, "bf16", data, True)
+    assert abs(Wb - W) <= 3e-2 * max(1.0, abs(W))
+    cos = []
+    for i, k in enumerate(sd):
+        r = rec("grad", k)
+        key = "full" if "full" in r else "sample"
+        a, b = GU.compact(gb[k], 100 + i)[key].double(), r[key].double()
+        if b.abs().max() > 0:
+            cos.append(torch.nn.functional.cosine_similarity(a, b, dim=0).item())
+    assert min(cos) > 0.95, cos
+
+
 def test_gradient_penalty_dead_rows(M):
     """A row whose input gradient is exactly zero (every ReLU unit behind the merge layer dead): the reference's
     gradients.norm(2, dim=1) back-propagates 0 there (torch's norm subgradient at 0), the penalty term is (0 - 1)^2.  The

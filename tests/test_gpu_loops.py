@@ -256,3 +256,49 @@ def test_video_full_size_iteration_properties(M):
         torch.cuda.empty_cache()
     for k in res[0]:
         assert abs(res[0][k][0] - res[1][k][0]) <= 2e-3 * max(1.0, abs(res[0][k][0])), (k, res[0][k], res[1][k])
+
+
+def test_full_size_iteration_with_generator_step(M):
+    """BASELINE configs[2] end to end: ONE gan_iteration at B = 65 536, D = 256 in the throughput arithmetic INCLUDING the G
+    step (2 + 2 critic steps, sampling pass, explicit generator step): everything finite, every network moves by at most
+    its number of Adam steps x lr, and the iteration is reproducible (same seed -> same costs and same weights: no atomics
+    are left on this path at this size)."""
+    from dhaug_amd.common.camera import camera_params9
+    from dhaug_amd.common.h36m_dataset import h36m_cameras_extrinsic_params, h36m_cameras_intrinsic_params
+    from dhaug_amd import ops
+    B, D = 65536, 256
+    args = _args(batch_size=B, Gen_DenseDim=D, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D)
+    ext = h36m_cameras_extrinsic_params["S1"][0]
+    cam = ([float(v) for v in ext["orientation"]], [float(v) / 1000.0 for v in ext["translation"]],
+           camera_params9(h36m_cameras_intrinsic_params[0]))
+    g = torch.Generator().manual_seed(3)
+    ang = (torch.randn(B, 37, generator=g) * 40).clamp(-180, 180).cuda()
+    bl = (torch.rand(B, 15, generator=g) * 0.4 + 0.1).cuda()
+    world = ops.fk_forward(ang, bl, (torch.randn(B, 3, generator=g) * 0.3).cuda())
+    real_cam, real_2d = ops.world_to_camera_project(world, *cam)
+    cp = torch.zeros(B, 16, device="cuda")
+    cp[:, 9:13] = torch.tensor(cam[0], device="cuda"); cp[:, 13:16] = torch.tensor(cam[1], device="cuda")
+
+    def run():
+        torch.manual_seed(77)
+        fk = M.fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+        d = M.train.my_get_poseFk_model(args, None, fk)
+        before = {k: d[k].flat_param.clone() for k in ("optimizer_G", "optimizer_d3d", "optimizer_d2d")}
+        draws = M.train.ConstDraws(scaler=[(torch.randint(-200, 200, (B, 8), generator=torch.Generator().manual_seed(5)) / 1000.0).cuda()])
+        r = M.train.gan_iteration(args, d, real_cam, cp, real_2d, ["S1"], None, None, do_g_step=True, camera=cam, draws=draws)
+        return d, before, r
+
+    d, before, r = run()
+    for k in ("Wasserstein_D_3D", "D_cost_3D", "Wasserstein_D_2D", "D_cost_2D", "G_cost"):
+        assert torch.isfinite(r[k]).item(), k
+    assert torch.isfinite(r["pos_3d_cam"]).all() and torch.isfinite(r["pos_2d"]).all()
+    for k, steps in (("optimizer_G", 1), ("optimizer_d3d", 2), ("optimizer_d2d", 2)):
+        moved = (d[k].flat_param - before[k]).abs()
+        assert torch.isfinite(d[k].flat_param).all() and int(d[k].step_dev.item()) == steps
+        assert moved.max().item() <= steps * 1.1e-4, (k, moved.max().item())   # (Adam's 2nd step can exceed lr by a few %: m / sqrt(v) with beta 0.5 / 0.9)
+        assert (moved > 0).float().mean().item() > 0.5, k          # (the step reaches the network)
+    d2, _, r2 = run()
+    for k in ("Wasserstein_D_3D", "D_cost_3D", "Wasserstein_D_2D", "D_cost_2D", "G_cost"):
+        assert abs(r2[k].item() - r[k].item()) <= 1e-6 * max(1.0, abs(r[k].item())), k
+    for k in ("optimizer_G", "optimizer_d3d", "optimizer_d2d"):
+        assert (d2[k].flat_param - d[k].flat_param).abs().max().item() <= 1e-7, k

@@ -536,6 +536,48 @@ def test_fused_forward_vs_reference_golden(M, golden):
     assert b["s3"] <= 5e-2 and b["s2"] <= 5e-2 and b["head"] <= 5e-2 * gg["head"].abs().max().item()
 
 
+def test_bench_forward_step_sequence_vs_reference_golden(M, golden):
+    """The exact call sequence bench.py times as its forward step -- Fk_Generator.sample_for_critics (trunk + FK tail + the
+    critics' inputs in one launch) followed by score_fake_pair (both critics in one launch) -- in the parity arithmetic
+    (f16x3), on the reference's D=256 goldens with the golden seeded weights and the injected jitter draw:
+    the generated pose is the reference's (gen_D256.fake, 1e-5 m), the critics' logits on the reference's own inputs are
+    the reference's (critics_D256, 1e-4 rel), and the logits of the generated batch are the pinned oracle's."""
+    from dhaug_amd import ops
+    from dhaug_amd.common.camera import camera_params9
+    from dhaug_amd.common.h36m_dataset import h36m_cameras_extrinsic_params, h36m_cameras_intrinsic_params
+    gc, gg = golden("critics_D256"), golden("gen_D256")
+    B, D = gg["z"].shape[0], 256
+    _, G, D3, D2 = _fused_nets(M, D, B)
+    sd3 = GU.seeded_state_dict(GU.shapes_d3(D), int(gc["weight_seed3"]))
+    sd2 = GU.seeded_state_dict(GU.shapes_d2(D), int(gc["weight_seed2"]))
+    sdG = GU.seeded_state_dict(GU.shapes_generator(D), int(gg["weight_seed"]))
+    D3, D2, G = load(D3, sd3, "f16x3"), load(D2, sd2, "f16x3"), load(G, sdG, "f16x3")
+    ext = h36m_cameras_extrinsic_params["S1"][0]
+    quat, trans = [float(v) for v in ext["orientation"]], [float(v) / 1000.0 for v in ext["translation"]]
+    cam9 = camera_params9(h36m_cameras_intrinsic_params[0])
+    G.GAN_generator_get_bone_length(gg["real16"].cuda())
+    with torch.no_grad():
+        fw, xc, kcs, p2 = G.sample_for_critics(gg["z"].cuda(), (quat, trans, cam9), bone_len_scaler=gg["scaler"], inputs_bf16=False)
+        l3, l2 = M.dis.score_fake_pair(D3, D2, xc, kcs, p2)
+        # the same launch on the reference's own critic inputs
+        x3 = gc["x3"].cuda().reshape(-1, 48)
+        k3 = ops.kcs_forward(x3, True, f32=True)[0]
+        g3, g2 = M.dis.score_fake_pair(D3, D2, x3, k3, gc["x2"].cuda())
+    assert maxabs(fw.reshape(B, 48), gg["fake"]) <= 1e-5
+    assert relerr(g3, gc["logit3"]) <= 1e-4 and relerr(g2, gc["logit2"]) <= 1e-4
+    # generated batch: centring / camera / projection of the launch's OWN pose and both critics on the launch's own outputs
+    # against the oracle (fp32, same weights) -- the pose itself is pinned to the reference above; the projection divides by
+    # the camera depth of a pose whose root ranges over +-10 m, so a 1e-5 m pose difference is not a 1e-5 projection difference
+    fwc = fw.reshape(B, 16, 3).cpu()
+    q, t, c9 = torch.tensor([quat]), torch.tensor([trans]), torch.tensor([cam9]).repeat(B, 1)
+    ref2 = O.project_to_2d(O.world_to_camera(fwc, q, t), c9).reshape(B, 32)
+    assert maxabs(xc.reshape(B, 48), (fwc - fwc[:, :1]).reshape(B, 48)) <= 2e-6
+    assert ((p2.reshape(B, 32).cpu() - ref2).abs() / (1 + ref2.abs())).max().item() <= 1e-5
+    r3 = O.d3_forward(xc.reshape(B, 16, 3).cpu(), sd3)
+    r2 = O.d2_forward(p2.reshape(B, 16, 2).cpu(), sd2)
+    assert relerr(l3, r3) <= 1e-4 and relerr(l2, r2) <= 1e-4, (relerr(l3, r3), relerr(l2, r2))
+
+
 @pytest.mark.parametrize("D,B", [(64, 333), (128, 200), (256, 1000), (256, 65536)])
 def test_fused_parity_mode_ragged_and_full_size(M, D, B):
     """f16x3 programs at ragged batch sizes (tail tiles) and at BASELINE's batch against the fp32 oracle on the same

@@ -162,6 +162,25 @@ def test_gradient_penalty_and_critic_step(golden, tag):
         assert maxabs(r["new_params"][k], g["new__" + k]) <= 2e-6, k      # one Adam step, lr 1e-4
 
 
+def _ref_record(g, kind, k):
+    return {part: g["%s__%s__%s" % (kind, part, k)] for part in ("full", "sample", "proj") if "%s__%s__%s" % (kind, part, k) in g}
+
+
+@pytest.mark.parametrize("tag", ["d3", "d2"])
+def test_critic_step_at_dense_dim_256(golden, tag):
+    """the oracle's critic step against the reference's train_Fk_discriminator at the benchmark's width (compact records of
+    the 0.9 M / 0.27 M gradients: tests/golden/make_golden_d256.py)"""
+    g = golden("critic_step_%s_D256" % tag)
+    shapes = GU.shapes_d3(256) if tag == "d3" else GU.shapes_d2(256)
+    fwd = O.d3_forward if tag == "d3" else O.d2_forward
+    sd = GU.seeded_state_dict(shapes, int(g["weight_seed"]))
+    r = O.critic_step(fwd, sd, g["real"], g["fake"], g["alpha"])
+    assert abs(r["Wasserstein_D"].item() - g["Wasserstein_D"].item()) < 2e-6
+    assert abs(r["D_cost"].item() - g["D_cost"].item()) <= 1e-5 * max(1.0, abs(g["D_cost"].item()))
+    for i, k in enumerate(sd):
+        GU.compact_close(r["grads"][k], _ref_record(g, "grad", k), 100 + i, 1e-6, 2e-4, k)
+
+
 def test_camera(golden):
     g = golden("camera_128")
     Xc = O.world_to_camera(g["X"], g["R"], g["t"])
