@@ -43,6 +43,15 @@ constexpr int BUF2_BYTES = MLP_BM * BUF2_PITCH * 2;                 // 32 768
 constexpr int MLP_LDS_BYTES = 2 * BUF01_BYTES + BUF2_BYTES;         // 163 840: all of the CU's LDS
 
 enum { U_LOAD_F32 = 0, U_LOAD_BF16 = 1, U_STORE_BF16 = 2, U_GEMM = 3 };
+// The forward-with-save translation unit (the training steps' sweep 1) propagates NaN through every activation: its ReLU is
+// max(v, v * 0) in fp32 like the LeakyReLU layers' mul + max (NaN * 0 = NaN, max(NaN, NaN) = NaN), so a diverged network is
+// REPORTED by D_cost as the reference's ATen ops report it.  The inference unit keeps the integer max on the packed bf16
+// pair (v_pk_max_i16: +NaN passes, -NaN -- what the matrix pipe produces -- becomes 0).
+#ifdef DHAUG_MLP_SAVE_TU
+constexpr bool NAN_SAFE_TU = true;
+#else
+constexpr bool NAN_SAFE_TU = false;
+#endif
 enum { F_OUT_F32 = 4, F_DOT_OUT = 16 };
 
 struct Unit {
@@ -285,7 +294,7 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
         // exactly as they would have been stored) with that layer's weights and leaves per-(wave, half) partial sums in
         // buffer dst as fp32 [8][128]; dot_output() adds them up.  w2 = fp32 [257]: the weights (bf16 values, zero beyond
         // N) and the bias at [256] (joins wave 0's partial sum).
-        const float neg = u->slope;
+        const float neg = act_neg(act, u->slope);
         const uint32_t lb = act == DHAUG_ACT_RELU ? 0u : 0x80008000u;
         // two partial sums per row tile (even / odd feature groups): eight independent FMA chains, not four serial ones
         float part[MLP_MT][2];
@@ -304,7 +313,7 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
                     }
         };
         if (wave < nslices) {
-            if (act != DHAUG_ACT_LRELU) dot_pairs([&](float a0, float a1) { return pk_relu(pack_bf16x2(a0, a1), lb); });
+            if (act != DHAUG_ACT_LRELU && !NAN_SAFE_TU) dot_pairs([&](float a0, float a1) { return pk_relu(pack_bf16x2(a0, a1), lb); });
             else dot_pairs([&](float a0, float a1) { return pack_bf16x2(act_fn(a0, neg), act_fn(a1, neg)); });
         }
         float* st = reinterpret_cast<float*>(dst) + (2 * wave + h) * MLP_BM + r31;
@@ -331,7 +340,7 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
                     for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[t][mt][4 * g + e], neg);
                     *reinterpret_cast<f32x4*>(st + (32 * mt + r31) * OUT_PITCH + 32 * slice + 4 * h + 8 * g) = v;
                 }
-        } else if (act != DHAUG_ACT_LRELU) {
+        } else if (act != DHAUG_ACT_LRELU && !NAN_SAFE_TU) {
             // ReLU on the packed pair: max as int16 against 0 (a negative bf16 is a negative int16); against INT16_MIN it
             // is the identity
             const uint32_t lb = act == DHAUG_ACT_RELU ? 0u : 0x80008000u;
@@ -347,7 +356,7 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
                 }
             }
         } else {
-            const float neg = u->slope;
+            const float neg = act_neg(act, u->slope);
 #pragma unroll
             for (int mt = 0; mt < MLP_MT; ++mt) {
                 const int row = 32 * mt + r31;
@@ -737,7 +746,7 @@ __device__ __forceinline__ void tail_gemm(const StackDesc& d, unsigned char* sme
             for (int mt = 0; mt < MLP_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(idf, rf[mt][ks2], acc[mt], 0, 0, 0);
         }
     }
-    if (d.act != DHAUG_ACT_LRELU) {
+    if (d.act != DHAUG_ACT_LRELU && !NAN_SAFE_TU) {
         const uint32_t lb = d.act == DHAUG_ACT_RELU ? 0u : 0x80008000u;
 #pragma unroll
         for (int mt = 0; mt < MLP_MT; ++mt)
@@ -749,7 +758,7 @@ __device__ __forceinline__ void tail_gemm(const StackDesc& d, unsigned char* sme
                 *reinterpret_cast<uint2*>(dst + chunk_off(32 * mt + r31, 4 * wave + g, pbd) + (h << 3)) = o;
             }
     } else {
-        const float neg = d.slope;
+        const float neg = act_neg(d.act, d.slope);
 #pragma unroll
         for (int mt = 0; mt < MLP_MT; ++mt)
 #pragma unroll
@@ -1117,7 +1126,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void fused_mlp_kernel(Program prog,
                     const int lead_ks = plan & 15, run = (plan >> 4) & 63;
                     const int tail = (plan & PLAN_TAIL) ? 1 : ((plan & PLAN_TAIL_BF16) ? 2 : 0);
                     UnitPtr f0 = u + (lead_ks != 0), tu = f0 + run;
-                    if (plan & PLAN_LEAKY) gemm_stack<true, false, SAVE>(u, lead_ks, f0, run, tail, smem, wave, lane, m0, M, tid);
+                    if ((plan & PLAN_LEAKY) || NAN_SAFE_TU) gemm_stack<true, false, SAVE>(u, lead_ks, f0, run, tail, smem, wave, lane, m0, M, tid);
                     else if (plan & PLAN_ALT) gemm_stack<false, true, SAVE>(u, lead_ks, f0, run, tail, smem, wave, lane, m0, M, tid);
                     else gemm_stack<false, false, SAVE>(u, lead_ks, f0, run, tail, smem, wave, lane, m0, M, tid);
                     lds_barrier();

@@ -79,6 +79,44 @@ def test_nan_and_inf_reach_the_logit_on_the_training_path(ops):
     assert torch.isnan(p[17]).item() and torch.isfinite(torch.cat((p[:17], p[18:]))).all()
 
 
+def test_nan_in_the_fused_step_forward(ops):
+    """sweep 1 of the explicit critic step (forward-with-save, one fused launch; its translation unit applies ReLU as
+    max(v, v * 0) in fp32 -- NaN-propagating -- where the inference unit uses an integer max on the packed bf16 pair that turns
+    the matrix pipe's -NaN into 0): a NaN input row never touches another row and reaches ITS logit in both critics,
+    train_Fk_discriminator's D_cost reports it, and diverged (NaN) weights give NaN logits everywhere -- as the reference's
+    ATen ops would."""
+    import argparse
+    from dhaug_amd import fused
+    from dhaug_amd.models_Fk_GAN import Fk_discriminator as dis, model_fk_gan_train as train
+    from test_gpu_models import make_args
+    B, D = 300, 256
+    args = make_args(batch_size=B, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D)
+    torch.manual_seed(3)
+    D3, D2 = dis.Fk_3D_Discriminator("cuda", args).cuda(), dis.Fk_2D_Discriminator(args, 16).cuda()
+    x3 = GU.synth_pose16(B, seed=5); x3 = (x3 - x3[:, :1]).reshape(B, 48).cuda()
+    x2 = ((torch.rand(B, 32) - 0.5) * 1.6).cuda()
+    clean3 = fused.critic3d_forward_save(D3, x3, ops.kcs_forward(x3, True, f32=True, bf16_ld=32)[1])["logits"].clone()
+    x3[7, 20] = float("nan"); x2[11, 3] = float("nan")
+    kf, kb = ops.kcs_forward(x3, True, f32=True, bf16_ld=32)
+    l3 = fused.critic3d_forward_save(D3, x3, kb)["logits"]
+    l2 = fused.critic2d_forward_save(D2, x2)["logits"]
+    keep = torch.arange(B, device="cuda") != 7
+    assert torch.equal(l3[keep], clean3[keep]) and torch.isnan(l3[7]).item()       # its own logit, no other row
+    bad2 = torch.isnan(l2[:, 0])
+    assert bad2[11].item() and bad2.sum().item() == 1
+    opt = train.FusedAdam(D2.parameters(), lr=1e-4, betas=(0.5, 0.9))
+    W, C = train.train_Fk_discriminator(D2, x2.clone(), (x2 + 0.01).clone(), argparse.Namespace(train_iter_num=0), None, "d2d", opt, args)
+    assert torch.isnan(C).item() and torch.isnan(W).item()
+    # a diverged 3D critic (one NaN weight in the first pose layer): every row's logit is NaN
+    with torch.no_grad():
+        D3.previous[0].weight[5, 9] = float("nan")
+    from dhaug_amd import autograd_ops as A
+    A.bump_weight_epoch()
+    x3c = x3.clone(); x3c[7, 20] = 0.1
+    l3d = fused.critic3d_forward_save(D3, x3c, ops.kcs_forward(x3c, True, f32=True, bf16_ld=32)[1])["logits"]
+    assert torch.isnan(l3d).all()
+
+
 def test_fk_angles_far_outside_the_joint_range(ops):
     g = torch.Generator().manual_seed(9)
     N = 4096
