@@ -29,6 +29,7 @@ SIGNATURES = {
     "dhaug_center_flip_backward": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "dhaug_gemm_bf16_dmask": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _f32, _vp, _i64, _i64, _i64, _i64, _vp],
     "dhaug_gemm_bf16_dmask_pad": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _f32, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
+    "dhaug_gemm_bf16_dbits": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _f32, _vp, _i64, _i64, _vp],
     "dhaug_gemm_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i32,
                         _f32, _vp],
     "dhaug_gemm_tn_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp],
@@ -57,7 +58,7 @@ class MlpUnit(ctypes.Structure):
     """struct dhaug_mlp_unit (include/dhaug.h)"""
     _fields_ = [("kind", _i32), ("flags", _i32), ("src", _i32), ("dst", _i32), ("res", _i32), ("src2", _i32),
                 ("ksteps2", _i32), ("ksteps", _i32), ("n", _i32), ("act", _i32), ("slope", _f32), ("cols", _i32),
-                ("ld", _i64), ("g", _vp), ("w", _vp), ("w2", _vp), ("bias", _vp), ("save", _vp), ("save_ld", _i64)]
+                ("ld", _i64), ("g", _vp), ("w", _vp), ("w2", _vp), ("bias", _vp), ("save", _vp), ("save_ld", _i64), ("bits", _vp)]
 
 
 class WfragDesc(ctypes.Structure):

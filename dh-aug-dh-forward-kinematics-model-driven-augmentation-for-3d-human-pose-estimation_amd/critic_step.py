@@ -260,11 +260,12 @@ def step_d2(D, optimizerD, real, fake, alpha, lam, prec=None):
     gz1 = L[1].bwd(m, gz2, d1, LRELU, s, skip=gz3)
     g = L[0].bwd(m, gz1[B2:], None, NONE, 0.0, out_f32=True)                 # (B,32) fp32: dD/dx_hat
     v, pen = ops.gp_penalty(g, 2.0 * lam / B)
-    u1 = L[0].tan(m, v, d1[B2:], inplace=True)
-    u2 = L[1].tan(m, u1, d2[B2:], inplace=True)
-    u3 = L[2].tan(m, u2, d3[B2:], skip=u1, inplace=True)
-    u4 = L[3].tan(m, u3, d4[B2:], inplace=True)
-    ul = L[4].tan(m, u4, dl[B2:], inplace=True)
+    tail = ops.tail_rows                                      # (x_hat rows of a saved activation, its sign bits attached)
+    u1 = L[0].tan(m, v, tail(d1, B2), inplace=True)
+    u2 = L[1].tan(m, u1, tail(d2, B2), inplace=True)
+    u3 = L[2].tan(m, u2, tail(d3, B2), skip=u1, inplace=True)
+    u4 = L[3].tan(m, u3, tail(d4, B2), inplace=True)
+    ul = L[4].tan(m, u4, tail(dl, B2), inplace=True)
     for lay, gz, x, u in ((L[0], gz1, X, v), (L[1], gz2, d1, u1), (L[2], gz3, d2, u2), (L[3], gz4, d3, u3),
                           (L[4], gzl, d4, u4), (L[5], gzp, dl, ul)):
         lay.grads(m, gz, x, B2, u)
@@ -329,7 +330,7 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
     for bi, br in enumerate(branches):
         us, uhs = [br.first.tan(m, T[bi], y[bi][0][B2:], inplace=True)], []
         for i, blk in enumerate(br.blocks):
-            hh, yy = blk.tan(m, us[-1], h[bi][i][B2:], y[bi][i + 1][B2:])
+            hh, yy = blk.tan(m, us[-1], ops.tail_rows(h[bi][i], B2), ops.tail_rows(y[bi][i + 1], B2))
             uhs.append(hh); us.append(yy)
         u.append(us); uh.append(uhs)
     if all(u[bi][-1].data_ptr() == cat[B2:, bi * Dw:].data_ptr() for bi in range(nb)):

@@ -36,6 +36,7 @@ struct GemmArgs {
     long long M, N, K, W;          // W = output width covered by tiles (N, or the zero-padded width)
     int act; float slope;
     const uint16_t* dmask; long long ld_dmask; float dneg;   // optional: result *= (dmask > 0 ? 1 : dneg)  (nt256 kernel only)
+    const uint32_t* dbits;                                   // the same mask as a sign-bit array (dhaug_mlp_unit.bits layout)
 };
 
 // branch-free activation: v > 0 ? v : v * neg, neg = 0 (ReLU) / slope (LeakyReLU) / 1 (identity)
@@ -1120,7 +1121,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_kernel(GemmArgs p) {
 // residual block (gz1 W1 + gz2) * relu'(x) and its tangent twin -- three operand streams, so the ring holds 2 tiles
 template <int KS, int MODE>
 __global__ __launch_bounds__(512, 1) void gemm_nt256s_kernel(GemmArgs p) {
-    constexpr bool RES = (MODE & 1) != 0, MASK = (MODE & 2) != 0;
+    // MODE bit 2: the mask comes as a sign-bit array (one dword per lane and tile, read by the compute waves themselves: no
+    // mask image, 1/16 of the bytes; the ring keeps the depth of the mode without a mask)
+    constexpr bool RES = (MODE & 1) != 0, MASK = (MODE & 2) != 0, BITS = (MODE & 4) != 0;
+    static_assert(!(MASK && BITS), "one mask source");
     constexpr int NSEC = (RES ? 1 : 0) + (MASK ? 1 : 0);
     constexpr bool SECOND = NSEC != 0;
     static_assert(KS == 8 || KS == 16, "K = 128 or 256");
@@ -1243,12 +1247,16 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256s_kernel(GemmArgs p) {
     const int lrx = (r31 * F_PITCH | ((x >> 1) << 5) | ((h ^ (x & 1)) << 4)) ^ (cw << 6);     // ^ (t << 8 | j << 5)
     const int lep = r31 * F_PITCH | (((4 * cw) ^ x) << 4) | (h << 3);                    // ^ ((16t+g) << 4)
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // sign bits of this wave's two slices for the lane's row of tile j: word ((tile * 4 + cw) * 64 + lane), one tile ahead
+    uint32_t bw_next = BITS ? p.dbits[((mt0 * 4) + cw) * 64 + lane] : 0u;
     f_lds_barrier();                                                         // tile 0 and the bias are in LDS
     for (int i = 0; i < nt; ++i) {
         const unsigned char* X = sX + (i % NX) * IMG;
         const unsigned char* R = sR + (i % NX) * IMG;
         const unsigned char* Mk = sM + (i % NX) * IMG;
         unsigned char* O = sO + (i & 1) * IMG;
+        const uint32_t bw = bw_next;
+        if (BITS && i + 1 < nt) bw_next = p.dbits[(((mt0 + (long long)(i + 1) * g) * 4) + cw) * 64 + lane];
         f32x16 acc[2];
         bf16x8 fx[4];
         constexpr int D = 3;
@@ -1294,6 +1302,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256s_kernel(GemmArgs p) {
                     v[2] = y2 > 0 ? v[2] : v[2] * p.dneg;
                     v[3] = y3 > 0 ? v[3] : v[3] * p.dneg;
                 }
+                if (BITS) {                                                  // pairs 8t + 2gq, +1: even element at bit p, odd at 16 + p
+                    const int p0 = 8 * t + 2 * gq;
+                    v[0] = ((bw >> p0) & 1u) ? v[0] : v[0] * p.dneg;
+                    v[1] = ((bw >> (16 + p0)) & 1u) ? v[1] : v[1] * p.dneg;
+                    v[2] = ((bw >> (p0 + 1)) & 1u) ? v[2] : v[2] * p.dneg;
+                    v[3] = ((bw >> (17 + p0)) & 1u) ? v[3] : v[3] * p.dneg;
+                }
                 // ReLU / identity on the packed pair: a negative bf16 is a negative int16 (lower bound 0 or INT16_MIN)
                 typedef short s16x2 __attribute__((ext_vector_type(2)));
                 uint2 o;
@@ -1309,7 +1324,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256s_kernel(GemmArgs p) {
 
 template <int KS, int MODE>
 int launch_nt256s_mode(hipStream_t s, const GemmArgs& p) {
-    constexpr int NSEC = (MODE & 1) + ((MODE >> 1) & 1);
+    constexpr int NSEC = (MODE & 1) + ((MODE >> 1) & 1);                   // (bit 2, the sign-bit mask, has no image)
     constexpr int BM = 32, NX = 4 - NSEC;
     constexpr int LDS = ((1 + NSEC) * NX + 2) * BM * F_PITCH + 1024;
     static bool configured = false;
@@ -1327,6 +1342,9 @@ int launch_nt256s_mode(hipStream_t s, const GemmArgs& p) {
 
 template <int KS>
 int launch_nt256s(hipStream_t s, const GemmArgs& p) {
+    if constexpr (KS == 16) {
+        if (p.dbits != nullptr) return p.res != nullptr ? launch_nt256s_mode<KS, 5>(s, p) : launch_nt256s_mode<KS, 4>(s, p);
+    }
     if (p.dmask != nullptr && p.res != nullptr) return launch_nt256s_mode<KS, 3>(s, p);
     if (p.dmask != nullptr) return launch_nt256s_mode<KS, 2>(s, p);
     if (p.res != nullptr) return launch_nt256s_mode<KS, 1>(s, p);
@@ -1407,7 +1425,7 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
     if (c_bf16) DHAUG_CHECK(ldc_bf16 % 8 == 0 && ldc_bf16 >= N && n_pad_zero <= ldc_bf16 && dhaug_aligned16(c_bf16), DHAUG_EALIGN);
     if (c_f32) DHAUG_CHECK(ldc_f32 >= N && ((ldc_f32 & 3) != 0 || dhaug_aligned16(c_f32)), DHAUG_EALIGN);
     GemmArgs p{A, lda, B, ldb, bias, residual, ld_res, residual_f32, ld_res_f32, c_bf16, ldc_bf16, c_bf16 ? (n_pad_zero > N ? n_pad_zero : N) : 0,
-               c_f32, ldc_f32, M, N, K, N, act, slope, nullptr, 0, 1.0f};
+               c_f32, ldc_f32, M, N, K, N, act, slope, nullptr, 0, 1.0f, nullptr};
     hipStream_t s = (hipStream_t)stream;
     const long long width = (c_bf16 && p.npad > N) ? p.npad : N;
     p.W = width;
@@ -1501,6 +1519,21 @@ int dhaug_gemm_bf16_dmask(const uint16_t* A, int64_t lda, const uint16_t* B, int
                           uint16_t* c_bf16, int64_t ldc_bf16, int64_t M, int64_t N, int64_t K, void* stream) {
     return dhaug_gemm_bf16_dmask_pad(A, lda, B, ldb, residual, ld_res, dmask, ld_dmask, dmask_act, dmask_slope, c_bf16, ldc_bf16,
                                      N, M, N, K, stream);
+}
+
+int dhaug_gemm_bf16_dbits(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* residual, int64_t ld_res,
+                          const uint32_t* bits, int dmask_act, float dmask_slope, uint16_t* c_bf16, int64_t ldc_bf16, int64_t M,
+                          void* stream) {
+    DHAUG_CHECK(dmask_act == DHAUG_ACT_RELU || dmask_act == DHAUG_ACT_LRELU, DHAUG_EINVAL);
+    DHAUG_CHECK(M >= 0 && M % 32 == 0, DHAUG_EUNSUPPORTED);
+    if (M == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(A); DHAUG_CHECK_PTR(B); DHAUG_CHECK_PTR(bits); DHAUG_CHECK_PTR(c_bf16);
+    DHAUG_CHECK(lda % 8 == 0 && ldb % 8 == 0 && lda >= 256 && ldb >= 256 && ldc_bf16 % 8 == 0 && ldc_bf16 >= 256, DHAUG_EALIGN);
+    DHAUG_CHECK(dhaug_aligned16(A) && dhaug_aligned16(B) && dhaug_aligned16(c_bf16) && dhaug_aligned16(bits), DHAUG_EALIGN);
+    if (residual) DHAUG_CHECK(ld_res % 8 == 0 && ld_res >= 256 && dhaug_aligned16(residual), DHAUG_EALIGN);
+    GemmArgs p{A, lda, B, ldb, nullptr, residual, ld_res, nullptr, 0, c_bf16, ldc_bf16, 256, nullptr, 0, M, 256, 256, 256,
+               DHAUG_ACT_NONE, 0.0f, nullptr, 0, dmask_act == DHAUG_ACT_RELU ? 0.0f : dmask_slope, bits};
+    return launch_nt256s<16>((hipStream_t)stream, p);
 }
 
 int dhaug_gemm_tn_bf16_rows(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,

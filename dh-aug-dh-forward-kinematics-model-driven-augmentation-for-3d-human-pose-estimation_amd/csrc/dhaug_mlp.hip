@@ -71,6 +71,8 @@ struct Unit {
     const float* bias;          // GEMM: fp32 [32 * nslices] (zero padded)
     uint16_t* save;             // GEMM, optional: the layer's output image also goes to global memory (M, save_ld) bf16,
     long long save_ld;          // columns [0, ceil16(N)) -- the training step's forward-with-save
+    uint32_t* bits;             // full-width layer inside a run, optional: one bit per output element, (y > 0) -- the mask
+                                // act'(y) of the backward / tangent sweeps in 1/16 of the bytes (see DHAUG_MLP_BITS in dhaug.h)
 };
 // plan of a GEMM unit.  Stack: bits 0-3 lead k-steps, 4-9 run.  Single layer: bits 16-23 shape (chunks * 16 + chunks of
 // source 1), 24-27 feature slices
@@ -476,7 +478,8 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 template <bool LEAKY, int RESMODE, int KS = MLP_MAX_KSTEPS, bool SAVE = false>
 __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc& nd, unsigned char* smem, int wave, int lane,
                                             const WHalf& wlo, WHalf& nlo, WHalf& whi, f32x16 (&seed)[MLP_NS],
-                                            const bf16x8 (&idf)[2], int dbg, __amdgpu_buffer_rsrc_t sv, int sv_ld) {
+                                            const bf16x8 (&idf)[2], int dbg, __amdgpu_buffer_rsrc_t sv, int sv_ld,
+                                            __amdgpu_buffer_rsrc_t brs) {
     DHAUG_LSTAMP(dbg)
     static_assert(KS == 16 || ((KS == 4 || KS == 8) && RESMODE == 0), "layer shape");
     constexpr bool LEAD = KS < MLP_MAX_KSTEPS;
@@ -565,6 +568,22 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
     //   after (k odd,  t0)  activation fragment of k+3                       ~30
     //   after (k odd,  t1)  one fragment of the next layer's weights + pack/ReLU of two pairs of the previous tile ~32
     uint32_t st0 = 0, st1 = 0;                                               // packed pairs waiting for their store
+    // SAVE: sign bits of the tile's output, (y > 0) per element: pair p = j / 2 of the lane's 32 elements puts its even element at
+    // bit p and its odd element at bit 16 + p (so that a consumer turns pair p into a 16-bit lane mask with one shift and one
+    // packed arithmetic shift); one dword per lane and 32-row tile at brs[((mt * 4 + wave) * 64 + lane) * 4]
+    uint32_t bacc = 0;
+    auto bits_or = [&](uint32_t packed, int pidx) {
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        const s16x2 zero2 = {0, 0};
+        const u16x2 one2 = {1, 1};
+        const s16x2 pos = __builtin_elementwise_max(__builtin_bit_cast(s16x2, packed), zero2);       // negative -> 0
+        const u16x2 m = __builtin_elementwise_min(__builtin_bit_cast(u16x2, pos), one2);              // positive -> 1
+        bacc |= __builtin_bit_cast(uint32_t, m) << pidx;
+    };
+    auto bits_store = [&](int mt) {
+        __builtin_amdgcn_raw_buffer_store_b32((int)bacc, brs, ((mt * 4 + wave) * 64 + lane) * 4, 0, 0);
+        bacc = 0;
+    };
     int sv_off[MLP_MT];                                                      // byte offset of the lane's chunk 0 of row tile mt, or out of range
     if (SAVE && !LEAD) {
 #pragma unroll
@@ -626,6 +645,11 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
                         if (mt > 0 && (k & 1)) {
                             st0 = pair_pack(acc[(mt - 1) & 1], 2 * k - 2);
                             st1 = pair_pack(acc[(mt - 1) & 1], 2 * k);
+                            if (SAVE) {
+                                bits_or(st0, k - 1);
+                                bits_or(st1, k);
+                                if (k == KS - 1) bits_store(mt - 1);         // all sixteen pairs of tile mt-1 are packed
+                            }
                         } else if (mt > 0 && k >= 2) {
                             quad_store(mt - 1, 2 * k - 4, st0, st1);
                         } else if (mt > 1 && k == 0) {
@@ -654,8 +678,15 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
     }
     if (!LEAD) quad_store(MLP_MT - 2, 28, st0, st1);
 #pragma unroll
-    for (int j = 0; j < 32; j += 4)
-        quad_store(MLP_MT - 1, j, pair_pack(acc[(MLP_MT - 1) & 1], j), pair_pack(acc[(MLP_MT - 1) & 1], j + 2));
+    for (int j = 0; j < 32; j += 4) {
+        const uint32_t p0 = pair_pack(acc[(MLP_MT - 1) & 1], j), p1 = pair_pack(acc[(MLP_MT - 1) & 1], j + 2);
+        quad_store(MLP_MT - 1, j, p0, p1);
+        if (SAVE && !LEAD) {
+            bits_or(p0, j >> 1);
+            bits_or(p1, (j >> 1) + 1);
+        }
+    }
+    if (SAVE && !LEAD) bits_store(MLP_MT - 1);
     DHAUG_LSTAMP(dbg + 5)
 #pragma unroll
     for (int t = 0; t < MLP_NS; ++t) seed[t] = nseed[t];
@@ -826,6 +857,12 @@ __device__ __forceinline__ void gemm_stack(UnitPtr lead, int lead_ks, UnitPtr fi
         return __builtin_amdgcn_make_buffer_rsrc(base != nullptr ? base + m0 * ld : reinterpret_cast<uint16_t*>(smem), 0,
                                                  base != nullptr ? (int)(rows * ld * 2) : 0, 0x27000);
     };
+    // the sign-bit array of a run layer's OWN output: 4 KB per 128-row tile (zero records: nothing asked for)
+    auto bits_of = [&](UnitPtr bu) -> __amdgpu_buffer_rsrc_t {
+        uint32_t* base = SAVE ? bu->bits : nullptr;
+        return __builtin_amdgcn_make_buffer_rsrc(base != nullptr ? base + (m0 / MLP_BM) * 1024 : reinterpret_cast<uint32_t*>(smem), 0,
+                                                 base != nullptr ? 4096 : 0, 0x27000);
+    };
     // units first[0 .. nt): the n full-width layers and, if `tail`, the output layer behind them
     const int nt = n + (tail ? 1 : 0);
     StackDesc cur = stack_desc(first), nxt = stack_desc(first + (nt > 1 ? 1 : 0));
@@ -852,14 +889,14 @@ __device__ __forceinline__ void gemm_stack(UnitPtr lead, int lead_ks, UnitPtr fi
             for (int t = 0; t < MLP_NS; ++t)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) loB[t][k] = b.frag(t, k);
-            stack_layer<LEAKY, 0, 8, false>(ld, cur, smem, wave, lane, loB, loA, hi, seed, idf, MLP_MAX_UNITS + 50, nosv, 0);
+            stack_layer<LEAKY, 0, 8, false>(ld, cur, smem, wave, lane, loB, loA, hi, seed, idf, MLP_MAX_UNITS + 50, nosv, 0, nosv);
         } else {
             const WBase<4> b(ld.w, wave, 4, lane);
 #pragma unroll
             for (int t = 0; t < MLP_NS; ++t)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) loB[t][k] = b.frag(t, k);
-            stack_layer<LEAKY, 0, 4, false>(ld, cur, smem, wave, lane, loB, loA, hi, seed, idf, MLP_MAX_UNITS + 50, nosv, 0);
+            stack_layer<LEAKY, 0, 4, false>(ld, cur, smem, wave, lane, loB, loA, hi, seed, idf, MLP_MAX_UNITS + 50, nosv, 0, nosv);
         }
         lds_barrier();
         DHAUG_LSTAMP(MLP_MAX_UNITS + 56)
@@ -884,10 +921,12 @@ __device__ __forceinline__ void gemm_stack(UnitPtr lead, int lead_ks, UnitPtr fi
         int ldb0, ldb1;
         const __amdgpu_buffer_rsrc_t sv0 = save_of(l == 0 ? lead : first + (l - 1), l != 0 || lead_ks != 0, ldb0);
         const __amdgpu_buffer_rsrc_t sv1 = save_of(first + l, true, ldb1);
-        stack_layer<LEAKY, ALT ? 0 : 2, MLP_MAX_KSTEPS, SAVE>(cur, nxt, smem, wave, lane, loA, loB, hi, seed, idf, dbg, sv0, ldb0);
+        stack_layer<LEAKY, ALT ? 0 : 2, MLP_MAX_KSTEPS, SAVE>(cur, nxt, smem, wave, lane, loA, loB, hi, seed, idf, dbg, sv0, ldb0,
+                                                              bits_of(first + l));
         lds_barrier();
         DHAUG_LSTAMP(dbg + 6)
-        stack_layer<LEAKY, ALT ? 1 : 2, MLP_MAX_KSTEPS, SAVE>(nxt, n2, smem, wave, lane, loB, loA, hi, seed, idf, dbg + 8, sv1, ldb1);
+        stack_layer<LEAKY, ALT ? 1 : 2, MLP_MAX_KSTEPS, SAVE>(nxt, n2, smem, wave, lane, loB, loA, hi, seed, idf, dbg + 8, sv1, ldb1,
+                                                              bits_of(first + l + 1));
         cur = n2;
         nxt = n3;
         if (l + 2 < nt) lds_barrier();
@@ -897,7 +936,8 @@ __device__ __forceinline__ void gemm_stack(UnitPtr lead, int lead_ks, UnitPtr fi
     if (odd) {
         int ldb;
         const __amdgpu_buffer_rsrc_t svo = save_of(l == 0 ? lead : first + (l - 1), l != 0 || lead_ks != 0, ldb);
-        stack_layer<LEAKY, 2, MLP_MAX_KSTEPS, SAVE>(cur, nxt, smem, wave, lane, loA, loB, hi, seed, idf, MLP_MAX_UNITS + 2, svo, ldb);
+        stack_layer<LEAKY, 2, MLP_MAX_KSTEPS, SAVE>(cur, nxt, smem, wave, lane, loA, loB, hi, seed, idf, MLP_MAX_UNITS + 2, svo, ldb,
+                                                    bits_of(first + l));
         cur = nxt;
         if (tail) lds_barrier();
     }
@@ -1318,7 +1358,12 @@ int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* 
         u.ksteps = s.ksteps; u.N = s.n; u.act = s.act; u.slope = s.slope; u.cols = s.cols; u.ld = s.ld;
         u.g = s.g; u.w = static_cast<const uint16_t*>(s.w); u.w2 = static_cast<const uint16_t*>(s.w2); u.bias = s.bias;
         u.save = static_cast<uint16_t*>(s.save); u.save_ld = s.save_ld;
+        u.bits = static_cast<uint32_t*>(s.bits);
         DHAUG_CHECK(u.kind >= U_LOAD_F32 && u.kind <= U_GEMM, DHAUG_EINVAL);
+        if (u.bits != nullptr) {                                             // (written by full-width run layers only: checked below)
+            DHAUG_CHECK(u.kind == U_GEMM && u.save != nullptr && u.N > 224, DHAUG_EINVAL);
+            DHAUG_CHECK(dhaug_aligned16(u.bits), DHAUG_EALIGN);
+        }
         if (u.save != nullptr) {
             DHAUG_CHECK(u.kind == U_GEMM && !(u.flags & (F_OUT_F32 | F_DOT_OUT)), DHAUG_EINVAL);
             DHAUG_CHECK(dhaug_aligned16(u.save) && u.save_ld % 8 == 0 && u.save_ld >= ((u.N + 15) & ~15), DHAUG_EALIGN);
@@ -1363,6 +1408,20 @@ int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* 
         }
     }
     for (int i = 0; i < prog.nunits; ++i) prog.u[i].plan = plan_unit(prog, i);
+    {   // sign bits are written by the layers of a run (not by the narrow layer feeding it, nor by layer-at-a-time units)
+        bool in_run[MLP_MAX_UNITS] = {};
+        for (int i = 0; i < prog.nunits;) {
+            const int plan = prog.u[i].plan;
+            if (prog.u[i].kind == U_GEMM && (plan & PLAN_STACK)) {
+                const int lead = (plan & 15) != 0, run = (plan >> 4) & 63;
+                for (int j = 0; j < run; ++j) in_run[i + lead + j] = true;
+                i += lead + run + ((plan & (PLAN_TAIL | PLAN_TAIL_BF16)) ? 1 : 0);
+            } else {
+                ++i;
+            }
+        }
+        for (int i = 0; i < prog.nunits; ++i) DHAUG_CHECK(prog.u[i].bits == nullptr || in_run[i], DHAUG_EUNSUPPORTED);
+    }
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<false>),

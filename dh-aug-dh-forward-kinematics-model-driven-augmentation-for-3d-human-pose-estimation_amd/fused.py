@@ -6,6 +6,7 @@ changes (the optimizer step invalidates the cache).  Used for the no-grad passes
 (model_fk_gan_train.py:305-308 `.data`), the flipped critic evaluations of the G step (:463-468) and inference.
 Same arithmetic as the layer-by-layer bf16 path (bf16 operands, fp32 accumulate, bf16 activations)."""
 import ctypes
+import os
 
 import torch
 
@@ -19,6 +20,7 @@ _vp = ctypes.c_void_p
 # (dhaug_mlp_forward_x3: operands as fp16 hi + lo pairs, three MFMA terms, fp32-grade -- the mode that meets the path's
 # 1e-4 logit tolerance against the fp32 reference)
 MODES = ("bf16", "f16x3")
+SIGN_BITS = os.environ.get("DHAUG_NO_SIGN_BITS") is None      # forward-with-save also emits (y > 0) bit arrays of its run layers
 
 
 def supported(*dims):
@@ -71,11 +73,16 @@ class _Layer:
 
 
 def _unit(kind, flags=0, src=-1, dst=-1, res=-1, src2=-1, ksteps2=0, ksteps=0, n=0, act=0, slope=0.0, cols=0, ld=0,
-          g=None, w=None, w2=None, bias=None, save=None):
+          g=None, w=None, w2=None, bias=None, save=None, bits=False):
     u = _lib.MlpUnit()
     if save is not None:                                      # forward-with-save: the layer's image also goes to `save`
         assert save.dtype == torch.bfloat16 and save.stride(1) == 1
         u.save, u.save_ld = save.data_ptr(), save.stride(0)
+        if bits and SIGN_BITS:
+            # the layer also leaves (y > 0) as one bit per element (struct dhaug_mlp_unit.bits): the backward / tangent sweeps
+            # read that instead of the bf16 image (critic_step.py); the array rides on the saved tensor
+            save._dhaug_bits = new_bits(save.shape[0], save.device)
+            u.bits = save._dhaug_bits.data_ptr()
     u.kind, u.flags, u.src, u.dst, u.res, u.src2, u.ksteps2 = kind, flags, src, dst, res, src2, ksteps2
     u.ksteps, u.n, u.act, u.slope, u.cols, u.ld = ksteps, n, act, float(slope), cols, ld
     u.g = None if g is None else g.data_ptr()
@@ -85,8 +92,33 @@ def _unit(kind, flags=0, src=-1, dst=-1, res=-1, src2=-1, ksteps2=0, ksteps=0, n
     return u
 
 
-def _gemm(layer, src, dst, act, slope=0.0, res=-1, out=None, src2=-1, save=None):
-    kw = dict(src=src, ksteps=layer.ksteps[0], n=layer.N, act=act, slope=slope, w=layer.w[0], bias=layer.bias, res=res, save=save)
+def new_bits(M, dev):
+    """sign-bit array of an (M, 256) activation: one dword per lane and 32-row tile, padded to whole 128-row tiles"""
+    return torch.empty(((M + 127) // 128 * 4 * 4 * 64,), dtype=torch.int32, device=dev)
+
+
+def decode_bits(bits, M):
+    """(M, 256) bool from a sign-bit array (layout: struct dhaug_mlp_unit.bits in include/dhaug.h) -- tests / debugging"""
+    w = bits.reshape(-1, 4, 64).cpu().numpy().astype("uint32")           # [T][wave][lane]
+    import numpy as np
+    T = w.shape[0]
+    out = np.zeros((T * 32, 256), dtype=bool)
+    lane = np.arange(64)
+    r31, h = lane & 31, lane >> 5
+    for wave in range(4):
+        for j in range(32):
+            t, g, e = j >> 4, (j >> 2) & 3, j & 3
+            pos = (j >> 1) + (16 if (j & 1) else 0)
+            feat = 32 * (wave + 4 * t) + 8 * g + 4 * h + e                  # per lane
+            val = (w[:, wave, :] >> pos) & 1                                # [T][lane]
+            for tt in range(T):
+                out[32 * tt + r31, feat] = val[tt].astype(bool)
+    return torch.from_numpy(out[:M])
+
+
+def _gemm(layer, src, dst, act, slope=0.0, res=-1, out=None, src2=-1, save=None, bits=False):
+    kw = dict(src=src, ksteps=layer.ksteps[0], n=layer.N, act=act, slope=slope, w=layer.w[0], bias=layer.bias, res=res, save=save,
+              bits=bits)
     if len(layer.w) == 2:
         kw.update(src2=src2, ksteps2=layer.ksteps[1], w2=layer.w[1])
     if out is not None:
@@ -266,8 +298,8 @@ def _d3s_program(D, L, inputs, M):
     def branch(u, b, first, names):
         u.append(_gemm(L[first], 1, 0, ACT_RELU, save=y[b][0]))
         for i, n in enumerate(names):
-            u.append(_gemm(L[n + ".fc1"], 0, 1, ACT_RELU, save=h[b][i]))
-            u.append(_gemm(L[n + ".fc2"], 1, 0, ACT_RELU, res=0, save=y[b][i + 1]))
+            u.append(_gemm(L[n + ".fc1"], 0, 1, ACT_RELU, save=h[b][i], bits=True))
+            u.append(_gemm(L[n + ".fc2"], 1, 0, ACT_RELU, res=0, save=y[b][i + 1], bits=True))
 
     u = [_unit(LOAD_BF16, dst=1, cols=32, ld=kcs.stride(0), g=kcs)]
     branch(u, 0, "special_KCS_previous.0", ("special_KCS_block1", "special_KCS_block2", "special_KCS_block3"))
@@ -296,10 +328,10 @@ def _d2s_program(D, L, inputs, M):
     logits = torch.empty((M, 1), dtype=torch.float32, device=dev)
     u = [_unit(LOAD_F32, dst=1, cols=32, ld=x.stride(0), g=x),
          _gemm(L["pose_layer_1"], 1, 0, ACT_LRELU, s, save=d[0]),
-         _gemm(L["pose_layer_2"], 0, 1, ACT_LRELU, s, save=d[1]),
-         _gemm(L["pose_layer_3"], 1, 0, ACT_LRELU, s, res=0, save=d[2]),
+         _gemm(L["pose_layer_2"], 0, 1, ACT_LRELU, s, save=d[1], bits=True),
+         _gemm(L["pose_layer_3"], 1, 0, ACT_LRELU, s, res=0, save=d[2], bits=True),
          _gemm(L["pose_layer_4"], 0, 1, ACT_NONE, save=d[3]),
-         _gemm(L["layer_last"], 1, 0, ACT_LRELU, s, save=d[4]),
+         _gemm(L["layer_last"], 1, 0, ACT_LRELU, s, save=d[4], bits=True),
          _gemm(L["layer_pred"], 0, 1, ACT_NONE, out=logits)]
     return u, dict(d=d, logits=logits)
 

@@ -294,10 +294,30 @@ def gemm_nt_dmask(A, B, N, K, dmask, dmask_act, dmask_slope=0.0, res_bf16=None, 
     if out is None:
         out = torch.empty((M, ceil_to(N, 16)), dtype=BF16, device=A.device)
     assert out.dtype == BF16 and out.stride(1) == 1 and out.shape[0] == M and out.shape[1] >= N
+    bits = getattr(dmask, "_dhaug_bits", None)
+    if (bits is not None and DBITS and N == 256 and K == 256 and M % 32 == 0 and M > 0 and dmask_act != 0
+            and A.stride(0) % 8 == 0 and out.stride(0) % 8 == 0):
+        # the mask as the sign-bit array its forward-with-save layer left beside the image: 32 bytes per row instead of 512
+        _lib.call("dhaug_gemm_bf16_dbits", _p(A), A.stride(0), _p(B), B.stride(0), _p(res_bf16),
+                  0 if res_bf16 is None else res_bf16.stride(0), _p(bits), dmask_act, float(dmask_slope), _p(out), out.stride(0), M,
+                  _stream())
+        return out
     _lib.call("dhaug_gemm_bf16_dmask_pad", _p(A), A.stride(0), _p(B), B.stride(0), _p(res_bf16),
               0 if res_bf16 is None else res_bf16.stride(0), _p(dmask), dmask.stride(0), dmask_act, float(dmask_slope),
               _p(out), out.stride(0), min(out.shape[1], ceil_to(N, 16)), M, N, K, _stream())
     return out
+
+
+DBITS = os.environ.get("DHAUG_NO_DBITS") is None          # consume sign-bit masks where a saved activation carries one
+
+
+def tail_rows(t, r0):
+    """t[r0:], keeping the sign-bit array of a saved activation attached (rows r0.. start at a 32-row tile)"""
+    v = t[r0:]
+    bits = getattr(t, "_dhaug_bits", None)
+    if bits is not None and r0 % 32 == 0:
+        v._dhaug_bits = bits[(r0 // 32) * 256:]
+    return v
 
 
 TN256 = os.environ.get("DHAUG_NO_TN256") is None

@@ -212,6 +212,15 @@ int dhaug_gemm_bf16_dmask_pad(const uint16_t* A, int64_t lda, const uint16_t* B,
                               uint16_t* c_bf16, int64_t ldc_bf16, int64_t n_pad_zero, int64_t M, int64_t N, int64_t K,
                               void* stream);
 
+/* The 256 -> 256 input-gradient / tangent step with the activation mask as a SIGN-BIT array:
+ *   c = (A * B^T + residual) * act'(y),   act'(y) read as one bit per element, (y > 0), from `bits` -- the array a
+ * forward-with-save layer leaves beside its image (struct dhaug_mlp_unit.bits: same layout, same 32-row tiles; pass the
+ * address of the word of the first row's tile when A starts at a later row, a multiple of 32).  M a multiple of 32,
+ * N = K = 256, bf16 in / out.  Same arithmetic as dhaug_gemm_bf16_dmask; the mask costs 32 bytes per row instead of 512. */
+int dhaug_gemm_bf16_dbits(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* residual, int64_t ld_res,
+                          const uint32_t* bits, int dmask_act, float dmask_slope, uint16_t* c_bf16, int64_t ldc_bf16, int64_t M,
+                          void* stream);
+
 /* Weight-gradient GEMM: C[N1,N2] (+)= A[M,N1]^T * B[M,N2], contraction over the batch dimension M
  * (split across workgroups, fp32 atomics into C).  bf16 operands, fp32 result.  `accumulate` != 0 adds
  * into C, otherwise C is overwritten (zeroed by the library on the stream first).  colsum_a (optional, fp32 [N1])
@@ -308,6 +317,12 @@ typedef struct dhaug_mlp_unit {
     int64_t save_ld;              /* goes to global memory as bf16 (M, save_ld), columns [0, ceil16(n)) (zero beyond n):   */
                                   /* forward-with-save of the training step (the saved activations of                     */
                                   /* R/models_Fk_GAN/model_fk_gan_train.py:177-230's autograd graph)                      */
+    void* bits;                   /* GEMM with `save`, a full-width (n > 224) layer INSIDE a run of such layers, optional:   */
+                                  /* one bit per output element, (y > 0) -- the mask act'(y) of the backward and tangent       */
+                                  /* sweeps in 1/16 of the bytes.  uint32 [ceil(M/128)*4][4][64]: word ((T*4 + w)*64 + l) of  */
+                                  /* 32-row tile T covers row 32 T + (l & 31), features 32 (w + 4 t) + 8 g + 4 (l >> 5) + e;   */
+                                  /* element j = 16 t + 4 g + e sits at bit j/2 (j even) or 16 + j/2 (j odd).  Consumed by    */
+                                  /* dhaug_gemm_bf16_dbits.  A unit that is not such a layer -> DHAUG_EUNSUPPORTED.          */
 } dhaug_mlp_unit;
 
 /* dhaug_pack_wfrag for every layer of a network in one launch (after each optimizer step of a training loop that runs the

@@ -256,3 +256,10 @@ def test_forward_with_save_layer_by_layer(M, tag):
         close(r["d"][4], lr(lin("layer_last", d[3])), D)
         logit = lin("layer_pred", d[4])
         assert (r["logits"] - logit).abs().max().item() <= 1e-4 * max(1.0, logit.abs().max().item())
+    # the sign-bit arrays the run layers leave beside their images: bit == (saved value > 0), element for element
+    from dhaug_amd import fused as F
+    saved = ([t for br in r["y"] for t in br] + [t for br in r["h"] for t in br]) if tag == "d3" else list(r["d"])
+    with_bits = [t for t in saved if getattr(t, "_dhaug_bits", None) is not None]
+    assert len(with_bits) == (12 if tag == "d3" else 3)
+    for t in with_bits:
+        assert torch.equal(F.decode_bits(t._dhaug_bits, rows), (t[:, :D].float() > 0).cpu())
