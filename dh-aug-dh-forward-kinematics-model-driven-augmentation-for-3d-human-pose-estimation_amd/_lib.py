@@ -48,7 +48,8 @@ SIGNATURES = {
     "dhaug_repack_weights": [_vp, _i32, _vp],
     "dhaug_gp_assemble": [_vp, _vp, _vp, _vp, _i64, _i64, _vp],
     "dhaug_gp_penalty": [_vp, _vp, _vp, _i64, _i64, _f32, _vp],
-    "dhaug_critic_scalars": [_vp, _i64, _vp, _i64, _i64, _f32, _vp, _vp],
+    "dhaug_critic_scalars": [_vp, _i64, _vp, _i64, _i64, _f32, _vp, _vp, _vp],
+    "dhaug_rank1_mask_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _f32, _vp],
     "dhaug_add_f32": [_vp, _vp, _vp, _i64, _vp],
     "dhaug_frame_reverse": [_vp, _vp, _i64, _i32, _i32, _vp],
     "dhaug_weighted_means": [ctypes.POINTER(_vp), ctypes.POINTER(_i64), ctypes.POINTER(_f32), _i32, _vp, _vp],

@@ -35,6 +35,7 @@ FUSED_STEP_FORWARD = os.environ.get("DHAUG_NO_FUSED_STEP_FORWARD") is None
 # sweep 4: the weight / bias gradients of all layers up to 256 wide in ONE grouped launch (ops.gemm_tn_group) instead of one
 # contraction launch per layer
 TN_GROUP = os.environ.get("DHAUG_NO_TN_GROUP") is None
+RANK1 = os.environ.get("DHAUG_NO_RANK1") is None
 
 BF16 = torch.bfloat16
 NONE, RELU, LRELU = A.ACT_NONE, A.ACT_RELU, A.ACT_LRELU
@@ -68,6 +69,10 @@ class _Math:
         kp = ceil16(k)
         Bop = A._w_nt(W, kp, self.prec) if orient == "nt" else A._w_nn(W, self.prec)
         a_op = self._a(a, k)
+        if (self.bf16 and RANK1 and orient == "nn" and N == 1 and a.dtype == BF16 and res is None and bias is None
+                and mask is not None and mask_act != NONE and not out_f32 and mask.stride(0) % 8 == 0 and mask.shape[1] >= ceil16(K)):
+            # the logit layer's input cotangent: seed (rows,1) x weight row (1,K), masked -- a streaming kernel, not a K = 1 GEMM
+            return ops.rank1_mask(a, A._w_nn(W, self.prec)[:, 0], mask, K, mask_act, slope, out=out)
         if self.bf16:
             rb = res if (res is not None and res.dtype == BF16) else None
             rf = res if (res is not None and res.dtype != BF16) else None
@@ -152,6 +157,9 @@ class _Lin:
     def fwd(self, m, x, res=None, out=None, out_f32=False):
         return m.mm(x, self.W, "nt", bias=self.b, res=res, act=self.act, slope=self.slope, out=out, out_f32=out_f32)
 
+    def _bslot(self):
+        return None if self.b is None else _slot(self.b)
+
     def bwd(self, m, gz, mask, mask_act, slope, skip=None, out=None, out_f32=False):
         """(gz W + skip) * mask_act'(mask): cotangent at the producer's pre-activation"""
         return m.mm(gz, self.W, "nn", res=skip, mask=mask, mask_act=mask_act, slope=slope, out=out, out_f32=out_f32)
@@ -164,21 +172,34 @@ class _Lin:
             out = y
         return m.mm(u, self.W, "nt", res=skip, mask=y, mask_act=self.act, slope=self.slope, out=out)
 
-    def grads(self, m, gz, x, B2, u):
-        """dW += gz[:2B]^T x[:2B] + gz[2B:]^T u,  db += colsum(gz[:2B])"""
+    def grads(self, m, gz, x, B2, u, bias_is_zero=False):
+        """dW += gz[:2B]^T x[:2B] + gz[2B:]^T u,  db += colsum(gz[:2B]).  bias_is_zero: the logit layer of a critic step --
+        its cotangent is -1/B on the B real rows and +1/B on the B fake rows, so the bias gradient is EXACTLY zero (the
+        reference's two backward passes cancel to the last bit as well; the pairing column-sum kernel reproduced that 0 in
+        26 us per step): the slot, zeroed by zero_grad, is left alone"""
+        if bias_is_zero:
+            bz = self.b
+            self.b = None
+            try:
+                return self._grads(m, gz, x, B2, u)
+            finally:
+                self.b = bz
+        return self._grads(m, gz, x, B2, u)
+
+    def _grads(self, m, gz, x, B2, u):
         if (m.bf16 and x.dtype == BF16 and u.dtype == BF16 and B2 % 128 == 0 and u.data_ptr() == x[B2:].data_ptr()
                 and u.stride(0) == x.stride(0)):
             # the tangent was written over the interpolated rows of x: one launch contracts all 3B rows
-            m.outer(gz, x, self.N, self.K, _slot(self.W), _slot(self.b), colsum_rows=B2)
+            m.outer(gz, x, self.N, self.K, _slot(self.W), self._bslot(), colsum_rows=B2)
             return
         if m.bf16 and x.dtype != BF16 and u.dtype != BF16 and B2 % 128 == 0 and x.shape[0] == B2 + u.shape[0]:
             # a network input layer: [x(real, fake); tangent seed] cast into one bf16 operand, one contraction
             xb = torch.empty((x.shape[0], ceil16(self.K)), dtype=BF16, device=x.device)
             ops.cast_pad_bf16(x[:B2], ceil16(self.K), out=xb[:B2])
             ops.cast_pad_bf16(u, ceil16(self.K), out=xb[B2:])
-            m.outer(gz, xb, self.N, self.K, _slot(self.W), _slot(self.b), colsum_rows=B2)
+            m.outer(gz, xb, self.N, self.K, _slot(self.W), self._bslot(), colsum_rows=B2)
             return
-        m.outer(gz[:B2], x[:B2], self.N, self.K, _slot(self.W), _slot(self.b))
+        m.outer(gz[:B2], x[:B2], self.N, self.K, _slot(self.W), self._bslot())
         m.outer(gz[B2:], u, self.N, self.K, _slot(self.W))
 
 
@@ -268,7 +289,7 @@ def step_d2(D, optimizerD, real, fake, alpha, lam, prec=None):
     ul = L[4].tan(m, u4, tail(dl, B2), inplace=True)
     for lay, gz, x, u in ((L[0], gz1, X, v), (L[1], gz2, d1, u1), (L[2], gz3, d2, u2), (L[3], gz4, d3, u3),
                           (L[4], gzl, d4, u4), (L[5], gzp, dl, ul)):
-        lay.grads(m, gz, x, B2, u)
+        lay.grads(m, gz, x, B2, u, bias_is_zero=(lay is L[5] and m.bf16))
     m.flush()
     return _finish(optimizerD, logits, pen, B, lam)
 
@@ -328,7 +349,7 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
     T = tangents(v.reshape(g.shape))
     u, uh = [], []
     for bi, br in enumerate(branches):
-        us, uhs = [br.first.tan(m, T[bi], y[bi][0][B2:], inplace=True)], []
+        us, uhs = [br.first.tan(m, T[bi], ops.tail_rows(y[bi][0], B2), inplace=True)], []
         for i, blk in enumerate(br.blocks):
             hh, yy = blk.tan(m, us[-1], ops.tail_rows(h[bi][i], B2), ops.tail_rows(y[bi][i + 1], B2))
             uhs.append(hh); us.append(yy)
@@ -349,7 +370,7 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
             blk.fc2.grads(m, g2[bi][i + 1], h[bi][i], B2, uh[bi][i])
     Lm.grads(m, gz_m0, cat, B2, ucat)
     Mb.fc1.grads(m, gz_m1, m0, B2, um0); Mb.fc2.grads(m, gz_m2, mh, B2, umh)
-    Lo.grads(m, gzo, m1, B2, um1)
+    Lo.grads(m, gzo, m1, B2, um1, bias_is_zero=m.bf16)
     m.flush()
     return _finish(optimizerD, logits, pen, gv.shape[0], lam, rows=B)
 

@@ -281,34 +281,20 @@ __global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ 
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = a[i] + b[i];
 }
 
-__global__ __launch_bounds__(1024) void critic_scalars_kernel(const float* __restrict__ logits, long long ld,
-                                                              const float* __restrict__ pen, long long B, long long P, float lambda,
-                                                              float* __restrict__ out) {
-    __shared__ float red[3][16];
+// stage 1: partial sums of the real logits, the fake logits and the penalties: block b -> part[3 b + k]; 64 blocks keep enough
+// requests in flight (one workgroup took 24 us for 0.8 MB)
+constexpr int CS_BLOCKS = 64;
+__global__ __launch_bounds__(256) void critic_scalars_partial_kernel(const float* __restrict__ logits, long long ld,
+                                                                      const float* __restrict__ pen, long long B, long long P,
+                                                                      float* __restrict__ part) {
+    __shared__ float red[3][4];
     float s[3] = {0.f, 0.f, 0.f};
-    long long i = threadIdx.x;
-    for (; i + 7 * 1024 < B; i += 8 * 1024) {                   // eight independent requests per array in flight
-        float a[8], b[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            a[j] = logits[(i + j * 1024) * ld];
-            b[j] = logits[(B + i + j * 1024) * ld];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { s[0] += a[j]; s[1] += b[j]; }
-    }
-    for (; i < B; i += 1024) {
+    const long long stride = (long long)CS_BLOCKS * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < B; i += stride) {
         s[0] += logits[i * ld];
         s[1] += logits[(B + i) * ld];
     }
-    for (i = threadIdx.x; i + 7 * 1024 < P; i += 8 * 1024) {
-        float c[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) c[j] = pen[i + j * 1024];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s[2] += c[j];
-    }
-    for (; i < P; i += 1024) s[2] += pen[i];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < P; i += stride) s[2] += pen[i];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
 #pragma unroll
@@ -316,12 +302,55 @@ __global__ __launch_bounds__(1024) void critic_scalars_kernel(const float* __res
         if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s[k];
     }
     __syncthreads();
+    if (threadIdx.x < 3) part[3 * blockIdx.x + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// stage 2: out[0..4] = D_real, D_fake, GP, Wasserstein_D = D_real - D_fake, D_cost = D_fake - D_real + GP (fixed summation order)
+__global__ __launch_bounds__(64) void critic_scalars_final_kernel(const float* __restrict__ part, long long B, long long P, float lambda,
+                                                                   float* __restrict__ out) {
+    float s[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        s[k] = threadIdx.x < CS_BLOCKS ? part[3 * threadIdx.x + k] : 0.f;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s[k] += __shfl_xor(s[k], o, 64);
+    }
     if (threadIdx.x == 0) {
-        float t[3] = {0.f, 0.f, 0.f};
-        for (int k = 0; k < 3; ++k)
-            for (int w = 0; w < 16; ++w) t[k] += red[k][w];
-        const float dr = t[0] / (float)B, df = t[1] / (float)B, gp = lambda * (t[2] / (float)P);
+        const float dr = s[0] / (float)B, df = s[1] / (float)B, gp = lambda * (s[2] / (float)P);
         out[0] = dr; out[1] = df; out[2] = gp; out[3] = dr - df; out[4] = df - dr + gp;
+    }
+}
+
+// (2) cotangent of a 1-wide linear layer's input behind an activation: out[r][c] = bf16(seed[r] * w[c]) * act'(mask[r][c]),
+// columns [N, pad) zero -- the rank-one first step of a critic's backward chain (the logit layer), which as a GEMM with
+// K = 1 spent 43 us on 44 MB
+__global__ __launch_bounds__(256) void rank1_mask_kernel(const uint16_t* __restrict__ seed, long long ld_seed,
+                                                         const uint16_t* __restrict__ w, long long ld_w,
+                                                         const uint16_t* __restrict__ mask, long long ld_mask,
+                                                         uint16_t* __restrict__ out, long long ld_out, long long M, int N, int pad,
+                                                         float dneg) {
+    const int cpr = pad >> 3;                                 // 16-byte chunks per row
+    const long long total = M * cpr;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / cpr;
+        const int c0 = (int)(i - r * cpr) * 8;
+        const float sv = dhaug_bf16_to_f32(seed[r * ld_seed]);
+        const uint4 mk = *reinterpret_cast<const uint4*>(mask + r * ld_mask + c0);
+        const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
+        uint32_t ow[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c = c0 + 2 * e + q;
+                const short y = (short)(q ? (mw[e] >> 16) : (mw[e] & 0xffffu));
+                const float g = c < N ? dhaug_bf16_to_f32(dhaug_f32_to_bf16(sv * dhaug_bf16_to_f32(w[(long long)c * ld_w]))) : 0.0f;
+                v[q] = y > 0 ? g : g * dneg;
+            }
+            ow[e] = (uint32_t)dhaug_f32_to_bf16(v[0]) | ((uint32_t)dhaug_f32_to_bf16(v[1]) << 16);
+        }
+        *reinterpret_cast<uint4*>(out + r * ld_out + c0) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
     }
 }
 
@@ -552,11 +581,28 @@ int dhaug_gp_penalty(const float* grad, float* v, float* pen, int64_t B, int64_t
 }
 
 int dhaug_critic_scalars(const float* logits, int64_t ld, const float* pen, int64_t B, int64_t P, float lambda, float* out5,
-                         void* stream) {
+                         float* scratch, void* stream) {
     DHAUG_CHECK(B >= 1 && P >= 1 && ld >= 1, DHAUG_EINVAL);
-    DHAUG_CHECK_PTR(logits); DHAUG_CHECK_PTR(pen); DHAUG_CHECK_PTR(out5);
-    hipLaunchKernelGGL(critic_scalars_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, (long long)ld, pen,
-                       (long long)B, (long long)P, lambda, out5);
+    DHAUG_CHECK_PTR(logits); DHAUG_CHECK_PTR(pen); DHAUG_CHECK_PTR(out5); DHAUG_CHECK_PTR(scratch);
+    hipLaunchKernelGGL(critic_scalars_partial_kernel, dim3(CS_BLOCKS), dim3(256), 0, (hipStream_t)stream, logits, (long long)ld, pen,
+                       (long long)B, (long long)P, scratch);
+    hipLaunchKernelGGL(critic_scalars_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, (long long)B, (long long)P,
+                       lambda, out5);
+    return dhaug_launch_status();
+}
+
+int dhaug_rank1_mask_bf16(const uint16_t* seed, int64_t ld_seed, const uint16_t* w, int64_t ld_w, const uint16_t* mask, int64_t ld_mask,
+                          uint16_t* out, int64_t ld_out, int64_t M, int64_t N, int64_t pad_cols, int mask_act, float mask_slope,
+                          void* stream) {
+    DHAUG_CHECK(M >= 0 && N >= 1 && pad_cols >= N && pad_cols % 8 == 0 && pad_cols <= (1 << 20), DHAUG_EINVAL);
+    DHAUG_CHECK(mask_act == DHAUG_ACT_RELU || mask_act == DHAUG_ACT_LRELU, DHAUG_EINVAL);
+    if (M == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(seed); DHAUG_CHECK_PTR(w); DHAUG_CHECK_PTR(mask); DHAUG_CHECK_PTR(out);
+    DHAUG_CHECK(ld_seed >= 1 && ld_w >= 1 && ld_mask >= pad_cols && ld_out >= pad_cols && ld_mask % 8 == 0 && ld_out % 8 == 0, DHAUG_EALIGN);
+    DHAUG_CHECK(dhaug_aligned16(mask) && dhaug_aligned16(out), DHAUG_EALIGN);
+    hipLaunchKernelGGL(rank1_mask_kernel, dim3(grid1d(M * (pad_cols >> 3), 256)), dim3(256), 0, (hipStream_t)stream, seed,
+                       (long long)ld_seed, w, (long long)ld_w, mask, (long long)ld_mask, out, (long long)ld_out, (long long)M, (int)N,
+                       (int)pad_cols, mask_act == DHAUG_ACT_RELU ? 0.0f : mask_slope);
     return dhaug_launch_status();
 }
 

@@ -475,7 +475,7 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 // LDS read, no exposed copy loop between the layers.  (Issuing the stores from all four waves and letting the range check
 // drop three quarters of them cost more than the stores themselves: 448 us with every store nullified against 336 us
 // without the instructions, 3D critic at 3B = 196 608 rows.)
-template <bool LEAKY, int RESMODE, int KS = MLP_MAX_KSTEPS, bool SAVE = false>
+template <bool LEAKY, int RESMODE, int KS = MLP_MAX_KSTEPS, bool SAVE = false, bool BITS = SAVE>
 __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc& nd, unsigned char* smem, int wave, int lane,
                                             const WHalf& wlo, WHalf& nlo, WHalf& whi, f32x16 (&seed)[MLP_NS],
                                             const bf16x8 (&idf)[2], int dbg, __amdgpu_buffer_rsrc_t sv, int sv_ld,
@@ -645,7 +645,7 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
                         if (mt > 0 && (k & 1)) {
                             st0 = pair_pack(acc[(mt - 1) & 1], 2 * k - 2);
                             st1 = pair_pack(acc[(mt - 1) & 1], 2 * k);
-                            if (SAVE) {
+                            if (BITS) {
                                 bits_or(st0, k - 1);
                                 bits_or(st1, k);
                                 if (k == KS - 1) bits_store(mt - 1);         // all sixteen pairs of tile mt-1 are packed
@@ -659,8 +659,14 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
 #pragma unroll
                         for (int q = 0; q < PAIRS; q += 2) {
                             const int j = 2 * (PAIRS * k + q);
-                            quad_store(mt - 1, j, pair_pack(acc[(mt - 1) & 1], j), pair_pack(acc[(mt - 1) & 1], j + 2));
+                            const uint32_t p0 = pair_pack(acc[(mt - 1) & 1], j), p1 = pair_pack(acc[(mt - 1) & 1], j + 2);
+                            quad_store(mt - 1, j, p0, p1);
+                            if (BITS) {
+                                bits_or(p0, j >> 1);
+                                bits_or(p1, (j >> 1) + 1);
+                            }
                         }
+                        if (BITS && k == KS - 1) bits_store(mt - 1);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -681,12 +687,12 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
     for (int j = 0; j < 32; j += 4) {
         const uint32_t p0 = pair_pack(acc[(MLP_MT - 1) & 1], j), p1 = pair_pack(acc[(MLP_MT - 1) & 1], j + 2);
         quad_store(MLP_MT - 1, j, p0, p1);
-        if (SAVE && !LEAD) {
+        if (BITS) {
             bits_or(p0, j >> 1);
             bits_or(p1, (j >> 1) + 1);
         }
     }
-    if (SAVE && !LEAD) bits_store(MLP_MT - 1);
+    if (BITS) bits_store(MLP_MT - 1);
     DHAUG_LSTAMP(dbg + 5)
 #pragma unroll
     for (int t = 0; t < MLP_NS; ++t) seed[t] = nseed[t];
@@ -889,14 +895,14 @@ __device__ __forceinline__ void gemm_stack(UnitPtr lead, int lead_ks, UnitPtr fi
             for (int t = 0; t < MLP_NS; ++t)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) loB[t][k] = b.frag(t, k);
-            stack_layer<LEAKY, 0, 8, false>(ld, cur, smem, wave, lane, loB, loA, hi, seed, idf, MLP_MAX_UNITS + 50, nosv, 0, nosv);
+            stack_layer<LEAKY, 0, 8, false, SAVE>(ld, cur, smem, wave, lane, loB, loA, hi, seed, idf, MLP_MAX_UNITS + 50, nosv, 0, bits_of(lead));
         } else {
             const WBase<4> b(ld.w, wave, 4, lane);
 #pragma unroll
             for (int t = 0; t < MLP_NS; ++t)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) loB[t][k] = b.frag(t, k);
-            stack_layer<LEAKY, 0, 4, false>(ld, cur, smem, wave, lane, loB, loA, hi, seed, idf, MLP_MAX_UNITS + 50, nosv, 0, nosv);
+            stack_layer<LEAKY, 0, 4, false, SAVE>(ld, cur, smem, wave, lane, loB, loA, hi, seed, idf, MLP_MAX_UNITS + 50, nosv, 0, bits_of(lead));
         }
         lds_barrier();
         DHAUG_LSTAMP(MLP_MAX_UNITS + 56)
@@ -1408,13 +1414,13 @@ int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* 
         }
     }
     for (int i = 0; i < prog.nunits; ++i) prog.u[i].plan = plan_unit(prog, i);
-    {   // sign bits are written by the layers of a run (not by the narrow layer feeding it, nor by layer-at-a-time units)
+    {   // sign bits are written by the layers of a run and by the narrow layer feeding it (not by layer-at-a-time units)
         bool in_run[MLP_MAX_UNITS] = {};
         for (int i = 0; i < prog.nunits;) {
             const int plan = prog.u[i].plan;
             if (prog.u[i].kind == U_GEMM && (plan & PLAN_STACK)) {
                 const int lead = (plan & 15) != 0, run = (plan >> 4) & 63;
-                for (int j = 0; j < run; ++j) in_run[i + lead + j] = true;
+                for (int j = 0; j < lead + run; ++j) in_run[i + j] = true;
                 i += lead + run + ((plan & (PLAN_TAIL | PLAN_TAIL_BF16)) ? 1 : 0);
             } else {
                 ++i;

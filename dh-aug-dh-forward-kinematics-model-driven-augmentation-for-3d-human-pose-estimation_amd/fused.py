@@ -296,7 +296,7 @@ def _d3s_program(D, L, inputs, M):
     logits = torch.empty((M, 1), dtype=torch.float32, device=dev)
 
     def branch(u, b, first, names):
-        u.append(_gemm(L[first], 1, 0, ACT_RELU, save=y[b][0]))
+        u.append(_gemm(L[first], 1, 0, ACT_RELU, save=y[b][0], bits=True))
         for i, n in enumerate(names):
             u.append(_gemm(L[n + ".fc1"], 0, 1, ACT_RELU, save=h[b][i], bits=True))
             u.append(_gemm(L[n + ".fc2"], 1, 0, ACT_RELU, res=0, save=y[b][i + 1], bits=True))
@@ -327,7 +327,7 @@ def _d2s_program(D, L, inputs, M):
     d = [_empty16(M, Dw, dev) for _ in range(5)]
     logits = torch.empty((M, 1), dtype=torch.float32, device=dev)
     u = [_unit(LOAD_F32, dst=1, cols=32, ld=x.stride(0), g=x),
-         _gemm(L["pose_layer_1"], 1, 0, ACT_LRELU, s, save=d[0]),
+         _gemm(L["pose_layer_1"], 1, 0, ACT_LRELU, s, save=d[0], bits=True),
          _gemm(L["pose_layer_2"], 0, 1, ACT_LRELU, s, save=d[1], bits=True),
          _gemm(L["pose_layer_3"], 1, 0, ACT_LRELU, s, res=0, save=d[2], bits=True),
          _gemm(L["pose_layer_4"], 0, 1, ACT_NONE, save=d[3]),

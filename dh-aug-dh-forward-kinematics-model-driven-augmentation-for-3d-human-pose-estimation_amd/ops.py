@@ -439,8 +439,20 @@ def gp_penalty(grad, coef):
 
 def critic_scalars(logits, pen, B, lam):
     """(5,) fp32: D_real, D_fake, GP, Wasserstein_D, D_cost (logit means over B rows per half, penalty mean over len(pen))"""
-    out = torch.empty((5,), dtype=torch.float32, device=logits.device)
-    _lib.call("dhaug_critic_scalars", _p(logits), logits.stride(0), _p(pen), B, pen.numel(), float(lam), _p(out), _stream())
+    buf = torch.empty((5 + 192,), dtype=torch.float32, device=logits.device)      # result + the partial sums of stage 1
+    _lib.call("dhaug_critic_scalars", _p(logits), logits.stride(0), _p(pen), B, pen.numel(), float(lam), _p(buf), _p(buf[8:]), _stream())
+    return buf[:5]
+
+
+def rank1_mask(seed, w_col, mask, n, act, slope=0.0, out=None):
+    """bf16 (M, pad): bf16(seed[r] * w[c]) * act'(mask[r][c]) -- the first backward step through a 1-wide logit layer.
+    seed (M, >=1) bf16 (column 0), w_col: bf16 view with the layer's n weights along dim 0 (any stride)"""
+    assert seed.dtype == BF16 and w_col.dtype == BF16 and mask.dtype == BF16
+    M, pad = mask.shape[0], min(mask.shape[1], ceil_to(n, 16))
+    if out is None:
+        out = torch.empty((M, ceil_to(n, 16)), dtype=BF16, device=mask.device)
+    _lib.call("dhaug_rank1_mask_bf16", _p(seed), seed.stride(0), _p(w_col), w_col.stride(0), _p(mask), mask.stride(0), _p(out),
+              out.stride(0), M, n, pad, act, float(slope), _stream())
     return out
 
 

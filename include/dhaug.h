@@ -433,7 +433,16 @@ int dhaug_weighted_means(const float* const* arrays, const int64_t* counts, cons
  * the logits (rows [0,B) real, [B,2B) fake, stride ld) and the P per-row penalties (P = B, or B * frames for the 2D motion
  * critic, whose penalty is taken per frame). */
 int dhaug_critic_scalars(const float* logits, int64_t ld, const float* pen, int64_t B, int64_t P, float lambda, float* out5,
-                         void* stream);
+                         float* scratch /* DHAUG_CRITIC_SCALARS_SCRATCH floats, any content */, void* stream);
+#define DHAUG_CRITIC_SCALARS_SCRATCH 192
+
+/* First step of a critic's backward chain, through its 1-wide logit layer: out[r][c] = bf16(seed[r] * w[c]) * act'(mask[r][c])
+ * for c < N, zero in [N, pad_cols) -- (gz W_out) * act'(y) of R/models_Fk_GAN/Fk_discriminator.py:201,266's backward, which as
+ * a GEMM has K = 1.  seed: bf16, one value per row (stride ld_seed); w: the layer's N weights as bf16 (stride ld_w); mask, out:
+ * bf16 (M, ld) with 16-byte aligned rows. */
+int dhaug_rank1_mask_bf16(const uint16_t* seed, int64_t ld_seed, const uint16_t* w, int64_t ld_w, const uint16_t* mask, int64_t ld_mask,
+                          uint16_t* out, int64_t ld_out, int64_t M, int64_t N, int64_t pad_cols, int mask_act, float mask_slope,
+                          void* stream);
 
 /* out = a + b over n fp32 values (the branch contributions to dD/dx_hat of a multi-branch critic). */
 int dhaug_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);

@@ -260,6 +260,6 @@ def test_forward_with_save_layer_by_layer(M, tag):
     from dhaug_amd import fused as F
     saved = ([t for br in r["y"] for t in br] + [t for br in r["h"] for t in br]) if tag == "d3" else list(r["d"])
     with_bits = [t for t in saved if getattr(t, "_dhaug_bits", None) is not None]
-    assert len(with_bits) == (12 if tag == "d3" else 3)
+    assert len(with_bits) == (14 if tag == "d3" else 4)
     for t in with_bits:
         assert torch.equal(F.decode_bits(t._dhaug_bits, rows), (t[:, :D].float() > 0).cpu())
