@@ -154,7 +154,8 @@ def parse(argv=None):
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel roofline timing loops (profiling runs)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="training workloads: replay the iteration as captured hipGraphs (auto: on for one rank)")
+                    help="training workloads: replay the iteration as captured hipGraphs (auto = on; with several ranks the "
+                         "graph is cut at the all-reduces)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only: every rank joins the process group, the timing exchange runs, rank 0 prints the line "
                          "(no GPU work; with DHAUG_DIST_BACKEND=gloo this rehearses the N-rank launch path on a CPU box)")
@@ -185,8 +186,30 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"metric": "augmented poses/sec (FK+GAN step), 16-joint batch=65536", "dry_run": True,
-                              "n_gpus": world, "max_over_ranks": tt.item(), "backend": backend if world > 1 else None}))
+            line = {"metric": "augmented poses/sec (FK+GAN step), 16-joint batch=65536", "dry_run": True,
+                    "n_gpus": world, "max_over_ranks": tt.item(), "backend": backend if world > 1 else None}
+            if a.workload in ("gan_step", "video"):
+                # what the exchange step of this workload moves: the flat gradient bucket of every network (host-side: the
+                # modules are only constructed), and what a real N-rank run of it prints beside `value`
+                from dhaug_amd.function_aug.config import synth_args as _sa
+                from dhaug_amd.models_Fk_GAN import Fk_discriminator as _dis, Fk_generator as _gen
+                vid = a.workload == "video"
+                Dd = a.dense if a.dense is not None else (1000 if vid else 256)
+                Rr = 9 if vid else 1
+                aa = _sa(a.batch or (512 if vid else 65536), Dd, **(dict(single_or_multi_train_mode="multi", architecture="3,3",
+                                                                        video_Dis_DenseDim_3D=Dd, video_Dis_DenseDim_2D=Dd) if vid else {}))
+                nets = {"G": (_gen.Video_Fk_Generator(Rr, None, aa, "cpu") if vid else _gen.Fk_Generator(None, aa, "cpu")),
+                        "d3d": _dis.Fk_3D_Discriminator("cpu", aa), "d2d": _dis.Fk_2D_Discriminator(aa, 16)}
+                if vid:
+                    nets["motion_d3d"] = _dis.Video_motion_Fk_3D_Discriminator("cpu", aa, Rr)
+                    nets["motion_d2d"] = _dis.Video_motion_Fk_2D_Discriminator("cpu", aa, Rr)
+                line["allreduce_bytes_per_optimizer_step"] = {k: 4 * sum(p.numel() for p in m.parameters()) for k, m in nets.items()}
+                line["optimizer_steps_per_iteration"] = ({"d3d": 2, "d2d": 2, "G": 0.2} if not vid else
+                                                         {"d3d": 2, "d2d": 2, "motion_d3d": 4, "motion_d2d": 4, "G": 0.2})
+                line["multi_rank_fields"] = ["value_gan_step", "gan_step_ms_per_step_max_over_ranks", "allreduce_alone",
+                                             "allreduce_us_per_optimizer_step", "allreduce_share_of_gan_step_upper_bound"]
+                line["hip_graph"] = "segmented (graph | all-reduce | graph ...)" if a.graph != "off" else False
+            print(json.dumps(line))
         return
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
@@ -257,7 +280,9 @@ def main():
             l3, l2 = score_fake_pair(D3, D2, xc, kcs, p2)                                    # both critics, one launch
         return l3, l2
 
-    use_graph = a.graph == "on" or (a.graph == "auto" and world == 1)
+    # one rank: the iteration is one hipGraph; several ranks: graph segments with the all-reduces between them
+    # (graphs.SegmentedCall).  --graph off: eager
+    use_graph = a.graph in ("on", "auto")
     graphed = None
     if use_graph and a.workload in ("gan_step", "video"):
         from dhaug_amd.graphs import GraphedGanIteration

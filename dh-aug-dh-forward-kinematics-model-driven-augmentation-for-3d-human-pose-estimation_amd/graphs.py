@@ -10,7 +10,11 @@ hipGraphLaunch on the host.  What makes the step replayable:
   * the weights' bf16 re-packing happens inside the captured region: before their first use (no packed copy made outside
     the capture is ever read by a captured kernel) and after every optimizer step;
   * inputs are copied into static buffers before each replay; the camera is a launch argument, so a graph is keyed by it.
-Not captured: the data-parallel all-reduce (multi-rank runs stay eager)."""
+Multi-rank runs (SegmentedCall): the collective stays eager, everything between two collective events is a graph -- the
+iteration is captured as SEGMENTS cut where FusedAdam starts an all-reduce or waits for one:
+    graph | all_reduce(d3 bucket, async) | graph | all_reduce(d2 bucket, async) | wait(d3) | graph (Adam d3, ...) | ...
+so an N-rank iteration costs a handful of hipGraphLaunch calls + its collectives on the host, not ~300 (single-frame) or
+~1 400 (video) kernel launches."""
 import itertools
 
 import torch
@@ -59,6 +63,82 @@ class GraphedCall:
         return self.out
 
 
+RECORDER = None          # the SegmentedCall being captured, if any: FusedAdam cuts the capture at its collective events
+
+
+class SegmentedCall:
+    """fn(*static_inputs) as a sequence of captured graphs with the data-parallel collectives between them.
+
+    While fn is captured, optim.FusedAdam calls cut(("allreduce", opt)) where it would start the all-reduce of its gradient
+    bucket and cut(("wait", opt)) where it would wait for it: the running capture ends, the event is recorded, a new capture
+    begins (same memory pool: tensors alive across a cut stay where they are).  Replay = graphs and events in order; the
+    all-reduce is issued on the replaying stream's timeline exactly as the eager path issues it (async_op; wait() makes the
+    stream wait, not the host, with RCCL)."""
+
+    def __init__(self, fn, example_inputs, warmup=2, prologue=None, state=()):
+        import torch.distributed as dist
+        self.dist = dist
+        self.static_in = [t.clone() if torch.is_tensor(t) else t for t in example_inputs]
+        saved = [t.clone() for t in state]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                                # (eager, collectives included: every rank runs the same)
+                fn(*self.static_in)
+            for t, s in zip(state, saved):
+                t.copy_(s)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if saved:
+            A.bump_weight_epoch()
+        global RECORDER
+        self.items, self.pool, self.cap = [], torch.cuda.graph_pool_handle(), torch.cuda.Stream()
+        self._g = None
+        A.CAPTURE_ID = next(_capture_ids)
+        RECORDER = self
+        try:
+            self.cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.cap):
+                self._begin()
+                if prologue is not None:
+                    prologue()
+                self.out = fn(*self.static_in)
+                self._end()
+            torch.cuda.current_stream().wait_stream(self.cap)
+        finally:
+            RECORDER = None
+            A.CAPTURE_ID = 0
+        self.work = {}
+
+    def _begin(self):
+        self._g = torch.cuda.CUDAGraph()
+        self._g.capture_begin(pool=self.pool)
+
+    def _end(self):
+        self._g.capture_end()
+        self.items.append(("graph", self._g))
+        self._g = None
+
+    def cut(self, event):
+        """called by FusedAdam during the capture: event = ("allreduce" | "wait", optimizer)"""
+        self._end()
+        self.items.append(event)
+        self._begin()
+
+    def __call__(self, *inputs):
+        for dst, src in zip(self.static_in, inputs):
+            if torch.is_tensor(dst):
+                dst.copy_(src, non_blocking=True)
+        for kind, obj in self.items:
+            if kind == "graph":
+                obj.replay()
+            elif kind == "allreduce":
+                self.work[id(obj)] = self.dist.all_reduce(obj.flat_grad, op=self.dist.ReduceOp.SUM, group=obj.process_group, async_op=True)
+            else:
+                self.work.pop(id(obj)).wait()
+        return self.out
+
+
 class GraphedGanIteration:
     """gan_iteration / video_gan_iteration behind hipGraphs: one graph per (camera, G-step or not).  Call like the eager
     function; the returned tensors live in the graph's static memory (copy what must outlive the next call)."""
@@ -84,8 +164,9 @@ class GraphedGanIteration:
                 o._ensure_packs()                              # (allocation + descriptor upload must not happen in a capture)
             state = [t for o in opts for t in (o.flat_param, o.exp_avg, o.exp_avg_sq, o.step_dev)]
             counts = [o.step_count for o in opts]
-            g = self.graphs[key] = GraphedCall(run, (inputs_3d, cam_param, inputs_2d), prologue=lambda: [o._repack() for o in opts],
-                                               state=state)
+            multi = any(o.world_size() > 1 for o in opts)          # collectives between graph segments
+            g = self.graphs[key] = (SegmentedCall if multi else GraphedCall)(
+                run, (inputs_3d, cam_param, inputs_2d), prologue=lambda: [o._repack() for o in opts], state=state)
             for o, c in zip(opts, counts):                     # (host-side bookkeeping of the warm-up calls)
                 o.step_count = c
         return g(inputs_3d, cam_param, inputs_2d)

@@ -117,11 +117,21 @@ class FusedAdam(torch.optim.Optimizer):
         if not self.flat_param.is_cuda:
             raise RuntimeError("FusedAdam needs GPU parameters (no CPU fallback exists)")
         if ws > 1:
-            work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
-            if self.overlap:
-                self._pending = (work, ws)
-                return None
-            work.wait()
+            from . import graphs
+            rec = graphs.RECORDER
+            if rec is not None:
+                # a segmented hipGraph capture (graphs.SegmentedCall): the collective is an event BETWEEN two graphs
+                rec.cut(("allreduce", self))
+                if self.overlap:
+                    self._pending = (None, ws)
+                    return None
+                rec.cut(("wait", self))
+            else:
+                work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+                if self.overlap:
+                    self._pending = (work, ws)
+                    return None
+                work.wait()
         self._apply(ws)
         return None
 
@@ -173,5 +183,9 @@ class FusedAdam(torch.optim.Optimizer):
         if self._pending is not None:
             work, ws = self._pending
             self._pending = None
-            work.wait()
+            if work is None:                                   # started inside a segmented capture: the wait is an event too
+                from . import graphs
+                graphs.RECORDER.cut(("wait", self))
+            else:
+                work.wait()
             self._apply(ws)

@@ -103,3 +103,26 @@ def test_bench_gpus_flag_launches_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env2,
                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r2.returncode != 0
+
+
+def test_bench_gan_step_dry_run_reports_the_exchange():
+    """`python bench.py --gpus 2 --workload gan_step --dry-run`: the N-rank launch of the TRAINING workload rehearsed on CPU
+    with gloo -- the line names the gradient buckets an optimizer step all-reduces (bytes from the constructed modules),
+    the optimizer steps per iteration, and the fields a real run prints for the scaled quantity."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["DHAUG_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "gan_step", "--dry-run"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["backend"] == "gloo"
+    by = line["allreduce_bytes_per_optimizer_step"]
+    # SURVEY.md section 8a: 436 771 / 881 585 / 271 873 parameters at DenseDim 256
+    assert by == {"G": 4 * 436771, "d3d": 4 * 881585, "d2d": 4 * 271873}
+    assert line["optimizer_steps_per_iteration"] == {"d3d": 2, "d2d": 2, "G": 0.2}
+    for k in ("value_gan_step", "allreduce_us_per_optimizer_step", "allreduce_share_of_gan_step_upper_bound"):
+        assert k in line["multi_rank_fields"]
+    assert "segmented" in line["hip_graph"]

@@ -234,3 +234,102 @@ def test_two_replica_loop_interleaved_overlap():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     _launch(_worker_loop, "loop", 31500 + (os.getpid() % 2000))
+
+
+def _run_graphs(rank, world, port, tag, q, gpu_ready):
+    """two replicas, each on its half of a batch, run N iterations (a) eagerly and (b) as SEGMENTED hipGraphs
+    (graphs.SegmentedCall: graph | all-reduce | graph ...) from the same weights with constant draws: same weights and
+    Adam state on both paths, replicas bit-identical, and the iteration really is a handful of graph segments"""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import golden_util as GU
+    import dhaug_amd
+    from dhaug_amd import graphs, parallel, autograd_ops as A
+    from dhaug_amd.common.camera import camera_params9
+    from dhaug_amd.common.h36m_dataset import h36m_cameras_extrinsic_params, h36m_cameras_intrinsic_params
+    from dhaug_amd.models_Fk_GAN import forward_kinematics_DH_model as fkm, model_fk_gan_train as train
+    from test_gpu_models import make_args
+    dist.init_process_group("gloo")
+    if rank > 0:
+        gpu_ready[rank - 1].wait(timeout=240)
+    torch.zeros(1, device="cuda").add_(1).item()
+    gpu_ready[rank].set()
+    parallel.init_from_env("gloo")
+    Bg, D, N = 512, 64, 5
+    b, e = parallel.shard_range(Bg, rank, world)
+    B = e - b
+    args = make_args(batch_size=B, Gen_DenseDim=D, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D)
+    ext = h36m_cameras_extrinsic_params["S1"][0]
+    cam = ([float(v) for v in ext["orientation"]], [float(v) / 1000.0 for v in ext["translation"]],
+           camera_params9(h36m_cameras_intrinsic_params[0]))
+    gen = torch.Generator().manual_seed(5)
+    x3 = (GU.synth_pose16(Bg, seed=3) + torch.tensor([0.0, 0.0, 4.5]))[b:e].cuda()
+    x2 = ((torch.rand(Bg, 16, 2, generator=gen) - 0.5) * 1.2)[b:e].cuda()
+    cp = torch.zeros(B, 16, device="cuda")
+    cp[:, 9:13] = torch.tensor(cam[0], device="cuda"); cp[:, 13:16] = torch.tensor(cam[1], device="cuda")
+    mk = lambda: train.ConstDraws(noise=[torch.randn(Bg, 128, generator=torch.Generator().manual_seed(1))[b:e].cuda()],
+                                  scaler=[(torch.randint(-200, 200, (Bg, 8), generator=torch.Generator().manual_seed(2)) / 1000.0)[b:e].cuda()],
+                                  alpha=[torch.rand(Bg, 1, generator=torch.Generator().manual_seed(3))[b:e].cuda()])
+
+    def build():
+        fk = fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+        d = train.my_get_poseFk_model(args, None, fk)
+        for key, shapes, seed in (("model_G", GU.shapes_generator(D), 11), ("model_d3d", GU.shapes_d3(D), 12), ("model_d2d", GU.shapes_d2(D), 13)):
+            sd = GU.seeded_state_dict(shapes, seed)
+            with torch.no_grad():
+                for k, p in d[key].named_parameters():
+                    p.copy_(sd[k].cuda())
+        A.bump_weight_epoch()
+        assert d["optimizer_d3d"].world_size() == world
+        return d
+
+    de, dr = build(), mk()
+    for i in range(N):
+        train.gan_iteration(args, de, x3, cp, x2, ["S1"], None, None, do_g_step=(i % 5 == 4), camera=cam, draws=dr)
+    dg, dr2 = build(), mk()
+    G = graphs.GraphedGanIteration(train.gan_iteration, args, dg, ["S1"], None)
+    for i in range(N):
+        G(x3, cp, x2, i % 5 == 4, cam, draws=dr2)
+    bad = []
+    calls = list(G.graphs.values())
+    if not all(isinstance(c, graphs.SegmentedCall) for c in calls):
+        bad.append(("not segmented", [type(c).__name__ for c in calls]))
+    for c in calls:
+        kinds = [k for k, _ in c.items]
+        # 4 critic steps (+ the G step): one all-reduce and one wait per optimizer step, graphs between them
+        want = 5 if any(True for k, o in c.items if k == "allreduce" and o is dg["optimizer_G"]) else 4
+        if kinds.count("allreduce") != want or kinds.count("wait") != want or kinds.count("graph") < want:
+            bad.append(("segments", kinds))
+    for key, steps in (("optimizer_d3d", 2 * N), ("optimizer_d2d", 2 * N), ("optimizer_G", 1)):
+        if int(dg[key].step_dev.item()) != steps or int(de[key].step_dev.item()) != steps:
+            bad.append(("steps", key, int(dg[key].step_dev.item()), int(de[key].step_dev.item())))
+        for name in ("flat_param", "exp_avg", "exp_avg_sq"):
+            a_, b_ = getattr(dg[key], name), getattr(de[key], name)
+            err, scale = (a_ - b_).abs().max().item(), b_.abs().max().item()
+            if err > 2e-5 * scale + 1e-12:            # (short-batch contractions add with atomics: run-to-run rounding)
+                bad.append(("graph vs eager", key, name, err, scale))
+        flat = dg[key].flat_param.detach().cpu()
+        other = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(other, flat)
+        if not all(torch.equal(o, flat) for o in other):
+            bad.append(("replicas diverged", key))
+    q.put((rank, bad))
+    dist.destroy_process_group()
+
+
+def _worker_graphs(rank, world, port, tag, q, gpu_ready):
+    try:
+        _run_graphs(rank, world, port, tag, q, gpu_ready)
+    except BaseException as ex:
+        import traceback
+        q.put((rank, [("exception", repr(ex), traceback.format_exc())]))
+        raise
+
+
+def test_two_replica_segmented_graphs_equal_eager():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _launch(_worker_graphs, "graphs", 33500 + (os.getpid() % 2000))
