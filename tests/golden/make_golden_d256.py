@@ -57,5 +57,44 @@ def main():
         print("wrote", path, os.path.getsize(path) // 1024, "KiB", "W %.6f C %.6f" % (W.item(), C.item()))
 
 
+def forward_second_seed():
+    """a SECOND set of forward goldens at DenseDim 256 (different weights, noise, poses, jitter): the parity-grade fused
+    forward holds north_star's tolerances (pose 1e-5 m, logits 1e-4 rel) on more than one vector --
+    tests/golden/{gen,critics}_D256_s2.npz, same fields as gen_D256 / critics_D256 of make_golden.py."""
+    M = RI.load_reference()
+    fkm, gen, dis = M["fkm"], M["gen"], M["dis"]
+    D, B = 256, 256
+    args = RI.make_args(batch_size=B, Gen_DenseDim=D, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D)
+    fk = fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+    G = gen.Fk_Generator(fk, args, "cpu")
+    G.load_state_dict(GU.seeded_state_dict(GU.shapes_generator(D), 1357))
+    real = GU.synth_pose16(B, seed=71)
+    G.GAN_generator_get_bone_length(real)
+    z = torch.randn(B, 128, generator=torch.Generator().manual_seed(72))
+    heads = []
+    hk = G.deconv_out.register_forward_hook(lambda m, i, o: heads.append(o.detach().clone()))
+    torch.manual_seed(4321)
+    scaler = torch.randint(-200, 200, size=(B, 8)) / 1000.0      # what forward draws first
+    torch.manual_seed(4321)
+    fake = G(z)
+    hk.remove()
+    path = os.path.join(HERE, "gen_D256_s2.npz")
+    np.savez_compressed(path, z=z.numpy(), real16=real.numpy(), bone_len=G.boneLength.detach().numpy(), scaler=scaler.numpy(),
+                        head=heads[0].numpy(), angle37=G.distribute_angle[-1].detach().numpy(), fake=fake.detach().numpy(),
+                        weight_seed=np.array(1357))
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+    D3, D2 = dis.Fk_3D_Discriminator("cpu", args), dis.Fk_2D_Discriminator(args, 16)
+    D3.load_state_dict(GU.seeded_state_dict(GU.shapes_d3(D), 2468)); D2.load_state_dict(GU.seeded_state_dict(GU.shapes_d2(D), 3579))
+    x3 = GU.synth_pose16(B, seed=73); x3 = x3 - x3[:, :1]
+    x2 = (torch.rand(B, 16, 2, generator=torch.Generator().manual_seed(74)) - 0.5) * 1.6
+    path = os.path.join(HERE, "critics_D256_s2.npz")
+    np.savez_compressed(path, x3=x3.numpy(), x2=x2.numpy(), logit3=D3(x3).detach().numpy(), logit2=D2(x2).detach().numpy(),
+                        weight_seed3=np.array(2468), weight_seed2=np.array(3579))
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "forward":
+        forward_second_seed()
+    else:
+        main()

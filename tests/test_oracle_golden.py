@@ -66,9 +66,9 @@ def test_kcs(golden):
     assert maxabs(O.kcs_features(g["pose16"], with_lengths=False), g["kcs15"]) < 2e-6
 
 
-@pytest.mark.parametrize("D", [32, 256])
-def test_generator(golden, D):
-    g = golden("gen_D%d" % D)
+@pytest.mark.parametrize("D,suffix", [(32, ""), (256, ""), (256, "_s2")])
+def test_generator(golden, D, suffix):
+    g = golden("gen_D%d%s" % (D, suffix))
     sd = GU.seeded_state_dict(GU.shapes_generator(D), int(g["weight_seed"]))
     assert maxabs(O.bone_lengths(g["real16"]), g["bone_len"]) < 1e-6
     head = O.gen_trunk(g["z"], sd)
@@ -97,9 +97,9 @@ def test_video_generator(golden):
     assert maxabs(fake, g["fake"]) < 1e-5
 
 
-@pytest.mark.parametrize("D", [32, 256])
-def test_critics(golden, D):
-    g = golden("critics_D%d" % D)
+@pytest.mark.parametrize("D,suffix", [(32, ""), (256, ""), (256, "_s2")])
+def test_critics(golden, D, suffix):
+    g = golden("critics_D%d%s" % (D, suffix))
     sd3 = GU.seeded_state_dict(GU.shapes_d3(D), int(g["weight_seed3"]))
     sd2 = GU.seeded_state_dict(GU.shapes_d2(D), int(g["weight_seed2"]))
     l3, l2 = O.d3_forward(g["x3"], sd3), O.d2_forward(g["x2"], sd2)
