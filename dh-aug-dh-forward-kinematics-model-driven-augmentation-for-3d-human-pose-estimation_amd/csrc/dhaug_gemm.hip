@@ -15,6 +15,7 @@
 // 256-B bank row; eight row pairs take eight different chunks).  TN tiles keep the global row-major layout
 // [64 m][160] (320-B rows: consecutive rows shift by 16 banks) and are read with ds_read_b64_tr_b16, the
 // hardware transpose read, because the contraction index m is the slow axis in memory.
+#include <cstdlib>
 #include "dhaug_common.h"
 #include <stdlib.h>
 
@@ -37,6 +38,7 @@ struct GemmArgs {
     int act; float slope;
     const uint16_t* dmask; long long ld_dmask; float dneg;   // optional: result *= (dmask > 0 ? 1 : dneg)  (nt256 kernel only)
     const uint32_t* dbits;                                   // the same mask as a sign-bit array (dhaug_mlp_unit.bits layout)
+    int abl;                                                 // development (big-tile kernel): 1 no epilogue, 2 no reads / MFMAs, 4 no copies
 };
 
 // branch-free activation: v > 0 ? v : v * neg, neg = 0 (ReLU) / slope (LeakyReLU) / 1 (identity)
@@ -47,84 +49,125 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 
 constexpr int BK = 64;
 
-// coalesced epilogue of an fp32 C tile staged in LDS ([BM][BN + 4]): bias, residual, activation, bf16 / fp32 stores
+// coalesced epilogue of an fp32 C tile staged in LDS ([BM][BN + 4]): bias, residual, activation, bf16 / fp32 stores.
+// A thread keeps ONE 8-column piece and walks the tile's rows (256 threads cover 256 / (BN / 8) rows per step): the bias of
+// its columns is loaded once, and the residual / mask values of RB rows are requested together before the first of them is
+// used.  (The first version re-loaded eight bias scalars and waited for its row's residual in every iteration: 16 dependent
+// memory round trips per thread for a 128 x 256 tile -- 36 us of the big-tile kernel's 87 us at 13 824 x 1000 x 1000.)
 template <int BM, int BN>
 __device__ __forceinline__ void nt_store_tile(const GemmArgs& p, const float* sC, long long m0, long long n0, int tid) {
     constexpr int CS = BN + 4;
-    constexpr int PIECES = BM * BN / 8;
-    for (int q = tid; q < PIECES; q += 256) {
-        const int row = q / (BN / 8), pc = q % (BN / 8);
-        const long long gm = m0 + row, n = n0 + pc * 8;
-        if (gm >= p.M) continue;
-        const bool any_out = n < p.N || (p.cb != nullptr && n < p.npad);
-        if (!any_out) continue;
-        float v[8];
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(sC + row * CS + pc * 8);
-        const f32x4 c1 = *reinterpret_cast<const f32x4*>(sC + row * CS + pc * 8 + 4);
+    constexpr int PPR = BN / 8;                                  // pieces per row
+    constexpr int RSTEP = 256 / PPR;                             // rows per step of the workgroup
+    constexpr int NIT = BM / RSTEP;                              // rows per thread
+    constexpr int RB = NIT >= 4 ? 4 : NIT;                       // rows whose global operands travel together
+    static_assert(256 % PPR == 0 && BM % RSTEP == 0 && NIT % RB == 0, "tile shape");
+    const int pc = tid % PPR, r0 = tid / PPR;
+    const long long n = n0 + pc * 8;
+    const bool any_out = n < p.N || (p.cb != nullptr && n < p.npad);
+    if (!any_out) return;
+    const bool full = n + 8 <= p.N;
+    float bias[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = c0[e]; v[4 + e] = c1[e]; }
-        const bool full = n + 8 <= p.N;
-        if (p.bias != nullptr) {
+    for (int e = 0; e < 8; ++e) bias[e] = 0.0f;
+    if (p.bias != nullptr) {
+        if (full && (reinterpret_cast<uintptr_t>(p.bias + n) & 15) == 0) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) if (full || n + e < p.N) v[e] += p.bias[n + e];
+            for (int e = 0; e < 4; ++e) { bias[e] = b0[e]; bias[4 + e] = b1[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (n + e < p.N) bias[e] = p.bias[n + e];
         }
-        if (p.resf != nullptr) {
+    }
+    const bool res_vec = p.res != nullptr && full && (p.ld_res & 7) == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0;
+    const bool msk_vec = p.dmask != nullptr && full && (p.ld_dmask & 7) == 0 && (reinterpret_cast<uintptr_t>(p.dmask) & 15) == 0;
+    const bool rf_vec = p.resf != nullptr && full && (p.ld_resf & 3) == 0 && (reinterpret_cast<uintptr_t>(p.resf) & 15) == 0;
+    for (int it0 = 0; it0 < NIT; it0 += RB) {
+        uint4 rr[RB], mm[RB];
+        f32x4 rf0[RB], rf1[RB];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) if (full || n + e < p.N) v[e] += p.resf[gm * p.ld_resf + n + e];
+        for (int j = 0; j < RB; ++j) {                           // all global operands of RB rows first
+            const long long gm = m0 + r0 + (it0 + j) * RSTEP;
+            rr[j] = make_uint4(0, 0, 0, 0); mm[j] = make_uint4(0, 0, 0, 0);
+            rf0[j] = f32x4{0.f, 0.f, 0.f, 0.f}; rf1[j] = rf0[j];
+            if (gm < p.M) {
+                if (res_vec) rr[j] = *reinterpret_cast<const uint4*>(p.res + gm * p.ld_res + n);
+                if (msk_vec) mm[j] = *reinterpret_cast<const uint4*>(p.dmask + gm * p.ld_dmask + n);
+                if (rf_vec) { rf0[j] = *reinterpret_cast<const f32x4*>(p.resf + gm * p.ld_resf + n); rf1[j] = *reinterpret_cast<const f32x4*>(p.resf + gm * p.ld_resf + n + 4); }
+            }
         }
-        if (p.res != nullptr) {
-            if (full) {
-                const uint4 rr = *reinterpret_cast<const uint4*>(p.res + gm * p.ld_res + n);
-                const uint32_t w[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[2 * e] += __builtin_bit_cast(float, w[e] << 16);
-                    v[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
+        for (int j = 0; j < RB; ++j) {
+            const int row = r0 + (it0 + j) * RSTEP;
+            const long long gm = m0 + row;
+            if (gm >= p.M) continue;
+            float v[8];
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(sC + row * CS + pc * 8);
+            const f32x4 c1 = *reinterpret_cast<const f32x4*>(sC + row * CS + pc * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = c0[e] + bias[e]; v[4 + e] = c1[e] + bias[4 + e]; }
+            if (p.resf != nullptr) {
+                if (rf_vec) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += rf0[j][e]; v[4 + e] += rf1[j][e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] += p.resf[gm * p.ld_resf + n + e];
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] += dhaug_bf16_to_f32(p.res[gm * p.ld_res + n + e]);
             }
-        }
+            if (p.res != nullptr) {
+                if (res_vec) {
+                    const uint32_t w[4] = {rr[j].x, rr[j].y, rr[j].z, rr[j].w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (full || n + e < p.N) ? apply_act(v[e], p.act, p.slope) : 0.0f;
-        if (p.dmask != nullptr) {                        // activation-backward mask of the producing layer
-            if (full && (p.ld_dmask & 7) == 0 && (reinterpret_cast<uintptr_t>(p.dmask) & 15) == 0) {
-                const uint4 mm = *reinterpret_cast<const uint4*>(p.dmask + gm * p.ld_dmask + n);
-                const uint32_t w[4] = {mm.x, mm.y, mm.z, mm.w};
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] += __builtin_bit_cast(float, w[e] << 16);
+                        v[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
+                    }
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {                // a positive bf16 is a positive int16
-                    v[2 * e] = (short)(w[e] & 0xffffu) > 0 ? v[2 * e] : v[2 * e] * p.dneg;
-                    v[2 * e + 1] = (short)(w[e] >> 16) > 0 ? v[2 * e + 1] : v[2 * e + 1] * p.dneg;
+                    for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] += dhaug_bf16_to_f32(p.res[gm * p.ld_res + n + e]);
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (full || n + e < p.N) v[e] = (short)p.dmask[gm * p.ld_dmask + n + e] > 0 ? v[e] : v[e] * p.dneg;
             }
-        }
-        if (p.cb != nullptr) {
-            if (n + 8 <= p.npad || full) {
-                uint4 o;
-                o.x = (uint32_t)dhaug_f32_to_bf16(v[0]) | ((uint32_t)dhaug_f32_to_bf16(v[1]) << 16);
-                o.y = (uint32_t)dhaug_f32_to_bf16(v[2]) | ((uint32_t)dhaug_f32_to_bf16(v[3]) << 16);
-                o.z = (uint32_t)dhaug_f32_to_bf16(v[4]) | ((uint32_t)dhaug_f32_to_bf16(v[5]) << 16);
-                o.w = (uint32_t)dhaug_f32_to_bf16(v[6]) | ((uint32_t)dhaug_f32_to_bf16(v[7]) << 16);
-                *reinterpret_cast<uint4*>(p.cb + gm * p.ldcb + n) = o;
-            } else {
-                const long long lim = p.npad > p.N ? p.npad : p.N;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) if (n + e < lim) p.cb[gm * p.ldcb + n + e] = dhaug_f32_to_bf16(v[e]);
+            for (int e = 0; e < 8; ++e) v[e] = (full || n + e < p.N) ? apply_act(v[e], p.act, p.slope) : 0.0f;
+            if (p.dmask != nullptr) {                            // activation-backward mask of the producing layer
+                if (msk_vec) {
+                    const uint32_t w[4] = {mm[j].x, mm[j].y, mm[j].z, mm[j].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {                // a positive bf16 is a positive int16
+                        v[2 * e] = (short)(w[e] & 0xffffu) > 0 ? v[2 * e] : v[2 * e] * p.dneg;
+                        v[2 * e + 1] = (short)(w[e] >> 16) > 0 ? v[2 * e + 1] : v[2 * e + 1] * p.dneg;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (full || n + e < p.N) v[e] = (short)p.dmask[gm * p.ld_dmask + n + e] > 0 ? v[e] : v[e] * p.dneg;
+                }
             }
-        }
-        if (p.cf != nullptr) {
-            if (full && (p.ldcf & 3) == 0) {
-                f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                *reinterpret_cast<f32x4*>(p.cf + gm * p.ldcf + n) = o0;
-                *reinterpret_cast<f32x4*>(p.cf + gm * p.ldcf + n + 4) = o1;
-            } else {
+            if (p.cb != nullptr) {
+                if (n + 8 <= p.npad || full) {
+                    uint4 o;
+                    o.x = (uint32_t)dhaug_f32_to_bf16(v[0]) | ((uint32_t)dhaug_f32_to_bf16(v[1]) << 16);
+                    o.y = (uint32_t)dhaug_f32_to_bf16(v[2]) | ((uint32_t)dhaug_f32_to_bf16(v[3]) << 16);
+                    o.z = (uint32_t)dhaug_f32_to_bf16(v[4]) | ((uint32_t)dhaug_f32_to_bf16(v[5]) << 16);
+                    o.w = (uint32_t)dhaug_f32_to_bf16(v[6]) | ((uint32_t)dhaug_f32_to_bf16(v[7]) << 16);
+                    *reinterpret_cast<uint4*>(p.cb + gm * p.ldcb + n) = o;
+                } else {
+                    const long long lim = p.npad > p.N ? p.npad : p.N;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) if (n + e < p.N) p.cf[gm * p.ldcf + n + e] = v[e];
+                    for (int e = 0; e < 8; ++e) if (n + e < lim) p.cb[gm * p.ldcb + n + e] = dhaug_f32_to_bf16(v[e]);
+                }
+            }
+            if (p.cf != nullptr) {
+                if (full && (p.ldcf & 3) == 0) {
+                    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                    *reinterpret_cast<f32x4*>(p.cf + gm * p.ldcf + n) = o0;
+                    *reinterpret_cast<f32x4*>(p.cf + gm * p.ldcf + n + 4) = o1;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (n + e < p.N) p.cf[gm * p.ldcf + n + e] = v[e];
+                }
             }
         }
     }
@@ -336,6 +379,115 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_pipe_kernel(GemmArgs p) {
     }
     p_lds_barrier();
     nt_store_tile<BM, BN>(p, sC, m0, n0, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Long batches of the same generic shapes (the DenseDim-1000 layers of the frame critics' steps in the video configuration:
+// 3 x 4 608 rows).  The 64 x 64-tile kernel above issues ONE matrix instruction per two fragment reads and moves
+// (64 + 64) x K operand bytes per 64 x 64 outputs: measured 297 TFLOP/s at 13 824 x 1000 x 1000 whatever the batch -- LDS reads
+// (2 KB per MFMA against 128 B/clk per CU) and L2 -> LDS traffic (32 flop per byte) bound it, not the matrix pipe.  Here a
+// workgroup owns 128 x 256 outputs and each of its four waves (one per SIMD) a 64 x 128 block of them: 2 + 4 fragment reads feed
+// 8 matrix instructions (0.75 KB per MFMA), 85 flop per L2 byte.  Same stage mechanics (global -> LDS without registers,
+// exact vmcnt waits, LDS-only barriers, three 48 KB stages), same coalesced epilogue through an fp32 C tile in LDS.
+// ---------------------------------------------------------------------------------------------------
+constexpr int G_BM = 128, G_BN = 256, G_NSTG = 3;
+constexpr int G_STG = (G_BM + G_BN) * BK * 2;                                // 49 152 bytes per stage
+constexpr int G_CS = G_BN + 4;
+constexpr int G_LDS = (G_NSTG * G_STG > G_BM * G_CS * 4) ? G_NSTG * G_STG : G_BM * G_CS * 4;   // 147 456
+
+__global__ __launch_bounds__(256, 1) void gemm_nt_big_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    float* sC = reinterpret_cast<float*>(gsm);                  // [G_BM][G_CS], reuses the staging buffers
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                    // 2 x 2 waves: rows [64 wm, +64), columns [128 wn, +128)
+    const long long ntn = (p.W + G_BN - 1) / G_BN;
+    // consecutive workgroups share the batch rows (the larger operand per tile) and walk the column tiles: the row block is
+    // fetched from HBM once and re-read from L2
+    const long long m0 = (long long)(blockIdx.x / ntn) * G_BM;
+    const long long n0 = (long long)(blockIdx.x % ntn) * G_BN;
+    const int nkt = (int)((p.K + BK - 1) / BK);
+    constexpr int NCP = (G_BM + G_BN) * 8 / 256;                // copies per lane and stage: 12 (4 of A, 8 of B)
+    const uint16_t* pg[NCP];
+    int rowoff[NCP];
+#pragma unroll
+    for (int i = 0; i < NCP; ++i) {
+        // copy i of wave w moves rows [8 (4 i + w), +8) of the stage image (A rows first, then B rows): 8 lanes per row
+        const int row0 = (4 * i + wave) * 8, row = row0 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+        if (i < G_BM / 32) {
+            const long long gm = m0 + row;
+            pg[i] = p.A + (gm < p.M ? gm : p.M - 1) * p.lda + c * 8;
+        } else {
+            const long long gn = n0 + row - G_BM;
+            pg[i] = p.B + (gn < p.N ? gn : p.N - 1) * p.ldb + c * 8;
+        }
+        rowoff[i] = row0 * (BK * 2);
+    }
+    auto copy_stage = [&](int kt) {
+        unsigned char* base = gsm + (kt % G_NSTG) * G_STG;
+        long long k0 = (long long)kt * BK;
+        if (k0 + BK > p.K) k0 = p.K - BK > 0 ? p.K - BK : 0;   // short last stage: the last full window (K >= 64)
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) p_copy16(pg[i] + k0, base + rowoff[i]);
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+#pragma unroll
+    for (int s2 = 0; s2 < G_NSTG - 1; ++s2)
+        if (s2 < nkt && !(p.abl & 4)) copy_stage(s2);
+    const int r31 = lane & 31, h = lane >> 5;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCP) : "memory");   // stage kt landed, kt+1 may fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p_lds_barrier();                                        // stage kt is in LDS for everybody, stage kt-1 is released
+        if (kt + G_NSTG - 1 < nkt && !(p.abl & 4)) copy_stage(kt + G_NSTG - 1);
+        if (p.abl & 2) continue;
+        const unsigned char* bufA = gsm + (kt % G_NSTG) * G_STG;
+        const unsigned char* bufB = bufA + G_BM * BK * 2;
+        const long long kbeg = (long long)kt * BK;
+        int ks0 = 0;
+        if (kbeg + BK > p.K && p.K >= BK) ks0 = (int)((kbeg - (p.K - BK)) >> 4);
+        const int ks1 = p.K >= BK ? 4 : (int)(p.K >> 4);
+        for (int ks = ks0; ks < ks1; ++ks) {
+            const int chunk = 2 * ks + h;
+            bf16x8 fx[2], fw[4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int row = 64 * wm + 32 * a + r31;
+                fx[a] = *reinterpret_cast<const bf16x8*>(bufA + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int row = 128 * wn + 32 * b + r31;
+                fw[b] = *reinterpret_cast<const bf16x8*>(bufB + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b], fx[a], acc[a][b], 0, 0, 0);
+        }
+    }
+    if (p.abl & 1) return;
+    p_lds_barrier();                                            // the staging buffers become the C tile
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int m = 64 * wm + 32 * a + r31;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = 128 * wn + 32 * b + 8 * g + 4 * h;
+                f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(sC + m * G_CS + n) = v;
+            }
+    }
+    p_lds_barrier();
+    nt_store_tile<G_BM, G_BN>(p, sC, m0, n0, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1425,7 +1577,7 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
     if (c_bf16) DHAUG_CHECK(ldc_bf16 % 8 == 0 && ldc_bf16 >= N && n_pad_zero <= ldc_bf16 && dhaug_aligned16(c_bf16), DHAUG_EALIGN);
     if (c_f32) DHAUG_CHECK(ldc_f32 >= N && ((ldc_f32 & 3) != 0 || dhaug_aligned16(c_f32)), DHAUG_EALIGN);
     GemmArgs p{A, lda, B, ldb, bias, residual, ld_res, residual_f32, ld_res_f32, c_bf16, ldc_bf16, c_bf16 ? (n_pad_zero > N ? n_pad_zero : N) : 0,
-               c_f32, ldc_f32, M, N, K, N, act, slope, nullptr, 0, 1.0f, nullptr};
+               c_f32, ldc_f32, M, N, K, N, act, slope, nullptr, 0, 1.0f, nullptr, 0};
     hipStream_t s = (hipStream_t)stream;
     const long long width = (c_bf16 && p.npad > N) ? p.npad : N;
     p.W = width;
@@ -1468,6 +1620,21 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
             case 16: return launch_ws<16>(s, p);
             default: break;
         }
+    }
+    if (width >= 512 && M >= 4096 && K >= 64 && lda >= 64 && ldb >= 64 && getenv("DHAUG_GEMM_NOBIG") == nullptr &&
+        getenv("DHAUG_GEMM_NOPIPE") == nullptr) {
+        // long batch, wide layer: 128 x 256 tiles, 64 x 128 per wave
+        static bool configured = false;
+        if (!configured) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
+            if (e != hipSuccess) return (int)e;
+            configured = true;
+        }
+        const long long grid = ((M + G_BM - 1) / G_BM) * ((width + G_BN - 1) / G_BN);
+        p.abl = getenv("DHAUG_BIG_ABL") ? atoi(getenv("DHAUG_BIG_ABL")) : 0;
+        hipLaunchKernelGGL(gemm_nt_big_kernel, dim3((unsigned)grid), dim3(256), G_LDS, s, p);
+        return dhaug_launch_status();
     }
     if (width > 64 && K >= 64 && lda >= 64 && ldb >= 64 && getenv("DHAUG_GEMM_NOPIPE") == nullptr) {
         const long long grid = ((M + 63) / 64) * ((width + 63) / 64);
@@ -1532,7 +1699,7 @@ int dhaug_gemm_bf16_dbits(const uint16_t* A, int64_t lda, const uint16_t* B, int
     DHAUG_CHECK(dhaug_aligned16(A) && dhaug_aligned16(B) && dhaug_aligned16(c_bf16) && dhaug_aligned16(bits), DHAUG_EALIGN);
     if (residual) DHAUG_CHECK(ld_res % 8 == 0 && ld_res >= 256 && dhaug_aligned16(residual), DHAUG_EALIGN);
     GemmArgs p{A, lda, B, ldb, nullptr, residual, ld_res, nullptr, 0, c_bf16, ldc_bf16, 256, nullptr, 0, M, 256, 256, 256,
-               DHAUG_ACT_NONE, 0.0f, nullptr, 0, dmask_act == DHAUG_ACT_RELU ? 0.0f : dmask_slope, bits};
+               DHAUG_ACT_NONE, 0.0f, nullptr, 0, dmask_act == DHAUG_ACT_RELU ? 0.0f : dmask_slope, bits, 0};
     return launch_nt256s<16>((hipStream_t)stream, p);
 }
 

@@ -189,7 +189,9 @@ def _bf(t):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (1000, 256, 128), (129, 100, 512), (4096, 35, 256), (777, 1, 112),
-                                   (64, 256, 48), (300, 256, 32), (2048, 112, 112), (515, 315, 1008)])
+                                   (64, 256, 48), (300, 256, 32), (2048, 112, 112), (515, 315, 1008),
+                                   # long batch x wide layer: the 128 x 256-tile kernel (ragged rows, K tail, ragged columns)
+                                   (4608, 1000, 1008), (4096 + 77, 512, 256), (13824, 1000, 1008)])
 def test_gemm_nt_plain(ops, M, N, K):
     gen = torch.Generator().manual_seed(M + N + K)
     A = _bf(torch.randn(M, K, generator=gen)).cuda()
@@ -218,6 +220,35 @@ def test_gemm_nt_epilogues(ops, act, slope):
     _, cf2 = ops.gemm_nt(A, B, N, K, bias=bias, res_f32=resf, act=0, out_f32=True)
     ref2 = A.float().cpu().double() @ B.float().cpu().double().t() + bias.cpu().double() + resf.cpu().double()
     assert maxabs(cf2, ref2) <= 3e-5 * ref2.abs().max().item()
+
+
+def test_gemm_nt_big_tiles_epilogues(ops):
+    """the 128 x 256-tile kernel with everything the DenseDim-1000 training layers ask of it: bias + bf16 residual + ReLU with a
+    zero-padded bf16 output (forward), and the masked input-gradient form (backward / tangent); against fp64 on the bf16
+    operands and against the 64 x 64-tile kernel it replaces for long batches"""
+    import os
+    gen = torch.Generator().manual_seed(5)
+    M, N, K, Kp = 4608 + 40, 1000, 1000, 1008
+    A = torch.zeros(M, Kp); A[:, :K] = torch.randn(M, K, generator=gen) * 0.5
+    W = torch.zeros(N, Kp); W[:, :K] = torch.randn(N, K, generator=gen) / K ** 0.5
+    R = torch.zeros(M, Kp); R[:, :N] = torch.randn(M, N, generator=gen)
+    Y = torch.zeros(M, Kp); Y[:, :N] = torch.randn(M, N, generator=gen)
+    A, W, R, Y = (_bf(t).cuda() for t in (A, W, R, Y))
+    bias = torch.randn(N, generator=gen).cuda()
+    pre = A.float().cpu().double() @ W.float().cpu().double().t()
+    cb, _ = ops.gemm_nt(A, W, N, Kp, bias=bias, res_bf16=R, act=1, out_bf16=True, n_pad=Kp)
+    ref = torch.relu(pre + bias.cpu().double() + R[:, :N].float().cpu().double())
+    assert cb.shape == (M, Kp) and cb[:, N:].abs().max().item() == 0.0
+    assert maxabs(cb[:, :N].float(), ref) <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
+    g = ops.gemm_nt_dmask(A, W, N, Kp, Y, 1, 0.0, res_bf16=R)
+    refg = (pre + R[:, :N].float().cpu().double()) * (Y[:, :N].float().cpu() > 0).double()
+    assert maxabs(g[:, :N].float(), refg) <= 2.0 ** -8 * max(1.0, refg.abs().max().item())
+    os.environ["DHAUG_GEMM_NOBIG"] = "1"
+    try:
+        cb_old, _ = ops.gemm_nt(A, W, N, Kp, bias=bias, res_bf16=R, act=1, out_bf16=True, n_pad=Kp)
+    finally:
+        del os.environ["DHAUG_GEMM_NOBIG"]
+    assert (cb.float() - cb_old.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("M,K,act,slope,use_bias,use_res", [(4096, 256, 1, 0.0, True, True), (65536, 256, 2, 0.01, True, False),
