@@ -79,7 +79,7 @@ class TnLayer(ctypes.Structure):
                 ("colsum_rows", _i64), ("M", _i64), ("N1", _i32), ("N2", _i32), ("accumulate", _i32), ("reserved", _i32)]
 
 
-TN_GROUP_MAX = 24
+TN_GROUP_MAX = 44
 TN_GROUP_WORKSPACE_FLOATS = 256 * (256 * 256 + 256)
 SIGNATURES["dhaug_gemm_tn_group_bf16"] = [ctypes.POINTER(TnLayer), _i32, _vp, _vp]
 SIGNATURES["dhaug_pack_wfrag"] = [_vp, _i64, _vp, _i64, _i64, _i64, _vp]

@@ -122,12 +122,16 @@ class _Math:
             narrow = N < 16
             M = gb.shape[0]
             cr = M if colsum_rows is None else colsum_rows
-            if TN_GROUP and N <= 256 and ops.tn_group_ok(M, N, min(K, 256), cr):
-                # joins the step's grouped launch; a wider input (the merge layer behind a concatenation) as column blocks
-                for k0 in range(0, K, 256):
-                    kk = min(256, K - k0)
-                    cs = bslot if (bslot is not None and not narrow and k0 == 0) else None
-                    self.tn.append((gb, xb[:, k0:], N, kk, wslot[:, k0:], cs, cr if cs is not None else 0, True, M, None, None))
+            if TN_GROUP and ops.tn_group_ok(M, min(N, 256), min(K, 256), cr):
+                # joins the step's grouped launch, as 256 x 256 blocks of the gradient (a DenseDim-1000 layer is 4 x 4 of them;
+                # the bias sums ride with the first column block of every row block)
+                for n0 in range(0, N, 256):
+                    nn = min(256, N - n0)
+                    for k0 in range(0, K, 256):
+                        kk = min(256, K - k0)
+                        cs = bslot[n0:] if (bslot is not None and not narrow and k0 == 0) else None
+                        self.tn.append((gb[:, n0:], xb[:, k0:], nn, kk, wslot[n0:, k0:], cs, cr if cs is not None else 0, True, M,
+                                        None, None))
             else:
                 ops.gemm_tn(gb, xb, N, K, colsum=bslot if (bslot is not None and not narrow) else None, out=wslot, accumulate=True,
                             colsum_rows=colsum_rows)

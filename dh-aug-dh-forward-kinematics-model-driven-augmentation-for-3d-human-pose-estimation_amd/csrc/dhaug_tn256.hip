@@ -266,7 +266,12 @@ int dhaug_gemm_tn_group_bf16(const dhaug_tn_layer* layers, int n, float* workspa
         stages += L.nst;
     }
     // deal the workgroups (one per CU) out in proportion to the operand bytes: at least one, at most one per stage
-    const int budget = (int)(stages < T2_MAX_WG ? stages : T2_MAX_WG);
+    // (a short batch leaves little to read per layer: every workgroup costs a 256 KB partial result to write and to sum, so
+    // the group gets about one workgroup per 768 KB of operands, at least one per layer, at most one per CU)
+    long long want = (long long)(total * 2.0 / (768.0 * 1024.0)) + 1;
+    if (want < n) want = n;
+    if (want > T2_MAX_WG) want = T2_MAX_WG;
+    const int budget = (int)(stages < want ? stages : want);
     int used = 0;
     for (int i = 0; i < n; ++i) {
         int w = (int)(budget * weight[i] / total);

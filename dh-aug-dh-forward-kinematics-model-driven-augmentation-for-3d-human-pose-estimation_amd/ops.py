@@ -335,7 +335,7 @@ def _tn_group_workspace(dev):
 
 def tn_group_ok(M, N1, N2, colsum_rows):
     """shapes dhaug_gemm_tn_group_bf16 takes (and where it pays: a long batch)"""
-    return M >= 2048 and M % 32 == 0 and colsum_rows % 32 == 0 and 1 <= N1 <= 256 and 1 <= N2 <= 256
+    return M >= 1024 and M % 32 == 0 and colsum_rows % 32 == 0 and 1 <= N1 <= 256 and 1 <= N2 <= 256
 
 
 def gemm_tn_group(items):

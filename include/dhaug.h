@@ -245,7 +245,7 @@ int dhaug_gemm_tn_bf16_rows(const uint16_t* A, int64_t lda, const uint16_t* B, i
  * `layers`: host array (read during the call).  `workspace`: DHAUG_TN_GROUP_WORKSPACE_FLOATS fp32 values owned by the
  * caller, any content (calls sharing it must be ordered on one stream).
  * Replaces the parameter-gradient half of loss.backward() in R/models_Fk_GAN/model_fk_gan_train.py:191-214. */
-#define DHAUG_TN_GROUP_MAX 24
+#define DHAUG_TN_GROUP_MAX 44
 #define DHAUG_TN_GROUP_WORKSPACE_FLOATS (256LL * (256 * 256 + 256))
 typedef struct dhaug_tn_layer {
     const uint16_t* A; int64_t lda;
