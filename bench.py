@@ -529,7 +529,7 @@ def main():
         tf_b = event_time(step_fk, 50, 10)
         out["roofline_fk"] = {"kernel": "fk_forward_kernel<0,16,true>", "bound": "hbm", "achieved": FK_BYTES_PER_POSE * nfk / tf / 1e9,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": FK_BYTES_PER_POSE * nfk / tf / 1e9 / HBM_PEAK_GBS,
-                              "traffic": pmc_traffic("fk_forward_kernel<0; 16; true; false>", "fk_"), "traffic_source": pmc_stamp(),
+                              "traffic": pmc_traffic("fk_forward_kernel<0; 16; true>", "fk_"), "traffic_source": pmc_stamp(),
                               "algorithmic_bytes": FK_BYTES_PER_POSE * nfk, "poses_per_launch": nfk, "avg_us": tf * 1e6,
                               "at_batch": {"poses": N, "avg_us": tf_b * 1e6, "achieved": FK_BYTES_PER_POSE * N / tf_b / 1e9}}
         del a4, b4, r4
