@@ -549,6 +549,7 @@ def main():
         out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()                           # rank 0's single-rank extras (roofline kernels) end before anybody tears down
         dist.destroy_process_group()
 
 

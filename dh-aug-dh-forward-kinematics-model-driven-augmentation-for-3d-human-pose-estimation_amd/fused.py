@@ -116,6 +116,27 @@ def decode_bits(bits, M):
     return torch.from_numpy(out[:M])
 
 
+def encode_bits(mask):
+    """sign-bit array (layout of struct dhaug_mlp_unit.bits) of an (M, 256) bool tensor -- the inverse of decode_bits, for tests"""
+    import numpy as np
+    m = mask.cpu().numpy().astype(bool)
+    M = m.shape[0]
+    T = (M + 127) // 128 * 4
+    pad = np.zeros((T * 32, 256), dtype=bool)
+    pad[:M] = m
+    w = np.zeros((T, 4, 64), dtype=np.uint32)
+    lane = np.arange(64)
+    r31, h = lane & 31, lane >> 5
+    for wave in range(4):
+        for j in range(32):
+            t, g, e = j >> 4, (j >> 2) & 3, j & 3
+            pos = (j >> 1) + (16 if (j & 1) else 0)
+            feat = 32 * (wave + 4 * t) + 8 * g + 4 * h + e
+            for tt in range(T):
+                w[tt, wave, :] |= pad[32 * tt + r31, feat].astype(np.uint32) << np.uint32(pos)
+    return torch.from_numpy(w.reshape(-1).view(np.int32).copy()).to(mask.device)
+
+
 def _gemm(layer, src, dst, act, slope=0.0, res=-1, out=None, src2=-1, save=None, bits=False):
     kw = dict(src=src, ksteps=layer.ksteps[0], n=layer.N, act=act, slope=slope, w=layer.w[0], bias=layer.bias, res=res, save=save,
               bits=bits)

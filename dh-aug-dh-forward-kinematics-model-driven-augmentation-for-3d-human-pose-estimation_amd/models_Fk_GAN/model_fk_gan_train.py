@@ -127,7 +127,7 @@ def train_Fk_discriminator(model_dis, data_real, data_fake, summary, writer, wri
         if alpha is None:
             alpha = torch.rand(rows, 1, device=device)
         sc = critic_step.critic_step(model_dis, optimizerD, data_real.reshape(rows, -1), data_fake.reshape(rows, -1),
-                                     alpha.to(device).reshape(rows, 1), args.GAN_LAMBDA)
+                                     alpha.to(device).reshape(-1, 1)[:rows], args.GAN_LAMBDA)     # (an injected draw may be longer)
         D_real, D_fake, Wasserstein_D, D_cost = sc[0], sc[1], sc[3], sc[4]
     else:
         model_dis.zero_grad()

@@ -99,3 +99,52 @@ def test_graphed_iterations_equal_eager(M, B, D):
         for k in sg:
             tol = 2e-5 if (mk_ == "model_G" or B < 2048) else 1e-7
             assert (sg[k] - se[k]).abs().max().item() <= tol * se[k].abs().max().item() + 1e-12, (mk_, k)
+
+
+def test_graphed_video_iterations_equal_eager(M):
+    """the video loop's iteration (four critics, playback copies, explicit G step) as hipGraphs against eager, like the
+    single-frame test above"""
+    from dhaug_amd.models_Fk_GAN import video_GAN_fun as V
+    import loop_util as LU
+    from test_gpu_models import make_args
+    B, R, D, N = 32, 9, 32, 5
+    args = make_args(batch_size=B, Gen_DenseDim=D, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D, video_Dis_DenseDim_3D=D, video_Dis_DenseDim_2D=D,
+                     single_or_multi_train_mode="multi", architecture="3,3", single_dis_warmup_epoch=0, GAN_video_playback_input=True,
+                     GAN_3d_motion_loss_weight=1.0, GAN_2d_motion_loss_weight=1.0)
+    x3 = (GU.synth_pose16(B * R, seed=3) + torch.tensor([0.0, 0.0, 4.5])).reshape(B, R, 16, 3).cuda()
+    x2 = ((torch.rand(B, R, 16, 2, generator=torch.Generator().manual_seed(5)) - 0.5) * 1.2).cuda()
+    cp = torch.zeros(B, 16, device="cuda")
+    cp[:, 9:13] = torch.tensor(M.cam[0], device="cuda"); cp[:, 13:16] = torch.tensor(M.cam[1], device="cuda")
+    mk = lambda: M.train.ConstDraws(noise=[torch.randn(B, 128, generator=torch.Generator().manual_seed(1)).cuda()],
+                                    scaler=[(torch.randint(-200, 200, (B, 8), generator=torch.Generator().manual_seed(2)) / 1000.0).cuda()],
+                                    alpha=[torch.rand(B * R, 1, generator=torch.Generator().manual_seed(3)).cuda()])
+
+    def build():
+        fk = M.fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+        d = M.train.video_mode_my_get_poseFk_model(args, None, fk, R)
+        s3, s2 = LU.motion_shapes(D, R)
+        for key, shapes, seed in (("model_G", GU.shapes_generator(D, frames=R), 11), ("model_d3d", GU.shapes_d3(D), 12),
+                                  ("model_d2d", GU.shapes_d2(D), 13), ("model_motion_d3d", s3, 14), ("model_motion_d2d", s2, 15)):
+            sd = GU.seeded_state_dict(shapes, seed)
+            with torch.no_grad():
+                for k, p in d[key].named_parameters():
+                    p.copy_(sd[k].cuda())
+        from dhaug_amd import autograd_ops as A
+        A.bump_weight_epoch()
+        return d
+
+    summ = argparse.Namespace(epoch=10, train_iter_num=0)
+    de, dr = build(), mk()
+    eager = []
+    for i in range(N):
+        r = V.video_gan_iteration(args, de, x3, cp, x2, ["S1"], summ, None, do_g_step=(i % 5 == 4), camera=M.cam, draws=dr)
+        eager.append(r["pos_3d_cam"].clone())
+    dg, dr2 = build(), mk()
+    G = M.graphs.GraphedGanIteration(V.video_gan_iteration, args, dg, ["S1"], summ)
+    for i in range(N):
+        r = G(x3, cp, x2, i % 5 == 4, M.cam, draws=dr2)
+        assert (r["pos_3d_cam"] - eager[i]).abs().max().item() <= 1e-5
+    for ok in ("optimizer_d3d", "optimizer_d2d", "optimizer_motion_d3d", "optimizer_motion_d2d", "optimizer_G"):
+        assert int(dg[ok].step_dev.item()) == int(de[ok].step_dev.item()) > 0, ok
+        a, b = dg[ok].flat_param, de[ok].flat_param
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-12, (ok, (a - b).abs().max().item())

@@ -463,6 +463,33 @@ def test_center_kcs_forward(ops, N):
     assert maxabs(kb.float()[:, :30], o_k) <= 2.0 ** -8 * 1.01 * max(1.0, o_k.abs().max().item())
 
 
+@pytest.mark.parametrize("M,act,slope,use_res,row0", [(4096, 1, 0.0, False, 0), (4096 + 32, 2, 0.01, True, 0), (2048, 1, 0.0, True, 1024)])
+def test_gemm_nt_dbits_equals_dmask(ops, M, act, slope, use_res, row0):
+    """the 256-wide backward / tangent step with the mask as a sign-bit array (dhaug_gemm_bf16_dbits) gives, bit for bit, what
+    the bf16-mask form gives -- incl. a row slice that starts at a later 32-row tile (the tangent sweep's x_hat rows)"""
+    from dhaug_amd import fused
+    gen = torch.Generator().manual_seed(M + act)
+    tot = M + row0
+    A = _bf(torch.randn(tot, 256, generator=gen)).cuda()
+    W = _bf(torch.randn(256, 256, generator=gen) / 16).cuda()
+    Y = _bf(torch.randn(tot, 256, generator=gen)).cuda()
+    Y[::7, ::5] = 0.0                                            # exact zeros: the mask is (y > 0), not (y >= 0)
+    R = _bf(torch.randn(tot, 256, generator=gen)).cuda() if use_res else None
+    ref = ops.gemm_nt_dmask(A[row0:], W, 256, 256, Y[row0:], act, slope, res_bf16=None if R is None else R[row0:])
+    Yb = Y.clone()
+    Yb._dhaug_bits = fused.encode_bits(Y.float() > 0)
+    assert torch.equal(fused.decode_bits(Yb._dhaug_bits, tot), (Y.float() > 0).cpu())
+    ys = ops.tail_rows(Yb, row0)
+    assert getattr(ys, "_dhaug_bits", None) is not None
+    calls = ops._lib.CALLS[0]
+    got = ops.gemm_nt_dmask(A[row0:], W, 256, 256, ys, act, slope, res_bf16=None if R is None else R[row0:])
+    assert ops._lib.CALLS[0] == calls + 1
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    # in place over the mask tensor (the tangent sweep writes u over y's x_hat rows): the bits, not y, are read
+    out = ops.gemm_nt_dmask(A[row0:], W, 256, 256, ys, act, slope, res_bf16=None if R is None else R[row0:], out=ys)
+    assert out.data_ptr() == ys.data_ptr() and torch.equal(out.view(torch.int16), ref.view(torch.int16))
+
+
 @pytest.mark.parametrize("M,N,K,act,slope,use_res", [(4096, 256, 256, 1, 0.0, False), (4096, 256, 256, 2, 0.01, False),
                                                    (1024, 256, 128, 1, 0.0, True), (1000, 104, 256, 1, 0.0, False)])
 def test_gemm_nt_dmask(ops, M, N, K, act, slope, use_res):
