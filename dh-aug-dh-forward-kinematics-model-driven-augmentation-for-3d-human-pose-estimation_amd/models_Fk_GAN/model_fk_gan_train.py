@@ -196,12 +196,42 @@ class FakePairBuffer:
             yield p3[j], p2[j], ['none'] * j.shape[0], c[j]
 
 
+CONCURRENT_CRITICS = os.environ.get("DHAUG_NO_CONCURRENT_CRITICS") is None
+_SIDE = {}
+
+
+def _side_streams(n):
+    dev = torch.cuda.current_device()
+    if len(_SIDE.get(dev, ())) < n:
+        _SIDE[dev] = [torch.cuda.Stream() for _ in range(n)]
+    return _SIDE[dev]
+
+
 def run_critic_steps(steps, optimizers, interleave):
     """steps: [(key, fn)] in the reference's order, fn() -> (Wasserstein_D, D_cost).  Returns {index: result}.
     interleave (multi-rank runs): the steps of different networks are independent given the fakes, so they are issued
     round-robin over the networks -- per-network order kept -- with the optimizers in overlap mode: while one network's
     gradient bucket is all-reduced, the next network's step computes.  Single-rank runs keep the reference's order."""
     res = {}
+    if not interleave and CONCURRENT_CRITICS and len({k for k, _ in steps}) > 1 and torch.cuda.is_available():
+        # single rank: the steps of DIFFERENT networks run on side streams, one per network (per-network order kept), and
+        # join before anything reads their results -- the launch-bound kernels of one critic's step (narrow layers,
+        # elementwise passes, the tails of the persistent kernels) fill what the other's leaves idle
+        main = torch.cuda.current_stream()
+        streams = _side_streams(len({k for k, _ in steps}))
+        keys = []
+        for k, _ in steps:
+            if k not in keys:
+                keys.append(k)
+        for k, st in zip(keys, streams):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                for i, (kk, fn) in enumerate(steps):
+                    if kk == k:
+                        res[i] = fn()
+        for st in streams[:len(keys)]:
+            main.wait_stream(st)
+        return res
     if not interleave:
         for i, (_, fn) in enumerate(steps):
             res[i] = fn()

@@ -327,7 +327,7 @@ _TN_WS = {}
 def _tn_group_workspace(dev):
     """DHAUG_TN_GROUP_WORKSPACE_FLOATS fp32 values per device: the per-workgroup partial results of dhaug_gemm_tn_group_bf16
     (any content; calls are ordered on the stream)"""
-    k = (dev.type, dev.index)
+    k = (dev.type, dev.index, torch.cuda.current_stream().cuda_stream)      # (per stream: concurrent critic steps)
     if k not in _TN_WS:
         _TN_WS[k] = torch.empty(_lib.TN_GROUP_WORKSPACE_FLOATS, dtype=torch.float32, device=dev)
     return _TN_WS[k]
