@@ -36,10 +36,22 @@ FUSED_STEP_FORWARD = os.environ.get("DHAUG_NO_FUSED_STEP_FORWARD") is None
 # contraction launch per layer
 TN_GROUP = os.environ.get("DHAUG_NO_TN_GROUP") is None
 RANK1 = os.environ.get("DHAUG_NO_RANK1") is None
+# sweep 4 in two parts: the real / fake rows' contractions are launched on a side stream right behind the backward chain and
+# run (HBM-bound) beside the penalty and the launch-bound tangent sweep; the interpolated rows' part follows the tangents
+TN_SPLIT = os.environ.get("DHAUG_NO_TN_SPLIT") is None
+_TN_SIDE = {}
 
 BF16 = torch.bfloat16
 NONE, RELU, LRELU = A.ACT_NONE, A.ACT_RELU, A.ACT_LRELU
 ceil16 = A.ceil16
+
+
+def tn_side_stream(cur):
+    """the stream a step running on `cur` launches the first part of its sweep 4 on"""
+    key = (cur.device.index, cur.cuda_stream)
+    if key not in _TN_SIDE:
+        _TN_SIDE[key] = torch.cuda.Stream()
+    return _TN_SIDE[key]
 
 
 class _Math:
@@ -104,9 +116,36 @@ class _Math:
 
     def flush(self):
         """launch the collected weight-gradient contractions (before the optimizer step reads the gradient bucket)"""
+        self.join()                          # (both parts accumulate into the same gradient slots: never concurrently)
         if self.tn:
             ops.gemm_tn_group(self.tn)
             self.tn = []
+
+    def flush_side(self):
+        """the same on a side stream of the current one (join() / flush() makes the current stream wait for it): the
+        operands stay referenced until then"""
+        if not self.tn:
+            return
+        cur = torch.cuda.current_stream()
+        st = tn_side_stream(cur)
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            ops.gemm_tn_group(self.tn)
+        self._side = (st, self.tn)
+        self.tn = []
+
+    def join(self):
+        side = getattr(self, "_side", None)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side[0])
+            self._side = None
+
+    def can_split(self, B):
+        """sweep 4 in two parts (TN_SPLIT): bf16, whole 32-row stages in both parts, batches long enough for the grouped launch"""
+        # (not inside a hipGraph capture: a step already runs on a forked stream there -- concurrent critics -- and
+        # hipStreamEndCapture of this HIP release crashes on a fork inside a fork, or on an edge between sibling branches)
+        return (self.bf16 and TN_SPLIT and TN_GROUP and B % 32 == 0 and ops.tn_group_ok(B, 1, 1, 0)
+                and not torch.cuda.is_current_stream_capturing())
 
     def fusable(self, n, k, rows):
         """the mask (and skip) ride the GEMM epilogue of every bf16 kernel (an element's mask value is read by the thread
@@ -190,6 +229,10 @@ class _Lin:
                 self.b = bz
         return self._grads(m, gz, x, B2, u)
 
+    def grads_part(self, m, g, x, with_bias):
+        """dW += g^T x over the given rows (one part of sweep 4), db += colsum(g) if with_bias"""
+        m.outer(g, x, self.N, self.K, _slot(self.W), self._bslot() if with_bias else None)
+
     def _grads(self, m, gz, x, B2, u):
         if (m.bf16 and x.dtype == BF16 and u.dtype == BF16 and B2 % 128 == 0 and u.data_ptr() == x[B2:].data_ptr()
                 and u.stride(0) == x.stride(0)):
@@ -242,6 +285,8 @@ _SEED_CACHE = {}
 def seeds(B, m, dev):
     key = (B, m.bf16, str(dev))
     if key not in _SEED_CACHE:
+        if torch.cuda.is_current_stream_capturing():         # (a cached tensor must not live in one graph's memory pool)
+            return _seeds(B, m, dev)
         _SEED_CACHE[key] = _seeds(B, m, dev)
     return _SEED_CACHE[key]
 
@@ -283,6 +328,11 @@ def step_d2(D, optimizerD, real, fake, alpha, lam, prec=None):
     gz3 = L[3].bwd(m, gz4, d3, LRELU, s)
     gz2 = L[2].bwd(m, gz3, d2, LRELU, s)
     gz1 = L[1].bwd(m, gz2, d1, LRELU, s, skip=gz3)
+    split = m.can_split(B)
+    if split:                                                 # sweep 4, real / fake rows: beside the penalty and the tangent sweep
+        for lay, gz, x in ((L[0], gz1, X), (L[1], gz2, d1), (L[2], gz3, d2), (L[3], gz4, d3), (L[4], gzl, d4), (L[5], gzp, dl)):
+            lay.grads_part(m, gz[:B2], x[:B2], lay is not L[5])
+        m.flush_side()
     g = L[0].bwd(m, gz1[B2:], None, NONE, 0.0, out_f32=True)                 # (B,32) fp32: dD/dx_hat
     v, pen = ops.gp_penalty(g, 2.0 * lam / B)
     tail = ops.tail_rows                                      # (x_hat rows of a saved activation, its sign bits attached)
@@ -291,9 +341,13 @@ def step_d2(D, optimizerD, real, fake, alpha, lam, prec=None):
     u3 = L[2].tan(m, u2, tail(d3, B2), skip=u1, inplace=True)
     u4 = L[3].tan(m, u3, tail(d4, B2), inplace=True)
     ul = L[4].tan(m, u4, tail(dl, B2), inplace=True)
-    for lay, gz, x, u in ((L[0], gz1, X, v), (L[1], gz2, d1, u1), (L[2], gz3, d2, u2), (L[3], gz4, d3, u3),
-                          (L[4], gzl, d4, u4), (L[5], gzp, dl, ul)):
-        lay.grads(m, gz, x, B2, u, bias_is_zero=(lay is L[5] and m.bf16))
+    layers = ((L[0], gz1, X, v), (L[1], gz2, d1, u1), (L[2], gz3, d2, u2), (L[3], gz4, d3, u3), (L[4], gzl, d4, u4), (L[5], gzp, dl, ul))
+    if split:
+        for lay, gz, x, u in layers:
+            lay.grads_part(m, gz[B2:], u, False)
+    else:
+        for lay, gz, x, u in layers:
+            lay.grads(m, gz, x, B2, u, bias_is_zero=(lay is L[5] and m.bf16))
     m.flush()
     return _finish(optimizerD, logits, pen, B, lam)
 
@@ -346,6 +400,17 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
             a1[i], a2[i] = br.blocks[i].bwd(m, a2[i + 1], h[bi][i], y[bi][i])
         g1.append(a1); g2.append(a2)
         gin.append(br.first.bwd(m, a2[0][B2:], None, NONE, 0.0, out_f32=True))   # (B, w_b) fp32, x_hat rows only
+    split = m.can_split(B)
+    if split:                                                # sweep 4, real / fake rows: beside the penalty and the tangent sweep
+        for bi, br in enumerate(branches):
+            br.first.grads_part(m, g2[bi][0][:B2], F[bi][:B2], True)
+            for i, blk in enumerate(br.blocks):
+                blk.fc1.grads_part(m, g1[bi][i][:B2], y[bi][i][:B2], True)
+                blk.fc2.grads_part(m, g2[bi][i + 1][:B2], h[bi][i][:B2], True)
+        Lm.grads_part(m, gz_m0[:B2], cat[:B2], True)
+        Mb.fc1.grads_part(m, gz_m1[:B2], m0[:B2], True); Mb.fc2.grads_part(m, gz_m2[:B2], mh[:B2], True)
+        Lo.grads_part(m, gzo[:B2], m1[:B2], False)           # (its bias gradient is exactly zero: see _Lin.grads)
+        m.flush_side()
     g = input_grad(gin)                                      # dD/dx_hat
     # ---- 3. penalty and tangent sweep (x_hat rows)
     gv = g if pen_view is None else g.reshape(pen_view)
@@ -366,15 +431,25 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
             ucat[:, bi * Dw:(bi + 1) * Dw].copy_(u[bi][-1][:, :Dw])
     um0 = Lm.tan(m, ucat, m0[B2:], inplace=True)
     umh, um1 = Mb.tan(m, um0, mh[B2:], m1[B2:])
-    # ---- 4. weight / bias gradients
-    for bi, br in enumerate(branches):
-        br.first.grads(m, g2[bi][0], F[bi], B2, T[bi])
-        for i, blk in enumerate(br.blocks):
-            blk.fc1.grads(m, g1[bi][i], y[bi][i], B2, u[bi][i])
-            blk.fc2.grads(m, g2[bi][i + 1], h[bi][i], B2, uh[bi][i])
-    Lm.grads(m, gz_m0, cat, B2, ucat)
-    Mb.fc1.grads(m, gz_m1, m0, B2, um0); Mb.fc2.grads(m, gz_m2, mh, B2, umh)
-    Lo.grads(m, gzo, m1, B2, um1, bias_is_zero=m.bf16)
+    # ---- 4. weight / bias gradients (the interpolated rows' part where the real / fake rows' part is already under way)
+    if split:
+        for bi, br in enumerate(branches):
+            br.first.grads_part(m, g2[bi][0][B2:], T[bi], False)
+            for i, blk in enumerate(br.blocks):
+                blk.fc1.grads_part(m, g1[bi][i][B2:], u[bi][i], False)
+                blk.fc2.grads_part(m, g2[bi][i + 1][B2:], uh[bi][i], False)
+        Lm.grads_part(m, gz_m0[B2:], ucat, False)
+        Mb.fc1.grads_part(m, gz_m1[B2:], um0, False); Mb.fc2.grads_part(m, gz_m2[B2:], umh, False)
+        Lo.grads_part(m, gzo[B2:], um1, False)
+    else:
+        for bi, br in enumerate(branches):
+            br.first.grads(m, g2[bi][0], F[bi], B2, T[bi])
+            for i, blk in enumerate(br.blocks):
+                blk.fc1.grads(m, g1[bi][i], y[bi][i], B2, u[bi][i])
+                blk.fc2.grads(m, g2[bi][i + 1], h[bi][i], B2, uh[bi][i])
+        Lm.grads(m, gz_m0, cat, B2, ucat)
+        Mb.fc1.grads(m, gz_m1, m0, B2, um0); Mb.fc2.grads(m, gz_m2, mh, B2, umh)
+        Lo.grads(m, gzo, m1, B2, um1, bias_is_zero=m.bf16)
     m.flush()
     return _finish(optimizerD, logits, pen, gv.shape[0], lam, rows=B)
 

@@ -327,6 +327,10 @@ _TN_WS = {}
 def _tn_group_workspace(dev):
     """DHAUG_TN_GROUP_WORKSPACE_FLOATS fp32 values per device: the per-workgroup partial results of dhaug_gemm_tn_group_bf16
     (any content; calls are ordered on the stream)"""
+    if torch.cuda.is_current_stream_capturing():
+        # inside a hipGraph capture the buffer must belong to THAT graph's pool (a cached one would be memory of whichever
+        # capture came first, gone with it): the pool hands the same block out again after each use
+        return torch.empty(_lib.TN_GROUP_WORKSPACE_FLOATS, dtype=torch.float32, device=dev)
     k = (dev.type, dev.index, torch.cuda.current_stream().cuda_stream)      # (per stream: concurrent critic steps)
     if k not in _TN_WS:
         _TN_WS[k] = torch.empty(_lib.TN_GROUP_WORKSPACE_FLOATS, dtype=torch.float32, device=dev)

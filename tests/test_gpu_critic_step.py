@@ -263,3 +263,26 @@ def test_forward_with_save_layer_by_layer(M, tag):
     assert len(with_bits) == (14 if tag == "d3" else 4)
     for t in with_bits:
         assert torch.equal(F.decode_bits(t._dhaug_bits, rows), (t[:, :D].float() > 0).cpu())
+
+
+@pytest.mark.parametrize("tag", ["d3", "d2"])
+def test_sweep4_in_two_parts_equals_one_part(M, tag):
+    """the weight gradients as two grouped launches (real / fake rows on a side stream beside the tangent sweep, interpolated
+    rows after it: critic_step.TN_SPLIT) against one launch over all 3B rows: the same sums in another order"""
+    B, D = 2048, 256
+    args = _args(B, D)
+    shapes = GU.shapes_d3(D) if tag == "d3" else GU.shapes_d2(D)
+    sd = GU.seeded_state_dict(shapes, 77)
+    data = _data(tag, B, 5)
+    assert M.cs.TN_SPLIT
+    W1, C1, g1, p1 = _run(M, tag, args, sd, "bf16", data, True)
+    M.cs.TN_SPLIT = False
+    try:
+        W0, C0, g0, p0 = _run(M, tag, args, sd, "bf16", data, True)
+    finally:
+        M.cs.TN_SPLIT = True
+    assert W1 == W0 and C1 == C0
+    for k in g0:
+        scale = g0[k].abs().max().item()
+        # (fp32 sums of the same terms in another grouping; the bias sums cancel to 1e-3 of their terms)
+        assert (g1[k] - g0[k]).abs().max().item() <= 1e-4 * scale + 1e-12, (k, (g1[k] - g0[k]).abs().max().item(), scale)

@@ -63,13 +63,20 @@ def test_graphed_iterations_equal_eager(M, B, D):
     # and Adam's g / (|g| + eps) turns a last-bit difference of a near-zero gradient into a visible one -- so nothing that
     # DEPENDS on the stepped generator is compared (a sixth iteration would be)
     N = 5
-    # ---- eager
+    # ---- eager (sweep 4 in one part, as a capture runs it: the two-part form adds the same terms in another order, and the
+    # critics are compared to the last bit here; the two forms are compared with each other in test_gpu_critic_step.py)
+    from dhaug_amd import critic_step as CS
     de = _build(M, args, D)
     dr = mk()
     eager = []
-    for i in range(N):
-        r = M.train.gan_iteration(args, de, x3, cp, x2, ["S1"], None, None, do_g_step=(i % 5 == 4), camera=M.cam, draws=dr)
-        eager.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in r.items()})
+    old_split = CS.TN_SPLIT
+    CS.TN_SPLIT = False
+    try:
+        for i in range(N):
+            r = M.train.gan_iteration(args, de, x3, cp, x2, ["S1"], None, None, do_g_step=(i % 5 == 4), camera=M.cam, draws=dr)
+            eager.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in r.items()})
+    finally:
+        CS.TN_SPLIT = old_split
     # ---- graphs (two graphs: with / without the G step); building one must not advance anything
     dg = _build(M, args, D)
     dr2 = mk()
