@@ -290,9 +290,11 @@ def main():
     vin3 = real_cam.reshape(B, R, 16, 3) if video else real_cam
     vin2 = real_2d.reshape(B, R, 16, 2) if video else real_2d
 
+    mode = {"graph": graphed is not None}                   # (auto, one rank: settled by a calibration below)
+
     def step_gan():
         g = it[0] % 5 == 4
-        if graphed is not None:
+        if mode["graph"]:
             graphed(vin3, cam_param, vin2, g, (quat, trans, cam9))
         else:
             T.gan_iteration(args, models, real_cam, cam_param, real_2d, ["S1"], summary=None, writer=None,
@@ -301,7 +303,7 @@ def main():
 
     def step_video():
         g = it[0] % 5 == 4
-        if graphed is not None:
+        if mode["graph"]:
             graphed(vin3, cam_param, vin2, g, (quat, trans, cam9))
         else:
             V.video_gan_iteration(args, models, vin3, cam_param, vin2, ["S1"], summary, None, do_g_step=g,
@@ -353,6 +355,20 @@ def main():
     main_prec = "f16x3" if (a.precision == "parity" and fwd_like) else "bf16"
     set_precision(main_prec)
     prewarm(steps[a.workload], training)
+    graph_calibration = None
+    if training and graphed is not None and a.graph == "auto" and world == 1:
+        # eager or hipGraph?  On a fast host the eager single-frame iteration wins (it overlaps the first part of the weight
+        # gradients with the tangent sweep, which a capture cannot: critic_step.TN_SPLIT), on a slow host or at ~1 400
+        # launches per iteration (video) the graph does: ten iterations each (two G steps), the faster one is timed
+        cal = {}
+        for name, flag in (("graph", True), ("eager", False)):
+            mode["graph"] = flag
+            it[0] = 0
+            tc, _ = timed(steps[a.workload], 10, 5)
+            cal[name] = tc / 10 * 1e3
+        mode["graph"] = cal["graph"] <= cal["eager"]
+        graph_calibration = {"graph_ms": cal["graph"], "eager_ms": cal["eager"], "picked": "graph" if mode["graph"] else "eager"}
+        it[0] = 0
     t, calls = timed(steps[a.workload], a.steps, a.warmup)
     value = N * world * a.steps / t
     out = {"metric": "augmented poses/sec (FK+GAN step), 16-joint batch=65536", "value": value, "unit": "poses/s",
@@ -362,7 +378,7 @@ def main():
            "config": {"workload": WORKLOADS[a.workload], "batch_per_gpu": B, "frames": R, "poses_per_gpu_per_step": N,
                       "global_batch": N * world, "dense_dim": D, "preAngle": True, "fk_dtype": "f32",
                       "dense_dtype": "bf16 MFMA, fp32 accumulate" if main_prec == "bf16" else "3 x fp16 MFMA (hi+lo operands), fp32 accumulate"},
-           "c_abi_calls_per_step": calls, "hip_graph": graphed is not None}
+           "c_abi_calls_per_step": calls, "hip_graph": bool(mode["graph"]), "graph_calibration": graph_calibration}
 
     # the forward workload in the OTHER arithmetic, same inputs (bf16 <-> parity), with its own step time
     if fwd_like:
