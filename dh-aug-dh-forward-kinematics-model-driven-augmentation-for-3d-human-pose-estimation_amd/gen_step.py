@@ -152,6 +152,42 @@ def _m2_value_grad(m, D, x, coef):
     return s["logits"], g.reshape(B * R, 32)
 
 
+CONCURRENT = __import__("os").environ.get("DHAUG_NO_CONCURRENT_CRITICS") is None
+_STREAMS = {}
+
+
+def _parallel(fns):
+    """[fn() for fn in fns], every fn on its own side stream (forked from the current one, joined before returning): the
+    critics' value + input-gradient chains are independent of each other and mostly launch-bound at the G step's B rows.
+    Tensors that come back were allocated on a side stream and are read on the current one: record_stream tells the
+    allocator."""
+    if not CONCURRENT or len(fns) < 2:
+        return [fn() for fn in fns]
+    cur = torch.cuda.current_stream()
+    key = (cur.device.index, cur.cuda_stream)
+    pool = _STREAMS.setdefault(key, [])
+    while len(pool) < len(fns):
+        if torch.cuda.is_current_stream_capturing():          # (no stream creation inside a capture: run the rest in line)
+            break
+        pool.append(torch.cuda.Stream())
+    out = []
+    for i, fn in enumerate(fns):
+        if i >= len(pool):
+            out.append(fn())
+            continue
+        st = pool[i]
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            r = fn()
+        for t in (r if isinstance(r, (tuple, list)) else (r,)):
+            if torch.is_tensor(t):
+                t.record_stream(cur)
+        out.append(r)
+    for st in pool[:len(fns)]:
+        cur.wait_stream(st)
+    return out
+
+
 def supported(G, oG, critics):
     """the explicit schedule covers the reference's generators and critics under a FusedAdam bucket, in every arithmetic of
     the layer path"""
@@ -202,39 +238,60 @@ def generator_step(args, G, oG, critics, weights, camera, flip, noise, scaler, f
     x2 = f2d.reshape(N, 32)
     # ---- critics: value + input gradient of -w * mean D(.) (the L/R-flipped copies halve the weight of the plain ones)
     half = 0.5 if flip else 1.0
-    terms = []                                                    # (logits, weight) of every mean in gen_loss
     m3d, m2d = CS._Math(graph_precision(critics[0].precision)), CS._Math(graph_precision(critics[1].precision))
-    l3, g_fc = _d3_value_grad(m3d, critics[0], fc, -weights[0] * half)
-    l2, g_x2 = _d2_value_grad(m2d, critics[1], x2, -weights[1] * half)
-    terms += [(l3, weights[0] * half), (l2, weights[1] * half)]
+    jobs = [lambda: _d3_value_grad(m3d, critics[0], fc, -weights[0] * half),
+            lambda: _d2_value_grad(m2d, critics[1], x2, -weights[1] * half)]
+    wts = [weights[0] * half, weights[1] * half]
+    kinds = ["fc", "x2"]
+    rev = lambda t: ops.frame_reverse(t.reshape(-1, R * 32), R, 32)
     if len(critics) == 4:
         mm3, mm2 = CS._Math(graph_precision(critics[2].precision)), CS._Math(graph_precision(critics[3].precision))
         ph = 0.5 if playback else 1.0
-        lm3, g = _m3_value_grad(mm3, critics[2], fc, -weights[2] * half * ph)
-        g_fc = ops.add_f32(g_fc, g)
-        lm2, g = _m2_value_grad(mm2, critics[3], x2, -weights[3] * half * ph)
-        g_x2 = ops.add_f32(g_x2, g)
-        terms += [(lm3, weights[2] * half * ph), (lm2, weights[3] * half * ph)]
+        jobs += [lambda: _m3_value_grad(mm3, critics[2], fc, -weights[2] * half * ph),
+                 lambda: _m2_value_grad(mm2, critics[3], x2, -weights[3] * half * ph)]
+        wts += [weights[2] * half * ph, weights[3] * half * ph]
+        kinds += ["fc", "x2"]
         if playback:
             # the reference reverses the frames of the clip VIEWED as (-1, R, 32) -- also for the 3D clip: a
             # permutation of the clip's values that is its own transpose
-            rev3 = ops.frame_reverse(fc.reshape(-1, R * 32), R, 32).reshape(N, 48)
-            lr3, g = _m3_value_grad(mm3, critics[2], rev3, -weights[2] * half * ph)
-            g_fc = ops.add_f32(g_fc, ops.frame_reverse(g.reshape(-1, R * 32), R, 32).reshape(N, 48))
-            rev2 = ops.frame_reverse(x2.reshape(-1, R * 32), R, 32).reshape(N, 32)
-            lr2, g = _m2_value_grad(mm2, critics[3], rev2, -weights[3] * half * ph)
-            g_x2 = ops.add_f32(g_x2, ops.frame_reverse(g.reshape(-1, R * 32), R, 32).reshape(N, 32))
-            terms += [(lr3, weights[2] * half * ph), (lr2, weights[3] * half * ph)]
+            def rev3_job():
+                l, g = _m3_value_grad(CS._Math(graph_precision(critics[2].precision)), critics[2], rev(fc).reshape(N, 48),
+                                      -weights[2] * half * ph)
+                return l, rev(g).reshape(N, 48)
+
+            def rev2_job():
+                l, g = _m2_value_grad(CS._Math(graph_precision(critics[3].precision)), critics[3], rev(x2).reshape(N, 32),
+                                      -weights[3] * half * ph)
+                return l, rev(g).reshape(N, 32)
+            jobs += [rev3_job, rev2_job]
+            wts += [weights[2] * half * ph, weights[3] * half * ph]
+            kinds += ["fc", "x2"]
+    flip_terms = []
     if flip:                                                      # value only (R/...:455-468): fused no-grad programs
-        with torch.no_grad():
-            fcf, x2f = ops.center_flip(fc.reshape(N, 16, 3), False, True), ops.center_flip(x2.reshape(N, 16, 2), False, True)
-            terms += [(critics[0](fcf), weights[0] * 0.5), (critics[1](x2f), weights[1] * 0.5)]
-            if len(critics) == 4:
-                ph = 0.5 if playback else 1.0
-                terms += [(critics[2](fcf.reshape(-1, 48)), weights[2] * 0.5 * ph), (critics[3](x2f.reshape(-1, 32)), weights[3] * 0.5 * ph)]
-                if playback:
-                    terms += [(critics[2](ops.frame_reverse(fcf.reshape(-1, R * 32), R, 32).reshape(-1, 48)), weights[2] * 0.5 * ph),
-                              (critics[3](ops.frame_reverse(x2f.reshape(-1, R * 32), R, 32).reshape(-1, 32)), weights[3] * 0.5 * ph)]
+        def flip_job():
+            with torch.no_grad():
+                fcf, x2f = ops.center_flip(fc.reshape(N, 16, 3), False, True), ops.center_flip(x2.reshape(N, 16, 2), False, True)
+                t = [(critics[0](fcf), weights[0] * 0.5), (critics[1](x2f), weights[1] * 0.5)]
+                if len(critics) == 4:
+                    ph2 = 0.5 if playback else 1.0
+                    t += [(critics[2](fcf.reshape(-1, 48)), weights[2] * 0.5 * ph2), (critics[3](x2f.reshape(-1, 32)), weights[3] * 0.5 * ph2)]
+                    if playback:
+                        t += [(critics[2](rev(fcf).reshape(-1, 48)), weights[2] * 0.5 * ph2),
+                              (critics[3](rev(x2f).reshape(-1, 32)), weights[3] * 0.5 * ph2)]
+            return tuple(l for l, _ in t), [w for _, w in t]
+        jobs.append(flip_job)
+    res = _parallel(jobs)
+    terms = []                                                    # (logits, weight) of every mean in gen_loss
+    g_fc = g_x2 = None
+    for (l, g), w, kind in zip(res[:len(wts)], wts, kinds):
+        terms.append((l, w))
+        if kind == "fc":
+            g_fc = g if g_fc is None else ops.add_f32(g_fc, g)
+        else:
+            g_x2 = g if g_x2 is None else ops.add_f32(g_x2, g)
+    if flip:
+        ls, ws = res[-1]
+        terms += list(zip(ls, ws))
     G_cost = ops.weighted_means([t for t, _ in terms], [-w for _, w in terms])          # -gen_loss
     # ---- back through centring, camera + projection, the FK tail
     g_fw = ops.add_f32(ops.center_flip(g_fc.reshape(N, 16, 3), True, False, adjoint=True).reshape(N, 48),
