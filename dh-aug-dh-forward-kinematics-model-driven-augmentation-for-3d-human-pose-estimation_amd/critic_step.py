@@ -46,12 +46,22 @@ NONE, RELU, LRELU = A.ACT_NONE, A.ACT_RELU, A.ACT_LRELU
 ceil16 = A.ceil16
 
 
+CAPTURE_ROOT = None        # handle of the stream the running hipGraph capture was begun on (graphs.capture_streams): the one
+                           # fork level a capture survives belongs to code running directly on it
+
+
 def tn_side_stream(cur):
     """the stream a step running on `cur` launches the first part of its sweep 4 on"""
     key = (cur.device.index, cur.cuda_stream)
     if key not in _TN_SIDE:
         _TN_SIDE[key] = torch.cuda.Stream()
     return _TN_SIDE[key]
+
+
+def capture_root():
+    """inside a hipGraph capture: is the current stream the one the capture was begun on (and its helper streams exist)?"""
+    cur = torch.cuda.current_stream()
+    return cur.cuda_stream == CAPTURE_ROOT and (cur.device.index, cur.cuda_stream) in _TN_SIDE
 
 
 class _Math:
@@ -142,10 +152,11 @@ class _Math:
 
     def can_split(self, B):
         """sweep 4 in two parts (TN_SPLIT): bf16, whole 32-row stages in both parts, batches long enough for the grouped launch"""
-        # (not inside a hipGraph capture: a step already runs on a forked stream there -- concurrent critics -- and
-        # hipStreamEndCapture of this HIP release crashes on a fork inside a fork, or on an edge between sibling branches)
+        # (inside a hipGraph capture only on the stream the capture was begun on: hipStreamEndCapture of this HIP release
+        # crashes on a fork inside a fork, or on an edge between sibling branches -- a step that runs on a forked stream
+        # there, concurrent critics, keeps sweep 4 in one part)
         return (self.bf16 and TN_SPLIT and TN_GROUP and B % 32 == 0 and ops.tn_group_ok(B, 1, 1, 0)
-                and not torch.cuda.is_current_stream_capturing())
+                and (not torch.cuda.is_current_stream_capturing() or capture_root()))
 
     def fusable(self, n, k, rows):
         """the mask (and skip) ride the GEMM epilogue of every bf16 kernel (an element's mask value is read by the thread

@@ -38,6 +38,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef X3_PRIO_SEL
+#define X3_PRIO_SEL 1
+#endif
 constexpr int X3_BM = 64;                                            // batch rows per tile
 constexpr int X3_MT = X3_BM / 32;
 constexpr int X3_THREADS = 512;
@@ -182,6 +185,13 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned cha
         }
     };
     read_frags(0, fx[0]);
+#if X3_PRIO_SEL
+    // the two waves of a SIMD start every layer together (barrier) and would share the matrix pipe turn by turn, reaching
+    // their epilogues together -- both exposed, and fighting over LDS.  The first wave of the pair takes the pipe (issue
+    // priority) and runs its epilogue UNDER the second wave's matrix phase: one epilogue per layer is exposed, alone on
+    // the SIMD.  (No arithmetic changes: results are the same bits.)
+    if (X3_PRIO_SEL == 1 ? wave < 4 : (wave & 1) == 0) __builtin_amdgcn_s_setprio(3);
+#endif
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
         const int c = k / X3_CH, q = k % X3_CH;
@@ -214,6 +224,9 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned cha
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[c & 1][q][0], fx[k & 1][mt][0], acc[mt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+#if X3_PRIO_SEL
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (ui >= 0) { X3_STAMP(4 * ui + 1) }
     // the ring and the seed are dead: the next layer's first fragments travel during the epilogue and the barrier
     if (next != nullptr) prefetch_layer(next, wave, lane, ring, seed);

@@ -156,6 +156,14 @@ CONCURRENT = __import__("os").environ.get("DHAUG_NO_CONCURRENT_CRITICS") is None
 _STREAMS = {}
 
 
+def side_streams(cur, n):
+    """the n side streams of `cur` (created on first use; graphs.prepare_streams makes them before a capture)"""
+    pool = _STREAMS.setdefault((cur.device.index, cur.cuda_stream), [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream())
+    return pool
+
+
 def _parallel(fns):
     """[fn() for fn in fns], every fn on its own side stream (forked from the current one, joined before returning): the
     critics' value + input-gradient chains are independent of each other and mostly launch-bound at the G step's B rows.
@@ -164,12 +172,13 @@ def _parallel(fns):
     if not CONCURRENT or len(fns) < 2:
         return [fn() for fn in fns]
     cur = torch.cuda.current_stream()
-    key = (cur.device.index, cur.cuda_stream)
-    pool = _STREAMS.setdefault(key, [])
-    while len(pool) < len(fns):
-        if torch.cuda.is_current_stream_capturing():          # (no stream creation inside a capture: run the rest in line)
-            break
-        pool.append(torch.cuda.Stream())
+    if torch.cuda.is_current_stream_capturing():
+        # no stream creation inside a capture, and forks only from the stream the capture was begun on (one level: see
+        # graphs.prepare_streams); whatever has no stream runs in line
+        from . import critic_step
+        pool = _STREAMS.get((cur.device.index, cur.cuda_stream), []) if cur.cuda_stream == critic_step.CAPTURE_ROOT else []
+    else:
+        pool = side_streams(cur, len(fns))
     out = []
     for i, fn in enumerate(fns):
         if i >= len(pool):

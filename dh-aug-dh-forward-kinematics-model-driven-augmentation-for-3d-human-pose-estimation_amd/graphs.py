@@ -24,6 +24,42 @@ from . import autograd_ops as A
 _capture_ids = itertools.count(1)
 
 
+_STREAMS = {}
+
+
+def capture_streams():
+    """(warm-up stream, capture stream) of the current device -- made once, shared by every graph (captures are built one
+    at a time), together with everything the captured code forks to from the capture stream: no stream is created inside a
+    capture, and torch's stream pool (32 handles, handed out round robin) is not walked through by building graphs."""
+    from . import critic_step as CS, gen_step
+    from .models_Fk_GAN import model_fk_gan_train as train
+    dev = torch.cuda.current_device()
+    if dev not in _STREAMS:
+        warm, cap = torch.cuda.Stream(), torch.cuda.Stream()
+        CS.tn_side_stream(cap)
+        train._side_streams(4)
+        gen_step.side_streams(cap, 8)
+        _STREAMS[dev] = (warm, cap)
+    return _STREAMS[dev]
+
+
+class _CaptureRoot:
+    """while a capture runs: critic_step.CAPTURE_ROOT names the stream it was begun on.  hipStreamEndCapture of this HIP
+    release survives ONE fork level; it belongs to code running directly on that stream (critic_step.can_split,
+    gen_step._parallel, the concurrent critics of run_critic_steps)."""
+
+    def __init__(self, stream):
+        self.h = stream.cuda_stream
+
+    def __enter__(self):
+        from . import critic_step as CS
+        self.old, CS.CAPTURE_ROOT = CS.CAPTURE_ROOT, self.h
+
+    def __exit__(self, *exc):
+        from . import critic_step as CS
+        CS.CAPTURE_ROOT = self.old
+
+
 class GraphedCall:
     """capture fn(*static_inputs) once (after warm-up calls that populate caches / one-time kernel configuration) and replay it"""
 
@@ -32,7 +68,7 @@ class GraphedCall:
         the capture, so building a graph advances nothing -- the first replay is the first iteration."""
         self.static_in = [t.clone() if torch.is_tensor(t) else t for t in example_inputs]
         saved = [t.clone() for t in state]
-        side = torch.cuda.Stream()
+        side, self.cap = capture_streams()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
@@ -48,7 +84,7 @@ class GraphedCall:
         # graph then owns the memory its kernels read and refreshes it on every replay
         A.CAPTURE_ID = next(_capture_ids)
         try:
-            with torch.cuda.graph(self.graph):
+            with _CaptureRoot(self.cap), torch.cuda.graph(self.graph, stream=self.cap):
                 if prologue is not None:
                     prologue()
                 self.out = fn(*self.static_in)
@@ -80,7 +116,7 @@ class SegmentedCall:
         self.dist = dist
         self.static_in = [t.clone() if torch.is_tensor(t) else t for t in example_inputs]
         saved = [t.clone() for t in state]
-        side = torch.cuda.Stream()
+        side, cap = capture_streams()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):                                # (eager, collectives included: every rank runs the same)
@@ -92,13 +128,13 @@ class SegmentedCall:
         if saved:
             A.bump_weight_epoch()
         global RECORDER
-        self.items, self.pool, self.cap = [], torch.cuda.graph_pool_handle(), torch.cuda.Stream()
+        self.items, self.pool, self.cap = [], torch.cuda.graph_pool_handle(), cap
         self._g = None
         A.CAPTURE_ID = next(_capture_ids)
         RECORDER = self
         try:
             self.cap.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.cap):
+            with _CaptureRoot(self.cap), torch.cuda.stream(self.cap):
                 self._begin()
                 if prologue is not None:
                     prologue()

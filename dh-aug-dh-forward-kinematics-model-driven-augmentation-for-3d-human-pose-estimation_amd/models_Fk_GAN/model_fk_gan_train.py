@@ -197,6 +197,7 @@ class FakePairBuffer:
 
 
 CONCURRENT_CRITICS = os.environ.get("DHAUG_NO_CONCURRENT_CRITICS") is None
+LONG_ROWS = 16384           # from this batch on one critic's kernels fill the card (run_critic_steps)
 _SIDE = {}
 
 
@@ -207,12 +208,21 @@ def _side_streams(n):
     return _SIDE[dev]
 
 
-def run_critic_steps(steps, optimizers, interleave):
+def run_critic_steps(steps, optimizers, interleave, long_rows=False):
     """steps: [(key, fn)] in the reference's order, fn() -> (Wasserstein_D, D_cost).  Returns {index: result}.
     interleave (multi-rank runs): the steps of different networks are independent given the fakes, so they are issued
     round-robin over the networks -- per-network order kept -- with the optimizers in overlap mode: while one network's
     gradient bucket is all-reduced, the next network's step computes.  Single-rank runs keep the reference's order."""
     res = {}
+    if (not interleave and long_rows and critic_step.TN_SPLIT and torch.cuda.is_available()
+            and torch.cuda.is_current_stream_capturing() and critic_step.capture_root()):
+        # a hipGraph capture allows ONE fork level (critic_step.can_split).  At long batches the kernels of two critics
+        # hardly overlap (each fills the card: 72 % of an eager iteration has one kernel resident, tools/timeline_analyze.py),
+        # what pays is sweep 4's first part beside the penalty and the tangent sweep: the steps stay on the capture's own
+        # stream and fork there
+        for i, (_, fn) in enumerate(steps):
+            res[i] = fn()
+        return res
     if not interleave and CONCURRENT_CRITICS and len({k for k, _ in steps}) > 1 and torch.cuda.is_available():
         # single rank: the steps of DIFFERENT networks run on side streams, one per network (per-network order kept), and
         # join before anything reads their results -- the launch-bound kernels of one critic's step (narrow layers,
@@ -365,7 +375,7 @@ def gan_iteration(args, poseFk_dict, inputs_3d, cam_param, target_d2d, train_sub
     if flip:
         steps.append(("d2", mk(D2, ops.center_flip(target_d2d, False, True), ops.center_flip(pos_2d, False, True), 'd2d', o2,
                                alphas[3])))
-    res = run_critic_steps(steps, (o3, o2), _multi_rank())
+    res = run_critic_steps(steps, (o3, o2), _multi_rank(), long_rows=B >= LONG_ROWS)
     if flip:
         W3, C3 = (res[0][0] + res[1][0]) / 2, (res[0][1] + res[1][1]) / 2
         W2, C2 = (res[2][0] + res[3][0]) / 2, (res[2][1] + res[3][1]) / 2

@@ -44,9 +44,15 @@ def _build(M, args, D):
     return d
 
 
-@pytest.mark.parametrize("B,D", [(96, 64), (2048, 256)])
-def test_graphed_iterations_equal_eager(M, B, D):
+@pytest.mark.parametrize("B,D,split", [(96, 64, False), (2048, 256, False), (2048, 256, True)])
+def test_graphed_iterations_equal_eager(M, B, D, split, monkeypatch):
+    """split: sweep 4 in two parts (critic_step.TN_SPLIT) in both forms -- the capture then keeps the critics' steps on its own
+    stream and forks there (run_critic_steps at 'long' batches; the threshold is lowered to this test's batch), the eager
+    iteration forks inside its concurrent critic streams.  Without it both forms sum in one part."""
     from test_gpu_models import make_args
+    from dhaug_amd import critic_step as CS
+    monkeypatch.setattr(CS, "TN_SPLIT", split)
+    monkeypatch.setattr(M.train, "LONG_ROWS", 1024 if split else 1 << 30)
     args = make_args(batch_size=B, Gen_DenseDim=D, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D)
     gen = torch.Generator().manual_seed(5)
     x3 = GU.synth_pose16(B, seed=3).cuda()
@@ -63,22 +69,15 @@ def test_graphed_iterations_equal_eager(M, B, D):
     # and Adam's g / (|g| + eps) turns a last-bit difference of a near-zero gradient into a visible one -- so nothing that
     # DEPENDS on the stepped generator is compared (a sixth iteration would be)
     N = 5
-    # ---- eager (sweep 4 in one part, as a capture runs it: the two-part form adds the same terms in another order, and the
-    # critics are compared to the last bit here; the two forms are compared with each other in test_gpu_critic_step.py)
-    from dhaug_amd import critic_step as CS
+    # ---- eager
     de = _build(M, args, D)
     dr = mk()
     eager = []
-    old_split = CS.TN_SPLIT
-    CS.TN_SPLIT = False
-    try:
-        for i in range(N):
-            r = M.train.gan_iteration(args, de, x3, cp, x2, ["S1"], None, None, do_g_step=(i % 5 == 4), camera=M.cam, draws=dr)
-            eager.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in r.items()})
-            if i == 0:
-                first_e = {ok: de[ok].flat_param.clone() for ok in ("optimizer_d3d", "optimizer_d2d")}
-    finally:
-        CS.TN_SPLIT = old_split
+    for i in range(N):
+        r = M.train.gan_iteration(args, de, x3, cp, x2, ["S1"], None, None, do_g_step=(i % 5 == 4), camera=M.cam, draws=dr)
+        eager.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in r.items()})
+        if i == 0:
+            first_e = {ok: de[ok].flat_param.clone() for ok in ("optimizer_d3d", "optimizer_d2d")}
     # ---- graphs (two graphs: with / without the G step); building one must not advance anything
     dg = _build(M, args, D)
     dr2 = mk()
