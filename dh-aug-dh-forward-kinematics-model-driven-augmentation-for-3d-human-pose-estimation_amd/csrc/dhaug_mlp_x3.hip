@@ -39,7 +39,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef X3_PRIO_SEL
-#define X3_PRIO_SEL 1
+#define X3_PRIO_SEL 2
+#endif
+#ifndef X3_STREAM
+#define X3_STREAM 0          // (1: the per-k-step weight stream below -- measured: no gain, see its comment)
 #endif
 constexpr int X3_BM = 64;                                            // batch rows per tile
 constexpr int X3_MT = X3_BM / 32;
@@ -149,6 +152,56 @@ __device__ __forceinline__ void prefetch_layer(UnitPtr u, int wave, int lane, Ri
     }
 }
 
+// The weight stream (X3_STREAM): one k-step entry (hi + lo fragment, 2 KB per wave) is requested per k-step, eight k-steps
+// ahead, into the ring entry the matrix instructions have just read -- and the stream runs on ACROSS the layer boundary: the
+// last eight k-steps of a layer request the first eight of the next one.  Measured on the version that requested half a
+// layer (two chunks + the bias, 20 KB per wave) behind the k loop: the eight waves' 160 KB take the CU's 64 B/clk
+// vector-memory path 2 500 clocks to ACCEPT, and a wave's epilogue cannot start before its loads have issued (in-order):
+// ~2 600 exposed clocks per 256 -> 256 layer (phase stamps of an MFMA-only build: 6 730 clocks of k loop + 2 780 of "nothing").
+// RESULT (r3, D3 at B = 65 536, same box): 391 us with the stream against 386 us without.  The epilogue did shrink (4 000 -
+// 5 300 -> 1 900 - 3 000 clocks) but the k loop grew by as much (6 400 - 6 900 -> 8 000 - 9 200): a wave issues in order, so
+// a load the path cannot accept yet holds back the matrix instructions behind it wherever it stands.  The layer's 256 KB
+// of fragments take 4 096 of the 6 144 matrix clocks on that path either way; only fewer bytes per row (a taller row tile,
+// which LDS has no room for) would change it.  Kept as a build option (-DX3_STREAM=1), off.
+struct NextW {                                       // the next GEMM unit's weight stream for this wave and lane
+    const _Float16* a;                               // source 1: entry q at a + q * 1024 (hi), + 512 (lo)
+    const _Float16* b;                               // source 2 (entries kp1 ..)
+    int kp1, total;                                  // k-steps of source 1 (chunk-padded) / of both
+};
+__device__ __forceinline__ NextW next_stream(UnitPtr u, int wave, int lane) {
+    NextW n;
+    n.kp1 = chunks_of(u->ksteps) * X3_CH;
+    const int ks2 = u->ksteps2, kp2 = ks2 > 0 ? chunks_of(ks2) * X3_CH : 0;
+    n.total = n.kp1 + kp2;
+    n.a = u->w + ((long long)wave * n.kp1 * 2 * 64 + lane) * 8;
+    n.b = ks2 > 0 ? u->w2 + ((long long)wave * kp2 * 2 * 64 + lane) * 8 : n.a;
+    return n;
+}
+__device__ __forceinline__ void load_next_entry(const NextW& n, int q, f16x8 (&e)[2]) {      // q < n.total (wave-uniform)
+    const _Float16* base = q < n.kp1 ? n.a + (long long)q * 1024 : n.b + (long long)(q - n.kp1) * 1024;
+    e[0] = *reinterpret_cast<const f16x8*>(base);
+    e[1] = *reinterpret_cast<const f16x8*>(base + 512);
+}
+// entry K (compile time) of THIS layer's concatenated sources
+template <int NCH, int NCH1>
+__device__ __forceinline__ void load_own_entry(int K, const _Float16* w1, const _Float16* w2, int wave, int lane, f16x8 (&e)[2]) {
+    const bool second = K >= NCH1 * X3_CH;                                    // (K: a constant once the k loop is unrolled)
+    const int kpad = (second ? NCH - NCH1 : NCH1) * X3_CH;
+    const int kk = second ? K - NCH1 * X3_CH : K;
+    const _Float16* base = (second ? w2 : w1) + ((long long)wave * kpad * 2 * 64 + lane) * 8 + (long long)kk * 1024;
+    e[0] = *reinterpret_cast<const f16x8*>(base);
+    e[1] = *reinterpret_cast<const f16x8*>(base + 512);
+}
+__device__ __forceinline__ void load_bias_seed(UnitPtr u, int wave, int lane, f32x16& seed) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(u->bias + 32 * wave + 4 * h + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) seed[4 * g + e] = b4[e];
+    }
+}
+
 // dst = act(W src [+ W2 src2] + bias + res), one layer.  NCH chunks of 64 k, the first NCH1 from source 1.  On entry the
 // ring holds this layer's chunks 0 (and 1) and `seed` its bias; before the epilogue `next` (the GEMM unit that runs after
 // this one, possibly of the next tile; nullptr: none) is prefetched the same way.  Waves whose slice lies beyond N only
@@ -172,11 +225,29 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned cha
     constexpr int KT = NCH * X3_CH;
     f16x8 fx[2][X3_MT][2];                           // activation fragments (hi, lo), read one k-step ahead (the SIMD's other
                                                      // wave covers the LDS latency; three stages spill at 256 registers)
+    // 256-wide sources live in buffers 0 / 1 (pitch and plane size are constants there): ONE address per k-step -- row
+    // 32 + r has r's swizzle (32 % 16 == 0) and the lo plane is a constant away, so the four fragments of a k-step are
+    // immediate offsets of it (2 VALU per k-step instead of 9 in front of the matrix instructions)
+#ifdef X3_OLD_ADDR
+    constexpr bool WIDE = false;
+#else
+    constexpr bool WIDE = NCH1 == 4 && (NCH == 4 || NCH == 8);
+#endif
+    const int wide_row = r31 * (P01 * 2), wide_sw = r31 & 15;
     auto read_frags = [&](int k, f16x8 (&f)[X3_MT][2]) {
         const bool second = k >= NCH1 * X3_CH;
         const unsigned char* src = second ? src2 : src1;
-        const int pbs = second ? pbs2 : pbs1, pl = second ? pl2 : pl1;
         const int kk = second ? k - NCH1 * X3_CH : k;
+        if (WIDE) {
+            const unsigned char* a = src + wide_row + (((2 * kk + h) ^ wide_sw) << 4);
+#pragma unroll
+            for (int mt = 0; mt < X3_MT; ++mt) {
+                f[mt][0] = *reinterpret_cast<const f16x8*>(a + mt * 32 * (P01 * 2));
+                f[mt][1] = *reinterpret_cast<const f16x8*>(a + mt * 32 * (P01 * 2) + PLANE01);
+            }
+            return;
+        }
+        const int pbs = second ? pbs2 : pbs1, pl = second ? pl2 : pl1;
 #pragma unroll
         for (int mt = 0; mt < X3_MT; ++mt) {
             const int o = chunk_off(32 * mt + r31, 2 * kk + h, pbs);
@@ -185,6 +256,10 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned cha
         }
     };
     read_frags(0, fx[0]);
+#if X3_STREAM
+    NextW nw = {};
+    if (next != nullptr) nw = next_stream(next, wave, lane);
+#endif
 #if X3_PRIO_SEL
     // the two waves of a SIMD start every layer together (barrier) and would share the matrix pipe turn by turn, reaching
     // their epilogues together -- both exposed, and fighting over LDS.  The first wave of the pair takes the pipe (issue
@@ -198,6 +273,7 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned cha
 #ifndef X3_ABL_NOREAD
         if (k + 1 < KT) read_frags(k + 1, fx[(k + 1) & 1]);
 #endif
+#if !X3_STREAM
 #ifdef X3_ABL_NOWLOAD
         if (false) {
 #else
@@ -211,6 +287,7 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned cha
             if (c + 1 == 6) load_chunk<6 < NCH ? 6 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[0]);
             if (c + 1 == 7) load_chunk<7 < NCH ? 7 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[1]);
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // small terms first, then hi * hi
 #pragma unroll
@@ -223,13 +300,30 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned cha
         for (int mt = 0; mt < X3_MT; ++mt)
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[c & 1][q][0], fx[k & 1][mt][0], acc[mt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+#if X3_STREAM && !defined(X3_ABL_NOWLOAD)
+        // the entry just read is free: request the one eight k-steps ahead into it -- this layer's, or the next layer's
+        if (k + 8 < KT) {
+            load_own_entry<NCH, NCH1>(k + 8, w1, w2, wave, lane, ring[c & 1][q]);
+        } else if (next != nullptr) {
+            if (KT >= 8) {
+                if (k + 8 - KT < nw.total) load_next_entry(nw, k + 8 - KT, ring[c & 1][q]);
+            } else {                                                      // a 4-k-step layer feeds two entries per step
+                if (k < nw.total) load_next_entry(nw, k, ring[0][q]);
+                if (k + 4 < nw.total) load_next_entry(nw, k + 4, ring[1][q]);
+            }
+        }
+        if (k == KT - 1 && next != nullptr) load_bias_seed(next, wave, lane, seed);   // (16 registers: not live across the loop)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 #if X3_PRIO_SEL
     __builtin_amdgcn_s_setprio(0);
 #endif
     if (ui >= 0) { X3_STAMP(4 * ui + 1) }
+#if !X3_STREAM
     // the ring and the seed are dead: the next layer's first fragments travel during the epilogue and the barrier
     if (next != nullptr) prefetch_layer(next, wave, lane, ring, seed);
+#endif
     const bool to_global = (u->flags & F_OUT_F32) != 0;
     unsigned char* dst = buf_base(smem, u->dst);
     const int pbd = buf_pitch_bytes(u->dst), pld = buf_plane(u->dst);
@@ -253,7 +347,7 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned cha
         return;
     }
 #ifdef X3_ABL_NOEPI
-    if (u->slope == 12345.f)
+    if (u->slope != 12345.f) return;
 #endif
     // all residual values first (16 reads in flight, one LDS round trip): read where they are used, every group's loads sat
     // behind the previous group's stores (dst may be res: they may alias, the compiler keeps the order) -- eight exposed LDS
