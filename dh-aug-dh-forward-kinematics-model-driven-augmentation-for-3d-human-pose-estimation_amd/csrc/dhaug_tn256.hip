@@ -245,8 +245,9 @@ int dhaug_gemm_tn_group_bf16(const dhaug_tn_layer* layers, int n, float* workspa
     g.nlayers = n;
     g.abl = getenv("DHAUG_TN256_ABL") ? atoi(getenv("DHAUG_TN256_ABL")) : 0;
     g.ws = workspace;
-    double weight[T2_MAX_LAYERS], total = 0.0;
+    double weight[T2_MAX_LAYERS], total = 0.0, bytes2 = 0.0;
     long long stages = 0;
+    static const int floor_cols = getenv("DHAUG_TN_FLOOR") ? atoi(getenv("DHAUG_TN_FLOOR")) : 448;
     for (int i = 0; i < n; ++i) {
         const dhaug_tn_layer& s = layers[i];
         DHAUG_CHECK(s.M >= T2_ROWS && s.M % T2_ROWS == 0 && s.M / T2_ROWS < (1LL << 30), DHAUG_EUNSUPPORTED);
@@ -261,37 +262,40 @@ int dhaug_gemm_tn_group_bf16(const dhaug_tn_layer* layers, int n, float* workspa
         L.A = s.A; L.B = s.B; L.C = s.C; L.colsum = s.colsum_a;
         L.lda = s.lda; L.ldb = s.ldb; L.ldc = s.ldc; L.cs_rows = s.colsum_a != nullptr ? s.colsum_rows : 0;
         L.nst = (int)(s.M / T2_ROWS); L.n1 = s.N1; L.n2 = s.N2; L.accumulate = s.accumulate;
-        weight[i] = (double)s.M * (((s.N1 + 7) & ~7) + ((s.N2 + 7) & ~7));        // operand bytes / 2
+        const int cols = ((s.N1 + 7) & ~7) + ((s.N2 + 7) & ~7);                   // operand bytes / 2 per row
+        bytes2 += (double)s.M * cols;
+        // what a row COSTS its workgroup: its bytes at the workgroup's share of HBM (13 B/clk), but never less than the
+        // stage's fixed work -- four LDS-DMA instructions per wave fill 32 KB at ~32 B/clk whatever the layer's width, plus
+        // the barrier.  Measured (tools/time_tn_group.py, the 3D critic's 19 contractions, 3.16 GB): floor 0 (bytes alone) 1 027 us, 224 693, 320 649, 448 583 = 5.4 TB/s, 512+ (rows alone) 605.  Dealt by bytes alone, the few workgroups of
+        // a NARROW layer (the 100 -> 1 logit layer: 128 columns, 6 144 stages over 4 workgroups) were the launch's long
+        // pole: 704 us of stage floor against 356 us for a 256 x 256 layer's workgroups.
+        weight[i] = (double)s.M * (cols > floor_cols ? cols : floor_cols);
         total += weight[i];
         stages += L.nst;
     }
-    // deal the workgroups (one per CU) out in proportion to the operand bytes: at least one, at most one per stage
+    // deal the workgroups (one per CU) out in proportion to that cost: at least one, at most one per stage
     // (a short batch leaves little to read per layer: every workgroup costs a 256 KB partial result to write and to sum, so
     // the group gets about one workgroup per 768 KB of operands, at least one per layer, at most one per CU)
-    long long want = (long long)(total * 2.0 / (768.0 * 1024.0)) + 1;
+    long long want = (long long)(bytes2 * 2.0 / (768.0 * 1024.0)) + 1;
     if (want < n) want = n;
     if (want > T2_MAX_WG) want = T2_MAX_WG;
     const int budget = (int)(stages < want ? stages : want);
+    // every layer one workgroup, then the next one always to the layer whose slowest workgroup finishes last: its time is
+    // (stages per workgroup, rounded UP) x (cost of a stage) -- the rounding matters, a layer's 6 144 stages over 17 or 18
+    // workgroups differ by a whole 6 %
     int used = 0;
+    double stage_cost[T2_MAX_LAYERS];
     for (int i = 0; i < n; ++i) {
-        int w = (int)(budget * weight[i] / total);
-        if (w < 1) w = 1;
-        if (w > g.L[i].nst) w = g.L[i].nst;
-        g.L[i].nwg = w;
-        used += w;
-    }
-    while (used > budget) {                                       // (rounding up of small layers): take from the best-served layer
-        int b = -1;
-        for (int i = 0; i < n; ++i)
-            if (g.L[i].nwg > 1 && (b < 0 || weight[i] / g.L[i].nwg < weight[b] / g.L[b].nwg)) b = i;
-        if (b < 0) break;
-        --g.L[b].nwg; --used;
+        g.L[i].nwg = 1;
+        stage_cost[i] = weight[i] / g.L[i].nst;
+        ++used;
     }
     DHAUG_CHECK(used <= T2_MAX_WG, DHAUG_EUNSUPPORTED);
-    while (used < budget) {                                       // left over: to the layer with the most bytes per workgroup
+    auto finish = [&](int i) { return (double)((g.L[i].nst + g.L[i].nwg - 1) / g.L[i].nwg) * stage_cost[i]; };
+    while (used < budget) {
         int b = -1;
         for (int i = 0; i < n; ++i)
-            if (g.L[i].nwg < g.L[i].nst && (b < 0 || weight[i] / g.L[i].nwg > weight[b] / g.L[b].nwg)) b = i;
+            if (g.L[i].nwg < g.L[i].nst && (b < 0 || finish(i) > finish(b))) b = i;
         if (b < 0) break;
         ++g.L[b].nwg; ++used;
     }
