@@ -92,7 +92,8 @@ class _Math:
         Bop = A._w_nt(W, kp, self.prec) if orient == "nt" else A._w_nn(W, self.prec)
         a_op = self._a(a, k)
         if (self.bf16 and RANK1 and orient == "nn" and N == 1 and a.dtype == BF16 and res is None and bias is None
-                and mask is not None and mask_act != NONE and not out_f32 and mask.stride(0) % 8 == 0 and mask.shape[1] >= ceil16(K)):
+                and mask is not None and mask_act != NONE and not out_f32 and mask.stride(0) % 8 == 0 and mask.shape[1] >= ceil16(K)
+                and ceil16(K) <= 1024):
             # the logit layer's input cotangent: seed (rows,1) x weight row (1,K), masked -- a streaming kernel, not a K = 1 GEMM
             return ops.rank1_mask(a, A._w_nn(W, self.prec)[:, 0], mask, K, mask_act, slope, out=out)
         if self.bf16:

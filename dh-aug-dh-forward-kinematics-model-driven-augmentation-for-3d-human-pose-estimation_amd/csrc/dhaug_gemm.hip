@@ -948,8 +948,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ws_kernel(GemmArgs p) {
             for (int i = 0; i < 4; ++i) {
                 const int q = tid + 256 * i, row = q >> 4, pc = q & 15;
                 const long long gm = m0 + row, n = n0 + pc * 8;
-                rres[i] = (gm < p.M && n + 8 <= p.N) ? *reinterpret_cast<const uint4*>(p.res + gm * p.ld_res + n)
-                                                     : make_uint4(0, 0, 0, 0);
+                // (a piece that straddles N -- columns 96..103 of a 100-wide layer -- is still read as one 16-byte load
+                // where the row pitch covers it: element-wise loads in the epilogue cost the workgroup a memory round trip
+                // per tile)
+                rres[i] = (gm < p.M && n < p.N && n + 8 <= p.ld_res) ? *reinterpret_cast<const uint4*>(p.res + gm * p.ld_res + n)
+                                                                     : make_uint4(0, 0, 0, 0);
             }
         }
         // ... and of the activation-backward mask (requested here, used in the epilogue: a load issued where its value is
@@ -961,8 +964,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ws_kernel(GemmArgs p) {
             for (int i = 0; i < 4; ++i) {
                 const int q = tid + 256 * i, row = q >> 4, pc = q & 15;
                 const long long gm = m0 + row, n = n0 + pc * 8;
-                rmask[i] = (gm < p.M && n + 8 <= p.N) ? *reinterpret_cast<const uint4*>(p.dmask + gm * p.ld_dmask + n)
-                                                      : make_uint4(0, 0, 0, 0);
+                rmask[i] = (gm < p.M && n < p.N && n + 8 <= p.ld_dmask) ? *reinterpret_cast<const uint4*>(p.dmask + gm * p.ld_dmask + n)
+                                                                        : make_uint4(0, 0, 0, 0);
             }
         }
         // compute
@@ -1022,7 +1025,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ws_kernel(GemmArgs p) {
                 for (int e = 0; e < 8; ++e) if (full || n + e < p.N) v[e] += p.resf[gm * p.ld_resf + n + e];
             }
             if (res_vec) {
-                if (full) {
+                if (full || n + 8 <= p.ld_res) {             // (elements beyond N are zeroed below)
                     const uint32_t w[4] = {rres[i].x, rres[i].y, rres[i].z, rres[i].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -1037,7 +1040,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ws_kernel(GemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (full || n + e < p.N) ? apply_act(v[e], p.act, p.slope) : 0.0f;
             if (p.dmask != nullptr) {                        // activation-backward mask of the producing layer
-                if (full && mask_vec) {
+                if (mask_vec && (full || n + 8 <= p.ld_dmask)) {
                     const uint4 mm = rmask[i];
                     const uint32_t w[4] = {mm.x, mm.y, mm.z, mm.w};
 #pragma unroll

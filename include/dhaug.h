@@ -439,7 +439,7 @@ int dhaug_critic_scalars(const float* logits, int64_t ld, const float* pen, int6
 /* First step of a critic's backward chain, through its 1-wide logit layer: out[r][c] = bf16(seed[r] * w[c]) * act'(mask[r][c])
  * for c < N, zero in [N, pad_cols) -- (gz W_out) * act'(y) of R/models_Fk_GAN/Fk_discriminator.py:201,266's backward, which as
  * a GEMM has K = 1.  seed: bf16, one value per row (stride ld_seed); w: the layer's N weights as bf16 (stride ld_w); mask, out:
- * bf16 (M, ld) with 16-byte aligned rows. */
+ * bf16 (M, ld) with 16-byte aligned rows; pad_cols <= 1024 (DHAUG_EUNSUPPORTED beyond). */
 int dhaug_rank1_mask_bf16(const uint16_t* seed, int64_t ld_seed, const uint16_t* w, int64_t ld_w, const uint16_t* mask, int64_t ld_mask,
                           uint16_t* out, int64_t ld_out, int64_t M, int64_t N, int64_t pad_cols, int mask_act, float mask_slope,
                           void* stream);
