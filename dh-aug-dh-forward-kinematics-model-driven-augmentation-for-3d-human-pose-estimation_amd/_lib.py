@@ -76,7 +76,7 @@ class RepackDesc(ctypes.Structure):
 class TnLayer(ctypes.Structure):
     """struct dhaug_tn_layer (include/dhaug.h)"""
     _fields_ = [("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("C", _vp), ("ldc", _i64), ("colsum_a", _vp),
-                ("colsum_rows", _i64), ("M", _i64), ("N1", _i32), ("N2", _i32), ("accumulate", _i32), ("reserved", _i32)]
+                ("colsum_rows", _i64), ("M", _i64), ("N1", _i32), ("N2", _i32), ("accumulate", _i32), ("max_workgroups", _i32)]
 
 
 TN_GROUP_MAX = 44

@@ -40,6 +40,10 @@ RANK1 = os.environ.get("DHAUG_NO_RANK1") is None
 # run (HBM-bound) beside the penalty and the launch-bound tangent sweep; the interpolated rows' part follows the tangents
 TN_SPLIT = os.environ.get("DHAUG_NO_TN_SPLIT") is None
 _TN_SIDE = {}
+# workgroups of sweep 4's side-stream part: it runs beside the penalty and the tangent sweep, whose kernels crawl while a
+# one-per-CU launch holds every CU (measured, iteration at B = 65 536: 256 -> 7.53 ms, 192 -> 7.44, 128 -> 7.31, 96 -> 7.28,
+# 80 -> 7.49, 64 -> 7.86: below ~90 the side part becomes the step's long pole)
+TN_SIDE_WGS = int(os.environ.get("DHAUG_TN_SIDE_WGS", "128"))
 
 BF16 = torch.bfloat16
 NONE, RELU, LRELU = A.ACT_NONE, A.ACT_RELU, A.ACT_LRELU
@@ -141,7 +145,7 @@ class _Math:
         st = tn_side_stream(cur)
         st.wait_stream(cur)
         with torch.cuda.stream(st):
-            ops.gemm_tn_group(self.tn)
+            ops.gemm_tn_group(self.tn, max_workgroups=TN_SIDE_WGS)
         self._side = (st, self.tn)
         self.tn = []
 

@@ -342,9 +342,10 @@ def tn_group_ok(M, N1, N2, colsum_rows):
     return M >= 1024 and M % 32 == 0 and colsum_rows % 32 == 0 and 1 <= N1 <= 256 and 1 <= N2 <= 256
 
 
-def gemm_tn_group(items):
+def gemm_tn_group(items, max_workgroups=0):
     """items: [(A, B, N1, N2, out, colsum | None, colsum_rows, accumulate, M | None, lda | None, ldb | None)] -- the weight
-    gradients C_i (+)= A_i^T B_i of several layers in one launch (+ one that sums the partial results)."""
+    gradients C_i (+)= A_i^T B_i of several layers in one launch (+ one that sums the partial results).
+    max_workgroups: leave CUs to kernels running beside this launch (0: one workgroup per CU)."""
     for i0 in range(0, len(items), _lib.TN_GROUP_MAX):
         chunk = items[i0:i0 + _lib.TN_GROUP_MAX]
         arr = (_lib.TnLayer * len(chunk))()
@@ -353,6 +354,7 @@ def gemm_tn_group(items):
             d.A, d.lda, d.B, d.ldb = _p(A), A.stride(0) if la is None else la, _p(B), B.stride(0) if lb is None else lb
             d.C, d.ldc, d.colsum_a, d.colsum_rows = _p(out), out.stride(0), _p(cs), cr
             d.M, d.N1, d.N2, d.accumulate = A.shape[0] if M is None else M, N1, N2, int(bool(accumulate))
+            d.max_workgroups = int(max_workgroups)
         _lib.call("dhaug_gemm_tn_group_bf16", arr, len(chunk), _p(_tn_group_workspace(chunk[0][0].device)), _stream())
 
 

@@ -241,7 +241,8 @@ int dhaug_gemm_tn_bf16_rows(const uint16_t* A, int64_t lda, const uint16_t* B, i
  * [0, colsum_rows), with N1, N2 <= 256, M and colsum_rows multiples of 32, operands bf16 with rows readable up to ceil8(N)
  * columns.  One workgroup per CU owns a layer's WHOLE output over its slice of the batch (every operand byte crosses
  * L2 -> LDS once; the 64 x 64-tile kernel behind dhaug_gemm_tn_bf16 re-reads each row four times); the workgroups are dealt
- * out to the layers in proportion to their operand bytes, so a step leaves 256 partial results in total, not per layer.
+ * out to the layers by what their 32-row stages cost (operand bytes, with a floor for narrow layers), so a step leaves 256
+ * partial results in total, not per layer.
  * `layers`: host array (read during the call).  `workspace`: DHAUG_TN_GROUP_WORKSPACE_FLOATS fp32 values owned by the
  * caller, any content (calls sharing it must be ordered on one stream).
  * Replaces the parameter-gradient half of loss.backward() in R/models_Fk_GAN/model_fk_gan_train.py:191-214. */
@@ -256,7 +257,8 @@ typedef struct dhaug_tn_layer {
     int64_t M;
     int32_t N1, N2;
     int32_t accumulate;         /* != 0: add into C / colsum_a, else overwrite */
-    int32_t reserved;
+    int32_t max_workgroups;     /* of layers[0]: the launch uses at most this many workgroups (0: one per CU) -- a launch that
+                                   runs beside other kernels leaves them CUs */
 } dhaug_tn_layer;
 int dhaug_gemm_tn_group_bf16(const dhaug_tn_layer* layers, int n, float* workspace, void* stream);
 
