@@ -278,12 +278,24 @@ class _Block:
 
     def bwd(self, m, gz2, h, x, x_act=RELU, out=None):
         """gz2: cotangent at fc2's pre-activation.  Returns (gz1, cotangent at the pre-activation of x's producer)."""
+        if x_act == RELU and _pair_ok(m, self.fc2, self.fc1, gz2, h, x, out):
+            # both layers in one launch: gz1 stays in LDS between them, gz2 is read once (dhaug_gemm_block2_bf16)
+            return ops.gemm_block2(gz2, A._w_nn(self.fc2.W, m.prec), A._w_nn(self.fc1.W, m.prec), h, x, RELU, 0.0, out2=out)
         gz1 = self.fc2.bwd(m, gz2, h, RELU, 0.0)
         return gz1, self.fc1.bwd(m, gz1, x, x_act, 0.0, skip=gz2, out=out)
 
     def tan(self, m, u, h, y):
+        if _pair_ok(m, self.fc1, self.fc2, u, h, y, y) and h.data_ptr() != u.data_ptr() and y.data_ptr() != u.data_ptr():
+            # (in place: the tangents overwrite the interpolated rows of h and y -- the masks are their sign bits)
+            return ops.gemm_block2(u, A._w_nt(self.fc1.W, 256, m.prec), A._w_nt(self.fc2.W, 256, m.prec), h, y, RELU, 0.0, out1=h, out2=y)
         uh = self.fc1.tan(m, u, h, inplace=True)
         return uh, self.fc2.tan(m, uh, y, skip=u, inplace=True)
+
+
+def _pair_ok(m, la, lb, x, mask1, mask2, out):
+    """two 256 -> 256 layers behind each other, bf16, both masks with sign bits: one launch (ops.gemm_block2)"""
+    return (m.bf16 and la.N == 256 and la.K == 256 and lb.N == 256 and lb.K == 256 and ops.block2_ok(x, mask1, mask2, x.shape[0])
+            and (out is None or (out.dtype == BF16 and out.stride(0) % 8 == 0 and out.shape[1] >= 256)))
 
 
 def _seeds(B, m, dev):
@@ -342,8 +354,11 @@ def step_d2(D, optimizerD, real, fake, alpha, lam, prec=None):
     gzl = L[5].bwd(m, gzp, dl, LRELU, s)
     gz4 = L[4].bwd(m, gzl, d4, NONE, 0.0)
     gz3 = L[3].bwd(m, gz4, d3, LRELU, s)
-    gz2 = L[2].bwd(m, gz3, d2, LRELU, s)
-    gz1 = L[1].bwd(m, gz2, d1, LRELU, s, skip=gz3)
+    if _pair_ok(m, L[2], L[1], gz3, d2, d1, None):            # d3 = lrelu(L3 d2 + d1): the same two-layer pattern as a myResNet block
+        gz2, gz1 = ops.gemm_block2(gz3, A._w_nn(L[2].W, m.prec), A._w_nn(L[1].W, m.prec), d2, d1, LRELU, s)
+    else:
+        gz2 = L[2].bwd(m, gz3, d2, LRELU, s)
+        gz1 = L[1].bwd(m, gz2, d1, LRELU, s, skip=gz3)
     split = m.can_split(B)
     if split:                                                 # sweep 4, real / fake rows: beside the penalty and the tangent sweep
         for lay, gz, x in ((L[0], gz1, X), (L[1], gz2, d1), (L[2], gz3, d2), (L[3], gz4, d3), (L[4], gzl, d4), (L[5], gzp, dl)):
@@ -353,8 +368,12 @@ def step_d2(D, optimizerD, real, fake, alpha, lam, prec=None):
     v, pen = ops.gp_penalty(g, 2.0 * lam / B)
     tail = ops.tail_rows                                      # (x_hat rows of a saved activation, its sign bits attached)
     u1 = L[0].tan(m, v, tail(d1, B2), inplace=True)
-    u2 = L[1].tan(m, u1, tail(d2, B2), inplace=True)
-    u3 = L[2].tan(m, u2, tail(d3, B2), skip=u1, inplace=True)
+    t2, t3 = tail(d2, B2), tail(d3, B2)
+    if _pair_ok(m, L[1], L[2], u1, t2, t3, t3) and t2.data_ptr() != u1.data_ptr():
+        u2, u3 = ops.gemm_block2(u1, A._w_nt(L[1].W, 256, m.prec), A._w_nt(L[2].W, 256, m.prec), t2, t3, LRELU, s, out1=t2, out2=t3)
+    else:
+        u2 = L[1].tan(m, u1, t2, inplace=True)
+        u3 = L[2].tan(m, u2, t3, skip=u1, inplace=True)
     u4 = L[3].tan(m, u3, tail(d4, B2), inplace=True)
     ul = L[4].tan(m, u4, tail(dl, B2), inplace=True)
     layers = ((L[0], gz1, X, v), (L[1], gz2, d1, u1), (L[2], gz3, d2, u2), (L[3], gz4, d3, u3), (L[4], gzl, d4, u4), (L[5], gzp, dl, ul))

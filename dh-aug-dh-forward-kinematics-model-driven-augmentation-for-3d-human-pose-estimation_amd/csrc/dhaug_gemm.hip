@@ -1477,6 +1477,195 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256s_kernel(GemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// TWO 256 -> 256 layers of a residual block in one launch (r3):
+//        Y1 = (X  W1^T) * act'(bits1)            Y2 = (Y1 W2^T + X) * act'(bits2)
+// = the backward step through myResNet (gz1 = gz2 W_fc2 * relu'(h); gz_in = (gz1 W_fc1 + gz2) * relu'(x),
+// R/models_Fk_GAN/special_operate.py:490-510 under autograd) and its tangent twin (uh = u W_fc1^T * relu'(h);
+// u' = (uh W_fc2^T + u) * relu'(y)).  As two gemm_nt256s launches the pair moves 500 MB per 3B-row block (X in, Y1 out | Y1 in,
+// X in as the skip, Y2 out); here Y1 stays in LDS between the layers and X is read once: 300 MB.
+// 512 threads, one persistent workgroup per CU, 32-row tiles, and the two layers as a two-stage pipeline over the tiles:
+//   waves 0..3 (stage A): tile i  : X image -> matrix pipe (W1 resident in registers) -> mask -> Y1 image (LDS)
+//   waves 4..7 (stage B): tile i-1: Y1 image -> matrix pipe (W2 resident) + X image on the identity fragments -> mask -> Y2 image
+// so a SIMD hosts one wave of each stage (256 registers each: 128 of weights).  There are no mover waves: every wave requests
+// its share of tile i+2 (LDS-DMA, inline assembly: see tn_copy16) and streams its share of the finished images (Y1 of tile i-1,
+// Y2 of tile i-2) out as whole rows at the top of an iteration, then computes; one LDS barrier per tile.  The sign bits of a
+// tile (1 KB per layer) travel with the tile.  LDS: 4 X images + 2 Y1 + 2 Y2 (16 KB each) + 4 x 2 KB of bits + 1 KB = 137 KB.
+// ---------------------------------------------------------------------------------------------------------------
+struct Block2Args {
+    const uint16_t* X; long long ldx;
+    const uint16_t* W1; long long ldw1;
+    const uint16_t* W2; long long ldw2;
+    const uint32_t* bits1; const uint32_t* bits2;
+    uint16_t* Y1; long long ldy1;
+    uint16_t* Y2; long long ldy2;
+    long long M;
+    float dneg;
+};
+constexpr int B2_BM = 32, B2_IMG = B2_BM * F_PITCH, B2_NX = 4;
+constexpr int B2_LDS = (B2_NX + 4) * B2_IMG + B2_NX * 2048 + 1024;
+
+__global__ __launch_bounds__(512, 1) void gemm_block2_kernel(Block2Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sX = smem;                                                // [4][IMG]
+    unsigned char* sG = smem + B2_NX * B2_IMG;                               // [2][IMG]  Y1
+    unsigned char* sO = sG + 2 * B2_IMG;                                     // [2][IMG]  Y2
+    unsigned char* sB = sO + 2 * B2_IMG;                                     // [4][2][1 KB] sign bits (layer 1 | layer 2)
+    unsigned char* sScratch = sB + B2_NX * 2048;                             // 1 KB: landing zone of the copies that only keep the count uniform
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool stageB = wave >= 4;
+    const int cw = wave & 3;
+    const int r31 = lane & 31, h = lane >> 5, x = lane & 15;
+    const long long mtiles = p.M / B2_BM, g = gridDim.x;
+    const long long mt0 = blockIdx.x;
+    if (mt0 >= mtiles) return;
+    const int nt = (int)((mtiles - mt0 + g - 1) / g);                        // tiles of this workgroup
+
+    // three copies per wave and tile: 2 of the 16 KB operand tile, one of the bits (waves 0 / 1: layer 1 / 2; the others
+    // repeat one into the scratch area so that every wave's vmcnt arithmetic is the same)
+    auto copy_tile = [&](int i) {
+        const long long tile = mt0 + (long long)i * g, m0 = tile * B2_BM;
+        const int buf = i % B2_NX;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row0 = (wave * 2 + q) * 2, row = row0 + (lane >> 5), c = (lane & 31) ^ (row & 15);
+            tn_copy16(p.X + (m0 + row) * p.ldx + c * 8, sX + buf * B2_IMG + row0 * F_PITCH);
+        }
+        const uint32_t* bsrc = ((wave & 1) ? p.bits2 : p.bits1) + tile * 256 + lane * 4;
+        tn_copy16(bsrc, wave < 2 ? sB + buf * 2048 + wave * 1024 : sScratch);
+    };
+    if (0 < nt) copy_tile(0);
+    if (1 < nt) copy_tile(1);
+
+    // this stage's weights: feature slices cw and cw + 4, resident for the whole launch
+    bf16x8 wf[2][16];
+    {
+        const uint16_t* W = stageB ? p.W2 : p.W1;
+        const long long ldw = stageB ? p.ldw2 : p.ldw1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint16_t* wrow = W + (long long)(32 * (cw + 4 * t) + r31) * ldw + 8 * h;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) wf[t][k] = *reinterpret_cast<const bf16x8*>(wrow + 16 * k);
+        }
+    }
+    bf16x8 idf[2];                                                           // A[n][k'] = (n == 16 j + k'), k' = 8h + i
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int dd = r31 - 16 * j - 8 * h;
+        unsigned v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (dd == 2 * q ? 0x3F80u : 0u) | (dd == 2 * q + 1 ? 0x3F800000u : 0u);
+        const uint4 u = make_uint4(v[0], v[1], v[2], v[3]);
+        idf[j] = __builtin_bit_cast(bf16x8, u);
+    }
+    const int lfx = r31 * F_PITCH | ((x >> 1) << 5) | ((h ^ (x & 1)) << 4);                  // ^ (k << 5): chunk 2k+h of row
+    const int lrx = (r31 * F_PITCH | ((x >> 1) << 5) | ((h ^ (x & 1)) << 4)) ^ (cw << 6);     // ^ (t << 8 | j << 5)
+    const int lep = r31 * F_PITCH | (((4 * cw) ^ x) << 4) | (h << 3);                        // ^ ((16t+g) << 4)
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // the weights (compiler-tracked loads) land HERE: the empty asm statements use them, so hipcc's waitcnt pass puts its
+    // waits in front of them -- left to their first use it repeats a countdown to vmcnt(0) inside the tile loop, which
+    // would drain the LDS-DMA copies it does not know about at every tile
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(wf[t][k]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f_lds_barrier();                                                         // tiles 0 and 1 are in LDS
+
+    for (int i = 0; i <= nt + 1; ++i) {
+        // ---- tile i+2's rows and bits into the image tile i-2 left (stage B was done with it at the last barrier).  (A fifth
+        // image / two tiles in flight was measured: 80.4 against 77.6 us at 3B rows -- the reads are not what waits.)
+        if (i + 2 < nt) copy_tile(i + 2);
+        // ---- finished images out as whole 512-byte rows (four 16-byte chunks per thread): stage A's waves take Y1 of tile i-1
+        // AFTER their matrix phase, stage B's take Y2 of tile i-2 BEFORE theirs -- the two waves of a SIMD are then in
+        // different phases (one on the matrix pipe, the other on LDS / the vector-memory path) instead of queueing for the
+        // same unit twice per tile.  Measured on the first version (every wave streaming first; phases switched off one by one
+        // through a run-time flag, 3B rows): they simply added up -- 21.7 us of launch + loop, + 12 epilogue, + 23 matrix, + 17 row
+        // stores, + 12 copies = 86; with the offset 77.6.
+        auto stream_out = [&]() {
+            const int jj = stageB ? i - 2 : i - 1;
+            if (jj < 0 || jj >= nt) return;                                  // (wave-uniform)
+            const unsigned char* I = (stageB ? sO : sG) + (jj & 1) * B2_IMG;
+            uint16_t* Y = stageB ? p.Y2 : p.Y1;
+            const long long ldy = stageB ? p.ldy2 : p.ldy1;
+            const int st = tid & 255;
+            u32x4 o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = st + 256 * q, row = e >> 5, c = e & 31;
+                o[q] = *reinterpret_cast<const u32x4*>(I + row * F_PITCH + ((c ^ (row & 15)) << 4));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = st + 256 * q, row = e >> 5, c = e & 31;
+                *reinterpret_cast<u32x4*>(Y + ((mt0 + (long long)jj * g) * B2_BM + row) * ldy + c * 8) = o[q];
+            }
+        };
+        if (stageB) stream_out();
+        // ---- compute: stage A tile i, stage B tile i-1
+        const int j = stageB ? i - 1 : i;
+        if (j >= 0 && j < nt) {                                              // (wave-uniform)
+            const unsigned char* Xj = sX + (j % B2_NX) * B2_IMG;
+            const unsigned char* S = stageB ? sG + (j & 1) * B2_IMG : Xj;    // this stage's operand image
+            unsigned char* D = (stageB ? sO : sG) + (j & 1) * B2_IMG;        // ... and its result image
+            const uint32_t bw = *reinterpret_cast<const uint32_t*>(sB + (j % B2_NX) * 2048 + (stageB ? 1024 : 0) + (cw * 64 + lane) * 4);
+            f32x16 acc[2];
+            bf16x8 fx[4];
+            constexpr int DEP = 3;
+#pragma unroll
+            for (int k = 0; k < DEP; ++k) fx[k] = *reinterpret_cast<const bf16x8*>(S + (lfx ^ (k << 5)));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k + DEP < 16) fx[(k + DEP) & 3] = *reinterpret_cast<const bf16x8*>(S + (lfx ^ ((k + DEP) << 5)));
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][k], fx[k & 3], k == 0 ? zero : acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (stageB) {                                                    // + X (the skip), exact on the matrix pipe
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const bf16x8 rf = *reinterpret_cast<const bf16x8*>(Xj + (lrx ^ (t << 8 | jj << 5)));
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(idf[jj], rf, acc[t], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[t][4 * gq + e];
+                    const int p0 = 8 * t + 2 * gq;                           // pairs 8t + 2gq, +1: even element at bit p, odd at 16 + p
+                    v[0] = ((bw >> p0) & 1u) ? v[0] : v[0] * p.dneg;
+                    v[1] = ((bw >> (16 + p0)) & 1u) ? v[1] : v[1] * p.dneg;
+                    v[2] = ((bw >> (p0 + 1)) & 1u) ? v[2] : v[2] * p.dneg;
+                    v[3] = ((bw >> (17 + p0)) & 1u) ? v[3] : v[3] * p.dneg;
+                    uint2 o;
+                    o.x = f_pack_bf16x2(v[0], v[1]);
+                    o.y = f_pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(D + (lep ^ ((16 * t + gq) << 4))) = o;
+                }
+        }
+        if (!stageB) stream_out();
+        if (i > nt) break;
+        // ---- tile i+1 must be in LDS when the barrier opens.  vmcnt retires in issue order; per wave and iteration the
+        // order is [3 copies] ... [4 row stores]: younger than tile i+1's copies (issued at the top of iteration i-1) are that
+        // iteration's 4 stores, this one's 3 copies and 4 stores.  The first iterations and the last ones (where some of those
+        // do not exist) drain instead.
+        if (i >= 3 && i + 2 < nt) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        f_lds_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <int KS, int MODE>
 int launch_nt256s_mode(hipStream_t s, const GemmArgs& p) {
     constexpr int NSEC = (MODE & 1) + ((MODE >> 1) & 1);                   // (bit 2, the sign-bit mask, has no image)
@@ -1704,6 +1893,33 @@ int dhaug_gemm_bf16_dbits(const uint16_t* A, int64_t lda, const uint16_t* B, int
     GemmArgs p{A, lda, B, ldb, nullptr, residual, ld_res, nullptr, 0, c_bf16, ldc_bf16, 256, nullptr, 0, M, 256, 256, 256,
                DHAUG_ACT_NONE, 0.0f, nullptr, 0, dmask_act == DHAUG_ACT_RELU ? 0.0f : dmask_slope, bits, 0};
     return launch_nt256s<16>((hipStream_t)stream, p);
+}
+
+/* see include/dhaug.h */
+int dhaug_gemm_block2_bf16(const uint16_t* X, int64_t ldx, const uint16_t* W1, int64_t ldw1, const uint16_t* W2, int64_t ldw2,
+                           const uint32_t* bits1, const uint32_t* bits2, int mask_act, float mask_slope,
+                           uint16_t* Y1, int64_t ldy1, uint16_t* Y2, int64_t ldy2, int64_t M, void* stream) {
+    DHAUG_CHECK(mask_act == DHAUG_ACT_RELU || mask_act == DHAUG_ACT_LRELU, DHAUG_EINVAL);
+    DHAUG_CHECK(M >= 0 && M % B2_BM == 0, DHAUG_EUNSUPPORTED);
+    if (M == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(X); DHAUG_CHECK_PTR(W1); DHAUG_CHECK_PTR(W2); DHAUG_CHECK_PTR(bits1); DHAUG_CHECK_PTR(bits2);
+    DHAUG_CHECK_PTR(Y1); DHAUG_CHECK_PTR(Y2);
+    DHAUG_CHECK(ldx % 8 == 0 && ldw1 % 8 == 0 && ldw2 % 8 == 0 && ldy1 % 8 == 0 && ldy2 % 8 == 0, DHAUG_EALIGN);
+    DHAUG_CHECK(ldx >= 256 && ldw1 >= 256 && ldw2 >= 256 && ldy1 >= 256 && ldy2 >= 256, DHAUG_EALIGN);
+    DHAUG_CHECK(dhaug_aligned16(X) && dhaug_aligned16(W1) && dhaug_aligned16(W2) && dhaug_aligned16(Y1) && dhaug_aligned16(Y2) &&
+                dhaug_aligned16(bits1) && dhaug_aligned16(bits2), DHAUG_EALIGN);
+    // Y1 may not alias X or Y2 (X is read as the skip after Y1's rows are stored); Y2 may overwrite nothing that is still read
+    DHAUG_CHECK(Y1 != X && Y2 != X && Y1 != Y2, DHAUG_EINVAL);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_block2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    Block2Args a{X, ldx, W1, ldw1, W2, ldw2, bits1, bits2, Y1, ldy1, Y2, ldy2, M, mask_act == DHAUG_ACT_RELU ? 0.0f : mask_slope};
+    const long long mtiles = M / B2_BM;
+    hipLaunchKernelGGL(gemm_block2_kernel, dim3((unsigned)(mtiles < 256 ? mtiles : 256)), dim3(512), B2_LDS, (hipStream_t)stream, a);
+    return dhaug_launch_status();
 }
 
 int dhaug_gemm_tn_bf16_rows(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,

@@ -295,6 +295,7 @@ def gemm_nt_dmask(A, B, N, K, dmask, dmask_act, dmask_slope=0.0, res_bf16=None, 
         out = torch.empty((M, ceil_to(N, 16)), dtype=BF16, device=A.device)
     assert out.dtype == BF16 and out.stride(1) == 1 and out.shape[0] == M and out.shape[1] >= N
     bits = getattr(dmask, "_dhaug_bits", None)
+    assert bits is None or bits.device == A.device, "sign bits must live on the operands' device"
     if (bits is not None and DBITS and N == 256 and K == 256 and M % 32 == 0 and M > 0 and dmask_act != 0
             and A.stride(0) % 8 == 0 and out.stride(0) % 8 == 0):
         # the mask as the sign-bit array its forward-with-save layer left beside the image: 32 bytes per row instead of 512
@@ -309,6 +310,28 @@ def gemm_nt_dmask(A, B, N, K, dmask, dmask_act, dmask_slope=0.0, res_bf16=None, 
 
 
 DBITS = os.environ.get("DHAUG_NO_DBITS") is None          # consume sign-bit masks where a saved activation carries one
+BLOCK2 = os.environ.get("DHAUG_NO_BLOCK2") is None        # the two layers of a residual block's backward / tangent step in one launch
+
+
+def block2_ok(x, mask1, mask2, M):
+    """can dhaug_gemm_block2_bf16 take this pair of 256 -> 256 layers?  (bf16 rows, whole 32-row tiles, both masks as sign bits)"""
+    return (BLOCK2 and DBITS and M > 0 and M % 32 == 0 and x.dtype == BF16 and x.shape[1] >= 256 and x.stride(0) % 8 == 0
+            and getattr(mask1, "_dhaug_bits", None) is not None and getattr(mask2, "_dhaug_bits", None) is not None)
+
+
+def gemm_block2(x, B1, B2, mask1, mask2, act, slope=0.0, out1=None, out2=None):
+    """y1 = (x B1^T) * act'(mask1); y2 = (y1 B2^T + x) * act'(mask2) -- x, y1, y2 bf16 (M, >= 256); B1, B2 bf16 (256, >= 256);
+    the masks by their sign-bit arrays.  Returns (y1, y2)."""
+    M = x.shape[0]
+    if out1 is None:
+        out1 = torch.empty((M, 256), dtype=BF16, device=x.device)
+    if out2 is None:
+        out2 = torch.empty((M, 256), dtype=BF16, device=x.device)
+    assert out1.dtype == BF16 and out2.dtype == BF16 and out1.shape[0] == M and out2.shape[0] == M
+    assert mask1._dhaug_bits.device == x.device and mask2._dhaug_bits.device == x.device, "sign bits must live on the operands' device"
+    _lib.call("dhaug_gemm_block2_bf16", _p(x), x.stride(0), _p(B1), B1.stride(0), _p(B2), B2.stride(0), _p(mask1._dhaug_bits),
+              _p(mask2._dhaug_bits), act, float(slope), _p(out1), out1.stride(0), _p(out2), out2.stride(0), M, _stream())
+    return out1, out2
 
 
 def tail_rows(t, r0):

@@ -221,6 +221,18 @@ int dhaug_gemm_bf16_dbits(const uint16_t* A, int64_t lda, const uint16_t* B, int
                           const uint32_t* bits, int dmask_act, float dmask_slope, uint16_t* c_bf16, int64_t ldc_bf16, int64_t M,
                           void* stream);
 
+/* Two 256 -> 256 layers of a residual block in one launch (the backward step through myResNet,
+ * R/models_Fk_GAN/special_operate.py:490-510 under loss.backward(), and its tangent twin in the gradient penalty's
+ * double backward, R/models_Fk_GAN/Fk_discriminator.py:205-231):
+ *     Y1 = (X W1^T) * act'(bits1)        Y2 = (Y1 W2^T + X) * act'(bits2)
+ * X, Y1, Y2: bf16 (M, ld >= 256), M a multiple of 32, three distinct buffers; W1, W2: bf16 (256, ld >= 256) with the
+ * contraction along the row (the operand dhaug_gemm_bf16_dbits takes as B); bits1, bits2: sign-bit arrays of the layers'
+ * saved activations (struct dhaug_mlp_unit.bits).  Y1 never leaves LDS between the layers and X is read once: 300 MB
+ * per 3 x 65 536-row block instead of the 500 MB of two dhaug_gemm_bf16_dbits launches. */
+int dhaug_gemm_block2_bf16(const uint16_t* X, int64_t ldx, const uint16_t* W1, int64_t ldw1, const uint16_t* W2, int64_t ldw2,
+                           const uint32_t* bits1, const uint32_t* bits2, int mask_act, float mask_slope,
+                           uint16_t* Y1, int64_t ldy1, uint16_t* Y2, int64_t ldy2, int64_t M, void* stream);
+
 /* Weight-gradient GEMM: C[N1,N2] (+)= A[M,N1]^T * B[M,N2], contraction over the batch dimension M
  * (split across workgroups, fp32 atomics into C).  bf16 operands, fp32 result.  `accumulate` != 0 adds
  * into C, otherwise C is overwritten (zeroed by the library on the stream first).  colsum_a (optional, fp32 [N1])

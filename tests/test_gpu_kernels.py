@@ -490,6 +490,46 @@ def test_gemm_nt_dbits_equals_dmask(ops, M, act, slope, use_res, row0):
     assert out.data_ptr() == ys.data_ptr() and torch.equal(out.view(torch.int16), ref.view(torch.int16))
 
 
+@pytest.mark.parametrize("M,act,slope,row0,ldx", [(32, 1, 0.0, 0, 256), (96, 2, 0.01, 0, 256), (32 * 37, 1, 0.0, 64, 512),
+                                                  (32 * 256 * 3 + 32, 1, 0.0, 0, 256), (196608, 2, 0.01, 131072 - 64, 256)])
+def test_gemm_block2_equals_two_layers(ops, M, act, slope, row0, ldx):
+    """both layers of a residual block's backward / tangent step in one launch (dhaug_gemm_block2_bf16) give, bit for bit, what
+    the two dhaug_gemm_bf16_dbits launches give -- one tile per workgroup, a ragged tile count, rows that start at a later tile,
+    an operand that is a column block of a wider buffer, the critic step's full size; and in place over the mask tensors"""
+    from dhaug_amd import fused
+    gen = torch.Generator().manual_seed(M + act)
+    tot = M + row0
+    X = _bf(torch.randn(tot, ldx, generator=gen)).cuda()[:, ldx - 256:]
+    W1 = _bf(torch.randn(256, 256, generator=gen) / 16).cuda()
+    W2 = _bf(torch.randn(256, 256, generator=gen) / 16).cuda()
+    m1 = torch.rand(tot, 256, generator=gen) > 0.45
+    m2 = torch.rand(tot, 256, generator=gen) > 0.55
+    Y1m = torch.zeros(tot, 256, dtype=torch.bfloat16, device="cuda"); Y1m._dhaug_bits = fused.encode_bits(m1.cuda())
+    Y2m = torch.zeros(tot, 256, dtype=torch.bfloat16, device="cuda"); Y2m._dhaug_bits = fused.encode_bits(m2.cuda())
+    t1, t2 = ops.tail_rows(Y1m, row0), ops.tail_rows(Y2m, row0)
+    x = X[row0:]
+    ref1 = ops.gemm_nt_dmask(x, W1, 256, 256, t1, act, slope)
+    ref2 = ops.gemm_nt_dmask(ref1, W2, 256, 256, t2, act, slope, res_bf16=x)
+    assert ops.block2_ok(x, t1, t2, M)
+    calls = ops._lib.CALLS[0]
+    y1, y2 = ops.gemm_block2(x, W1, W2, t1, t2, act, slope)
+    assert ops._lib.CALLS[0] == calls + 1
+    assert torch.equal(y1.view(torch.int16), ref1.view(torch.int16))
+    assert torch.equal(y2.view(torch.int16), ref2.view(torch.int16))
+    # against fp64 on a sample of rows (the two-launch form is itself tested against fp64 above)
+    rows = torch.arange(0, M, max(1, M // 64))
+    xs = x[rows].float().cpu().double()
+    neg = 0.0 if act == 1 else slope
+    z1 = xs @ W1.float().cpu().double().t()
+    z1 = torch.where(m1[row0:][rows], z1, z1 * neg)
+    assert maxabs(y1[rows], z1) <= 2e-2 * max(1.0, z1.abs().max().item())
+    # in place over the mask tensors (the tangent sweep): their bits, not their values, are read
+    o1, o2 = ops.gemm_block2(x, W1, W2, t1, t2, act, slope, out1=t1, out2=t2)
+    assert o1.data_ptr() == t1.data_ptr() and torch.equal(o1.view(torch.int16), ref1.view(torch.int16))
+    assert torch.equal(o2.view(torch.int16), ref2.view(torch.int16))
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("M,N,K,act,slope,use_res", [(4096, 256, 256, 1, 0.0, False), (4096, 256, 256, 2, 0.01, False),
                                                    (1024, 256, 128, 1, 0.0, True), (1000, 104, 256, 1, 0.0, False)])
 def test_gemm_nt_dmask(ops, M, N, K, act, slope, use_res):
