@@ -83,6 +83,7 @@ class TnLayer(ctypes.Structure):
 TN_GROUP_MAX = 44
 TN_GROUP_WORKSPACE_FLOATS = 256 * (256 * 256 + 256)
 SIGNATURES["dhaug_gemm_tn_group_bf16"] = [ctypes.POINTER(TnLayer), _i32, _vp, _vp]
+SIGNATURES["dhaug_gemm_tn_group_bf16_phase"] = [ctypes.POINTER(TnLayer), _i32, _vp, _i32, _vp]
 SIGNATURES["dhaug_pack_wfrag"] = [_vp, _i64, _vp, _i64, _i64, _i64, _vp]
 SIGNATURES["dhaug_pack_wfrag_batch"] = [_vp, _i32, _vp]
 SIGNATURES["dhaug_mlp_forward"] = [ctypes.POINTER(MlpUnit), _i32, _i64, _vp]

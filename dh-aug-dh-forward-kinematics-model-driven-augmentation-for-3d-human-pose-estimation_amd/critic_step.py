@@ -44,6 +44,10 @@ _TN_SIDE = {}
 # one-per-CU launch holds every CU (measured, iteration at B = 65 536: 256 -> 7.53 ms, 192 -> 7.44, 128 -> 7.31, 96 -> 7.28,
 # 80 -> 7.49, 64 -> 7.86: below ~90 the side part becomes the step's long pole)
 TN_SIDE_WGS = int(os.environ.get("DHAUG_TN_SIDE_WGS", "128"))
+# the second part's contractions started beside what is left of the first (only the sums wait): measured 6.87 against 6.94 ms
+# per iteration -- the contractions are HBM-bound either way -- so it is an option, off
+TN_PHASED = os.environ.get("DHAUG_TN_PHASED") is not None
+TN_MAIN_WGS = int(os.environ.get("DHAUG_TN_MAIN_WGS", "0"))  # workgroups of the second part (0: one per CU)
 
 BF16 = torch.bfloat16
 NONE, RELU, LRELU = A.ACT_NONE, A.ACT_RELU, A.ACT_LRELU
@@ -131,6 +135,15 @@ class _Math:
 
     def flush(self):
         """launch the collected weight-gradient contractions (before the optimizer step reads the gradient bucket)"""
+        if self.tn and TN_PHASED and getattr(self, "_side", None) is not None and len(self.tn) <= ops._lib.TN_GROUP_MAX:
+            # both parts add into the same gradient slots -- but only their SUMS touch the slots: this part's contractions
+            # start now, beside what is left of the side part, and only the sums wait for it
+            ws = ops._tn_group_workspace(self.tn[0][0].device)
+            ops.gemm_tn_group(self.tn, phase=1, workspace=ws, max_workgroups=TN_MAIN_WGS)
+            self.join()
+            ops.gemm_tn_group(self.tn, phase=2, workspace=ws, max_workgroups=TN_MAIN_WGS)
+            self.tn = []
+            return
         self.join()                          # (both parts accumulate into the same gradient slots: never concurrently)
         if self.tn:
             ops.gemm_tn_group(self.tn)

@@ -236,7 +236,14 @@ extern "C" {
 static_assert(DHAUG_TN_GROUP_WORKSPACE_FLOATS == (long long)T2_MAX_WG * T2_WS_STRIDE, "workspace size");
 
 /* see include/dhaug.h */
+int dhaug_gemm_tn_group_bf16_phase(const dhaug_tn_layer* layers, int n, float* workspace, int phase, void* stream);
+
 int dhaug_gemm_tn_group_bf16(const dhaug_tn_layer* layers, int n, float* workspace, void* stream) {
+    return dhaug_gemm_tn_group_bf16_phase(layers, n, workspace, 0, stream);
+}
+
+int dhaug_gemm_tn_group_bf16_phase(const dhaug_tn_layer* layers, int n, float* workspace, int phase, void* stream) {
+    DHAUG_CHECK(phase >= 0 && phase <= 2, DHAUG_EINVAL);
     DHAUG_CHECK(n >= 0 && n <= T2_MAX_LAYERS, DHAUG_EINVAL);
     if (n == 0) return DHAUG_OK;
     DHAUG_CHECK_PTR(layers); DHAUG_CHECK_PTR(workspace);
@@ -310,9 +317,13 @@ int dhaug_gemm_tn_group_bf16(const dhaug_tn_layer* layers, int n, float* workspa
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    hipLaunchKernelGGL(gemm_tn_group_kernel, dim3((unsigned)wg), dim3(512), T2_LDS, s, g);
-    int rc = dhaug_launch_status();
-    if (rc != DHAUG_OK) return rc;
+    // phase 1: the partial results only; phase 2: only their sums into the gradient slots (the same dealing, recomputed from
+    // the same descriptors); 0: both
+    if (phase != 2) {
+        hipLaunchKernelGGL(gemm_tn_group_kernel, dim3((unsigned)wg), dim3(512), T2_LDS, s, g);
+        int rc = dhaug_launch_status();
+        if (rc != DHAUG_OK || phase == 1) return rc;
+    }
     hipLaunchKernelGGL(tn_group_reduce_kernel, dim3(256, (unsigned)n), dim3(256), 0, s, g);
     return dhaug_launch_status();
 }

@@ -365,10 +365,13 @@ def tn_group_ok(M, N1, N2, colsum_rows):
     return M >= 1024 and M % 32 == 0 and colsum_rows % 32 == 0 and 1 <= N1 <= 256 and 1 <= N2 <= 256
 
 
-def gemm_tn_group(items, max_workgroups=0):
+def gemm_tn_group(items, max_workgroups=0, phase=0, workspace=None):
     """items: [(A, B, N1, N2, out, colsum | None, colsum_rows, accumulate, M | None, lda | None, ldb | None)] -- the weight
     gradients C_i (+)= A_i^T B_i of several layers in one launch (+ one that sums the partial results).
-    max_workgroups: leave CUs to kernels running beside this launch (0: one workgroup per CU)."""
+    max_workgroups: leave CUs to kernels running beside this launch (0: one workgroup per CU).
+    phase 1: the contractions only (partial results into `workspace`); phase 2: only their sums into the outputs (same items,
+    same workspace; one chunk of at most TN_GROUP_MAX items); 0: both."""
+    assert phase == 0 or (len(items) <= _lib.TN_GROUP_MAX and workspace is not None)
     for i0 in range(0, len(items), _lib.TN_GROUP_MAX):
         chunk = items[i0:i0 + _lib.TN_GROUP_MAX]
         arr = (_lib.TnLayer * len(chunk))()
@@ -378,7 +381,8 @@ def gemm_tn_group(items, max_workgroups=0):
             d.C, d.ldc, d.colsum_a, d.colsum_rows = _p(out), out.stride(0), _p(cs), cr
             d.M, d.N1, d.N2, d.accumulate = A.shape[0] if M is None else M, N1, N2, int(bool(accumulate))
             d.max_workgroups = int(max_workgroups)
-        _lib.call("dhaug_gemm_tn_group_bf16", arr, len(chunk), _p(_tn_group_workspace(chunk[0][0].device)), _stream())
+        ws = workspace if workspace is not None else _tn_group_workspace(chunk[0][0].device)
+        _lib.call("dhaug_gemm_tn_group_bf16_phase", arr, len(chunk), _p(ws), int(phase), _stream())
 
 
 def gemm_tn(A, B, N1, N2, out=None, accumulate=False, M=None, lda=None, ldb=None, colsum=None, colsum_rows=None):

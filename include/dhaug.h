@@ -273,6 +273,11 @@ typedef struct dhaug_tn_layer {
                                    runs beside other kernels leaves them CUs */
 } dhaug_tn_layer;
 int dhaug_gemm_tn_group_bf16(const dhaug_tn_layer* layers, int n, float* workspace, void* stream);
+/* The same in two calls: phase 1 launches the contractions (partial results into `workspace`), phase 2 the sums into the
+ * gradient slots -- same `layers`, same `workspace`; phase 0 = both.  Only the sums touch C / colsum_a, so the contractions
+ * of one part of a step may run beside another part's (R/models_Fk_GAN/model_fk_gan_train.py:191-214: the three backward
+ * passes of a critic step add into the same .grad). */
+int dhaug_gemm_tn_group_bf16_phase(const dhaug_tn_layer* layers, int n, float* workspace, int phase, void* stream);
 
 /* fp32 -> bf16 (round-to-nearest-even) with zero padding: src (rows, cols) ld_src -> dst (rows, ld_dst),
  * columns [cols, pad_cols) zero-filled.  Used to pack weights / inputs as GEMM operands. */
