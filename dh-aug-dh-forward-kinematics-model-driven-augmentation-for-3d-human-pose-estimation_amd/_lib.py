@@ -80,6 +80,14 @@ class TnLayer(ctypes.Structure):
                 ("colsum_rows", _i64), ("M", _i64), ("N1", _i32), ("N2", _i32), ("accumulate", _i32), ("max_workgroups", _i32)]
 
 
+class Block2(ctypes.Structure):
+    """struct dhaug_block2 (include/dhaug.h)"""
+    _fields_ = [("W1", _vp), ("ldw1", _i64), ("W2", _vp), ("ldw2", _i64), ("bits1", _vp), ("bits2", _vp), ("Y1", _vp), ("ldy1", _i64),
+                ("Y2", _vp), ("ldy2", _i64)]
+
+
+BLOCK2_MAX = 3
+SIGNATURES["dhaug_gemm_block2_stack_bf16"] = [_vp, _i64, ctypes.POINTER(Block2), _i32, _i32, _f32, _i64, _vp]
 TN_GROUP_MAX = 44
 TN_GROUP_WORKSPACE_FLOATS = 256 * (256 * 256 + 256)
 SIGNATURES["dhaug_gemm_tn_group_bf16"] = [ctypes.POINTER(TnLayer), _i32, _vp, _vp]

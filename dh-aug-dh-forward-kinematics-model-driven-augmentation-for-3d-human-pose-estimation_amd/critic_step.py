@@ -305,6 +305,48 @@ class _Block:
         return uh, self.fc2.tan(m, uh, y, skip=u, inplace=True)
 
 
+BLOCK2_STACK = os.environ.get("DHAUG_NO_BLOCK2_STACK") is None
+
+
+def stack_bwd(m, blocks, top, hs, ys):
+    """the backward chain through a branch's blocks (last to first): top = cotangent at the last block's fc2 pre-activation;
+    hs[i], ys[i]: block i's hidden activation and INPUT.  Returns (a1, a2) with a1[i] = cotangent at block i's fc1
+    pre-activation... of fc2's input, a2[i] = cotangent at the pre-activation producing ys[i]; a2[n] = top."""
+    n = len(blocks)
+    a2, a1 = [None] * n + [top], [None] * n
+    if (BLOCK2_STACK and 2 <= n <= ops._lib.BLOCK2_MAX and all(_pair_ok(m, b.fc2, b.fc1, top, hs[i], ys[i], None) for i, b in enumerate(blocks))):
+        # one launch for the whole chain (dhaug_gemm_block2_stack_bf16): block i takes block i + 1's result
+        desc = [(A._w_nn(blocks[i].fc2.W, m.prec), A._w_nn(blocks[i].fc1.W, m.prec), hs[i], ys[i], None, None) for i in range(n - 1, -1, -1)]
+        outs = ops.gemm_block2_stack(top, desc, RELU, 0.0)
+        for j, i in enumerate(range(n - 1, -1, -1)):
+            a1[i], a2[i] = outs[j]
+        return a1, a2
+    for i in range(n - 1, -1, -1):
+        a1[i], a2[i] = blocks[i].bwd(m, a2[i + 1], hs[i], ys[i])
+    return a1, a2
+
+
+def stack_tan(m, blocks, u0, hs, ys):
+    """the tangent chain through a branch's blocks (first to last), in place over hs[i] / ys[i] (x_hat rows of the saved hidden
+    activations / block OUTPUTS, sign bits attached).  Returns (uh, u): uh[i] = tangent of block i's hidden activation,
+    u[i] = tangent of its output."""
+    n = len(blocks)
+    ok = BLOCK2_STACK and 2 <= n <= ops._lib.BLOCK2_MAX
+    x = u0
+    for i, b in enumerate(blocks):
+        ok = ok and _pair_ok(m, b.fc1, b.fc2, u0, hs[i], ys[i], ys[i]) and hs[i].data_ptr() != x.data_ptr() and ys[i].data_ptr() != x.data_ptr()
+        x = ys[i]
+    if ok:
+        desc = [(A._w_nt(b.fc1.W, 256, m.prec), A._w_nt(b.fc2.W, 256, m.prec), hs[i], ys[i], hs[i], ys[i]) for i, b in enumerate(blocks)]
+        outs = ops.gemm_block2_stack(u0, desc, RELU, 0.0)
+        return [o[0] for o in outs], [o[1] for o in outs]
+    uh, u, x = [], [], u0
+    for i, b in enumerate(blocks):
+        hh, x = b.tan(m, x, hs[i], ys[i])
+        uh.append(hh); u.append(x)
+    return uh, u
+
+
 def _pair_ok(m, la, lb, x, mask1, mask2, out):
     """two 256 -> 256 layers behind each other, bf16, both masks with sign bits: one launch (ops.gemm_block2)"""
     return (m.bf16 and la.N == 256 and la.K == 256 and lb.N == 256 and lb.K == 256 and ops.block2_ok(x, mask1, mask2, x.shape[0])
@@ -442,10 +484,8 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
     gcat = Lm.bwd(m, gz_m0, cat, RELU, 0.0)                  # (3B, nb*D): cotangents at every branch's last fc2
     g1, g2, gin = [], [], []
     for bi, br in enumerate(branches):
-        n = len(br.blocks)
-        a2, a1 = [None] * n + [gcat[:, bi * Dw:(bi + 1) * Dw]], [None] * n    # a2[i]: cotangent at the pre-activation producing y[i]
-        for i in range(n - 1, -1, -1):
-            a1[i], a2[i] = br.blocks[i].bwd(m, a2[i + 1], h[bi][i], y[bi][i])
+        # a2[i]: cotangent at the pre-activation producing y[i]
+        a1, a2 = stack_bwd(m, br.blocks, gcat[:, bi * Dw:(bi + 1) * Dw], h[bi], y[bi])
         g1.append(a1); g2.append(a2)
         gin.append(br.first.bwd(m, a2[0][B2:], None, NONE, 0.0, out_f32=True))   # (B, w_b) fp32, x_hat rows only
     split = m.can_split(B)
@@ -466,11 +506,9 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
     T = tangents(v.reshape(g.shape))
     u, uh = [], []
     for bi, br in enumerate(branches):
-        us, uhs = [br.first.tan(m, T[bi], ops.tail_rows(y[bi][0], B2), inplace=True)], []
-        for i, blk in enumerate(br.blocks):
-            hh, yy = blk.tan(m, us[-1], ops.tail_rows(h[bi][i], B2), ops.tail_rows(y[bi][i + 1], B2))
-            uhs.append(hh); us.append(yy)
-        u.append(us); uh.append(uhs)
+        u_first = br.first.tan(m, T[bi], ops.tail_rows(y[bi][0], B2), inplace=True)
+        uhs, uo = stack_tan(m, br.blocks, u_first, [ops.tail_rows(t, B2) for t in h[bi]], [ops.tail_rows(t, B2) for t in y[bi][1:]])
+        u.append([u_first] + uo); uh.append(uhs)
     if all(u[bi][-1].data_ptr() == cat[B2:, bi * Dw:].data_ptr() for bi in range(nb)):
         ucat = cat[B2:]                                      # every branch tangent was written in place
     else:

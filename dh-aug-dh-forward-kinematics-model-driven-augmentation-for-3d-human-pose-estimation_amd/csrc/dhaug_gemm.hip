@@ -1492,13 +1492,21 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256s_kernel(GemmArgs p) {
 // Y2 of tile i-2) out as whole rows at the top of an iteration, then computes; one LDS barrier per tile.  The sign bits of a
 // tile (1 KB per layer) travel with the tile.  LDS: 4 X images + 2 Y1 + 2 Y2 (16 KB each) + 4 x 2 KB of bits + 1 KB = 137 KB.
 // ---------------------------------------------------------------------------------------------------------------
-struct Block2Args {
-    const uint16_t* X; long long ldx;
+struct Block2One {
     const uint16_t* W1; long long ldw1;
     const uint16_t* W2; long long ldw2;
     const uint32_t* bits1; const uint32_t* bits2;
     uint16_t* Y1; long long ldy1;
     uint16_t* Y2; long long ldy2;
+};
+// A STACK of blocks (<= DHAUG_BLOCK2_MAX): block b + 1 takes block b's Y2 as its X.  Row tiles are independent, and a
+// workgroup owns the same tiles in every block, so it walks its tiles through block 0, reloads its weight registers, walks
+// them through block 1 (reading back rows it wrote itself: drained + L1 invalidated in between) ... -- one launch, one
+// pipeline fill and one set of launch latencies for the three blocks of a residual stack (~12 us each as separate launches).
+struct Block2Args {
+    int nb;
+    const uint16_t* X; long long ldx;
+    Block2One b[DHAUG_BLOCK2_MAX];
     long long M;
     float dneg;
 };
@@ -1522,17 +1530,35 @@ __global__ __launch_bounds__(512, 1) void gemm_block2_kernel(Block2Args p) {
     if (mt0 >= mtiles) return;
     const int nt = (int)((mtiles - mt0 + g - 1) / g);                        // tiles of this workgroup
 
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int lfx = r31 * F_PITCH | ((x >> 1) << 5) | ((h ^ (x & 1)) << 4);                  // ^ (k << 5): chunk 2k+h of row
+    const int lrx = (r31 * F_PITCH | ((x >> 1) << 5) | ((h ^ (x & 1)) << 4)) ^ (cw << 6);     // ^ (t << 8 | j << 5)
+    const int lep = r31 * F_PITCH | (((4 * cw) ^ x) << 4) | (h << 3);                        // ^ ((16t+g) << 4)
+    const unsigned char __attribute__((address_space(4)))* ka =
+        (const unsigned char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef const Block2One __attribute__((address_space(4)))* OnePtr;       // (indexed dynamically: read from the kernarg segment)
+    const int nblk = p.nb;
+#pragma unroll 1
+    for (int blk = 0; blk < nblk; ++blk) {
+    OnePtr P = (OnePtr)(ka + __builtin_offsetof(Block2Args, b)) + blk;
+    const uint16_t* Xb = blk == 0 ? p.X : (const uint16_t*)P[-1].Y2;
+    const long long ldxb = blk == 0 ? p.ldx : P[-1].ldy2;
+    const uint32_t* bits1 = P->bits1;
+    const uint32_t* bits2 = P->bits2;
     // three copies per wave and tile: 2 of the 16 KB operand tile, one of the bits (waves 0 / 1: layer 1 / 2; the others
     // repeat one into the scratch area so that every wave's vmcnt arithmetic is the same)
     auto copy_tile = [&](int i) {
         const long long tile = mt0 + (long long)i * g, m0 = tile * B2_BM;
         const int buf = i % B2_NX;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                 // lane-derived offsets are recomputed here, not parked in (spilled) registers
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int row0 = (wave * 2 + q) * 2, row = row0 + (lane >> 5), c = (lane & 31) ^ (row & 15);
-            tn_copy16(p.X + (m0 + row) * p.ldx + c * 8, sX + buf * B2_IMG + row0 * F_PITCH);
+            const int row0 = (wave * 2 + q) * 2, row = row0 + (ln >> 5), c = (ln & 31) ^ (row & 15);
+            tn_copy16(Xb + (m0 + row) * ldxb + c * 8, sX + buf * B2_IMG + row0 * F_PITCH);
         }
-        const uint32_t* bsrc = ((wave & 1) ? p.bits2 : p.bits1) + tile * 256 + lane * 4;
+        const uint32_t* bsrc = ((wave & 1) ? bits2 : bits1) + tile * 256 + ln * 4;
         tn_copy16(bsrc, wave < 2 ? sB + buf * 2048 + wave * 1024 : sScratch);
     };
     if (0 < nt) copy_tile(0);
@@ -1541,8 +1567,8 @@ __global__ __launch_bounds__(512, 1) void gemm_block2_kernel(Block2Args p) {
     // this stage's weights: feature slices cw and cw + 4, resident for the whole launch
     bf16x8 wf[2][16];
     {
-        const uint16_t* W = stageB ? p.W2 : p.W1;
-        const long long ldw = stageB ? p.ldw2 : p.ldw1;
+        const uint16_t* W = stageB ? P->W2 : P->W1;
+        const long long ldw = stageB ? P->ldw2 : P->ldw1;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const uint16_t* wrow = W + (long long)(32 * (cw + 4 * t) + r31) * ldw + 8 * h;
@@ -1550,21 +1576,6 @@ __global__ __launch_bounds__(512, 1) void gemm_block2_kernel(Block2Args p) {
             for (int k = 0; k < 16; ++k) wf[t][k] = *reinterpret_cast<const bf16x8*>(wrow + 16 * k);
         }
     }
-    bf16x8 idf[2];                                                           // A[n][k'] = (n == 16 j + k'), k' = 8h + i
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int dd = r31 - 16 * j - 8 * h;
-        unsigned v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = (dd == 2 * q ? 0x3F80u : 0u) | (dd == 2 * q + 1 ? 0x3F800000u : 0u);
-        const uint4 u = make_uint4(v[0], v[1], v[2], v[3]);
-        idf[j] = __builtin_bit_cast(bf16x8, u);
-    }
-    const int lfx = r31 * F_PITCH | ((x >> 1) << 5) | ((h ^ (x & 1)) << 4);                  // ^ (k << 5): chunk 2k+h of row
-    const int lrx = (r31 * F_PITCH | ((x >> 1) << 5) | ((h ^ (x & 1)) << 4)) ^ (cw << 6);     // ^ (t << 8 | j << 5)
-    const int lep = r31 * F_PITCH | (((4 * cw) ^ x) << 4) | (h << 3);                        // ^ ((16t+g) << 4)
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     // the weights (compiler-tracked loads) land HERE: the empty asm statements use them, so hipcc's waitcnt pass puts its
     // waits in front of them -- left to their first use it repeats a countdown to vmcnt(0) inside the tile loop, which
     // would drain the LDS-DMA copies it does not know about at every tile
@@ -1589,19 +1600,23 @@ __global__ __launch_bounds__(512, 1) void gemm_block2_kernel(Block2Args p) {
             const int jj = stageB ? i - 2 : i - 1;
             if (jj < 0 || jj >= nt) return;                                  // (wave-uniform)
             const unsigned char* I = (stageB ? sO : sG) + (jj & 1) * B2_IMG;
-            uint16_t* Y = stageB ? p.Y2 : p.Y1;
-            const long long ldy = stageB ? p.ldy2 : p.ldy1;
-            const int st = tid & 255;
-            u32x4 o[4];
+            uint16_t* Y = stageB ? P->Y2 : P->Y1;
+            const long long ldy = stageB ? P->ldy2 : P->ldy1;
+            int st = tid & 255;
+            asm volatile("" : "+v"(st));             // (as in copy_tile)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = st + 256 * q, row = e >> 5, c = e & 31;
-                o[q] = *reinterpret_cast<const u32x4*>(I + row * F_PITCH + ((c ^ (row & 15)) << 4));
-            }
+            for (int q0 = 0; q0 < 4; q0 += 2) {                              // (two at a time: 8 registers, not 16)
+                u32x4 o[2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = st + 256 * q, row = e >> 5, c = e & 31;
-                *reinterpret_cast<u32x4*>(Y + ((mt0 + (long long)jj * g) * B2_BM + row) * ldy + c * 8) = o[q];
+                for (int q = 0; q < 2; ++q) {
+                    const int e = st + 256 * (q0 + q), row = e >> 5, c = e & 31;
+                    o[q] = *reinterpret_cast<const u32x4*>(I + row * F_PITCH + ((c ^ (row & 15)) << 4));
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int e = st + 256 * (q0 + q), row = e >> 5, c = e & 31;
+                    *reinterpret_cast<u32x4*>(Y + ((mt0 + (long long)jj * g) * B2_BM + row) * ldy + c * 8) = o[q];
+                }
             }
         };
         if (stageB) stream_out();
@@ -1628,12 +1643,20 @@ __global__ __launch_bounds__(512, 1) void gemm_block2_kernel(Block2Args p) {
             }
             if (stageB) {                                                    // + X (the skip), exact on the matrix pipe
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
+                for (int jj = 0; jj < 2; ++jj) {
+                    // identity fragment A[n][k'] = (n == 16 jj + k'), k' = 8h + i: built here (8 registers not kept across the tile)
+                    const int dd = r31 - 16 * jj - 8 * h;
+                    unsigned v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = (dd == 2 * q ? 0x3F80u : 0u) | (dd == 2 * q + 1 ? 0x3F800000u : 0u);
+                    const uint4 uu = make_uint4(v[0], v[1], v[2], v[3]);
+                    const bf16x8 idf = __builtin_bit_cast(bf16x8, uu);
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const bf16x8 rf = *reinterpret_cast<const bf16x8*>(Xj + (lrx ^ (t << 8 | jj << 5)));
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(idf[jj], rf, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(idf, rf, acc[t], 0, 0, 0);
                     }
+                }
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -1663,7 +1686,10 @@ __global__ __launch_bounds__(512, 1) void gemm_block2_kernel(Block2Args p) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         f_lds_barrier();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // every row this workgroup stored is in L2 (its next block reads them back: through a clean L1), every image is free
+    asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_inv sc1" ::: "memory");
+    f_lds_barrier();
+    }
 }
 
 template <int KS, int MODE>
@@ -1896,30 +1922,45 @@ int dhaug_gemm_bf16_dbits(const uint16_t* A, int64_t lda, const uint16_t* B, int
 }
 
 /* see include/dhaug.h */
-int dhaug_gemm_block2_bf16(const uint16_t* X, int64_t ldx, const uint16_t* W1, int64_t ldw1, const uint16_t* W2, int64_t ldw2,
-                           const uint32_t* bits1, const uint32_t* bits2, int mask_act, float mask_slope,
-                           uint16_t* Y1, int64_t ldy1, uint16_t* Y2, int64_t ldy2, int64_t M, void* stream) {
+int dhaug_gemm_block2_stack_bf16(const uint16_t* X, int64_t ldx, const dhaug_block2* blocks, int nb, int mask_act, float mask_slope,
+                                 int64_t M, void* stream) {
     DHAUG_CHECK(mask_act == DHAUG_ACT_RELU || mask_act == DHAUG_ACT_LRELU, DHAUG_EINVAL);
+    DHAUG_CHECK(nb >= 1 && nb <= DHAUG_BLOCK2_MAX, DHAUG_EINVAL);
     DHAUG_CHECK(M >= 0 && M % B2_BM == 0, DHAUG_EUNSUPPORTED);
     if (M == 0) return DHAUG_OK;
-    DHAUG_CHECK_PTR(X); DHAUG_CHECK_PTR(W1); DHAUG_CHECK_PTR(W2); DHAUG_CHECK_PTR(bits1); DHAUG_CHECK_PTR(bits2);
-    DHAUG_CHECK_PTR(Y1); DHAUG_CHECK_PTR(Y2);
-    DHAUG_CHECK(ldx % 8 == 0 && ldw1 % 8 == 0 && ldw2 % 8 == 0 && ldy1 % 8 == 0 && ldy2 % 8 == 0, DHAUG_EALIGN);
-    DHAUG_CHECK(ldx >= 256 && ldw1 >= 256 && ldw2 >= 256 && ldy1 >= 256 && ldy2 >= 256, DHAUG_EALIGN);
-    DHAUG_CHECK(dhaug_aligned16(X) && dhaug_aligned16(W1) && dhaug_aligned16(W2) && dhaug_aligned16(Y1) && dhaug_aligned16(Y2) &&
-                dhaug_aligned16(bits1) && dhaug_aligned16(bits2), DHAUG_EALIGN);
-    // Y1 may not alias X or Y2 (X is read as the skip after Y1's rows are stored); Y2 may overwrite nothing that is still read
-    DHAUG_CHECK(Y1 != X && Y2 != X && Y1 != Y2, DHAUG_EINVAL);
+    DHAUG_CHECK_PTR(X); DHAUG_CHECK_PTR(blocks);
+    DHAUG_CHECK(ldx % 8 == 0 && ldx >= 256 && dhaug_aligned16(X), DHAUG_EALIGN);
+    Block2Args a;
+    a.nb = nb; a.X = X; a.ldx = ldx; a.M = M; a.dneg = mask_act == DHAUG_ACT_RELU ? 0.0f : mask_slope;
+    const uint16_t* in = X;
+    for (int i = 0; i < nb; ++i) {
+        const dhaug_block2& b = blocks[i];
+        DHAUG_CHECK_PTR(b.W1); DHAUG_CHECK_PTR(b.W2); DHAUG_CHECK_PTR(b.bits1); DHAUG_CHECK_PTR(b.bits2); DHAUG_CHECK_PTR(b.Y1); DHAUG_CHECK_PTR(b.Y2);
+        DHAUG_CHECK(b.ldw1 % 8 == 0 && b.ldw2 % 8 == 0 && b.ldy1 % 8 == 0 && b.ldy2 % 8 == 0, DHAUG_EALIGN);
+        DHAUG_CHECK(b.ldw1 >= 256 && b.ldw2 >= 256 && b.ldy1 >= 256 && b.ldy2 >= 256, DHAUG_EALIGN);
+        DHAUG_CHECK(dhaug_aligned16(b.W1) && dhaug_aligned16(b.W2) && dhaug_aligned16(b.Y1) && dhaug_aligned16(b.Y2) &&
+                    dhaug_aligned16(b.bits1) && dhaug_aligned16(b.bits2), DHAUG_EALIGN);
+        // a block's Y1 / Y2 may not alias its input (read as the skip after Y1's rows are stored) or each other
+        DHAUG_CHECK(b.Y1 != in && b.Y2 != in && b.Y1 != b.Y2, DHAUG_EINVAL);
+        a.b[i] = Block2One{b.W1, b.ldw1, b.W2, b.ldw2, b.bits1, b.bits2, b.Y1, b.ldy1, b.Y2, b.ldy2};
+        in = b.Y2;
+    }
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_block2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    Block2Args a{X, ldx, W1, ldw1, W2, ldw2, bits1, bits2, Y1, ldy1, Y2, ldy2, M, mask_act == DHAUG_ACT_RELU ? 0.0f : mask_slope};
     const long long mtiles = M / B2_BM;
     hipLaunchKernelGGL(gemm_block2_kernel, dim3((unsigned)(mtiles < 256 ? mtiles : 256)), dim3(512), B2_LDS, (hipStream_t)stream, a);
     return dhaug_launch_status();
+}
+
+int dhaug_gemm_block2_bf16(const uint16_t* X, int64_t ldx, const uint16_t* W1, int64_t ldw1, const uint16_t* W2, int64_t ldw2,
+                           const uint32_t* bits1, const uint32_t* bits2, int mask_act, float mask_slope,
+                           uint16_t* Y1, int64_t ldy1, uint16_t* Y2, int64_t ldy2, int64_t M, void* stream) {
+    const dhaug_block2 b{W1, ldw1, W2, ldw2, bits1, bits2, Y1, ldy1, Y2, ldy2};
+    return dhaug_gemm_block2_stack_bf16(X, ldx, &b, 1, mask_act, mask_slope, M, stream);
 }
 
 int dhaug_gemm_tn_bf16_rows(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,

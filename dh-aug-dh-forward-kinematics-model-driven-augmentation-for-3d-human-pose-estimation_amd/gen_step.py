@@ -61,10 +61,8 @@ class _BranchNet:
         gcat = self.Lm.bwd(m, gz_m0, s["cat"], RELU, 0.0)
         gin = []
         for bi, br in enumerate(self.br):
-            a2 = gcat[:, bi * Dw:(bi + 1) * Dw]
-            for i in range(len(br.blocks) - 1, -1, -1):
-                _, a2 = br.blocks[i].bwd(m, a2, s["h"][bi][i], s["y"][bi][i])
-            gin.append(br.first.bwd(m, a2, None, NONE, 0.0, out_f32=True))
+            _, a2 = CS.stack_bwd(m, br.blocks, gcat[:, bi * Dw:(bi + 1) * Dw], s["h"][bi], s["y"][bi])
+            gin.append(br.first.bwd(m, a2[0], None, NONE, 0.0, out_f32=True))
         return gin
 
 

@@ -334,6 +334,28 @@ def gemm_block2(x, B1, B2, mask1, mask2, act, slope=0.0, out1=None, out2=None):
     return out1, out2
 
 
+def gemm_block2_stack(x, blocks, act, slope=0.0):
+    """a chain of gemm_block2 steps in one launch: blocks = [(B1, B2, mask1, mask2, out1 | None, out2 | None)], block i + 1 takes
+    block i's y2 as its x.  Returns [(y1, y2)]."""
+    M = x.shape[0]
+    assert 1 <= len(blocks) <= _lib.BLOCK2_MAX and x.dtype == BF16
+    arr = (_lib.Block2 * len(blocks))()
+    outs = []
+    for d, (B1, B2, mask1, mask2, out1, out2) in zip(arr, blocks):
+        if out1 is None:
+            out1 = torch.empty((M, 256), dtype=BF16, device=x.device)
+        if out2 is None:
+            out2 = torch.empty((M, 256), dtype=BF16, device=x.device)
+        assert out1.dtype == BF16 and out2.dtype == BF16 and out1.shape[0] == M and out2.shape[0] == M
+        assert mask1._dhaug_bits.device == x.device and mask2._dhaug_bits.device == x.device, "sign bits must live on the operands' device"
+        d.W1, d.ldw1, d.W2, d.ldw2 = _p(B1), B1.stride(0), _p(B2), B2.stride(0)
+        d.bits1, d.bits2 = _p(mask1._dhaug_bits), _p(mask2._dhaug_bits)
+        d.Y1, d.ldy1, d.Y2, d.ldy2 = _p(out1), out1.stride(0), _p(out2), out2.stride(0)
+        outs.append((out1, out2))
+    _lib.call("dhaug_gemm_block2_stack_bf16", _p(x), x.stride(0), arr, len(blocks), act, float(slope), M, _stream())
+    return outs
+
+
 def tail_rows(t, r0):
     """t[r0:], keeping the sign-bit array of a saved activation attached (rows r0.. start at a 32-row tile)"""
     v = t[r0:]

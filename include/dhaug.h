@@ -232,6 +232,19 @@ int dhaug_gemm_bf16_dbits(const uint16_t* A, int64_t lda, const uint16_t* B, int
 int dhaug_gemm_block2_bf16(const uint16_t* X, int64_t ldx, const uint16_t* W1, int64_t ldw1, const uint16_t* W2, int64_t ldw2,
                            const uint32_t* bits1, const uint32_t* bits2, int mask_act, float mask_slope,
                            uint16_t* Y1, int64_t ldy1, uint16_t* Y2, int64_t ldy2, int64_t M, void* stream);
+/* A chain of such blocks in one launch: block i + 1 takes block i's Y2 as its X (the three myResNet blocks of a branch of the
+ * critics, backward: block 3, 2, 1; tangent: 1, 2, 3).  Row tiles are independent and a workgroup keeps its tiles through the
+ * chain, so the launch needs no device-wide synchronisation between the blocks.  `blocks`: host array, read during the call. */
+#define DHAUG_BLOCK2_MAX 3
+typedef struct dhaug_block2 {
+    const uint16_t* W1; int64_t ldw1;
+    const uint16_t* W2; int64_t ldw2;
+    const uint32_t* bits1; const uint32_t* bits2;
+    uint16_t* Y1; int64_t ldy1;
+    uint16_t* Y2; int64_t ldy2;
+} dhaug_block2;
+int dhaug_gemm_block2_stack_bf16(const uint16_t* X, int64_t ldx, const dhaug_block2* blocks, int nb, int mask_act, float mask_slope,
+                                 int64_t M, void* stream);
 
 /* Weight-gradient GEMM: C[N1,N2] (+)= A[M,N1]^T * B[M,N2], contraction over the batch dimension M
  * (split across workgroups, fp32 atomics into C).  bf16 operands, fp32 result.  `accumulate` != 0 adds

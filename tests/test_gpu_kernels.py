@@ -530,6 +530,39 @@ def test_gemm_block2_equals_two_layers(ops, M, act, slope, row0, ldx):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("M,nb", [(32, 2), (32 * 37, 3), (32 * 256 * 2 + 64, 3), (65536, 3)])
+def test_gemm_block2_stack_equals_single_blocks(ops, M, nb):
+    """a chain of blocks in one launch (dhaug_gemm_block2_stack_bf16: a workgroup walks its row tiles through block 0, reloads
+    its weights, reads back the rows it wrote ...) equals the blocks launched one after the other, bit for bit -- also in place"""
+    from dhaug_amd import fused
+    gen = torch.Generator().manual_seed(M + nb)
+    x = _bf(torch.randn(M, 256, generator=gen)).cuda()
+    Ws = [(_bf(torch.randn(256, 256, generator=gen) / 16).cuda(), _bf(torch.randn(256, 256, generator=gen) / 16).cuda()) for _ in range(nb)]
+    masks = []
+    for _ in range(nb):
+        pair = []
+        for thr in (0.45, 0.55):
+            t = torch.zeros(M, 256, dtype=torch.bfloat16, device="cuda")
+            t._dhaug_bits = fused.encode_bits((torch.rand(M, 256, generator=gen) > thr).cuda())
+            pair.append(t)
+        masks.append(pair)
+    ref, cur = [], x
+    for (W1, W2), (m1, m2) in zip(Ws, masks):
+        y1, y2 = ops.gemm_block2(cur, W1, W2, m1, m2, 1, 0.0)
+        ref.append((y1, y2)); cur = y2
+    calls = ops._lib.CALLS[0]
+    got = ops.gemm_block2_stack(x, [(W1, W2, m1, m2, None, None) for (W1, W2), (m1, m2) in zip(Ws, masks)], 1, 0.0)
+    assert ops._lib.CALLS[0] == calls + 1
+    for (g1, g2), (r1, r2) in zip(got, ref):
+        assert torch.equal(g1.view(torch.int16), r1.view(torch.int16)) and torch.equal(g2.view(torch.int16), r2.view(torch.int16))
+    # in place over the mask tensors (the tangent sweep)
+    got = ops.gemm_block2_stack(x, [(W1, W2, m1, m2, m1, m2) for (W1, W2), (m1, m2) in zip(Ws, masks)], 1, 0.0)
+    for (g1, g2), (r1, r2), (m1, m2) in zip(got, ref, masks):
+        assert g1.data_ptr() == m1.data_ptr() and torch.equal(g1.view(torch.int16), r1.view(torch.int16))
+        assert torch.equal(g2.view(torch.int16), r2.view(torch.int16))
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("M,N,K,act,slope,use_res", [(4096, 256, 256, 1, 0.0, False), (4096, 256, 256, 2, 0.01, False),
                                                    (1024, 256, 128, 1, 0.0, True), (1000, 104, 256, 1, 0.0, False)])
 def test_gemm_nt_dmask(ops, M, N, K, act, slope, use_res):
