@@ -481,6 +481,8 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
     gzo = seeds(B, m, dev)
     gz_m2 = Lo.bwd(m, gzo, m1, RELU, 0.0)
     gz_m1, gz_m0 = Mb.bwd(m, gz_m2, mh, m0)
+    if Dw == 256 and all(getattr(y[bi][-1], "_dhaug_bits", None) is not None for bi in range(nb)):
+        cat._dhaug_bits_cols = [y[bi][-1]._dhaug_bits for bi in range(nb)]      # (the mask of column block bi: its branch's sign bits)
     gcat = Lm.bwd(m, gz_m0, cat, RELU, 0.0)                  # (3B, nb*D): cotangents at every branch's last fc2
     g1, g2, gin = [], [], []
     for bi, br in enumerate(branches):

@@ -38,6 +38,7 @@ struct GemmArgs {
     int act; float slope;
     const uint16_t* dmask; long long ld_dmask; float dneg;   // optional: result *= (dmask > 0 ? 1 : dneg)  (nt256 kernel only)
     const uint32_t* dbits;                                   // the same mask as a sign-bit array (dhaug_mlp_unit.bits layout)
+    const uint32_t* dbits2;                                  // ... of output columns 256..511 (gemm_nt_ws_kernel: a layer whose output is two 256-wide blocks)
     int abl;                                                 // development (big-tile kernel): 1 no epilogue, 2 no reads / MFMAs, 4 no copies
 };
 
@@ -968,6 +969,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ws_kernel(GemmArgs p) {
                                                                         : make_uint4(0, 0, 0, 0);
             }
         }
+        // ... or the same mask as sign bits (dhaug_mlp_unit.bits layout, one array per 256 output columns): a piece's 8 features
+        // 8g .. 8g+7 of slice (wave_f + 4 t) are pairs 8t + 2g, +1 of the row's two lanes (h = 0: features +0..3, h = 1: +4..7)
+        uint32_t rb0[4], rb1[4];
+        const bool bits_mode = p.dbits != nullptr;
+        if (bits_mode) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = tid + 256 * i, row = q >> 4, pc = q & 15;
+                const long long gm = m0 + row, n = n0 + pc * 8;
+                rb0[i] = rb1[i] = 0u;
+                if (gm < p.M && n + 8 <= p.N) {
+                    const uint32_t* bb = n >= 256 ? p.dbits2 : p.dbits;
+                    const int f = (int)(n & 255);
+                    const long long w = ((gm >> 5) * 4 + ((f >> 5) & 3)) * 64 + (gm & 31);
+                    rb0[i] = bb[w];
+                    rb1[i] = bb[w + 32];
+                }
+            }
+        }
         // compute
         const uint16_t* img = reinterpret_cast<const uint16_t*>(smem_raw + buf * WS_BUF_BYTES);
         f32x16 acc[2];
@@ -1039,6 +1059,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ws_kernel(GemmArgs p) {
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (full || n + e < p.N) ? apply_act(v[e], p.act, p.slope) : 0.0f;
+            if (bits_mode) {
+                const int f = (int)(n & 255), p0 = 8 * (f >> 7) + 2 * ((f & 31) >> 3);
+                const uint32_t w0 = rb0[i], w1 = rb1[i];
+                v[0] = ((w0 >> p0) & 1u) ? v[0] : v[0] * p.dneg;
+                v[1] = ((w0 >> (16 + p0)) & 1u) ? v[1] : v[1] * p.dneg;
+                v[2] = ((w0 >> (p0 + 1)) & 1u) ? v[2] : v[2] * p.dneg;
+                v[3] = ((w0 >> (17 + p0)) & 1u) ? v[3] : v[3] * p.dneg;
+                v[4] = ((w1 >> p0) & 1u) ? v[4] : v[4] * p.dneg;
+                v[5] = ((w1 >> (16 + p0)) & 1u) ? v[5] : v[5] * p.dneg;
+                v[6] = ((w1 >> (p0 + 1)) & 1u) ? v[6] : v[6] * p.dneg;
+                v[7] = ((w1 >> (17 + p0)) & 1u) ? v[7] : v[7] * p.dneg;
+            }
             if (p.dmask != nullptr) {                        // activation-backward mask of the producing layer
                 if (mask_vec && (full || n + 8 <= p.ld_dmask)) {
                     const uint4 mm = rmask[i];
@@ -1795,7 +1827,7 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
     if (c_bf16) DHAUG_CHECK(ldc_bf16 % 8 == 0 && ldc_bf16 >= N && n_pad_zero <= ldc_bf16 && dhaug_aligned16(c_bf16), DHAUG_EALIGN);
     if (c_f32) DHAUG_CHECK(ldc_f32 >= N && ((ldc_f32 & 3) != 0 || dhaug_aligned16(c_f32)), DHAUG_EALIGN);
     GemmArgs p{A, lda, B, ldb, bias, residual, ld_res, residual_f32, ld_res_f32, c_bf16, ldc_bf16, c_bf16 ? (n_pad_zero > N ? n_pad_zero : N) : 0,
-               c_f32, ldc_f32, M, N, K, N, act, slope, nullptr, 0, 1.0f, nullptr, 0};
+               c_f32, ldc_f32, M, N, K, N, act, slope, nullptr, 0, 1.0f, nullptr, nullptr, 0};
     hipStream_t s = (hipStream_t)stream;
     const long long width = (c_bf16 && p.npad > N) ? p.npad : N;
     p.W = width;
@@ -1917,8 +1949,35 @@ int dhaug_gemm_bf16_dbits(const uint16_t* A, int64_t lda, const uint16_t* B, int
     DHAUG_CHECK(dhaug_aligned16(A) && dhaug_aligned16(B) && dhaug_aligned16(c_bf16) && dhaug_aligned16(bits), DHAUG_EALIGN);
     if (residual) DHAUG_CHECK(ld_res % 8 == 0 && ld_res >= 256 && dhaug_aligned16(residual), DHAUG_EALIGN);
     GemmArgs p{A, lda, B, ldb, nullptr, residual, ld_res, nullptr, 0, c_bf16, ldc_bf16, 256, nullptr, 0, M, 256, 256, 256,
-               DHAUG_ACT_NONE, 0.0f, nullptr, 0, dmask_act == DHAUG_ACT_RELU ? 0.0f : dmask_slope, bits, 0};
+               DHAUG_ACT_NONE, 0.0f, nullptr, 0, dmask_act == DHAUG_ACT_RELU ? 0.0f : dmask_slope, bits, nullptr, 0};
     return launch_nt256s<16>((hipStream_t)stream, p);
+}
+
+/* see include/dhaug.h */
+int dhaug_gemm_bf16_dbits_wide(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint32_t* bits_lo,
+                               const uint32_t* bits_hi, int dmask_act, float dmask_slope, uint16_t* c_bf16, int64_t ldc_bf16,
+                               int64_t M, int64_t N, int64_t K, void* stream) {
+    DHAUG_CHECK(dmask_act == DHAUG_ACT_RELU || dmask_act == DHAUG_ACT_LRELU, DHAUG_EINVAL);
+    DHAUG_CHECK(M >= 0 && (N == 256 || N == 512) && K >= 16 && K <= 256 && K % 16 == 0, DHAUG_EUNSUPPORTED);
+    if (M == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(A); DHAUG_CHECK_PTR(B); DHAUG_CHECK_PTR(bits_lo); DHAUG_CHECK_PTR(c_bf16);
+    if (N == 512) DHAUG_CHECK_PTR(bits_hi);
+    DHAUG_CHECK(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && ldc_bf16 % 8 == 0 && ldc_bf16 >= N, DHAUG_EALIGN);
+    DHAUG_CHECK(dhaug_aligned16(A) && dhaug_aligned16(B) && dhaug_aligned16(c_bf16) && dhaug_aligned16(bits_lo) &&
+                (bits_hi == nullptr || dhaug_aligned16(bits_hi)), DHAUG_EALIGN);
+    GemmArgs p{A, lda, B, ldb, nullptr, nullptr, 0, nullptr, 0, c_bf16, ldc_bf16, N, nullptr, 0, M, N, K, N,
+               DHAUG_ACT_NONE, 0.0f, nullptr, 0, dmask_act == DHAUG_ACT_RELU ? 0.0f : dmask_slope, bits_lo, bits_hi, 0};
+    hipStream_t s = (hipStream_t)stream;
+    switch (K / 16) {
+        case 1: return launch_ws<1>(s, p);
+        case 2: return launch_ws<2>(s, p);
+        case 3: return launch_ws<3>(s, p);
+        case 4: return launch_ws<4>(s, p);
+        case 7: return launch_ws<7>(s, p);
+        case 8: return launch_ws<8>(s, p);
+        case 16: return launch_ws<16>(s, p);
+        default: return DHAUG_EUNSUPPORTED;
+    }
 }
 
 /* see include/dhaug.h */

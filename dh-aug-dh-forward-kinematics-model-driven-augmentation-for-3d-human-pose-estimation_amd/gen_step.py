@@ -58,7 +58,10 @@ class _BranchNet:
         Dw = self.br[0].first.N
         gz_m2 = self.Lo.bwd(m, seed, s["m1"], RELU, 0.0)
         _, gz_m0 = self.Mb.bwd(m, gz_m2, s["mh"], s["m0"])
-        gcat = self.Lm.bwd(m, gz_m0, s["cat"], RELU, 0.0)
+        cat = s["cat"]
+        if Dw == 256 and all(getattr(s["y"][bi][-1], "_dhaug_bits", None) is not None for bi in range(len(self.br))):
+            cat._dhaug_bits_cols = [s["y"][bi][-1]._dhaug_bits for bi in range(len(self.br))]
+        gcat = self.Lm.bwd(m, gz_m0, cat, RELU, 0.0)
         gin = []
         for bi, br in enumerate(self.br):
             _, a2 = CS.stack_bwd(m, br.blocks, gcat[:, bi * Dw:(bi + 1) * Dw], s["h"][bi], s["y"][bi])

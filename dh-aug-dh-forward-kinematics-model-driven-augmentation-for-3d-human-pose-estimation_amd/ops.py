@@ -294,6 +294,14 @@ def gemm_nt_dmask(A, B, N, K, dmask, dmask_act, dmask_slope=0.0, res_bf16=None, 
     if out is None:
         out = torch.empty((M, ceil_to(N, 16)), dtype=BF16, device=A.device)
     assert out.dtype == BF16 and out.stride(1) == 1 and out.shape[0] == M and out.shape[1] >= N
+    cols = getattr(dmask, "_dhaug_bits_cols", None)
+    if (cols is not None and DBITS and N == 256 * len(cols) and len(cols) <= 2 and K in (16, 32, 48, 64, 112, 128, 256) and res_bf16 is None
+            and dmask_act != 0 and M > 0 and A.stride(0) % 8 == 0 and out.stride(0) % 8 == 0):
+        # a wide output whose 256-column blocks carry their own sign bits (the cotangent of the 3D critic's concatenation)
+        assert all(c.device == A.device for c in cols), "sign bits must live on the operands' device"
+        _lib.call("dhaug_gemm_bf16_dbits_wide", _p(A), A.stride(0), _p(B), B.stride(0), _p(cols[0]), _p(cols[1]) if len(cols) > 1 else 0,
+                  dmask_act, float(dmask_slope), _p(out), out.stride(0), M, N, K, _stream())
+        return out
     bits = getattr(dmask, "_dhaug_bits", None)
     assert bits is None or bits.device == A.device, "sign bits must live on the operands' device"
     if (bits is not None and DBITS and N == 256 and K == 256 and M % 32 == 0 and M > 0 and dmask_act != 0

@@ -221,6 +221,14 @@ int dhaug_gemm_bf16_dbits(const uint16_t* A, int64_t lda, const uint16_t* B, int
                           const uint32_t* bits, int dmask_act, float dmask_slope, uint16_t* c_bf16, int64_t ldc_bf16, int64_t M,
                           void* stream);
 
+/* (A B^T) * act'(mask) for an output of one or two 256-wide column blocks whose masks are sign-bit arrays (bits_lo: columns
+ * 0..255, bits_hi: 256..511; N = 256 or 512, K <= 256 one of 16, 32, 48, 64, 112, 128, 256): the input-gradient step through
+ * the 3D critic's merge layer, R/models_Fk_GAN/Fk_discriminator.py:192-197 under loss.backward() -- the cotangent of the two
+ * concatenated branch outputs, each masked by ITS branch's last ReLU. */
+int dhaug_gemm_bf16_dbits_wide(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint32_t* bits_lo,
+                               const uint32_t* bits_hi, int dmask_act, float dmask_slope, uint16_t* c_bf16, int64_t ldc_bf16,
+                               int64_t M, int64_t N, int64_t K, void* stream);
+
 /* Two 256 -> 256 layers of a residual block in one launch (the backward step through myResNet,
  * R/models_Fk_GAN/special_operate.py:490-510 under loss.backward(), and its tangent twin in the gradient penalty's
  * double backward, R/models_Fk_GAN/Fk_discriminator.py:205-231):

@@ -530,6 +530,30 @@ def test_gemm_block2_equals_two_layers(ops, M, act, slope, row0, ldx):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("M,K,nblk", [(64, 112, 2), (1000, 112, 2), (4096 + 32, 256, 2), (196608, 112, 2), (2048, 64, 1)])
+def test_gemm_nt_dbits_wide_equals_dmask(ops, M, K, nblk):
+    """the input-gradient step through a layer whose output is one or two 256-wide column blocks, each masked by ITS sign-bit
+    array (dhaug_gemm_bf16_dbits_wide: the 3D critic's merge layer), equals the form that reads the bf16 mask image, bit for bit"""
+    from dhaug_amd import fused
+    gen = torch.Generator().manual_seed(M + K)
+    N = 256 * nblk
+    A = _bf(torch.randn(M, K, generator=gen)).cuda()
+    A[:, 100:] = 0
+    B = _bf(torch.randn(N, K, generator=gen) / 10).cuda()
+    Y = _bf(torch.randn(M, N, generator=gen)).cuda()
+    Y[::7, ::5] = 0.0
+    ref = ops.gemm_nt_dmask(A, B, N, K, Y, 1, 0.0)
+    Yb = Y.clone()
+    Yb._dhaug_bits_cols = [fused.encode_bits(Y[:, 256 * b:256 * (b + 1)].float() > 0) for b in range(nblk)]
+    calls = ops._lib.CALLS[0]
+    got = ops.gemm_nt_dmask(A, B, N, K, Yb, 1, 0.0)
+    assert ops._lib.CALLS[0] == calls + 1
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    got2 = ops.gemm_nt_dmask(A, B, N, K, Yb, 2, 0.01)
+    ref2 = ops.gemm_nt_dmask(A, B, N, K, Y, 2, 0.01)
+    assert torch.equal(got2.view(torch.int16), ref2.view(torch.int16))
+
+
 @pytest.mark.parametrize("M,nb", [(32, 2), (32 * 37, 3), (32 * 256 * 2 + 64, 3), (65536, 3)])
 def test_gemm_block2_stack_equals_single_blocks(ops, M, nb):
     """a chain of blocks in one launch (dhaug_gemm_block2_stack_bf16: a workgroup walks its row tiles through block 0, reloads
