@@ -16,6 +16,14 @@ static inline int dhaug_launch_status() {
 
 static inline bool dhaug_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Workgroups a one-per-CU (persistent) launch may take: 256, or what dhaug_set_workgroup_cap() left it -- two chains of such
+// launches on two streams then run SIDE BY SIDE on disjoint sets of CUs instead of queueing for the whole card.
+extern "C" int dhaug_workgroup_cap_;
+static inline unsigned dhaug_persistent_grid(long long tiles) {
+    const long long cap = dhaug_workgroup_cap_ > 0 && dhaug_workgroup_cap_ < 256 ? dhaug_workgroup_cap_ : 256;
+    return (unsigned)(tiles < cap ? tiles : cap);
+}
+
 // Grid for one-tile-per-wave streaming kernels: enough workgroups to fill 256 CUs several times over,
 // capped so the tail is a grid-stride loop (cdna_hip_programming.md Guideline 11).
 static inline int dhaug_stream_grid(int64_t tiles, int tiles_per_block, int max_blocks = 256 * 8) {

@@ -613,6 +613,16 @@ int dhaug_rank1_mask_bf16(const uint16_t* seed, int64_t ld_seed, const uint16_t*
     return dhaug_launch_status();
 }
 
+int dhaug_workgroup_cap_ = 0;
+
+/* see include/dhaug.h */
+int dhaug_set_workgroup_cap(int n) {
+    DHAUG_CHECK(n >= 0 && n <= 256, DHAUG_EINVAL);
+    const int old = dhaug_workgroup_cap_;
+    dhaug_workgroup_cap_ = n;
+    return old;
+}
+
 int dhaug_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
     DHAUG_CHECK(n >= 0, DHAUG_EINVAL);
     if (n == 0) return DHAUG_OK;

@@ -1737,7 +1737,7 @@ int launch_nt256s_mode(hipStream_t s, const GemmArgs& p) {
         configured = true;
     }
     const long long mtiles = p.M / BM;
-    const unsigned grid = (unsigned)(mtiles < 256 ? mtiles : 256);
+    const unsigned grid = dhaug_persistent_grid(mtiles);
     hipLaunchKernelGGL((gemm_nt256s_kernel<KS, MODE>), dim3(grid), dim3(512), LDS, s, p);
     return dhaug_launch_status();
 }
@@ -1769,7 +1769,7 @@ int launch_nt256(hipStream_t s, const GemmArgs& p) {
         configured = true;
     }
     const long long mtiles = p.M / F_BM;
-    const unsigned grid = (unsigned)(mtiles < 256 ? mtiles : 256);
+    const unsigned grid = dhaug_persistent_grid(mtiles);
     if (p.dmask != nullptr) hipLaunchKernelGGL((gemm_nt256_kernel<KS, 2>), dim3(grid), dim3(256), F_LDS_BYTES, s, p);
     else if (p.res != nullptr) hipLaunchKernelGGL((gemm_nt256_kernel<KS, 1>), dim3(grid), dim3(256), F_LDS_BYTES, s, p);
     else hipLaunchKernelGGL((gemm_nt256_kernel<KS, 0>), dim3(grid), dim3(256), F_LDS_BYTES, s, p);
@@ -1786,7 +1786,7 @@ int launch_ws(hipStream_t s, const GemmArgs& p) {
         configured = true;
     }
     const long long ntiles = (p.W + WS_BN - 1) / WS_BN, mtiles = (p.M + WS_BM - 1) / WS_BM;
-    long long gx = 512 / ntiles;
+    long long gx = 2 * (long long)dhaug_persistent_grid(256) / ntiles;          // two workgroups per CU
     if (gx < 1) gx = 1;
     if (gx > mtiles) gx = mtiles;
     hipLaunchKernelGGL(gemm_nt_ws_kernel<KSTEPS>, dim3((unsigned)gx, (unsigned)ntiles), dim3(256), 2 * WS_BUF_BYTES, s, p);
@@ -2011,7 +2011,7 @@ int dhaug_gemm_block2_stack_bf16(const uint16_t* X, int64_t ldx, const dhaug_blo
         configured = true;
     }
     const long long mtiles = M / B2_BM;
-    hipLaunchKernelGGL(gemm_block2_kernel, dim3((unsigned)(mtiles < 256 ? mtiles : 256)), dim3(512), B2_LDS, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(gemm_block2_kernel, dim3(dhaug_persistent_grid(mtiles)), dim3(512), B2_LDS, (hipStream_t)stream, a);
     return dhaug_launch_status();
 }
 

@@ -1436,7 +1436,7 @@ int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* 
         configured = true;
     }
     const long long ntiles = (M + MLP_BM - 1) / MLP_BM;
-    const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);           // one persistent workgroup per CU
+    const unsigned grid = dhaug_persistent_grid(ntiles);           // one persistent workgroup per CU
     // forward-with-save (a unit asks for its image in global memory) is a second instantiation: the inference kernel's
     // schedule is exactly what it was
     if (any_save) return dhaug_mlp_launch_save_(&prog, (long long)M, grid, stream);        // (csrc/dhaug_mlp_save.hip)

@@ -580,7 +580,7 @@ int dhaug_mlp_forward_x3(const dhaug_mlp_unit* units, int nunits, int64_t M, voi
         configured = true;
     }
     const long long ntiles = (M + X3_BM - 1) / X3_BM;
-    const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);           // one persistent workgroup per CU
+    const unsigned grid = dhaug_persistent_grid(ntiles);           // one persistent workgroup per CU
     hipLaunchKernelGGL(fused_mlp_x3_kernel, dim3(grid), dim3(X3_THREADS), X3_LDS_BYTES, (hipStream_t)stream, prog, (long long)M);
     return dhaug_launch_status();
 }

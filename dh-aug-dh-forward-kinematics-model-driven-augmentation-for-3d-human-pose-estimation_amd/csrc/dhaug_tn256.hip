@@ -285,7 +285,8 @@ int dhaug_gemm_tn_group_bf16_phase(const dhaug_tn_layer* layers, int n, float* w
     // the group gets about one workgroup per 768 KB of operands, at least one per layer, at most one per CU)
     long long want = (long long)(bytes2 * 2.0 / (768.0 * 1024.0)) + 1;
     if (want < n) want = n;
-    const int cap = layers[0].max_workgroups > 0 && layers[0].max_workgroups < T2_MAX_WG ? layers[0].max_workgroups : T2_MAX_WG;
+    int cap = layers[0].max_workgroups > 0 && layers[0].max_workgroups < T2_MAX_WG ? layers[0].max_workgroups : T2_MAX_WG;
+    if ((int)dhaug_persistent_grid(T2_MAX_WG) < cap) cap = (int)dhaug_persistent_grid(T2_MAX_WG);
     if (want > cap) want = cap;
     const int budget = (int)(stages < want ? stages : want);
     // every layer one workgroup, then the next one always to the layer whose slowest workgroup finishes last: its time is

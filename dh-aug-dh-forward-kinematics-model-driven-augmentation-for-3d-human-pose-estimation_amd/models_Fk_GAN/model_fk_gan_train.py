@@ -198,6 +198,12 @@ class FakePairBuffer:
 
 CONCURRENT_CRITICS = os.environ.get("DHAUG_NO_CONCURRENT_CRITICS") is None
 LONG_ROWS = 16384           # from this batch on one critic's kernels fill the card (run_critic_steps)
+# critics side by side on disjoint CU sets (run_critic_steps).  Measured (B = 65 536): one critic's step alone on 256 / 192 / 128 / 64
+# CUs takes 2.47 / 2.64 / 3.16 / 5.79 ms (3D) and 0.84 / 0.91 / 1.07 / 1.83 ms (2D) -- but the iteration with the 3D critic held to 192
+# and the 2D critic to 64 takes 6.97 ms against 6.90 with each launch on the whole card (176/80: 7.43, 208/48: 7.37): the chains
+# are HBM-bound together.  An option, off.
+PARTITION = os.environ.get("DHAUG_PARTITION") is not None
+CU_SHARES = {("d3", "d2"): tuple(int(v) for v in os.environ.get("DHAUG_CU_SHARES", "192,64").split(","))}
 _SIDE = {}
 
 
@@ -233,6 +239,29 @@ def run_critic_steps(steps, optimizers, interleave, long_rows=False):
         for k, _ in steps:
             if k not in keys:
                 keys.append(k)
+        shares = CU_SHARES.get(tuple(keys)) if (long_rows and PARTITION and not torch.cuda.is_current_stream_capturing()) else None
+        if shares is not None:
+            # long batches: every persistent launch of a critic's step fills the card, so two critics' steps on two streams
+            # merely take turns.  Here each network's launches are held to ITS share of the CUs (dhaug_set_workgroup_cap) and the
+            # steps are issued round robin over the networks: the chains then really run side by side, and what one leaves of
+            # HBM in its matrix-bound phases (the forward-with-save launch) the other uses.
+            for st in streams[:len(keys)]:
+                st.wait_stream(main)
+            queues = {k: [(i, fn) for i, (kk, fn) in enumerate(steps) if kk == k] for k in keys}
+            old_split = critic_step.TN_SPLIT
+            critic_step.TN_SPLIT = False                      # (a third concurrent launch would oversubscribe the CUs)
+            try:
+                while any(queues.values()):
+                    for k, st, share in zip(keys, streams, shares):
+                        if queues[k]:
+                            i, fn = queues[k].pop(0)
+                            with torch.cuda.stream(st), ops.workgroup_cap(share):
+                                res[i] = fn()
+            finally:
+                critic_step.TN_SPLIT = old_split
+            for st in streams[:len(keys)]:
+                main.wait_stream(st)
+            return res
         for k, st in zip(keys, streams):
             st.wait_stream(main)
             with torch.cuda.stream(st):

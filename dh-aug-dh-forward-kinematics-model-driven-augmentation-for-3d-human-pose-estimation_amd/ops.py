@@ -390,6 +390,21 @@ def _tn_group_workspace(dev):
     return _TN_WS[k]
 
 
+class workgroup_cap:
+    """with workgroup_cap(n): the persistent launches issued inside take at most n workgroups (dhaug_set_workgroup_cap)"""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.old = _lib.lib().dhaug_set_workgroup_cap(self.n) if self.n else None
+        return self
+
+    def __exit__(self, *exc):
+        if self.old is not None:
+            _lib.lib().dhaug_set_workgroup_cap(self.old)
+
+
 def tn_group_ok(M, N1, N2, colsum_rows):
     """shapes dhaug_gemm_tn_group_bf16 takes (and where it pays: a long batch)"""
     return M >= 1024 and M % 32 == 0 and colsum_rows % 32 == 0 and 1 <= N1 <= 256 and 1 <= N2 <= 256

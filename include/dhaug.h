@@ -229,6 +229,12 @@ int dhaug_gemm_bf16_dbits_wide(const uint16_t* A, int64_t lda, const uint16_t* B
                                const uint32_t* bits_hi, int dmask_act, float dmask_slope, uint16_t* c_bf16, int64_t ldc_bf16,
                                int64_t M, int64_t N, int64_t K, void* stream);
 
+/* The one-workgroup-per-CU (persistent) launches of this library -- the fused programs, the 256-wide layer kernels, the block
+ * kernel, the grouped weight gradients -- take at most n workgroups from now on (0 or 256: the whole card); returns the
+ * previous value.  Process-wide, read at launch time: set it around the launches of one stream and to the complement around
+ * another stream's, and the two chains run side by side on disjoint sets of CUs instead of queueing for the whole card. */
+int dhaug_set_workgroup_cap(int n);
+
 /* Two 256 -> 256 layers of a residual block in one launch (the backward step through myResNet,
  * R/models_Fk_GAN/special_operate.py:490-510 under loss.backward(), and its tangent twin in the gradient penalty's
  * double backward, R/models_Fk_GAN/Fk_discriminator.py:205-231):

@@ -554,6 +554,37 @@ def test_gemm_nt_dbits_wide_equals_dmask(ops, M, K, nblk):
     assert torch.equal(got2.view(torch.int16), ref2.view(torch.int16))
 
 
+def test_workgroup_cap_changes_nothing_but_the_grid(ops):
+    """dhaug_set_workgroup_cap: the persistent launches (block kernel, 256-wide layer, grouped weight gradients) on a part of
+    the card give the same bits as on the whole card; the previous cap comes back from the setter"""
+    from dhaug_amd import fused
+    gen = torch.Generator().manual_seed(5)
+    M = 32 * 700
+    x = _bf(torch.randn(M, 256, generator=gen)).cuda()
+    W1 = _bf(torch.randn(256, 256, generator=gen) / 16).cuda(); W2 = _bf(torch.randn(256, 256, generator=gen) / 16).cuda()
+    m1 = torch.zeros(M, 256, dtype=torch.bfloat16, device="cuda"); m1._dhaug_bits = fused.encode_bits((torch.rand(M, 256, generator=gen) > 0.5).cuda())
+    m2 = torch.zeros(M, 256, dtype=torch.bfloat16, device="cuda"); m2._dhaug_bits = fused.encode_bits((torch.rand(M, 256, generator=gen) > 0.5).cuda())
+    g = _bf(torch.randn(M, 256, generator=gen)).cuda()
+
+    def run():
+        y1, y2 = ops.gemm_block2(x, W1, W2, m1, m2, 1, 0.0)
+        z = ops.gemm_nt_dmask(x, W1, 256, 256, m1, 1, 0.0)
+        dw = ops.gemm_tn(g, x, 256, 256)
+        return y1, y2, z, dw
+
+    ref = run()
+    L = ops._lib.lib()
+    assert L.dhaug_set_workgroup_cap(0) == 0
+    with ops.workgroup_cap(64):
+        assert L.dhaug_set_workgroup_cap(64) == 64
+        got = run()
+    assert L.dhaug_set_workgroup_cap(0) == 0                                  # restored by the context manager
+    for a, b in zip(got[:3], ref[:3]):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    assert (got[3] - ref[3]).abs().max().item() <= 1e-4 * ref[3].abs().max().item()   # (other partial sums: fp32 rounding only)
+    assert L.dhaug_set_workgroup_cap(300) != 0 and L.dhaug_set_workgroup_cap(0) == 0  # out of range: an error code, nothing set
+
+
 @pytest.mark.parametrize("M,nb", [(32, 2), (32 * 37, 3), (32 * 256 * 2 + 64, 3), (65536, 3)])
 def test_gemm_block2_stack_equals_single_blocks(ops, M, nb):
     """a chain of blocks in one launch (dhaug_gemm_block2_stack_bf16: a workgroup walks its row tiles through block 0, reloads

@@ -11,6 +11,8 @@ from dhaug_amd.common.camera import camera_params9
 from dhaug_amd.common.h36m_dataset import h36m_cameras_extrinsic_params, h36m_cameras_intrinsic_params
 
 B, D = 65536, 256
+if os.environ.get("CAP"):
+    ops._lib.lib().dhaug_set_workgroup_cap(int(os.environ["CAP"]))       # persistent launches on a part of the card
 args = synth_args(B, D)
 fk = Forward_Kinematics_DH_Model(args, ["S1"], None)
 m = T.my_get_poseFk_model(args, None, fk)
