@@ -1625,7 +1625,9 @@ __global__ __launch_bounds__(512, 1) void gemm_block2_kernel(Block2Args p) {
         // ---- finished images out as whole 512-byte rows (four 16-byte chunks per thread): stage A's waves take Y1 of tile i-1
         // AFTER their matrix phase, stage B's take Y2 of tile i-2 BEFORE theirs -- the two waves of a SIMD are then in
         // different phases (one on the matrix pipe, the other on LDS / the vector-memory path) instead of queueing for the
-        // same unit twice per tile.  Measured on the first version (every wave streaming first; phases switched off one by one
+        // same unit twice per tile.  (Giving ALL copies to stage A's waves and ALL row stores to stage B's -- so that a wait for
+        // copies never waits for older stores in the same in-order queue -- was measured too: 88.5 us, stage B's chain becomes
+        // the long one.)  Measured on the first version (every wave streaming first; phases switched off one by one
         // through a run-time flag, 3B rows): they simply added up -- 21.7 us of launch + loop, + 12 epilogue, + 23 matrix, + 17 row
         // stores, + 12 copies = 86; with the offset 77.6.
         auto stream_out = [&]() {
