@@ -62,7 +62,8 @@ class MlpUnit(ctypes.Structure):
     """struct dhaug_mlp_unit (include/dhaug.h)"""
     _fields_ = [("kind", _i32), ("flags", _i32), ("src", _i32), ("dst", _i32), ("res", _i32), ("src2", _i32),
                 ("ksteps2", _i32), ("ksteps", _i32), ("n", _i32), ("act", _i32), ("slope", _f32), ("cols", _i32),
-                ("ld", _i64), ("g", _vp), ("w", _vp), ("w2", _vp), ("bias", _vp), ("save", _vp), ("save_ld", _i64), ("bits", _vp)]
+                ("ld", _i64), ("g", _vp), ("w", _vp), ("w2", _vp), ("bias", _vp), ("save", _vp), ("save_ld", _i64), ("bits", _vp),
+                ("save_rows", _i64)]
 
 
 class WfragDesc(ctypes.Structure):

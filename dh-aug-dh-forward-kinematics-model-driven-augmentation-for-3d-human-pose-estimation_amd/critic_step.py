@@ -35,6 +35,9 @@ FUSED_STEP_FORWARD = os.environ.get("DHAUG_NO_FUSED_STEP_FORWARD") is None
 # sweep 4: the weight / bias gradients of all layers up to 256 wide in ONE grouped launch (ops.gemm_tn_group) instead of one
 # contraction launch per layer
 TN_GROUP = os.environ.get("DHAUG_NO_TN_GROUP") is None
+# the forward-with-save launch writes the block layers' images for the real / fake rows only (the interpolated rows are read
+# through their sign bits alone, and receive the tangents): a third fewer stores in the launch that pays most for them
+SKIP_XHAT_SAVES = os.environ.get("DHAUG_SAVE_ALL_ROWS") is None
 RANK1 = os.environ.get("DHAUG_NO_RANK1") is None
 # sweep 4 in two parts: the real / fake rows' contractions are launched on a side stream right behind the backward chain and
 # run (HBM-bound) beside the penalty and the launch-bound tangent sweep; the interpolated rows' part follows the tangents
@@ -396,7 +399,7 @@ def step_d2(D, optimizerD, real, fake, alpha, lam, prec=None):
     B2 = 2 * B
     from . import fused
     if m.bf16 and FUSED_STEP_FORWARD and fused.step_forward_supported(D):
-        r = fused.critic2d_forward_save(D, X)
+        r = fused.critic2d_forward_save(D, X, save_rows=B2 if (SKIP_XHAT_SAVES and fused.partial_save_ok(B2)) else 0)
         (d1, d2, d3, d4, dl), logits = r["d"], r["logits"]
     else:
         d1 = L[0].fwd(m, X)
@@ -554,12 +557,13 @@ def step_d3(D, optimizerD, real, fake, alpha, lam, prec=None):
     from . import fused
     use = m.bf16 and FUSED_STEP_FORWARD and fused.step_forward_supported(D)
     kf, kb = ops.kcs_forward(X, True, f32=True, bf16_ld=32 if use else 0)    # fp32 features (first layer's weight gradient) [+ bf16 operand]
+    sr = 2 * B if (use and SKIP_XHAT_SAVES and fused.partial_save_ok(2 * B)) else 0
     return step_branchnet(
         m, optimizerD, br, _Lin(D.merge_previous[0], RELU), _Block(D.merge_block1), _Lin(D.output, NONE), X, B, lam,
         feats=lambda X: [kf, X],
         input_grad=lambda gs: ops.add_f32(ops.kcs_backward(xh, gs[0], True), gs[1]),      # KCS^T path + pose path
         tangents=lambda v: [ops.kcs_jvp(xh, v, True), v],
-        fwd=(lambda: fused.critic3d_forward_save(D, X, kb)) if use else None)
+        fwd=(lambda: fused.critic3d_forward_save(D, X, kb, save_rows=sr)) if use else None)
 
 
 def step_m3(D, optimizerD, real, fake, alpha, lam, prec=None):

@@ -71,6 +71,7 @@ struct Unit {
     const float* bias;          // GEMM: fp32 [32 * nslices] (zero padded)
     uint16_t* save;             // GEMM, optional: the layer's output image also goes to global memory (M, save_ld) bf16,
     long long save_ld;          // columns [0, ceil16(N)) -- the training step's forward-with-save
+    long long save_rows;        // rows [0, save_rows) of the output are saved (the host stores M for "all", 0 for "none")
     uint32_t* bits;             // full-width layer inside a run, optional: one bit per output element, (y > 0) -- the mask
                                 // act'(y) of the backward / tangent sweeps in 1/16 of the bytes (see DHAUG_MLP_BITS in dhaug.h)
 };
@@ -635,7 +636,7 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, fx[s & 3]), sv, sv_rot + 32 * k, 0, 0);
                 if (false)
 #elif !defined(SAVE_ABL_NOSTORE)
-                if (SAVE && !LEAD && t == 0 && mt == wave)               // chunk 2k+h of the lane's row: this k-step's fragment
+                if (SAVE && !LEAD && t == 0 && mt == wave && sv_ld != 0) // chunk 2k+h of the lane's row: this k-step's fragment
 #else
                 if (false)
 #endif
@@ -854,8 +855,14 @@ __device__ __forceinline__ void gemm_stack(UnitPtr lead, int lead_ks, UnitPtr fi
     (void)tid;
     auto save_of = [&](UnitPtr su, bool on, int& ld_bytes) -> __amdgpu_buffer_rsrc_t {
         uint16_t* base = (SAVE && on) ? su->save : nullptr;
-        const long long ld = (SAVE && on) ? su->save_ld : 0;
-        const long long rows = M - m0 < MLP_BM ? M - m0 : MLP_BM;
+        long long ld = (SAVE && on) ? su->save_ld : 0;
+        // rows [0, save_rows) only (the interpolated rows of a step's 3B-row batch leave nothing but their sign bits): a tile
+        // beyond them gets ld = 0 -- stack_layer then issues no store instructions at all (a nullified store still costs its
+        // issue on the vector-memory path: 426 us with every store dropped by the range check against 333 without the
+        // instructions, 3D critic at 3B rows)
+        const long long lim = (SAVE && on) ? su->save_rows : 0;
+        long long rows = lim - m0 < MLP_BM ? lim - m0 : MLP_BM;
+        if (rows <= 0) { rows = 0; ld = 0; base = nullptr; }
         ld_bytes = (int)(ld * 2);
 #if defined(SAVE_ABL_NOSTORE) || defined(SAVE_ABL_NULLSTORES)          /* timing only: every store of the run falls outside its resource */
         base = nullptr;
@@ -1178,9 +1185,9 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void fused_mlp_kernel(Program prog,
                     lds_barrier();
                     if (SAVE) {                                              // (inside the run every layer saved its input)
                         UnitPtr lu = tu - 1;                                 // the run's last layer: nobody in the run read its image
-                        if (lu->save != nullptr) save_image(lu->dst, lu->save, lu->save_ld, (lu->N + 15) & ~15, smem, m0, M, tid);
+                        if (lu->save != nullptr) save_image(lu->dst, lu->save, lu->save_ld, (lu->N + 15) & ~15, smem, m0, lu->save_rows, tid);
                         if (tail == 2 && tu->save != nullptr)
-                            save_image(tu->dst, tu->save, tu->save_ld, (tu->N + 15) & ~15, smem, m0, M, tid);
+                            save_image(tu->dst, tu->save, tu->save_ld, (tu->N + 15) & ~15, smem, m0, tu->save_rows, tid);
                     }
                     if (tail == 1) {
                         store_output(tu, smem, m0, M, tid);
@@ -1214,7 +1221,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void fused_mlp_kernel(Program prog,
             }
             lds_barrier();
             if (SAVE && kind == U_GEMM && !(plan & (PLAN_OUT | PLAN_DOT)) && u->save != nullptr)
-                save_image(u->dst, u->save, u->save_ld, (u->N + 15) & ~15, smem, m0, M, tid);
+                save_image(u->dst, u->save, u->save_ld, (u->N + 15) & ~15, smem, m0, u->save_rows, tid);
             DHAUG_LSTAMP(MLP_MAX_UNITS + 64 + 4 * ui + 3)
         }
         DHAUG_STAMP(nunits)
@@ -1364,6 +1371,7 @@ int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* 
         u.ksteps = s.ksteps; u.N = s.n; u.act = s.act; u.slope = s.slope; u.cols = s.cols; u.ld = s.ld;
         u.g = s.g; u.w = static_cast<const uint16_t*>(s.w); u.w2 = static_cast<const uint16_t*>(s.w2); u.bias = s.bias;
         u.save = static_cast<uint16_t*>(s.save); u.save_ld = s.save_ld;
+        u.save_rows = s.save_rows == 0 ? M : (s.save_rows < 0 ? 0 : (s.save_rows < M ? s.save_rows : M));
         u.bits = static_cast<uint32_t*>(s.bits);
         DHAUG_CHECK(u.kind >= U_LOAD_F32 && u.kind <= U_GEMM, DHAUG_EINVAL);
         if (u.bits != nullptr) {                                             // (written by full-width run layers only: checked below)

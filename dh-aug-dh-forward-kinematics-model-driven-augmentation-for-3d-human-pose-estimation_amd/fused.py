@@ -73,11 +73,14 @@ class _Layer:
 
 
 def _unit(kind, flags=0, src=-1, dst=-1, res=-1, src2=-1, ksteps2=0, ksteps=0, n=0, act=0, slope=0.0, cols=0, ld=0,
-          g=None, w=None, w2=None, bias=None, save=None, bits=False):
+          g=None, w=None, w2=None, bias=None, save=None, bits=False, save_rows=0):
     u = _lib.MlpUnit()
     if save is not None:                                      # forward-with-save: the layer's image also goes to `save`
         assert save.dtype == torch.bfloat16 and save.stride(1) == 1
         u.save, u.save_ld = save.data_ptr(), save.stride(0)
+        # rows [0, save_rows) only (0: all, < 0: none) -- honoured only where the sign bits are written too: whoever asks for
+        # fewer rows reads the other rows' masks from the bits
+        u.save_rows = int(save_rows) if (bits and SIGN_BITS) else 0
         if bits and SIGN_BITS:
             # the layer also leaves (y > 0) as one bit per element (struct dhaug_mlp_unit.bits): the backward / tangent sweeps
             # read that instead of the bf16 image (critic_step.py); the array rides on the saved tensor
@@ -137,9 +140,9 @@ def encode_bits(mask):
     return torch.from_numpy(w.reshape(-1).view(np.int32).copy()).to(mask.device)
 
 
-def _gemm(layer, src, dst, act, slope=0.0, res=-1, out=None, src2=-1, save=None, bits=False):
+def _gemm(layer, src, dst, act, slope=0.0, res=-1, out=None, src2=-1, save=None, bits=False, save_rows=0):
     kw = dict(src=src, ksteps=layer.ksteps[0], n=layer.N, act=act, slope=slope, w=layer.w[0], bias=layer.bias, res=res, save=save,
-              bits=bits)
+              bits=bits, save_rows=save_rows)
     if len(layer.w) == 2:
         kw.update(src2=src2, ksteps2=layer.ksteps[1], w2=layer.w[1])
     if out is not None:
@@ -316,11 +319,17 @@ def _d3s_program(D, L, inputs, M):
     m0, mh, m1 = _empty16(M, mp.N, dev), _empty16(M, mp.N, dev), _empty16(M, mp.N, dev)
     logits = torch.empty((M, 1), dtype=torch.float32, device=dev)
 
+    # save_rows: rows of the BLOCK layers' outputs that are written as bf16 images (0: all).  The critic step passes 2B of its
+    # 3B rows: the interpolated rows' activations are read by nothing -- their masks are the sign bits, their rows of the
+    # buffers receive the tangents (critic_step.py) -- and the G step passes -1 (it only needs masks).  The lead layers and the
+    # 100-wide top keep every row: their masks are read as images.
+    sr = inputs.get("save_rows", 0)
+
     def branch(u, b, first, names):
         u.append(_gemm(L[first], 1, 0, ACT_RELU, save=y[b][0], bits=True))
         for i, n in enumerate(names):
-            u.append(_gemm(L[n + ".fc1"], 0, 1, ACT_RELU, save=h[b][i], bits=True))
-            u.append(_gemm(L[n + ".fc2"], 1, 0, ACT_RELU, res=0, save=y[b][i + 1], bits=True))
+            u.append(_gemm(L[n + ".fc1"], 0, 1, ACT_RELU, save=h[b][i], bits=True, save_rows=sr))
+            u.append(_gemm(L[n + ".fc2"], 1, 0, ACT_RELU, res=0, save=y[b][i + 1], bits=True, save_rows=sr))
 
     u = [_unit(LOAD_BF16, dst=1, cols=32, ld=kcs.stride(0), g=kcs)]
     branch(u, 0, "special_KCS_previous.0", ("special_KCS_block1", "special_KCS_block2", "special_KCS_block3"))
@@ -349,8 +358,8 @@ def _d2s_program(D, L, inputs, M):
     logits = torch.empty((M, 1), dtype=torch.float32, device=dev)
     u = [_unit(LOAD_F32, dst=1, cols=32, ld=x.stride(0), g=x),
          _gemm(L["pose_layer_1"], 1, 0, ACT_LRELU, s, save=d[0], bits=True),
-         _gemm(L["pose_layer_2"], 0, 1, ACT_LRELU, s, save=d[1], bits=True),
-         _gemm(L["pose_layer_3"], 1, 0, ACT_LRELU, s, res=0, save=d[2], bits=True),
+         _gemm(L["pose_layer_2"], 0, 1, ACT_LRELU, s, save=d[1], bits=True, save_rows=inputs.get("save_rows", 0)),    # (see _d3s_program)
+         _gemm(L["pose_layer_3"], 1, 0, ACT_LRELU, s, res=0, save=d[2], bits=True, save_rows=inputs.get("save_rows", 0)),
          _gemm(L["pose_layer_4"], 0, 1, ACT_NONE, save=d[3]),
          _gemm(L["layer_last"], 1, 0, ACT_LRELU, s, save=d[4], bits=True),
          _gemm(L["layer_pred"], 0, 1, ACT_NONE, out=logits)]
@@ -371,13 +380,20 @@ def step_forward_supported(D):
     return False
 
 
-def critic3d_forward_save(D, x, kcs):
+def critic3d_forward_save(D, x, kcs, save_rows=0):
     """x (M,48) fp32 root-relative poses, kcs (M,32) bf16 operand -> saved activations + logits (see _d3s_program)"""
-    return _net(D, D3S, "bf16", "+save").run(dict(x=x, kcs=kcs), x.shape[0])
+    return _net(D, D3S, "bf16", "+save").run(dict(x=x, kcs=kcs, save_rows=save_rows), x.shape[0])
 
 
-def critic2d_forward_save(D, x):
-    return _net(D, D2S, "bf16", "+save").run(dict(x=x), x.shape[0])
+def critic2d_forward_save(D, x, save_rows=0):
+    return _net(D, D2S, "bf16", "+save").run(dict(x=x, save_rows=save_rows), x.shape[0])
+
+
+def partial_save_ok(rows):
+    """may a step ask the forward-with-save programs to write only `rows` rows of the block layers' images?  Only if every
+    consumer of the other rows' masks reads the sign bits (32-row tiles, bits written and consumed)"""
+    from . import ops
+    return SIGN_BITS and ops.DBITS and rows % 32 == 0
 
 
 def generator_head(G, z, mode="bf16"):

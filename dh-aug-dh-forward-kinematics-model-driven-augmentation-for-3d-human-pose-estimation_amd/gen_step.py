@@ -82,7 +82,8 @@ def _d3_value_grad(m, D, fc, coef):
     N = fc.shape[0]
     use = m.bf16 and CS.FUSED_STEP_FORWARD and fused.step_forward_supported(D)
     kf, kb = ops.kcs_forward(fc, True, f32=True, bf16_ld=32 if use else 0)
-    s = net.forward(m, [kf, fc], fwd=(lambda: fused.critic3d_forward_save(D, fc, kb)) if use else None)
+    sr = -1 if (CS.SKIP_XHAT_SAVES and fused.partial_save_ok(N)) else 0          # (only masks are read back: the block layers leave their sign bits)
+    s = net.forward(m, [kf, fc], fwd=(lambda: fused.critic3d_forward_save(D, fc, kb, save_rows=sr)) if use else None)
     gk, gp = net.input_grads(m, s, _const_seed(N, coef / N, m, fc.device))
     return s["logits"], ops.add_f32(ops.kcs_backward(fc, gk, True), gp)
 
@@ -95,7 +96,7 @@ def _d2_value_grad(m, D, x, coef):
          CS._Lin(D.pose_layer_4, NONE), CS._Lin(D.layer_last, LRELU, sl), CS._Lin(D.layer_pred, NONE)]
     N = x.shape[0]
     if m.bf16 and CS.FUSED_STEP_FORWARD and fused.step_forward_supported(D):
-        r = fused.critic2d_forward_save(D, x)
+        r = fused.critic2d_forward_save(D, x, save_rows=-1 if (CS.SKIP_XHAT_SAVES and fused.partial_save_ok(N)) else 0)
         (d1, d2, d3, d4, dl), logits = r["d"], r["logits"]
     else:
         d1 = L[0].fwd(m, x)

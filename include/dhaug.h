@@ -369,6 +369,10 @@ typedef struct dhaug_mlp_unit {
                                   /* 32-row tile T covers row 32 T + (l & 31), features 32 (w + 4 t) + 8 g + 4 (l >> 5) + e;   */
                                   /* element j = 16 t + 4 g + e sits at bit j/2 (j even) or 16 + j/2 (j odd).  Consumed by    */
                                   /* dhaug_gemm_bf16_dbits.  A unit that is not such a layer -> DHAUG_EUNSUPPORTED.          */
+    int64_t save_rows;            /* with `save`: 0 = every row is saved; n > 0 = rows [0, n) only; < 0 = none (the sign bits are   */
+                                  /* written for every row regardless).  The interpolated rows of a critic step's batch are read   */
+                                  /* back by nothing but their masks: R/models_Fk_GAN/Fk_discriminator.py:205-231 needs D(x_hat)'s  */
+                                  /* input gradient, not its activations.                                                          */
 } dhaug_mlp_unit;
 
 /* dhaug_pack_wfrag for every layer of a network in one launch (after each optimizer step of a training loop that runs the

@@ -345,3 +345,37 @@ def test_block_launches_equal_single_layer_launches(M, tag):
     for k in g0:
         if g0[k].numel() > 1:
             assert torch.equal(g1[k], g0[k]), k
+
+
+@pytest.mark.parametrize("tag", ["d3", "d2"])
+def test_step_reads_no_unwritten_memory(M, tag, monkeypatch):
+    """the forward-with-save launch writes the block layers' images for the real / fake rows only, the interpolated rows are
+    read through their sign bits and then receive the tangents (critic_step.SKIP_XHAT_SAVES): with every torch.empty buffer
+    pre-filled with NaN (or a huge value) the step's gradients, scalars and stepped weights are the same bits as without --
+    nothing reads a row nobody wrote.  (tools/poison.py runs the same probe over whole iterations, eager and as hipGraphs.)"""
+    B, D = 2048, 256
+    args = _args(B, D)
+    shapes = GU.shapes_d3(D) if tag == "d3" else GU.shapes_d2(D)
+    sd = GU.seeded_state_dict(shapes, 51)
+    data = _data(tag, B, 13)
+    assert M.cs.SKIP_XHAT_SAVES
+    ref = _run(M, tag, args, sd, "bf16", data, True)
+    real_empty, real_empty_like = torch.empty, torch.empty_like
+    for poison in (float("nan"), 3.0e38):
+        def fill(t):
+            if t.is_cuda and t.numel():
+                if t.dtype.is_floating_point:
+                    t.fill_(poison)
+                else:
+                    t.view(torch.uint8).fill_(255)
+            return t
+        monkeypatch.setattr(torch, "empty", lambda *a, **k: fill(real_empty(*a, **k)))
+        monkeypatch.setattr(torch, "empty_like", lambda *a, **k: fill(real_empty_like(*a, **k)))
+        got = _run(M, tag, args, sd, "bf16", data, True)
+        monkeypatch.setattr(torch, "empty", real_empty)
+        monkeypatch.setattr(torch, "empty_like", real_empty_like)
+        assert got[0] == ref[0] and got[1] == ref[1], (tag, poison)
+        for k in ref[2]:
+            if ref[2][k].numel() > 1:
+                assert torch.equal(got[2][k], ref[2][k]), (tag, poison, k)
+                assert torch.equal(got[3][k], ref[3][k]), (tag, poison, k)
