@@ -321,12 +321,12 @@ def _d3s_program(D, L, inputs, M):
 
     # save_rows: rows of the BLOCK layers' outputs that are written as bf16 images (0: all).  The critic step passes 2B of its
     # 3B rows: the interpolated rows' activations are read by nothing -- their masks are the sign bits, their rows of the
-    # buffers receive the tangents (critic_step.py) -- and the G step passes -1 (it only needs masks).  The lead layers and the
-    # 100-wide top keep every row: their masks are read as images.
+    # buffers receive the tangents (critic_step.py) -- and the G step passes -1 (it only needs masks).  The 100-wide top keeps
+    # every row: its masks are read as images.
     sr = inputs.get("save_rows", 0)
 
     def branch(u, b, first, names):
-        u.append(_gemm(L[first], 1, 0, ACT_RELU, save=y[b][0], bits=True))
+        u.append(_gemm(L[first], 1, 0, ACT_RELU, save=y[b][0], bits=True, save_rows=sr))
         for i, n in enumerate(names):
             u.append(_gemm(L[n + ".fc1"], 0, 1, ACT_RELU, save=h[b][i], bits=True, save_rows=sr))
             u.append(_gemm(L[n + ".fc2"], 1, 0, ACT_RELU, res=0, save=y[b][i + 1], bits=True, save_rows=sr))
@@ -357,7 +357,7 @@ def _d2s_program(D, L, inputs, M):
     d = [_empty16(M, Dw, dev) for _ in range(5)]
     logits = torch.empty((M, 1), dtype=torch.float32, device=dev)
     u = [_unit(LOAD_F32, dst=1, cols=32, ld=x.stride(0), g=x),
-         _gemm(L["pose_layer_1"], 1, 0, ACT_LRELU, s, save=d[0], bits=True),
+         _gemm(L["pose_layer_1"], 1, 0, ACT_LRELU, s, save=d[0], bits=True, save_rows=inputs.get("save_rows", 0)),
          _gemm(L["pose_layer_2"], 0, 1, ACT_LRELU, s, save=d[1], bits=True, save_rows=inputs.get("save_rows", 0)),    # (see _d3s_program)
          _gemm(L["pose_layer_3"], 1, 0, ACT_LRELU, s, res=0, save=d[2], bits=True, save_rows=inputs.get("save_rows", 0)),
          _gemm(L["pose_layer_4"], 0, 1, ACT_NONE, save=d[3]),

@@ -304,6 +304,12 @@ def gemm_nt_dmask(A, B, N, K, dmask, dmask_act, dmask_slope=0.0, res_bf16=None, 
         return out
     bits = getattr(dmask, "_dhaug_bits", None)
     assert bits is None or bits.device == A.device, "sign bits must live on the operands' device"
+    if (bits is not None and DBITS and N == 256 and K in (16, 32, 48, 64, 112, 128) and res_bf16 is None and dmask_act != 0
+            and M > 0 and M % 32 == 0 and A.stride(0) % 8 == 0 and out.stride(0) % 8 == 0):
+        # a 256-wide layer behind a NARROW one (the tangent through a branch's first layer): the same mask bits, K < 256
+        _lib.call("dhaug_gemm_bf16_dbits_wide", _p(A), A.stride(0), _p(B), B.stride(0), _p(bits), 0, dmask_act, float(dmask_slope),
+                  _p(out), out.stride(0), M, N, K, _stream())
+        return out
     if (bits is not None and DBITS and N == 256 and K == 256 and M % 32 == 0 and M > 0 and dmask_act != 0
             and A.stride(0) % 8 == 0 and out.stride(0) % 8 == 0):
         # the mask as the sign-bit array its forward-with-save layer left beside the image: 32 bytes per row instead of 512
