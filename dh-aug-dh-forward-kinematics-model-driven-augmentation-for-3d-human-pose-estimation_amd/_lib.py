@@ -32,6 +32,7 @@ SIGNATURES = {
     "dhaug_gemm_bf16_dbits": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _f32, _vp, _i64, _i64, _vp],
     "dhaug_gemm_block2_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _i64, _vp, _i64, _i64, _vp],
     "dhaug_set_workgroup_cap": [_i32],
+    "dhaug_rank1_bits_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _f32, _vp],
     "dhaug_gemm_bf16_dbits_wide": [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _i64, _i64, _i64, _i64, _vp],
     "dhaug_gemm_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i32,
                         _f32, _vp],

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void rank1_mask_kernel(const uint16_t* __restr
                                                          const uint16_t* __restrict__ w, long long ld_w,
                                                          const uint16_t* __restrict__ mask, long long ld_mask,
                                                          uint16_t* __restrict__ out, long long ld_out, long long M, int N, int pad,
-                                                         float dneg) {
+                                                         float dneg, const uint32_t* __restrict__ bits) {
     // the weight row once per workgroup (it is a strided column of the packed matrix: read per element in the loop, every
     // thread waited for eight 2-byte gathers -- 54 us for the 88 MB of the 3D critic's logit layer, 1.6 TB/s)
     __shared__ float sw[DHAUG_RANK1_MAX_N];
@@ -341,8 +341,21 @@ __global__ __launch_bounds__(256) void rank1_mask_kernel(const uint16_t* __restr
         const long long r = i / cpr;
         const int c0 = (int)(i - r * cpr) * 8;
         const float sv = dhaug_bf16_to_f32(seed[r * ld_seed]);
-        const uint4 mk = *reinterpret_cast<const uint4*>(mask + r * ld_mask + c0);
-        const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
+        uint32_t mw[4];                                        // per element pair: (y > 0) of the even / odd element in bits 0 / 16
+        if (bits != nullptr) {
+            // the mask as sign bits (dhaug_mlp_unit.bits, a 256-wide layer): features c0 .. c0+3 sit in the word of the row's
+            // lane h = 0, c0+4 .. c0+7 in the word of lane h = 1, pairs 8t + 2g (+1) at bit p / 16 + p
+            const long long wi = ((r >> 5) * 4 + ((c0 >> 5) & 3)) * 64 + (r & 31);
+            const uint32_t w0 = bits[wi], w1 = bits[wi + 32];
+            const int p0 = 8 * (c0 >> 7) + 2 * ((c0 & 31) >> 3);
+            mw[0] = ((w0 >> p0) & 1u) | (((w0 >> (16 + p0)) & 1u) << 16);
+            mw[1] = ((w0 >> (p0 + 1)) & 1u) | (((w0 >> (17 + p0)) & 1u) << 16);
+            mw[2] = ((w1 >> p0) & 1u) | (((w1 >> (16 + p0)) & 1u) << 16);
+            mw[3] = ((w1 >> (p0 + 1)) & 1u) | (((w1 >> (17 + p0)) & 1u) << 16);
+        } else {
+            const uint4 mk = *reinterpret_cast<const uint4*>(mask + r * ld_mask + c0);
+            mw[0] = mk.x; mw[1] = mk.y; mw[2] = mk.z; mw[3] = mk.w;
+        }
         uint32_t ow[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -609,7 +622,22 @@ int dhaug_rank1_mask_bf16(const uint16_t* seed, int64_t ld_seed, const uint16_t*
     DHAUG_CHECK(dhaug_aligned16(mask) && dhaug_aligned16(out), DHAUG_EALIGN);
     hipLaunchKernelGGL(rank1_mask_kernel, dim3(grid1d(M * (pad_cols >> 3), 256)), dim3(256), 0, (hipStream_t)stream, seed,
                        (long long)ld_seed, w, (long long)ld_w, mask, (long long)ld_mask, out, (long long)ld_out, (long long)M, (int)N,
-                       (int)pad_cols, mask_act == DHAUG_ACT_RELU ? 0.0f : mask_slope);
+                       (int)pad_cols, mask_act == DHAUG_ACT_RELU ? 0.0f : mask_slope, (const uint32_t*)nullptr);
+    return dhaug_launch_status();
+}
+
+/* see include/dhaug.h */
+int dhaug_rank1_bits_bf16(const uint16_t* seed, int64_t ld_seed, const uint16_t* w, int64_t ld_w, const uint32_t* bits,
+                          uint16_t* out, int64_t ld_out, int64_t M, int mask_act, float mask_slope, void* stream) {
+    DHAUG_CHECK(M >= 0, DHAUG_EINVAL);
+    DHAUG_CHECK(mask_act == DHAUG_ACT_RELU || mask_act == DHAUG_ACT_LRELU, DHAUG_EINVAL);
+    if (M == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(seed); DHAUG_CHECK_PTR(w); DHAUG_CHECK_PTR(bits); DHAUG_CHECK_PTR(out);
+    DHAUG_CHECK(ld_seed >= 1 && ld_w >= 1 && ld_out >= 256 && ld_out % 8 == 0, DHAUG_EALIGN);
+    DHAUG_CHECK(dhaug_aligned16(out) && dhaug_aligned16(bits), DHAUG_EALIGN);
+    hipLaunchKernelGGL(rank1_mask_kernel, dim3(grid1d(M * 32, 256)), dim3(256), 0, (hipStream_t)stream, seed, (long long)ld_seed, w,
+                       (long long)ld_w, (const uint16_t*)nullptr, 0LL, out, (long long)ld_out, (long long)M, 256, 256,
+                       mask_act == DHAUG_ACT_RELU ? 0.0f : mask_slope, bits);
     return dhaug_launch_status();
 }
 

@@ -73,14 +73,15 @@ class _Layer:
 
 
 def _unit(kind, flags=0, src=-1, dst=-1, res=-1, src2=-1, ksteps2=0, ksteps=0, n=0, act=0, slope=0.0, cols=0, ld=0,
-          g=None, w=None, w2=None, bias=None, save=None, bits=False, save_rows=0):
+          g=None, w=None, w2=None, bias=None, save=None, bits=False, save_rows=0, unmasked=False):
     u = _lib.MlpUnit()
     if save is not None:                                      # forward-with-save: the layer's image also goes to `save`
         assert save.dtype == torch.bfloat16 and save.stride(1) == 1
         u.save, u.save_ld = save.data_ptr(), save.stride(0)
         # rows [0, save_rows) only (0: all, < 0: none) -- honoured only where the sign bits are written too: whoever asks for
         # fewer rows reads the other rows' masks from the bits
-        u.save_rows = int(save_rows) if (bits and SIGN_BITS) else 0
+        # (or where the layer has no activation -- `unmasked`: no mask is ever read from its image)
+        u.save_rows = int(save_rows) if ((bits and SIGN_BITS) or unmasked) else 0
         if bits and SIGN_BITS:
             # the layer also leaves (y > 0) as one bit per element (struct dhaug_mlp_unit.bits): the backward / tangent sweeps
             # read that instead of the bf16 image (critic_step.py); the array rides on the saved tensor
@@ -142,7 +143,7 @@ def encode_bits(mask):
 
 def _gemm(layer, src, dst, act, slope=0.0, res=-1, out=None, src2=-1, save=None, bits=False, save_rows=0):
     kw = dict(src=src, ksteps=layer.ksteps[0], n=layer.N, act=act, slope=slope, w=layer.w[0], bias=layer.bias, res=res, save=save,
-              bits=bits, save_rows=save_rows)
+              bits=bits, save_rows=save_rows, unmasked=(act == ACT_NONE and save is not None))
     if len(layer.w) == 2:
         kw.update(src2=src2, ksteps2=layer.ksteps[1], w2=layer.w[1])
     if out is not None:
@@ -360,8 +361,8 @@ def _d2s_program(D, L, inputs, M):
          _gemm(L["pose_layer_1"], 1, 0, ACT_LRELU, s, save=d[0], bits=True, save_rows=inputs.get("save_rows", 0)),
          _gemm(L["pose_layer_2"], 0, 1, ACT_LRELU, s, save=d[1], bits=True, save_rows=inputs.get("save_rows", 0)),    # (see _d3s_program)
          _gemm(L["pose_layer_3"], 1, 0, ACT_LRELU, s, res=0, save=d[2], bits=True, save_rows=inputs.get("save_rows", 0)),
-         _gemm(L["pose_layer_4"], 0, 1, ACT_NONE, save=d[3]),
-         _gemm(L["layer_last"], 1, 0, ACT_LRELU, s, save=d[4], bits=True),
+         _gemm(L["pose_layer_4"], 0, 1, ACT_NONE, save=d[3], save_rows=inputs.get("save_rows", 0)),
+         _gemm(L["layer_last"], 1, 0, ACT_LRELU, s, save=d[4], bits=True, save_rows=inputs.get("save_rows", 0)),
          _gemm(L["layer_pred"], 0, 1, ACT_NONE, out=logits)]
     return u, dict(d=d, logits=logits)
 

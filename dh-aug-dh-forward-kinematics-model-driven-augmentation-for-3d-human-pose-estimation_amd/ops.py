@@ -535,6 +535,12 @@ def rank1_mask(seed, w_col, mask, n, act, slope=0.0, out=None):
     M, pad = mask.shape[0], min(mask.shape[1], ceil_to(n, 16))
     if out is None:
         out = torch.empty((M, ceil_to(n, 16)), dtype=BF16, device=mask.device)
+    bits = getattr(mask, "_dhaug_bits", None)
+    if bits is not None and DBITS and n == 256 and act != 0 and out.stride(0) % 8 == 0 and out.shape[1] >= 256:
+        assert bits.device == out.device, "sign bits must live on the operands' device"
+        _lib.call("dhaug_rank1_bits_bf16", _p(seed), seed.stride(0), _p(w_col), w_col.stride(0), _p(bits), _p(out), out.stride(0), M,
+                  act, float(slope), _stream())
+        return out
     _lib.call("dhaug_rank1_mask_bf16", _p(seed), seed.stride(0), _p(w_col), w_col.stride(0), _p(mask), mask.stride(0), _p(out),
               out.stride(0), M, n, pad, act, float(slope), _stream())
     return out

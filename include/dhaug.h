@@ -493,6 +493,9 @@ int dhaug_critic_scalars(const float* logits, int64_t ld, const float* pen, int6
 int dhaug_rank1_mask_bf16(const uint16_t* seed, int64_t ld_seed, const uint16_t* w, int64_t ld_w, const uint16_t* mask, int64_t ld_mask,
                           uint16_t* out, int64_t ld_out, int64_t M, int64_t N, int64_t pad_cols, int mask_act, float mask_slope,
                           void* stream);
+/* The same for a 256-wide hidden layer whose mask is a sign-bit array (struct dhaug_mlp_unit.bits): no mask image is read. */
+int dhaug_rank1_bits_bf16(const uint16_t* seed, int64_t ld_seed, const uint16_t* w, int64_t ld_w, const uint32_t* bits,
+                          uint16_t* out, int64_t ld_out, int64_t M, int mask_act, float mask_slope, void* stream);
 
 /* out = a + b over n fp32 values (the branch contributions to dD/dx_hat of a multi-branch critic). */
 int dhaug_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);

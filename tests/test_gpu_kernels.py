@@ -554,6 +554,25 @@ def test_gemm_nt_dbits_wide_equals_dmask(ops, M, K, nblk):
     assert torch.equal(got2.view(torch.int16), ref2.view(torch.int16))
 
 
+@pytest.mark.parametrize("M,act,slope", [(64, 1, 0.0), (32 * 101, 2, 0.01)])
+def test_rank1_on_sign_bits_equals_mask_image(ops, M, act, slope):
+    """the first backward step through a 1-wide logit layer behind a 256-wide hidden layer: mask as a sign-bit array
+    (dhaug_rank1_bits_bf16) against the mask image (dhaug_rank1_mask_bf16), bit for bit"""
+    from dhaug_amd import fused
+    gen = torch.Generator().manual_seed(M)
+    seed = _bf(torch.randn(M, 16, generator=gen)).cuda()
+    w = _bf(torch.randn(256, 16, generator=gen)).cuda()                       # the layer's weights along dim 0, strided
+    y = _bf(torch.randn(M, 256, generator=gen)).cuda()
+    y[::5, ::3] = 0.0
+    ref = ops.rank1_mask(seed, w[:, 0], y, 256, act, slope)
+    yb = torch.zeros_like(y)
+    yb._dhaug_bits = fused.encode_bits(y.float() > 0)
+    calls = ops._lib.CALLS[0]
+    got = ops.rank1_mask(seed, w[:, 0], yb, 256, act, slope)
+    assert ops._lib.CALLS[0] == calls + 1
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+
+
 def test_workgroup_cap_changes_nothing_but_the_grid(ops):
     """dhaug_set_workgroup_cap: the persistent launches (block kernel, 256-wide layer, grouped weight gradients) on a part of
     the card give the same bits as on the whole card; the previous cap comes back from the setter"""
