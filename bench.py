@@ -428,6 +428,26 @@ def main():
                 k = max(5, min(a.steps, 50 if name != "gan_step" else 10))
                 try:
                     te, ce = timed(steps[name], k, 5 if name == "gan_step" else 3)
+                    if name == "gan_step" and world == 1 and a.graph == "auto":
+                        # the same iterations as captured hipGraphs: the faster form is the one reported (as --workload gan_step
+                        # would pick it); which one wins depends on the box's host (eager issues 137 C-ABI calls per iteration)
+                        try:
+                            from dhaug_amd.graphs import GraphedGanIteration
+                            gg = GraphedGanIteration(T.gan_iteration, args, models, ["S1"], summary)
+
+                            def step_graphed():
+                                gg(real_cam, cam_param, real_2d, it[0] % 5 == 4, (quat, trans, cam9))
+                                it[0] += 1
+                            it[0] = 0
+                            tg, cg = timed(step_graphed, k, 10)              # (warm-up covers both graphs: with / without the G step)
+                            extra["gan_step_eager_ms_per_step"] = te / k * 1e3
+                            extra["gan_step_graph_ms_per_step"] = tg / k * 1e3
+                            extra["gan_step_hip_graph"] = bool(tg < te)
+                            if tg < te:
+                                te, ce = tg, cg
+                            del gg
+                        except Exception as ex:
+                            extra["gan_step_graph_error"] = repr(ex)[:200]
                     extra[name + "_poses_per_s"] = N * world * k / te
                     extra[name + "_ms_per_step"] = te / k * 1e3
                     extra[name + "_c_abi_calls_per_step"] = ce
