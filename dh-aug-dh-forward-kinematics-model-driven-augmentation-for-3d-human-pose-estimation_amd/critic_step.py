@@ -399,7 +399,7 @@ def step_d2(D, optimizerD, real, fake, alpha, lam, prec=None):
     B2 = 2 * B
     from . import fused
     if m.bf16 and FUSED_STEP_FORWARD and fused.step_forward_supported(D):
-        r = fused.critic2d_forward_save(D, X, save_rows=B2 if (SKIP_XHAT_SAVES and fused.partial_save_ok(B2)) else 0)
+        r = fused.critic2d_forward_save(D, X, save_rows=B2 if (SKIP_XHAT_SAVES and fused.partial_save_ok(B)) else 0)
         (d1, d2, d3, d4, dl), logits = r["d"], r["logits"]
     else:
         d1 = L[0].fwd(m, X)
@@ -557,7 +557,7 @@ def step_d3(D, optimizerD, real, fake, alpha, lam, prec=None):
     from . import fused
     use = m.bf16 and FUSED_STEP_FORWARD and fused.step_forward_supported(D)
     kf, kb = ops.kcs_forward(X, True, f32=True, bf16_ld=32 if use else 0)    # fp32 features (first layer's weight gradient) [+ bf16 operand]
-    sr = 2 * B if (use and SKIP_XHAT_SAVES and fused.partial_save_ok(2 * B)) else 0
+    sr = 2 * B if (use and SKIP_XHAT_SAVES and fused.partial_save_ok(B)) else 0
     return step_branchnet(
         m, optimizerD, br, _Lin(D.merge_previous[0], RELU), _Block(D.merge_block1), _Lin(D.output, NONE), X, B, lam,
         feats=lambda X: [kf, X],

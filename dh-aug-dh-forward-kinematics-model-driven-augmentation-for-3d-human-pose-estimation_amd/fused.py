@@ -391,10 +391,12 @@ def critic2d_forward_save(D, x, save_rows=0):
 
 
 def partial_save_ok(rows):
-    """may a step ask the forward-with-save programs to write only `rows` rows of the block layers' images?  Only if every
-    consumer of the other rows' masks reads the sign bits (32-row tiles, bits written and consumed)"""
+    """may a step whose batch is made of `rows`-row parts (real | fake | interpolated; or the G step's one part) ask the
+    forward-with-save programs to leave some parts' block-layer images unwritten?  Only if every consumer of those rows' masks
+    reads the sign bits: bits written and consumed, and every part -- hence every launch over 1, 2 or 3 parts -- made of whole
+    32-row tiles (a launch over rows that are not is served by the kernels that read the mask IMAGE)"""
     from . import ops
-    return SIGN_BITS and ops.DBITS and rows % 32 == 0
+    return SIGN_BITS and ops.DBITS and rows > 0 and rows % 32 == 0
 
 
 def generator_head(G, z, mode="bf16"):

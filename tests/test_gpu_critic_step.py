@@ -379,3 +379,28 @@ def test_step_reads_no_unwritten_memory(M, tag, monkeypatch):
             if ref[2][k].numel() > 1:
                 assert torch.equal(got[2][k], ref[2][k]), (tag, poison, k)
                 assert torch.equal(got[3][k], ref[3][k]), (tag, poison, k)
+
+
+@pytest.mark.parametrize("tag", ["d3", "d2"])
+def test_ragged_batch_keeps_every_saved_row(M, tag, monkeypatch):
+    """B = 48: the two real / fake parts make whole 32-row tiles (96) but the interpolated part does not start a launch over whole
+    tiles (3B = 144), so the backward sweep reads mask IMAGES -- the forward-with-save launch must then write every row
+    (fused.partial_save_ok): the step equals the one with DHAUG_SAVE_ALL_ROWS semantics, and poisoned buffers change nothing"""
+    B, D = 48, 256
+    args = _args(B, D)
+    shapes = GU.shapes_d3(D) if tag == "d3" else GU.shapes_d2(D)
+    sd = GU.seeded_state_dict(shapes, 61)
+    data = _data(tag, B, 17)
+    ref = _run(M, tag, args, sd, "bf16", data, True)
+    monkeypatch.setattr(M.cs, "SKIP_XHAT_SAVES", False)
+    allrows = _run(M, tag, args, sd, "bf16", data, True)
+    monkeypatch.setattr(M.cs, "SKIP_XHAT_SAVES", True)
+    assert ref[0] == allrows[0] and ref[1] == allrows[1]
+    real_empty = torch.empty
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: (lambda t: t.fill_(float("nan")) if (t.is_cuda and t.dtype.is_floating_point and t.numel()) else t)(real_empty(*a, **k)))
+    got = _run(M, tag, args, sd, "bf16", data, True)
+    monkeypatch.setattr(torch, "empty", real_empty)
+    assert got[0] == ref[0] and got[1] == ref[1]
+    for k in ref[2]:
+        if ref[2][k].numel() > 1:
+            assert torch.equal(got[2][k], ref[2][k]) and torch.equal(allrows[2][k], ref[2][k]), (tag, k)
