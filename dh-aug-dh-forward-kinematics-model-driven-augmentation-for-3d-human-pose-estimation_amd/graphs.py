@@ -99,7 +99,10 @@ class GraphedCall:
         return self.out
 
 
-RECORDER = None          # the SegmentedCall being captured, if any: FusedAdam cuts the capture at its collective events
+RECORDER = None          # the SegmentedCall / ForkedCall being captured, if any: FusedAdam cuts the capture at its collective
+                         # events, run_critic_steps forks it where independent chains begin
+import os as _os
+FORKED = _os.environ.get("DHAUG_NO_FORKED_GRAPHS") is None
 
 
 class SegmentedCall:
@@ -175,6 +178,96 @@ class SegmentedCall:
         return self.out
 
 
+class ForkedCall:
+    """fn(*static_inputs) as captured graphs in which INDEPENDENT CHAINS are graphs of their own, replayed side by side.
+
+    The branches of ONE hipGraph do overlap on this HIP release (sweep 4's side branch is worth 0.38 ms of a 7.4 ms single-frame
+    iteration), but four long chains of short kernels -- the video iteration's four critics, ~1 400 nodes -- replay faster as four
+    graphs launched on four streams than as four branches of one graph: 18.9 -> 18.05 ms per iteration (measured).  So while fn
+    is captured, run_critic_steps hands the chains of independent work to fork(): the running capture ends, every chain is
+    captured on its own stream into its own graph (and its own memory pool: the chains' graphs are in flight together), a
+    new capture begins behind them.  Replay: graph | event | the chains' graphs on their streams | join | graph ..."""
+
+    def __init__(self, fn, example_inputs, warmup=2, prologue=None, state=()):
+        self.static_in = [t.clone() if torch.is_tensor(t) else t for t in example_inputs]
+        saved = [t.clone() for t in state]
+        side, cap = capture_streams()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fn(*self.static_in)
+            for t, s in zip(state, saved):
+                t.copy_(s)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if saved:
+            A.bump_weight_epoch()
+        global RECORDER
+        self.items, self.pool, self.cap = [], torch.cuda.graph_pool_handle(), cap
+        self._g = None
+        A.CAPTURE_ID = next(_capture_ids)
+        RECORDER = self
+        try:
+            self.cap.wait_stream(torch.cuda.current_stream())
+            with _CaptureRoot(self.cap), torch.cuda.stream(self.cap):
+                self._begin()
+                if prologue is not None:
+                    prologue()
+                self.out = fn(*self.static_in)
+                self._end()
+            torch.cuda.current_stream().wait_stream(self.cap)
+        finally:
+            RECORDER = None
+            A.CAPTURE_ID = 0
+
+    def _begin(self):
+        self._g = torch.cuda.CUDAGraph()
+        self._g.capture_begin(pool=self.pool)
+
+    def _end(self):
+        self._g.capture_end()
+        self.items.append(("graph", self._g))
+        self._g = None
+
+    def fork(self, chains):
+        """chains: [(stream, fn)] -- independent of each other, dependent only on what was captured so far.  Called on the
+        capture stream; returns [fn()]."""
+        from . import critic_step as CS
+        self._end()
+        subs, outs = [], []
+        root, CS.CAPTURE_ROOT = CS.CAPTURE_ROOT, None          # (a chain's stream is not the stream a fork may start from)
+        try:
+            for st, fn in chains:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(st):
+                    g.capture_begin(pool=torch.cuda.graph_pool_handle())
+                    outs.append(fn())
+                    g.capture_end()
+                subs.append((st, g))
+        finally:
+            CS.CAPTURE_ROOT = root
+        self.items.append(("fork", subs))
+        self._begin()
+        return outs
+
+    def __call__(self, *inputs):
+        for dst, src in zip(self.static_in, inputs):
+            if torch.is_tensor(dst):
+                dst.copy_(src, non_blocking=True)
+        cur = torch.cuda.current_stream()
+        for kind, obj in self.items:
+            if kind == "graph":
+                obj.replay()
+            else:
+                for st, g in obj:
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        g.replay()
+                for st, _ in obj:
+                    cur.wait_stream(st)
+        return self.out
+
+
 class GraphedGanIteration:
     """gan_iteration / video_gan_iteration behind hipGraphs: one graph per (camera, G-step or not).  Call like the eager
     function; the returned tensors live in the graph's static memory (copy what must outlive the next call)."""
@@ -201,7 +294,7 @@ class GraphedGanIteration:
             state = [t for o in opts for t in (o.flat_param, o.exp_avg, o.exp_avg_sq, o.step_dev)]
             counts = [o.step_count for o in opts]
             multi = any(o.world_size() > 1 for o in opts)          # collectives between graph segments
-            g = self.graphs[key] = (SegmentedCall if multi else GraphedCall)(
+            g = self.graphs[key] = (SegmentedCall if multi else (ForkedCall if FORKED else GraphedCall))(
                 run, (inputs_3d, cam_param, inputs_2d), prologue=lambda: [o._repack() for o in opts], state=state)
             for o, c in zip(opts, counts):                     # (host-side bookkeeping of the warm-up calls)
                 o.step_count = c

@@ -229,6 +229,20 @@ def run_critic_steps(steps, optimizers, interleave, long_rows=False):
         for i, (_, fn) in enumerate(steps):
             res[i] = fn()
         return res
+    from .. import graphs
+    rec = graphs.RECORDER
+    if (not interleave and rec is not None and hasattr(rec, "fork") and CONCURRENT_CRITICS and len({k for k, _ in steps}) > 1
+            and torch.cuda.is_current_stream_capturing()):
+        # inside a forked capture (graphs.ForkedCall): every network's steps become a graph of their own, replayed side by side
+        keys = []
+        for k, _ in steps:
+            if k not in keys:
+                keys.append(k)
+        streams = _side_streams(len(keys))
+        chain = lambda k: (lambda: {i: fn() for i, (kk, fn) in enumerate(steps) if kk == k})
+        for part in rec.fork([(st, chain(k)) for k, st in zip(keys, streams)]):
+            res.update(part)
+        return res
     if not interleave and CONCURRENT_CRITICS and len({k for k, _ in steps}) > 1 and torch.cuda.is_available():
         # single rank: the steps of DIFFERENT networks run on side streams, one per network (per-network order kept), and
         # join before anything reads their results -- the launch-bound kernels of one critic's step (narrow layers,
