@@ -28,6 +28,7 @@
 //     register quad; the epilogue (bias = accumulator seed, residual from the LDS planes, activation, hi/lo split) writes
 //     8 + 8 bytes per lane into the next layer's operand planes.  In-place residual layers are safe (own elements only).
 #include "dhaug_common.h"
+#include "dhaug_fk_math.h"
 
 namespace {
 
@@ -57,7 +58,7 @@ constexpr int BUF01 = 2 * PLANE01, BUF2 = 2 * PLANE2;                // hi plane
 constexpr int X3_LDS_BYTES = 2 * BUF01 + BUF2;                       // 163 840
 constexpr int OUT_PITCH = 68;                                        // floats per row of the fp32 output staging image
 
-enum { U_LOAD_F32 = 0, U_GEMM = 3 };
+enum { U_LOAD_F32 = 0, U_GEMM = 3, U_LOAD_KCS = 5 };
 enum { F_OUT_F32 = 4 };
 
 struct Unit {
@@ -423,6 +424,49 @@ __device__ __forceinline__ void load_unit(UnitPtr u, unsigned char* smem, long l
     }
 }
 
+// LOAD_KCS: the 30 KCS features of a tile's poses (global fp32 (M, ld >= 48), root-relative or not: bones are differences),
+// computed here in the arithmetic of the stand-alone dhaug_kcs_forward (kcs_features, dhaug_fk_math.h: IEEE sqrt and divide) ->
+// hi / lo planes of buffer dst, columns 30..63 zero.  One lane per pose for the features (64 of the 512 threads; the tile's
+// 12 KB of poses are read with 16-byte loads), every thread for the zero fill.  Replaces a separate 9 us launch + 8 MB round
+// trip in front of the 3D critic's parity program.
+__device__ __forceinline__ void load_kcs_unit(UnitPtr u, unsigned char* smem, long long m0, long long M, int tid) {
+    asm volatile("" : "+v"(tid));
+    const float* g = static_cast<const float*>(u->g);
+    const long long ld = u->ld;
+    const int id = u->dst;
+    unsigned char* dst = buf_base(smem, id);
+    const int pb = buf_pitch_bytes(id), pl = buf_plane(id);
+    // pairs 15 .. 31 of every row: zero
+    for (int s = tid; s < X3_BM * 17; s += X3_THREADS) {
+        const int row = s / 17, c2 = 15 + (s - row * 17);
+        const int o = chunk_off(row, c2 >> 2, pb) + ((c2 & 3) << 2);
+        *reinterpret_cast<uint32_t*>(dst + o) = 0u;
+        *reinterpret_cast<uint32_t*>(dst + pl + o) = 0u;
+    }
+    if (tid < X3_BM) {
+        const int row = tid;
+        float f[30];
+        if (m0 + row < M) {
+            const float* pr = g + (m0 + row) * ld;
+            dhaug_fk::V3 p[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) p[j] = dhaug_fk::mk(pr[3 * j], pr[3 * j + 1], pr[3 * j + 2]);
+            dhaug_fk::kcs_features(p, f);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 30; ++c) f[c] = 0.0f;
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < 15; ++c2) {
+            uint32_t hi, lo;
+            split2(f[2 * c2], f[2 * c2 + 1], hi, lo);
+            const int o = chunk_off(row, c2 >> 2, pb) + ((c2 & 3) << 2);
+            *reinterpret_cast<uint32_t*>(dst + o) = hi;
+            *reinterpret_cast<uint32_t*>(dst + pl + o) = lo;
+        }
+    }
+}
+
 __device__ __forceinline__ void store_output(UnitPtr u, unsigned char* smem, long long m0, long long M, int tid) {
     const float* st = reinterpret_cast<const float*>(buf_base(smem, u->dst));
     float* out = static_cast<float*>(const_cast<void*>(u->g));
@@ -457,6 +501,8 @@ __global__ __launch_bounds__(X3_THREADS, 1) void fused_mlp_x3_kernel(Program pro
             if (tile == blockIdx.x) { X3_STAMP(4 * i) }
             if (kind == U_LOAD_F32) {
                 load_unit(u, smem, m0, M, tid);
+            } else if (kind == U_LOAD_KCS) {
+                load_kcs_unit(u, smem, m0, M, tid);
             } else {
                 // the GEMM unit that runs after this one: plan bits 0..7 hold its index + 1 (0: this is the program's last;
                 // the next tile then starts over at the first)
@@ -536,7 +582,7 @@ int dhaug_mlp_forward_x3(const dhaug_mlp_unit* units, int nunits, int64_t M, voi
         u.ksteps = s.ksteps; u.N = s.n; u.act = s.act; u.slope = s.slope; u.cols = s.cols; u.ld = s.ld; u.g = s.g;
         u.w = static_cast<const _Float16*>(s.w); u.w2 = static_cast<const _Float16*>(s.w2); u.bias = s.bias;
         u.plan = 0;
-        DHAUG_CHECK(u.kind == U_LOAD_F32 || u.kind == U_GEMM, DHAUG_EUNSUPPORTED);
+        DHAUG_CHECK(u.kind == U_LOAD_F32 || u.kind == U_GEMM || u.kind == U_LOAD_KCS, DHAUG_EUNSUPPORTED);
         if (u.kind == U_GEMM) {
             DHAUG_CHECK(okbuf(u.src) && u.ksteps >= 1 && u.ksteps <= X3_MAX_KSTEPS && u.N >= 1 && u.N <= 256, DHAUG_EUNSUPPORTED);
             DHAUG_CHECK(((u.ksteps + 3) / 4) * 64 <= pitch(u.src), DHAUG_EUNSUPPORTED);
@@ -559,6 +605,8 @@ int dhaug_mlp_forward_x3(const dhaug_mlp_unit* units, int nunits, int64_t M, voi
                 DHAUG_CHECK(u.res < 0 || ((u.N + 31) / 32) * 32 <= pitch(u.res), DHAUG_EUNSUPPORTED);
             }
             u.plan = (sh << 16) | (((u.N + 31) >> 5) << 24);                  // bits 0..7: index + 1 of the next GEMM unit (below)
+        } else if (u.kind == U_LOAD_KCS) {
+            DHAUG_CHECK(okbuf(u.dst) && u.g != nullptr && u.ld >= 48 && 64 <= pitch(u.dst), DHAUG_EINVAL);
         } else {
             DHAUG_CHECK(okbuf(u.dst) && u.g != nullptr && u.cols >= 2 && ((u.cols + 63) & ~63) <= pitch(u.dst), DHAUG_EINVAL);
             DHAUG_CHECK(u.cols % 2 == 0 && u.ld % 2 == 0 && u.ld >= u.cols && (reinterpret_cast<uintptr_t>(u.g) & 7u) == 0, DHAUG_EALIGN);

@@ -13,7 +13,7 @@ import torch
 from . import _lib, ops
 from .autograd_ops import ACT_LRELU, ACT_NONE, ACT_RELU
 
-LOAD_F32, LOAD_BF16, STORE_BF16, GEMM = 0, 1, 2, 3
+LOAD_F32, LOAD_BF16, STORE_BF16, GEMM, LOAD_KCS = 0, 1, 2, 3, 5
 F_OUT_F32, F_DOT_OUT = 4, 16
 _vp = ctypes.c_void_p
 # arithmetic of a fused program: "bf16" (dhaug_mlp_forward: one bf16 MFMA pass, bf16 activations in LDS) or "f16x3"
@@ -276,8 +276,12 @@ def _d3_program(D, L, inputs, M):
     x, kcs = inputs["x"], inputs["kcs"]
     out = torch.empty((M, 1), dtype=torch.float32, device=x.device)
     mp = L["merge_previous.0"]
-    kload = (_unit(LOAD_BF16, dst=1, cols=32, ld=kcs.stride(0), g=kcs) if kcs.dtype == torch.bfloat16 else
-             _unit(LOAD_F32, dst=1, cols=kcs.shape[1], ld=kcs.stride(0), g=kcs))          # f16x3: the fp32 (N,30) features
+    if kcs is None:                                          # f16x3: the features are computed from the poses inside the launch
+        assert x.dtype == torch.float32
+        kload = _unit(LOAD_KCS, dst=1, ld=x.stride(0), g=x)
+    else:
+        kload = (_unit(LOAD_BF16, dst=1, cols=32, ld=kcs.stride(0), g=kcs) if kcs.dtype == torch.bfloat16 else
+                 _unit(LOAD_F32, dst=1, cols=kcs.shape[1], ld=kcs.stride(0), g=kcs))      # f16x3: the fp32 (N,30) features
     u = [kload, _gemm(L["special_KCS_previous.0"], 1, 0, ACT_RELU)]
     _res_blocks(L, u, ("special_KCS_block1", "special_KCS_block2", "special_KCS_block3"))
     # cat(kcs_out, pos_out) -> merge layer, in two halves: LDS cannot hold the KCS branch's 64 KB result beside the two
@@ -415,7 +419,7 @@ def critics(D3_mod, D2_mod, x3, kcs, x2, mode="bf16"):
     x3 = x3.reshape(-1, 48).contiguous()                    # fp32, or bf16 as Fk_Generator.sample_for_critics can emit them
     x2 = x2.reshape(-1, 32).contiguous()
     M = x3.shape[0]
-    assert x2.shape[0] == M and kcs.shape[0] == M
+    assert x2.shape[0] == M and (kcs.shape[0] == M if kcs is not None else mode == "f16x3")
     u3, (o3,) = D3["program"](D3_mod, _net(D3_mod, D3, mode)._fresh(), dict(x=x3, kcs=kcs), M)
     u2, o2 = D2["program"](D2_mod, _net(D2_mod, D2, mode)._fresh(), dict(x=x2), M)
     launch(u3 + u2, M, mode)
@@ -429,8 +433,9 @@ def critic3d(D, x, center=False, kcs=None, mode="bf16"):
     if mode == "f16x3":
         if center:
             x = ops.center_flip(x.reshape(-1, 16, 3), True, False).reshape(-1, 48)
-        if kcs is None or kcs.dtype != torch.float32:
-            kcs, _ = ops.kcs_forward(x, True, f32=True)
+        if kcs is not None and kcs.dtype != torch.float32:
+            kcs = None                                        # (the features come from x inside the launch: LOAD_KCS)
+        x = x.float()
     elif kcs is not None:
         pass
     elif center:

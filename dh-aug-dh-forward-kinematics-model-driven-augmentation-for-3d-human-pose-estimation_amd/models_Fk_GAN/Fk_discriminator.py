@@ -213,9 +213,8 @@ def score_fake_pair(d3d, d2d, pose_centered, kcs, proj2d):
     if both and d3d.precision == "f16x3":                                  # fp32-grade: fp32 inputs, fp32 KCS features
         from .. import ops
         x3 = x3.float()
-        if kcs.dtype != torch.float32:
-            kcs, _ = ops.kcs_forward(x3, True, f32=True)
-        return fused.critics(d3d, d2d, x3, kcs, proj2d.float(), "f16x3")
+        # (fp32 features handed in are used; the bf16 operand of the bf16 path is not: the launch computes them from x3)
+        return fused.critics(d3d, d2d, x3, kcs if kcs.dtype == torch.float32 else None, proj2d.float(), "f16x3")
     if both:
         keep = lambda t: t if t.dtype == torch.bfloat16 else t.float()      # bf16 inputs are loaded as they are
         return fused.critics(d3d, d2d, keep(x3), kcs, keep(proj2d))

@@ -340,6 +340,9 @@ int dhaug_pack_wfrag(const float* W, int64_t ldw, uint16_t* dst, int64_t N, int6
 #define DHAUG_MLP_LOAD_BF16   1   /* global bf16 (M, ld) columns [0, cols) -> buffer dst                              */
 #define DHAUG_MLP_STORE_BF16  2   /* buffer src columns [0, cols) -> global bf16 (M, ld)                              */
 #define DHAUG_MLP_GEMM        3   /* one layer: dst = act(W * src [+ W2 * src2] + bias + res)                          */
+#define DHAUG_MLP_LOAD_KCS    5   /* dhaug_mlp_forward_x3 only: global fp32 poses (M, ld >= 48) -> their 30 KCS features  */
+                                  /* (special_KCS_Input_transform, R/models_Fk_GAN/Fk_discriminator.py:36-146) in buffer   */
+                                  /* dst, columns 30..63 zero: the 3D critic's KCS branch without a launch of its own        */
 #define DHAUG_MLP_F_OUT_F32   4   /* network output (n <= 64): fp32 (M, ld) to g, staged through buffer dst (0 or 1)    */
 #define DHAUG_MLP_F_DOT_OUT  16   /* GEMM whose only consumer is a 1-wide linear layer (a critic's logit): the activation  */
                                   /* is not stored; its dot product with w2 = fp32 [257] (that layer's weights as bf16      */

@@ -657,3 +657,32 @@ def test_fused_weights_refresh_in_one_launch(M):
             scratch = run(net)
             assert torch.equal(refreshed, scratch)
             del calls0
+
+
+def test_parity_program_computes_kcs_itself(M):
+    """f16x3: the 3D critic's program takes the poses alone and computes the KCS features inside the launch (DHAUG_MLP_LOAD_KCS,
+    the arithmetic of dhaug_kcs_forward) -- the same logits as with the features handed in, and no separate KCS launch"""
+    from dhaug_amd import fused, ops
+    D = 256
+    args = make_args(batch_size=300, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D)
+    torch.manual_seed(5)
+    D3 = M.dis.Fk_3D_Discriminator("cuda", args).cuda()
+    D2 = M.dis.Fk_2D_Discriminator(args, 16).cuda()
+    D3.precision = D2.precision = "f16x3"
+    x3 = GU.synth_pose16(300, seed=9)
+    x3 = (x3 - x3[:, :1]).reshape(300, 48).cuda()
+    x2 = ((torch.rand(300, 32) - 0.5) * 1.4).cuda()
+    kf, _ = ops.kcs_forward(x3, True, f32=True)
+    ref3, ref2 = fused.critics(D3, D2, x3, kf, x2, "f16x3")
+    calls = ops._lib.CALLS[0]
+    got3, got2 = fused.critics(D3, D2, x3, None, x2, "f16x3")
+    assert ops._lib.CALLS[0] == calls + 1                       # one launch: no KCS kernel in front
+    assert (got3 - ref3).abs().max().item() <= 2e-6 * max(1.0, ref3.abs().max().item())
+    assert torch.equal(got2, ref2)
+    # the path bench.py and the loops take: score_fake_pair with the bf16 operand of the tail kernel at hand
+    _, kb = ops.kcs_forward(x3, True, f32=False, bf16_ld=32)
+    calls = ops._lib.CALLS[0]
+    with torch.no_grad():
+        s3, s2 = M.dis.score_fake_pair(D3, D2, x3, kb, x2.reshape(300, 16, 2))
+    assert ops._lib.CALLS[0] == calls + 1
+    assert torch.equal(s3, got3) and torch.equal(s2, got2)
