@@ -190,13 +190,23 @@ def _parallel(fns):
         st.wait_stream(cur)
         with torch.cuda.stream(st):
             r = fn()
-        for t in (r if isinstance(r, (tuple, list)) else (r,)):
-            if torch.is_tensor(t):
-                t.record_stream(cur)
+        _record_stream(r, cur)
         out.append(r)
     for st in pool[:len(fns)]:
         cur.wait_stream(st)
     return out
+
+
+def _record_stream(r, stream):
+    """every tensor of a (nested) result: it was allocated on a side stream and will be read on `stream`"""
+    if torch.is_tensor(r):
+        r.record_stream(stream)
+    elif isinstance(r, (tuple, list)):
+        for t in r:
+            _record_stream(t, stream)
+    elif isinstance(r, dict):
+        for t in r.values():
+            _record_stream(t, stream)
 
 
 def supported(G, oG, critics):

@@ -147,6 +147,23 @@ class SegmentedCall:
         finally:
             RECORDER = None
             A.CAPTURE_ID = 0
+            if self._g is not None:                                # an exception inside the capture: end it, keep the error
+                try:
+                    self._g.capture_end()
+                except Exception:
+                    pass
+                self._g = None
+        # every all-reduce that was started is waited for inside the same iteration (an optimizer left with a pending
+        # exchange -- overlap=True and no flush() -- would replay a collective nobody waits for)
+        open_ = []
+        for kind, obj in self.items:
+            if kind == "allreduce":
+                assert id(obj) not in open_, "two all-reduces of one optimizer without a wait between them"
+                open_.append(id(obj))
+            elif kind == "wait":
+                assert id(obj) in open_, "a wait without its all-reduce in the captured iteration"
+                open_.remove(id(obj))
+        assert not open_, "captured iteration ends with %d all-reduce(s) nobody waits for (FusedAdam.flush() missing)" % len(open_)
         self.work = {}
 
     def _begin(self):

@@ -521,10 +521,16 @@ def gp_penalty(grad, coef):
     return v, pen
 
 
+CRITIC_SCALARS_SCRATCH = 192      # floats: DHAUG_CRITIC_SCALARS_SCRATCH of include/dhaug.h (tests/test_cpu_boundary.py compares)
+
+
 def critic_scalars(logits, pen, B, lam):
     """(5,) fp32: D_real, D_fake, GP, Wasserstein_D, D_cost (logit means over B rows per half, penalty mean over len(pen))"""
-    buf = torch.empty((5 + 192,), dtype=torch.float32, device=logits.device)      # result + the partial sums of stage 1
-    _lib.call("dhaug_critic_scalars", _p(logits), logits.stride(0), _p(pen), B, pen.numel(), float(lam), _p(buf), _p(buf[8:]), _stream())
+    # result (5 floats, padded to 8 so that the scratch stays 32-byte aligned) + the partial sums of stage 1
+    buf = torch.empty((8 + CRITIC_SCALARS_SCRATCH,), dtype=torch.float32, device=logits.device)
+    scratch = buf[8:]
+    assert scratch.numel() >= CRITIC_SCALARS_SCRATCH
+    _lib.call("dhaug_critic_scalars", _p(logits), logits.stride(0), _p(pen), B, pen.numel(), float(lam), _p(buf), _p(scratch), _stream())
     return buf[:5]
 
 

@@ -121,6 +121,9 @@ class FusedAdam(torch.optim.Optimizer):
             rec = graphs.RECORDER
             if rec is not None:
                 # a segmented hipGraph capture (graphs.SegmentedCall): the collective is an event BETWEEN two graphs
+                if not hasattr(rec, "cut"):
+                    raise RuntimeError("FusedAdam.step with world_size > 1 inside a %s capture: only graphs.SegmentedCall can "
+                                       "cut a capture at a collective" % type(rec).__name__)
                 rec.cut(("allreduce", self))
                 if self.overlap:
                     self._pending = (None, ws)
@@ -185,7 +188,11 @@ class FusedAdam(torch.optim.Optimizer):
             self._pending = None
             if work is None:                                   # started inside a segmented capture: the wait is an event too
                 from . import graphs
-                graphs.RECORDER.cut(("wait", self))
+                rec = graphs.RECORDER
+                if rec is None or not hasattr(rec, "cut"):
+                    raise RuntimeError("FusedAdam.flush: an all-reduce started inside a segmented capture is pending, but the "
+                                       "capture is gone (an exception between step() and flush()?)")
+                rec.cut(("wait", self))
             else:
                 work.wait()
             self._apply(ws)

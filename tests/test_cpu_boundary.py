@@ -41,6 +41,13 @@ def test_library_exports_every_declared_symbol(built):
     assert bound == set(names) - {"dhaug_version", "dhaug_arch"}
 
 
+def test_scratch_sizes_mirror_the_header(built):
+    """the binding's scratch sizes are the header's (a short scratch is an out-of-bounds write on the device)"""
+    from dhaug_amd import ops
+    hdr = open(os.path.join(ROOT, "include", "dhaug.h")).read()
+    assert int(re.search(r"#define\s+DHAUG_CRITIC_SCALARS_SCRATCH\s+(\d+)", hdr).group(1)) == ops.CRITIC_SCALARS_SCRATCH
+
+
 def test_argument_errors_are_returned_not_thrown(built):
     """host-side validation happens before any launch, so it can be exercised without a GPU"""
     import dhaug_amd

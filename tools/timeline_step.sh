@@ -14,8 +14,6 @@ print(len(rows), "dispatches; columns:", list(rows[0].keys()))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 keep = rows[int(len(rows) * 0.55):]
 t0 = int(keep[0]["Start_Timestamp"])
-with open("gpurun_out/timeline_%s.csv" % sys.argv[1].split("/")[-1][:0] or "gpurun_out/timeline.csv", "w") as f:
-    pass
 out = open("gpurun_out/timeline.csv", "w")
 out.write("start_ns,end_ns,queue,stream,grid,wg,lds,name\n")
 for r in keep:
