@@ -6,27 +6,36 @@
 // two orders of magnitude.  Here every operand is carried as an fp16 PAIR  x = hi + lo  (hi = fp16(x), lo = fp16(x - hi):
 // 22 mantissa bits) and a product is three v_mfma_f32_32x32x16_f16 terms accumulated in fp32:
 //        W x  ~=  Whi Xhi + Whi Xlo + Wlo Xhi                       (the dropped Wlo Xlo is 2^-22 relative)
-// fp16 products are exact in fp32 (11 x 11 bits), so the result differs from fp32 arithmetic by ~2^-21 per operand:
-// measured against the reference's logits 2e-5 in the tests' strict relative metric, 1e-6 of the logit scale.  The F16
+// fp16 products are exact in fp32 (11 x 11 bits), so the result differs from fp32 arithmetic by ~2^-21 per operand.  The F16
 // MFMA runs at the BF16 rate, so this mode costs 3 matrix instructions per k-step instead of 1 -- its roofline is a third
 // of the dense peak in ALGORITHMIC flops.  Range: |x| < 65 504 (fp16); values below 2^-14 keep an ABSOLUTE error of 2^-25.
 //
-// Structure (512 threads = 8 waves = TWO per SIMD, 256 registers each; one persistent workgroup per CU walking 64-row
-// batch tiles).  Measured on the first version of this kernel (4 waves, one per SIMD; ablation builds, D3 at B = 65 536:
-// 459 us as built, 411 without weight reloads, 352 without epilogue, 297 with MFMAs only against 145 us of pure MFMA issue):
-// what a single wave per SIMD cannot hide is (a) the epilogue -- the fp32 -> hi/lo split is ~6 VALU per element pair -- and
-// (b) the start of every layer, where the first weight fragments and the bias are requested and waited for.  Hence:
-//   * wave w owns feature slice w (32 features) for all 64 rows: while one wave of a SIMD runs its epilogue or waits at the
-//     layer boundary, the other one issues MFMAs;
-//   * the NEXT layer's first two weight chunks and its bias are requested before the current layer's epilogue (the unit
-//     program is scanned ahead; across tiles it wraps around to the first layer);
-//   * activations: fp16 hi / lo planes [64 rows][256] per buffer (two 64 KB buffers + one 32 KB [64][128] buffer = all
-//     160 KB of LDS), 16-byte chunks XOR-swizzled by (row & 15) -> conflict-free ds_read_b128 of MFMA B fragments;
-//   * weights: pre-split and pre-packed in A-fragment order (dhaug_pack_wfrag_f16x2): per (32-feature slice, k-step)
-//     two contiguous 1 KB blocks (hi, lo), streamed from L2 through a 2-slot register ring (4 k-steps per slot);
-//   * MFMA issued swapped (A = weights, B = activations): a lane owns one batch row and 4 consecutive features per
-//     register quad; the epilogue (bias = accumulator seed, residual from the LDS planes, activation, hi/lo split) writes
-//     8 + 8 bytes per lane into the next layer's operand planes.  In-place residual layers are safe (own elements only).
+// Structure (round 4; the round-3 kernel -- 64-row tiles, two images, eight waves -- stood at 0.35 of the matrix peak because
+// per 256 -> 256 layer and tile its three resources were of equal size: 6 144 clocks of matrix issue, 4 096 of the 64 B/clk
+// vector-memory path for 256 KB of weight fragments, 4 096 of LDS fragment reads; what had to shrink was the fragment bytes
+// PER ROW):
+//   * 128-row batch tiles: a layer's hi + lo weight fragments (256 KB, streamed from L2) serve twice the rows -- the
+//     vector-memory path drops to a third of the matrix time.  B = 65 536 is exactly two tiles per CU;
+//   * ONE activation image per tile, updated IN PLACE: hi / lo planes [128][256] fp16 = 128 KB of the 160 KB (two images do
+//     not fit).  A layer reads the image through its whole k loop, all waves meet at a barrier, then every lane writes the
+//     elements it owns.  What a later layer adds as a residual is therefore NOT in LDS any more when it is needed, and the
+//     register file has no room for it either (128 accumulators + 128 residual values + fragments: hipcc spills from ~330
+//     live registers of the 512): the layer that PRODUCES such a value also writes it, fp32, into a per-workgroup global
+//     workspace (region 0; 16 bytes per lane and register quad, in accumulator order -- written and read back by the same
+//     lane, it never leaves L2 / the Infinity Cache), and the layer that adds it requests it tile by tile in its epilogue,
+//     two accumulator tiles ahead;
+//   * a partial result that has to wait while ANOTHER branch uses the image (the 3D critic's KCS half of the merge layer,
+//     fused.py `_d3_program`) is parked the same way (region 1), no longer in a third LDS buffer;
+//   * four waves (one per SIMD, 512 registers): wave w owns 64 features x 128 rows of a 256-wide layer = 128 accumulator
+//     registers, 24 matrix instructions per k-step and 4 KB of weights + 8 KB of LDS fragment reads for them (round 3:
+//     6 per 2 KB + 4 KB), fragments of the next k-step(s) always in flight.  Narrow layers are dealt as (slices x row tiles)
+//     blocks so that every wave has work: 1 x 4 (N <= 128), 1 x 2 (N <= 64), 1 x 1 (N <= 32);
+//   * the virtual three-buffer programs of include/dhaug.h are kept: the host planner below proves that a program can run on
+//     one image (every value is either in the image or in the workspace when it is read) and annotates its units;
+//   * weights: pre-split and pre-packed in A-fragment order (dhaug_pack_wfrag_f16x2); MFMA issued swapped (A = weights,
+//     B = activations): a lane owns one batch row and 4 consecutive features per register quad;
+//   * per output element the order of summation is the round-3 kernel's (k ascending, per k-step Wlo Xhi, Whi Xlo, Whi Xhi,
+//     bias as the accumulator seed, residual added last) -- the residual itself is now the exact fp32 value, not hi + lo.
 #include "dhaug_common.h"
 #include "dhaug_fk_math.h"
 
@@ -38,38 +47,41 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef X3_PRIO_SEL
-#define X3_PRIO_SEL 2
-#endif
-#ifndef X3_STREAM
-#define X3_STREAM 0          // (1: the per-k-step weight stream below -- measured: no gain, see its comment)
-#endif
-constexpr int X3_BM = 64;                                            // batch rows per tile
+constexpr int X3_BM = 128;                                           // batch rows per tile
 constexpr int X3_MT = X3_BM / 32;
-constexpr int X3_THREADS = 512;
-constexpr int X3_WAVES = X3_THREADS / 64;
-constexpr int X3_CH = 4;                                             // k-steps per ring slot (64 k)
+constexpr int X3_NW = 4;                                             // waves per workgroup (one per SIMD)
+constexpr int X3_THREADS = 64 * X3_NW;
 constexpr int X3_MAX_UNITS = 32;
-constexpr int X3_MAX_KSTEPS = 16;
-constexpr int P01 = 256, P2 = 128;                                   // pitch (elements) of buffers 0/1 and 2
-constexpr int PLANE01 = X3_BM * P01 * 2, PLANE2 = X3_BM * P2 * 2;    // bytes of one fp16 plane
-constexpr int BUF01 = 2 * PLANE01, BUF2 = 2 * PLANE2;                // hi plane, lo plane
-constexpr int X3_LDS_BYTES = 2 * BUF01 + BUF2;                       // 163 840
+constexpr int PITCHB = 512;                                          // bytes per image row and plane (256 fp16)
+constexpr int PLANE = X3_BM * PITCHB;                                // 65 536: the hi plane; the lo plane follows
+constexpr int X3_LDS_BYTES = 2 * PLANE;                              // 131 072
 constexpr int OUT_PITCH = 68;                                        // floats per row of the fp32 output staging image
+#ifndef X3_SPREAD
+#define X3_SPREAD 1
+#endif
+constexpr int RING = 3;                                              // weight k-steps in registers (two requested ahead)
+constexpr int WS_FLOATS_PER_WAVE = 64 * 128;                         // 64 lanes x (2 x 4 x 16) accumulator values
+constexpr int WS_REGION_FLOATS = 256 * X3_NW * WS_FLOATS_PER_WAVE;   // one region: every workgroup's tile, 32 MB
 
 enum { U_LOAD_F32 = 0, U_GEMM = 3, U_LOAD_KCS = 5 };
 enum { F_OUT_F32 = 4 };
+// what the planner found out about a GEMM unit (plan bits 20..)
+enum { PF_ADD_R0 = 1,          // epilogue: + the values waiting in workspace region 0 (a residual)
+       PF_ADD_R1 = 2,          // epilogue: + the values waiting in region 1 (a parked partial result)
+       PF_COPY_R0 = 4,         // epilogue: the result also goes to region 0 (a later unit adds it as a residual)
+       PF_TO_PARK = 8 };       // epilogue: the result goes to region 1 ONLY, the image stays
+enum { MAP_2x4 = 0, MAP_1x4 = 1, MAP_1x2 = 2, MAP_1x1 = 3 };        // (feature slices x row tiles) per wave
 
 struct Unit {
     int kind, plan, flags;
-    int src, dst, res, src2, ksteps2, ksteps, N, act;
+    int ksteps, N, act;
     float slope;
     int cols;
     long long ld;
     const void* g;
     const _Float16* w;
-    const _Float16* w2;
     const float* bias;
 };
 struct Program {
@@ -78,32 +90,17 @@ struct Program {
 };
 typedef const Unit __attribute__((address_space(4))) * UnitPtr;      // units are read from the kernarg segment (s_load)
 
-__device__ __forceinline__ unsigned char* buf_base(unsigned char* smem, int id) {
-    return smem + (id == 0 ? 0 : (id == 1 ? BUF01 : 2 * BUF01));
-}
-__device__ __forceinline__ int buf_pitch_bytes(int id) { return (id == 2 ? P2 : P01) * 2; }
-__device__ __forceinline__ int buf_plane(int id) { return id == 2 ? PLANE2 : PLANE01; }
-__device__ __forceinline__ int chunk_off(int row, int c, int pitch_bytes) { return row * pitch_bytes + ((c ^ (row & 15)) << 4); }
+__device__ __forceinline__ int chunk_off(int row, int c) { return row * PITCHB + ((c ^ (row & 15)) << 4); }
 __device__ __forceinline__ float act_neg(int act, float slope) {
     return act == DHAUG_ACT_RELU ? 0.0f : (act == DHAUG_ACT_LRELU ? slope : 1.0f);
 }
 __device__ __forceinline__ float act_fn(float v, float neg) { return fmaxf(v, v * neg); }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// x0, x1 -> packed fp16 pairs (hi, lo) with x = hi + lo to 22 bits
-__device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
-    const f32x2 v = {x0, x1};
-    const f16x2 h = __builtin_convertvector(v, f16x2);
-    const f32x2 hf = __builtin_convertvector(h, f32x2);
-    const f16x2 l = __builtin_convertvector(v - hf, f16x2);
-    hi = __builtin_bit_cast(uint32_t, h);
-    lo = __builtin_bit_cast(uint32_t, l);
-}
-
-__device__ __forceinline__ int chunks_of(int ksteps) { return (ksteps + X3_CH - 1) / X3_CH; }
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo);
 
 #ifdef X3_TIMING
-__device__ long long g_x3_stamps[4 * X3_MAX_UNITS + 4];
+__device__ long long g_x3_stamps[8 * X3_MAX_UNITS + 8];
 #ifndef X3_STAMP_TID
 #define X3_STAMP_TID 0
 #endif
@@ -111,293 +108,322 @@ __device__ long long g_x3_stamps[4 * X3_MAX_UNITS + 4];
 #else
 #define X3_STAMP(i)
 #endif
-typedef f16x8 Ring[2][X3_CH][2];                  // [slot][k-step in chunk][piece]: chunk c lives in slot c & 1
 
-// global loads of chunk C (of the concatenated sources; the first has NCH1 chunks) of this wave's slice into a ring slot
-template <int C, int NCH, int NCH1>
-__device__ __forceinline__ void load_chunk(const _Float16* w1, const _Float16* w2, int wave, int lane, f16x8 (&slot)[X3_CH][2]) {
-    constexpr bool second = C >= NCH1;
-    constexpr int kpad = (second ? NCH - NCH1 : NCH1) * X3_CH;
-    constexpr int k0 = (second ? C - NCH1 : C) * X3_CH;
-    const _Float16* base = (second ? w2 : w1) + ((long long)wave * kpad * 2 * 64 + lane) * 8 + (long long)k0 * 2 * 512;
-#pragma unroll
-    for (int q = 0; q < X3_CH; ++q)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) slot[q][p] = *reinterpret_cast<const f16x8*>(base + (2 * q + p) * 512);
+typedef f16x8 WRing[RING][2][2];                  // [k-step % RING][slice of the wave][piece]
+typedef f32x16 Seed[2];                           // bias of the wave's slice(s) in accumulator order
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const _Float16* w, int slice0, int kt) {
+    // a slice holds kt k-steps of (hi, lo) 1 KB blocks
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(w) + (long long)slice0 * kt * 1024, 0, 0x7fffffff, 0x27000);
 }
-
-// chunks 0 and 1 and the bias of GEMM unit `u` for this wave's slice (shape known only at run time): requested ahead of the
-// layer, i.e. before the previous layer's epilogue and barrier.  Slices beyond N are zero rows of the blob (it always holds
-// 8 slices), so every wave may load.
-__device__ __forceinline__ void prefetch_layer(UnitPtr u, int wave, int lane, Ring& ring, f32x16& seed) {
-    const int kp1 = chunks_of(u->ksteps) * X3_CH, ks2 = u->ksteps2;
-    const _Float16* b0 = u->w + ((long long)wave * kp1 * 2 * 64 + lane) * 8;
-#pragma unroll
-    for (int q = 0; q < X3_CH; ++q)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) ring[0][q][p] = *reinterpret_cast<const f16x8*>(b0 + (2 * q + p) * 512);
-    if (kp1 > X3_CH || ks2 > 0) {                                            // a second chunk exists (wave-uniform)
-        const _Float16* b1 = kp1 > X3_CH ? b0 + X3_CH * 2 * 512
-                                         : u->w2 + ((long long)wave * (chunks_of(ks2) * X3_CH) * 2 * 64 + lane) * 8;
-#pragma unroll
-        for (int q = 0; q < X3_CH; ++q)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) ring[1][q][p] = *reinterpret_cast<const f16x8*>(b1 + (2 * q + p) * 512);
-    }
-    const int h = lane >> 5;
+__device__ __forceinline__ f16x8 load_frag(__amdgpu_buffer_rsrc_t rs, int lane16, int kt, int s, int k, int p) {
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, ((s * kt + k) * 2 + p) * 1024, 0));
+}
+// this wave's slot of the workspace (region 0: residual copies, region 1: parked partial sums): values lie in accumulator order,
+// 16 bytes per lane and register quad -- written and read back by the same lane
+__device__ __forceinline__ float* ws_base(const void* g, int wave, int lane, int region) {
+    return static_cast<float*>(const_cast<void*>(g)) + (long long)region * WS_REGION_FLOATS +
+           ((long long)blockIdx.x * X3_NW + wave) * WS_FLOATS_PER_WAVE + lane * 4;
+}
+__device__ __forceinline__ void load_ws_tile(const float* src, int t, f32x16& x) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(u->bias + 32 * wave + 4 * h + 8 * g);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (t * 4 + g) * 256);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) seed[4 * g + e] = b4[e];
+        for (int e = 0; e < 4; ++e) x[4 * g + e] = v[e];
     }
 }
 
-// The weight stream (X3_STREAM): one k-step entry (hi + lo fragment, 2 KB per wave) is requested per k-step, eight k-steps
-// ahead, into the ring entry the matrix instructions have just read -- and the stream runs on ACROSS the layer boundary: the
-// last eight k-steps of a layer request the first eight of the next one.  Measured on the version that requested half a
-// layer (two chunks + the bias, 20 KB per wave) behind the k loop: the eight waves' 160 KB take the CU's 64 B/clk
-// vector-memory path 2 500 clocks to ACCEPT, and a wave's epilogue cannot start before its loads have issued (in-order):
-// ~2 600 exposed clocks per 256 -> 256 layer (phase stamps of an MFMA-only build: 6 730 clocks of k loop + 2 780 of "nothing").
-// RESULT (r3, D3 at B = 65 536, same box): 391 us with the stream against 386 us without.  The epilogue did shrink (4 000 -
-// 5 300 -> 1 900 - 3 000 clocks) but the k loop grew by as much (6 400 - 6 900 -> 8 000 - 9 200): a wave issues in order, so
-// a load the path cannot accept yet holds back the matrix instructions behind it wherever it stands.  The layer's 256 KB
-// of fragments take 4 096 of the 6 144 matrix clocks on that path either way; only fewer bytes per row (a taller row tile,
-// which LDS has no room for) would change it.  Kept as a build option (-DX3_STREAM=1), off.
-struct NextW {                                       // the next GEMM unit's weight stream for this wave and lane
-    const _Float16* a;                               // source 1: entry q at a + q * 1024 (hi), + 512 (lo)
-    const _Float16* b;                               // source 2 (entries kp1 ..)
-    int kp1, total;                                  // k-steps of source 1 (chunk-padded) / of both
-};
-__device__ __forceinline__ NextW next_stream(UnitPtr u, int wave, int lane) {
-    NextW n;
-    n.kp1 = chunks_of(u->ksteps) * X3_CH;
-    const int ks2 = u->ksteps2, kp2 = ks2 > 0 ? chunks_of(ks2) * X3_CH : 0;
-    n.total = n.kp1 + kp2;
-    n.a = u->w + ((long long)wave * n.kp1 * 2 * 64 + lane) * 8;
-    n.b = ks2 > 0 ? u->w2 + ((long long)wave * kp2 * 2 * 64 + lane) * 8 : n.a;
-    return n;
-}
-__device__ __forceinline__ void load_next_entry(const NextW& n, int q, f16x8 (&e)[2]) {      // q < n.total (wave-uniform)
-    const _Float16* base = q < n.kp1 ? n.a + (long long)q * 1024 : n.b + (long long)(q - n.kp1) * 1024;
-    e[0] = *reinterpret_cast<const f16x8*>(base);
-    e[1] = *reinterpret_cast<const f16x8*>(base + 512);
-}
-// entry K (compile time) of THIS layer's concatenated sources
-template <int NCH, int NCH1>
-__device__ __forceinline__ void load_own_entry(int K, const _Float16* w1, const _Float16* w2, int wave, int lane, f16x8 (&e)[2]) {
-    const bool second = K >= NCH1 * X3_CH;                                    // (K: a constant once the k loop is unrolled)
-    const int kpad = (second ? NCH - NCH1 : NCH1) * X3_CH;
-    const int kk = second ? K - NCH1 * X3_CH : K;
-    const _Float16* base = (second ? w2 : w1) + ((long long)wave * kpad * 2 * 64 + lane) * 8 + (long long)kk * 1024;
-    e[0] = *reinterpret_cast<const f16x8*>(base);
-    e[1] = *reinterpret_cast<const f16x8*>(base + 512);
-}
-__device__ __forceinline__ void load_bias_seed(UnitPtr u, int wave, int lane, f32x16& seed) {
-    const int h = lane >> 5;
+// k-step 0 and the bias of GEMM unit `u` for this wave's slice(s) (shape known only at run time): requested ahead of the
+// layer, i.e. before the previous layer's epilogue and barriers -- and no more than that: the CU's vector-memory path takes
+// 64 B/clk, and the four waves ask at the same moment (two k-steps + bias = 96 KB: 1 500 clocks before the first wave got past
+// its requests, phase stamps).  Slices beyond N are zero rows of the blob (it always holds 8 slices), so every wave may load.
+__device__ __forceinline__ void prefetch_layer(UnitPtr u, int wave, int lane, WRing& ring, Seed& seed) {
+    const int plan = u->plan;
+    const int lg = (plan >> 8) & 15, map = (plan >> 12) & 15, kt = ((plan >> 16) & 15) * 4;
+    const int sw = map == MAP_2x4 ? 2 : 1;
+    const int slice0 = (wave & ((1 << lg) - 1)) * sw;
+    const __amdgpu_buffer_rsrc_t rs = weight_rsrc(u->w, slice0, kt);
+    const int lane16 = lane << 4, h = lane >> 5;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) ring[0][0][p] = load_frag(rs, lane16, kt, 0, 0, p);
+    if (sw == 2) {                                                            // (wave-uniform)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) ring[0][1][p] = load_frag(rs, lane16, kt, 1, 0, p);
+    }
+    const float* b = u->bias + 32 * slice0 + 4 * h;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(u->bias + 32 * wave + 4 * h + 8 * g);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(b + 8 * g);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) seed[4 * g + e] = b4[e];
+        for (int e = 0; e < 4; ++e) seed[0][4 * g + e] = b4[e];
+    }
+    if (sw == 2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(b + 32 + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) seed[1][4 * g + e] = b4[e];
+        }
     }
 }
 
-// dst = act(W src [+ W2 src2] + bias + res), one layer.  NCH chunks of 64 k, the first NCH1 from source 1.  On entry the
-// ring holds this layer's chunks 0 (and 1) and `seed` its bias; before the epilogue `next` (the GEMM unit that runs after
-// this one, possibly of the next tile; nullptr: none) is prefetched the same way.  Waves whose slice lies beyond N only
-// take part in the prefetch.
-template <int NCH, int NCH1>
-__device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned char* smem, int wave, int lane, Ring& ring, f32x16& seed, int ui = 0) {
-    asm volatile("" : "+v"(lane));                   // lane-derived constants are recomputed per unit, not parked across units
-    const int r31 = lane & 31, h = lane >> 5;
-    const int nslices = (u->N + 31) >> 5;
-    if (wave >= nslices) {                           // wave-uniform
-        if (next != nullptr) prefetch_layer(next, wave, lane, ring, seed);
-        return;
+// v0, v1 -> packed fp16 pairs (hi, lo) with v = hi + lo to 22 bits.  lo = fp16(v - hi) in one instruction per element:
+// v_fma_mix computes 1.0 * v - float(hi) in fp32 (exact: hi is v rounded to 11 bits) and rounds it to fp16.
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    const f32x2 v = {x0, x1};
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %3, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=&v"(lo) : "v"(x0), "v"(hi), "v"(x1));
+}
+
+// the lo halves of a pair whose hi halves are packed in `hi`
+__device__ __forceinline__ uint32_t split_lo(float x0, float x1, uint32_t hi) {
+    uint32_t lo;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %3, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=&v"(lo) : "v"(x0), "v"(hi), "v"(x1));
+    return lo;
+}
+
+// The epilogue of one layer for the wave's SW x RW accumulator tiles, one tile (16 values per lane) at a time:
+//   v = act(acc [+ what waits in the workspace at `rin`, four tiles in flight]);  [v -> workspace at `rout`: a later layer's residual];
+//   v -> (hi, lo) -> this lane's elements of the image  |  v -> the fp32 staging image of a network output  |  nothing (PARK)
+enum { EP_IMAGE = 0, EP_OUT = 1, EP_PARK = 2 };
+template <int SW, int RW, int MODE, bool COPY, bool ADD>
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[SW][RW], f32x4 (&rq)[4][4], const float* rin, float* rout, unsigned char* img, int row0,
+                                         int slice0, int h, float neg) {
+    constexpr int G = SW * RW;
+    // the lane's image addresses: one per slice and register quad (row tiles and the lo plane are constants away)
+    int oaddr[SW][4];
+    if (MODE == EP_IMAGE) {
+#pragma unroll
+        for (int s = 0; s < SW; ++s)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) oaddr[s][g] = chunk_off(row0, 4 * (slice0 + s) + g) + (h << 3);
     }
-    const _Float16* w1 = u->w;
-    const _Float16* w2 = NCH1 < NCH ? u->w2 : u->w;
-    f32x16 acc[X3_MT];
-    const unsigned char* src1 = buf_base(smem, u->src);
-    const int pbs1 = buf_pitch_bytes(u->src), pl1 = buf_plane(u->src);
-    const unsigned char* src2 = NCH1 < NCH ? buf_base(smem, u->src2) : src1;
-    const int pbs2 = NCH1 < NCH ? buf_pitch_bytes(u->src2) : pbs1, pl2 = NCH1 < NCH ? buf_plane(u->src2) : pl1;
-    constexpr int KT = NCH * X3_CH;
-    f16x8 fx[2][X3_MT][2];                           // activation fragments (hi, lo), read one k-step ahead (the SIMD's other
-                                                     // wave covers the LDS latency; three stages spill at 256 registers)
-    // 256-wide sources live in buffers 0 / 1 (pitch and plane size are constants there): ONE address per k-step -- row
-    // 32 + r has r's swizzle (32 % 16 == 0) and the lo plane is a constant away, so the four fragments of a k-step are
-    // immediate offsets of it (2 VALU per k-step instead of 9 in front of the matrix instructions)
-#ifdef X3_OLD_ADDR
-    constexpr bool WIDE = false;
-#else
-    constexpr bool WIDE = NCH1 == 4 && (NCH == 4 || NCH == 8);
-#endif
-    const int wide_row = r31 * (P01 * 2), wide_sw = r31 & 15;
-    auto read_frags = [&](int k, f16x8 (&f)[X3_MT][2]) {
-        const bool second = k >= NCH1 * X3_CH;
-        const unsigned char* src = second ? src2 : src1;
-        const int kk = second ? k - NCH1 * X3_CH : k;
-        if (WIDE) {
-            const unsigned char* a = src + wide_row + (((2 * kk + h) ^ wide_sw) << 4);
 #pragma unroll
-            for (int mt = 0; mt < X3_MT; ++mt) {
-                f[mt][0] = *reinterpret_cast<const f16x8*>(a + mt * 32 * (P01 * 2));
-                f[mt][1] = *reinterpret_cast<const f16x8*>(a + mt * 32 * (P01 * 2) + PLANE01);
-            }
-            return;
-        }
-        const int pbs = second ? pbs2 : pbs1, pl = second ? pl2 : pl1;
+    for (int t = 0; t < G; ++t) {
+        const int s = t / RW, mt = t % RW;
+        // a lone wave issues a dependent instruction ~8 clocks behind its producer but an independent one after 4: the tile's
+        // 16 values go through every step TOGETHER (left alone the scheduler chains mul -> max -> cvt -> mix per value)
+        f32x4 v[4];
 #pragma unroll
-        for (int mt = 0; mt < X3_MT; ++mt) {
-            const int o = chunk_off(32 * mt + r31, 2 * kk + h, pbs);
-            f[mt][0] = *reinterpret_cast<const f16x8*>(src + o);
-            f[mt][1] = *reinterpret_cast<const f16x8*>(src + pl + o);
-        }
-    };
-    read_frags(0, fx[0]);
-#if X3_STREAM
-    NextW nw = {};
-    if (next != nullptr) nw = next_stream(next, wave, lane);
-#endif
-#if X3_PRIO_SEL
-    // the two waves of a SIMD start every layer together (barrier) and would share the matrix pipe turn by turn, reaching
-    // their epilogues together -- both exposed, and fighting over LDS.  The first wave of the pair takes the pipe (issue
-    // priority) and runs its epilogue UNDER the second wave's matrix phase: one epilogue per layer is exposed, alone on
-    // the SIMD.  (No arithmetic changes: results are the same bits.)
-    if (X3_PRIO_SEL == 1 ? wave < 4 : (wave & 1) == 0) __builtin_amdgcn_s_setprio(3);
-#endif
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int k = 0; k < KT; ++k) {
-        const int c = k / X3_CH, q = k % X3_CH;
-#ifndef X3_ABL_NOREAD
-        if (k + 1 < KT) read_frags(k + 1, fx[(k + 1) & 1]);
-#endif
-#if !X3_STREAM
-#ifdef X3_ABL_NOWLOAD
-        if (false) {
-#else
-        // chunk c+1 is requested when chunk c starts, into the slot chunk c-1 just left (chunk 1 came with the prefetch)
-        if (q == 0 && c >= 1 && c + 1 < NCH) {
-#endif
-            if (c + 1 == 2) load_chunk<2 < NCH ? 2 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[0]);
-            if (c + 1 == 3) load_chunk<3 < NCH ? 3 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[1]);
-            if (c + 1 == 4) load_chunk<4 < NCH ? 4 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[0]);
-            if (c + 1 == 5) load_chunk<5 < NCH ? 5 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[1]);
-            if (c + 1 == 6) load_chunk<6 < NCH ? 6 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[0]);
-            if (c + 1 == 7) load_chunk<7 < NCH ? 7 : 0, NCH, NCH1>(w1, w2, wave, lane, ring[1]);
-        }
-#endif
+            for (int e = 0; e < 4; ++e) v[g][e] = ADD ? acc[s][mt][4 * g + e] + rq[t % 4][g][e] : acc[s][mt][4 * g + e];
         __builtin_amdgcn_sched_barrier(0);
-        // small terms first, then hi * hi
+        if (ADD && t + 4 < G) {                      // the tile's residual registers are free: request tile t + 4 into them
 #pragma unroll
-        for (int mt = 0; mt < X3_MT; ++mt)
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[c & 1][q][1], fx[k & 1][mt][0], k == 0 ? seed : acc[mt], 0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < X3_MT; ++mt)
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[c & 1][q][0], fx[k & 1][mt][1], acc[mt], 0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < X3_MT; ++mt)
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[c & 1][q][0], fx[k & 1][mt][0], acc[mt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#if X3_STREAM && !defined(X3_ABL_NOWLOAD)
-        // the entry just read is free: request the one eight k-steps ahead into it -- this layer's, or the next layer's
-        if (k + 8 < KT) {
-            load_own_entry<NCH, NCH1>(k + 8, w1, w2, wave, lane, ring[c & 1][q]);
-        } else if (next != nullptr) {
-            if (KT >= 8) {
-                if (k + 8 - KT < nw.total) load_next_entry(nw, k + 8 - KT, ring[c & 1][q]);
-            } else {                                                      // a 4-k-step layer feeds two entries per step
-                if (k < nw.total) load_next_entry(nw, k, ring[0][q]);
-                if (k + 4 < nw.total) load_next_entry(nw, k + 4, ring[1][q]);
-            }
+            for (int g = 0; g < 4; ++g) rq[t % 4][g] = *reinterpret_cast<const f32x4*>(rin + ((t + 4) * 4 + g) * 256);
         }
-        if (k == KT - 1 && next != nullptr) load_bias_seed(next, wave, lane, seed);   // (16 registers: not live across the loop)
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
-#if X3_PRIO_SEL
-    __builtin_amdgcn_s_setprio(0);
-#endif
-    if (ui >= 0) { X3_STAMP(4 * ui + 1) }
-#if !X3_STREAM
-    // the ring and the seed are dead: the next layer's first fragments travel during the epilogue and the barrier
-    if (next != nullptr) prefetch_layer(next, wave, lane, ring, seed);
-#endif
-    const bool to_global = (u->flags & F_OUT_F32) != 0;
-    unsigned char* dst = buf_base(smem, u->dst);
-    const int pbd = buf_pitch_bytes(u->dst), pld = buf_plane(u->dst);
-    const int resid = to_global ? -1 : u->res;
-    const unsigned char* res = buf_base(smem, resid >= 0 ? resid : 0);
-    const int pbr = buf_pitch_bytes(resid >= 0 ? resid : 0), plr = buf_plane(resid >= 0 ? resid : 0);
-    const float neg = act_neg(u->act, u->slope);
-    const int slice = wave;
-    // epilogue: this lane owns row (32 mt + r31), features 32*slice + 8g + 4h .. +3
-    if (to_global) {
-        float* st = reinterpret_cast<float*>(dst);
+        f32x4 w[4];
 #pragma unroll
-        for (int mt = 0; mt < X3_MT; ++mt)
+        for (int g = 0; g < 4; ++g) w[g] = v[g] * neg;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], w[g][e]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (COPY || MODE == EP_PARK) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(rout + (t * 4 + g) * 256) = v[g];
+        }
+        if (MODE == EP_OUT) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (slice0 + s < 2)                                              // (N <= 64)
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(img) + (row0 + 32 * mt) * OUT_PITCH + 32 * (slice0 + s) + 4 * h + 8 * g) = v[g];
+        } else if (MODE == EP_IMAGE) {
+            uint2 oh[4], ol[4];
+#ifdef X3_ABL_NOSPLIT
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[mt][4 * g + e], neg);
-                *reinterpret_cast<f32x4*>(st + (32 * mt + r31) * OUT_PITCH + 32 * slice + 4 * h + 8 * g) = v;
+                oh[g].x = __builtin_bit_cast(uint32_t, v[g][0]); oh[g].y = __builtin_bit_cast(uint32_t, v[g][1]);
+                ol[g].x = __builtin_bit_cast(uint32_t, v[g][2]); ol[g].y = __builtin_bit_cast(uint32_t, v[g][3]);
             }
+#else
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                oh[g].x = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v[g][0], v[g][1]}, f16x2));
+                oh[g].y = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v[g][2], v[g][3]}, f16x2));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                ol[g].x = split_lo(v[g][0], v[g][1], oh[g].x);
+                ol[g].y = split_lo(v[g][2], v[g][3], oh[g].y);
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef X3_ABL_NOWRITE
+#pragma unroll
+            for (int g = 0; g < 4; ++g) asm volatile("" :: "v"(oh[g].x), "v"(oh[g].y), "v"(ol[g].x), "v"(ol[g].y));
+#else
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned char* o = img + oaddr[s][g] + mt * 32 * PITCHB;
+                *reinterpret_cast<uint2*>(o) = oh[g];
+                *reinterpret_cast<uint2*>(o + PLANE) = ol[g];
+            }
+#endif
+        }
+        // (one accumulator tile at a time: left alone the scheduler copies all 128 accumulators out of the AGPRs first)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Scheduling directive for one k-step: its NM matrix instructions with the ND LDS reads and NV weight loads of the coming
+// k-steps dealt out between them, one request per group of matrix instructions.
+template <int NM, int ND, int NV>
+__device__ __forceinline__ void spread_requests() {
+    constexpr int PER = NM / ND;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (i < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (i + ND < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    if (NM - PER * ND > 0) __builtin_amdgcn_sched_group_barrier(0x008, NM - PER * ND, 0);
+}
+
+// image = act(W image + bias [+ xin]), one layer, in place.  KT k-steps (a multiple of 4: the blob is padded with zeros);
+// the wave computes SW feature slices x RW row tiles.  On entry the ring holds this layer's k-steps 0 and 1 and `seed` its
+// bias; before the epilogue `next` (the GEMM unit that runs after this one, possibly of the next tile; nullptr: none) is
+// prefetched the same way.  Waves without a block of this layer only take part in the prefetch and the barrier.
+// ADD: the layer adds what waits in the workspace (a residual, a parked partial sum) in its epilogue, LAST, as the reference
+// does ((W y + b) + x; starting the accumulators from x instead moved the generator's head error from 8.3e-7 to 9.5e-7 on the
+// second golden set -- 1.55e-5 m of pose through the 10 tanh root); the first four tiles are requested under the last two
+// k-steps, the others as registers come free.
+template <int KT, int SW, int RW, bool ADD>
+__device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned char* smem, int wave, int lane, WRing& ring, Seed& seed,
+                                           int ui) {
+    asm volatile("" : "+v"(lane));                   // lane-derived constants are recomputed per unit, not parked across units
+    const int r31 = lane & 31, h = lane >> 5, lane16 = lane << 4;
+    const int plan = u->plan;
+    const int lg = (plan >> 8) & 15, pf = plan >> 20;
+    const int sg = wave & ((1 << lg) - 1), rg = wave >> lg;
+    const bool active = rg * RW < X3_MT;             // wave-uniform
+    const int slice0 = sg * SW, row0 = rg * RW * 32 + r31;
+    unsigned char* img = smem;
+    if (!active) {                                   // no block of this layer: the prefetch and the layer's barrier, nothing else
+        if (next != nullptr) prefetch_layer(next, wave, lane, ring, seed);
+        if (!(pf & PF_TO_PARK)) lds_barrier();
+        return;
+    }
+    f32x16 acc[SW][RW];
+    const float* rin = ws_base(u->g, wave, lane, (pf & PF_ADD_R1) ? 1 : 0);
+    f32x4 rq[4][4];                                  // (ADD) tiles of what the epilogue adds, four in flight
+    {
+        const __amdgpu_buffer_rsrc_t rs = weight_rsrc(u->w, slice0, KT);
+        f16x8 fx[2][RW][2];                          // activation fragments (hi, lo) of the wave's row tiles, one k-step ahead
+        // one address per k-step: row 32 mt + r has r's swizzle (32 % 16 == 0) and the lo plane is a constant away
+        const int frag_row = row0 * PITCHB, frag_sw = r31 & 15;
+        auto read_frags = [&](int k, f16x8 (&f)[RW][2]) {
+            const unsigned char* a = img + frag_row + (((2 * k + h) ^ frag_sw) << 4);
+#pragma unroll
+            for (int mt = 0; mt < RW; ++mt) {
+                f[mt][0] = *reinterpret_cast<const f16x8*>(a + mt * 32 * PITCHB);
+                f[mt][1] = *reinterpret_cast<const f16x8*>(a + mt * 32 * PITCHB + PLANE);
+            }
+        };
+        read_frags(0, fx[0]);
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+#ifndef X3_ABL_NOREAD
+            if (k + 1 < KT) read_frags(k + 1, fx[(k + 1) & 1]);
+#endif
+#ifndef X3_ABL_NOWLOAD
+            if (k == 0) {                            // (the prefetch brought k-step 0 only)
+#pragma unroll
+                for (int s = 0; s < SW; ++s)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) ring[1][s][p] = load_frag(rs, lane16, KT, s, 1, p);
+            }
+            if (k + 2 < KT) {                        // two k-steps ahead, into the entry k-step k - 1 just left
+#pragma unroll
+                for (int s = 0; s < SW; ++s)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) ring[(k + 2) % RING][s][p] = load_frag(rs, lane16, KT, s, k + 2, p);
+            }
+#endif
+            if (ADD && k == KT - 2) {                // what the epilogue adds: its first tiles travel under the last two k-steps
+#pragma unroll
+                for (int t = 0; t < (SW * RW < 4 ? SW * RW : 4); ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) rq[t][g] = *reinterpret_cast<const f32x4*>(rin + (t * 4 + g) * 256);
+            }
+#if X3_SPREAD
+            // the k-step's requests are dealt out between its matrix instructions: a lone wave that computes right behind its
+            // own read burst pays for the burst (MI355X_MICROARCH.md, two waves per SIMD, item 7)
+#else
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            // small terms first, then hi * hi (the order of the round-3 kernel)
+#pragma unroll
+            for (int s = 0; s < SW; ++s)
+#pragma unroll
+                for (int mt = 0; mt < RW; ++mt)
+                    acc[s][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[k % RING][s][1], fx[k & 1][mt][0], k == 0 ? seed[s] : acc[s][mt], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < SW; ++s)
+#pragma unroll
+                for (int mt = 0; mt < RW; ++mt)
+                    acc[s][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[k % RING][s][0], fx[k & 1][mt][1], acc[s][mt], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < SW; ++s)
+#pragma unroll
+                for (int mt = 0; mt < RW; ++mt)
+                    acc[s][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[k % RING][s][0], fx[k & 1][mt][0], acc[s][mt], 0, 0, 0);
+#if X3_SPREAD
+            if (k == 0) spread_requests<3 * SW * RW, 2 * RW, 4 * SW>();
+            else if (k + 2 < KT) spread_requests<3 * SW * RW, 2 * RW, 2 * SW>();
+            else if (k + 1 < KT) spread_requests<3 * SW * RW, 2 * RW, ADD ? (SW * RW < 4 ? SW * RW : 4) * 4 : 0>();
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (ui >= 0) { X3_STAMP(8 * ui + 1) }
+    if (ADD && KT < 2) {
+#pragma unroll
+        for (int t = 0; t < (SW * RW < 4 ? SW * RW : 4); ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rq[t][g] = *reinterpret_cast<const f32x4*>(rin + (t * 4 + g) * 256);
+    }
+    // the ring and the seed are dead: the next layer's first fragments travel during the epilogue and the barrier
+    if (next != nullptr) prefetch_layer(next, wave, lane, ring, seed);
+    if (ui >= 0) { X3_STAMP(8 * ui + 4) }
+    const float neg = act_neg(u->act, u->slope);
+    // this lane owns row (row0 + 32 mt), features 32 (slice0 + s) + 8 g + 4 h .. + 3 of the result
+    float* rout = ws_base(u->g, wave, lane, (pf & PF_TO_PARK) ? 1 : 0);
+    const bool copy = (pf & PF_COPY_R0) != 0;
+    if (pf & PF_TO_PARK) {                           // (no barrier: the image is not touched)
+        epilogue<SW, RW, EP_PARK, false, ADD>(acc, rq, rin, rout, img, row0, slice0, h, neg);
+        return;
+    }
+    // All waves finish their k loops at about the same time (one per SIMD, same work), so the barrier comes FIRST and the
+    // conversion is fused with the stores behind it: nothing but the accumulators waits across the barrier.
+    lds_barrier();                                   // every wave has read the image for the last time
+    if (ui >= 0) { X3_STAMP(8 * ui + 5) }
+    if (u->flags & F_OUT_F32) {                      // the image becomes the fp32 staging area of the network's output
+        epilogue<SW, RW, EP_OUT, false, ADD>(acc, rq, rin, rout, img, row0, slice0, h, neg);
         return;
     }
 #ifdef X3_ABL_NOEPI
     if (u->slope != 12345.f) return;
 #endif
-    // all residual values first (16 reads in flight, one LDS round trip): read where they are used, every group's loads sat
-    // behind the previous group's stores (dst may be res: they may alias, the compiler keeps the order) -- eight exposed LDS
-    // round trips per epilogue under the other wave's fragment traffic (phase stamps: 4 - 5.6 k clocks per epilogue)
-    f16x4 rhv[X3_MT][4], rlv[X3_MT][4];
-    if (resid >= 0) {
-#pragma unroll
-        for (int mt = 0; mt < X3_MT; ++mt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ro = chunk_off(32 * mt + r31, 4 * slice + g, pbr) + (h << 3);
-                rhv[mt][g] = *reinterpret_cast<const f16x4*>(res + ro);
-                rlv[mt][g] = *reinterpret_cast<const f16x4*>(res + plr + ro);
-            }
-    }
-#pragma unroll
-    for (int mt = 0; mt < X3_MT; ++mt) {
-        const int row = 32 * mt + r31;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[mt][4 * g + e];
-            if (resid >= 0) {
-                const f16x4 rh = rhv[mt][g], rl = rlv[mt][g];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)rh[e] + (float)rl[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_fn(v[e], neg);
-            uint2 oh, ol;
-            split2(v[0], v[1], oh.x, ol.x);
-            split2(v[2], v[3], oh.y, ol.y);
-            const int o = chunk_off(row, 4 * slice + g, pbd) + (h << 3);
-            *reinterpret_cast<uint2*>(dst + o) = oh;
-            *reinterpret_cast<uint2*>(dst + pld + o) = ol;
-        }
-    }
+    if (copy) epilogue<SW, RW, EP_IMAGE, true, ADD>(acc, rq, rin, rout, img, row0, slice0, h, neg);
+    else epilogue<SW, RW, EP_IMAGE, false, ADD>(acc, rq, rin, rout, img, row0, slice0, h, neg);
 }
 
-// LOAD: global fp32 (M, ld) columns [0, cols) -> hi / lo planes of buffer dst, zero-filled up to the next multiple of 64
+// LOAD: global fp32 (M, ld) columns [0, cols) -> hi / lo planes of the image, zero-filled up to the next multiple of 64
 // columns and below row M.  cols and ld even: a thread moves column pairs (8-byte loads, 4-byte LDS writes).
 __device__ __forceinline__ void load_unit(UnitPtr u, unsigned char* smem, long long m0, long long M, int tid) {
     asm volatile("" : "+v"(tid));
     const float* g = static_cast<const float*>(u->g);
     const long long ld = u->ld;
-    const int cols = u->cols, id = u->dst;
-    unsigned char* dst = buf_base(smem, id);
-    const int pb = buf_pitch_bytes(id), pl = buf_plane(id);
+    const int cols = u->cols;
     const int pairs = ((cols + 63) & ~63) >> 1;                              // per row, zero fill included: 32, 64 or 128
     const int sh = pairs == 32 ? 5 : (pairs == 64 ? 6 : 7);
     const int total = X3_BM << sh;
@@ -416,9 +442,9 @@ __device__ __forceinline__ void load_unit(UnitPtr u, unsigned char* smem, long l
             uint32_t hi, lo;
             split2(v[j][0], v[j][1], hi, lo);
             if (i < total) {
-                const int o = chunk_off(row, c2 >> 2, pb) + ((c2 & 3) << 2);
-                *reinterpret_cast<uint32_t*>(dst + o) = hi;
-                *reinterpret_cast<uint32_t*>(dst + pl + o) = lo;
+                const int o = chunk_off(row, c2 >> 2) + ((c2 & 3) << 2);
+                *reinterpret_cast<uint32_t*>(smem + o) = hi;
+                *reinterpret_cast<uint32_t*>(smem + PLANE + o) = lo;
             }
         }
     }
@@ -426,22 +452,18 @@ __device__ __forceinline__ void load_unit(UnitPtr u, unsigned char* smem, long l
 
 // LOAD_KCS: the 30 KCS features of a tile's poses (global fp32 (M, ld >= 48), root-relative or not: bones are differences),
 // computed here in the arithmetic of the stand-alone dhaug_kcs_forward (kcs_features, dhaug_fk_math.h: IEEE sqrt and divide) ->
-// hi / lo planes of buffer dst, columns 30..63 zero.  One lane per pose for the features (64 of the 512 threads; the tile's
-// 12 KB of poses are read with 16-byte loads), every thread for the zero fill.  Replaces a separate 9 us launch + 8 MB round
-// trip in front of the 3D critic's parity program.
+// hi / lo planes of the image, columns 30..63 zero.  One lane per pose for the features (128 of the 256 threads), every
+// thread for the zero fill.  Replaces a separate launch + 8 MB round trip in front of the 3D critic's parity program.
 __device__ __forceinline__ void load_kcs_unit(UnitPtr u, unsigned char* smem, long long m0, long long M, int tid) {
     asm volatile("" : "+v"(tid));
     const float* g = static_cast<const float*>(u->g);
     const long long ld = u->ld;
-    const int id = u->dst;
-    unsigned char* dst = buf_base(smem, id);
-    const int pb = buf_pitch_bytes(id), pl = buf_plane(id);
     // pairs 15 .. 31 of every row: zero
     for (int s = tid; s < X3_BM * 17; s += X3_THREADS) {
         const int row = s / 17, c2 = 15 + (s - row * 17);
-        const int o = chunk_off(row, c2 >> 2, pb) + ((c2 & 3) << 2);
-        *reinterpret_cast<uint32_t*>(dst + o) = 0u;
-        *reinterpret_cast<uint32_t*>(dst + pl + o) = 0u;
+        const int o = chunk_off(row, c2 >> 2) + ((c2 & 3) << 2);
+        *reinterpret_cast<uint32_t*>(smem + o) = 0u;
+        *reinterpret_cast<uint32_t*>(smem + PLANE + o) = 0u;
     }
     if (tid < X3_BM) {
         const int row = tid;
@@ -460,15 +482,15 @@ __device__ __forceinline__ void load_kcs_unit(UnitPtr u, unsigned char* smem, lo
         for (int c2 = 0; c2 < 15; ++c2) {
             uint32_t hi, lo;
             split2(f[2 * c2], f[2 * c2 + 1], hi, lo);
-            const int o = chunk_off(row, c2 >> 2, pb) + ((c2 & 3) << 2);
-            *reinterpret_cast<uint32_t*>(dst + o) = hi;
-            *reinterpret_cast<uint32_t*>(dst + pl + o) = lo;
+            const int o = chunk_off(row, c2 >> 2) + ((c2 & 3) << 2);
+            *reinterpret_cast<uint32_t*>(smem + o) = hi;
+            *reinterpret_cast<uint32_t*>(smem + PLANE + o) = lo;
         }
     }
 }
 
 __device__ __forceinline__ void store_output(UnitPtr u, unsigned char* smem, long long m0, long long M, int tid) {
-    const float* st = reinterpret_cast<const float*>(buf_base(smem, u->dst));
+    const float* st = reinterpret_cast<const float*>(smem);
     float* out = static_cast<float*>(const_cast<void*>(u->g));
     const long long ld = u->ld;
     const int N = u->N;
@@ -488,8 +510,8 @@ __global__ __launch_bounds__(X3_THREADS, 1) void fused_mlp_x3_kernel(Program pro
     UnitPtr units = (UnitPtr)(ka + __builtin_offsetof(Program, u));
     const int nunits = *(const int __attribute__((address_space(4)))*)(ka + __builtin_offsetof(Program, nunits));
     const int first_gemm = *(const int __attribute__((address_space(4)))*)(ka + __builtin_offsetof(Program, first_gemm));
-    Ring ring;
-    f32x16 seed;
+    WRing ring;
+    Seed seed;
     if ((long long)blockIdx.x < ntiles) prefetch_layer(units + first_gemm, wave, lane, ring, seed);
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long m0 = tile * X3_BM;
@@ -498,7 +520,8 @@ __global__ __launch_bounds__(X3_THREADS, 1) void fused_mlp_x3_kernel(Program pro
         for (int i = 0; i < nunits; ++i) {
             UnitPtr u = units + i;
             const int kind = u->kind, plan = u->plan;
-            if (tile == blockIdx.x) { X3_STAMP(4 * i) }
+            const int si = tile == blockIdx.x ? i : -1;
+            if (si >= 0) { X3_STAMP(8 * i) }
             if (kind == U_LOAD_F32) {
                 load_unit(u, smem, m0, M, tid);
             } else if (kind == U_LOAD_KCS) {
@@ -508,23 +531,32 @@ __global__ __launch_bounds__(X3_THREADS, 1) void fused_mlp_x3_kernel(Program pro
                 // the next tile then starts over at the first)
                 const int nx = plan & 255;
                 UnitPtr next = nx != 0 ? units + (nx - 1) : (more ? units + first_gemm : (UnitPtr) nullptr);
-                switch ((plan >> 16) & 255) {                          /* validated on the host */
-                    case 1 * 16 + 1: gemm_layer<1, 1>(u, next, smem, wave, lane, ring, seed, tile == blockIdx.x ? i : -1); break;
-                    case 2 * 16 + 2: gemm_layer<2, 2>(u, next, smem, wave, lane, ring, seed, tile == blockIdx.x ? i : -1); break;
-                    case 2 * 16 + 1: gemm_layer<2, 1>(u, next, smem, wave, lane, ring, seed, tile == blockIdx.x ? i : -1); break;
-                    case 4 * 16 + 4: gemm_layer<4, 4>(u, next, smem, wave, lane, ring, seed, tile == blockIdx.x ? i : -1); break;
-                    case 4 * 16 + 2: gemm_layer<4, 2>(u, next, smem, wave, lane, ring, seed, tile == blockIdx.x ? i : -1); break;
-                    case 8 * 16 + 4: gemm_layer<8, 4>(u, next, smem, wave, lane, ring, seed, tile == blockIdx.x ? i : -1); break;
+#define X3_CASE(CH, MAP, SW, RW) \
+    case (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, false>(u, next, smem, wave, lane, ring, seed, si); break;
+#define X3_CASE_ADD(CH, MAP, SW, RW) \
+    case 256 + (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, true>(u, next, smem, wave, lane, ring, seed, si); break;
+                /* (chunks, map, adds something): validated on the host */
+                switch (((plan >> 12) & 255) | ((plan & ((PF_ADD_R0 | PF_ADD_R1) << 20)) ? 256 : 0)) {
+                    X3_CASE(1, MAP_2x4, 2, 4) X3_CASE(2, MAP_2x4, 2, 4) X3_CASE(4, MAP_2x4, 2, 4)
+                    X3_CASE(1, MAP_1x4, 1, 4) X3_CASE(2, MAP_1x4, 1, 4) X3_CASE(4, MAP_1x4, 1, 4)
+                    X3_CASE(1, MAP_1x2, 1, 2) X3_CASE(2, MAP_1x2, 1, 2) X3_CASE(4, MAP_1x2, 1, 2)
+                    X3_CASE(1, MAP_1x1, 1, 1) X3_CASE(2, MAP_1x1, 1, 1) X3_CASE(4, MAP_1x1, 1, 1)
+                    X3_CASE_ADD(1, MAP_2x4, 2, 4) X3_CASE_ADD(2, MAP_2x4, 2, 4) X3_CASE_ADD(4, MAP_2x4, 2, 4)
+                    X3_CASE_ADD(1, MAP_1x4, 1, 4) X3_CASE_ADD(2, MAP_1x4, 1, 4) X3_CASE_ADD(4, MAP_1x4, 1, 4)
+                    X3_CASE_ADD(1, MAP_1x2, 1, 2) X3_CASE_ADD(2, MAP_1x2, 1, 2) X3_CASE_ADD(4, MAP_1x2, 1, 2)
+                    X3_CASE_ADD(1, MAP_1x1, 1, 1) X3_CASE_ADD(2, MAP_1x1, 1, 1) X3_CASE_ADD(4, MAP_1x1, 1, 1)
                     default: break;
                 }
+#undef X3_CASE_ADD
+#undef X3_CASE
                 if (u->flags & F_OUT_F32) {
                     lds_barrier();
                     store_output(u, smem, m0, M, tid);
                 }
             }
-            if (tile == blockIdx.x) { X3_STAMP(4 * i + 2) }
+            if (si >= 0) { X3_STAMP(8 * i + 2) }
             lds_barrier();
-            if (tile == blockIdx.x) { X3_STAMP(4 * i + 3) }
+            if (si >= 0) { X3_STAMP(8 * i + 3) }
         }
     }
     (void)prog;
@@ -558,7 +590,7 @@ int dhaug_pack_wfrag_f16x2(const float* W, int64_t ldw, uint16_t* dst, int64_t N
     DHAUG_CHECK_PTR(W); DHAUG_CHECK_PTR(dst);
     DHAUG_CHECK(dhaug_aligned16(dst), DHAUG_EALIGN);
     const int ksteps = (int)((K + 63) / 64) * 4, nslices = 8;
-    DHAUG_CHECK(ksteps <= X3_MAX_KSTEPS && N <= 256, DHAUG_EUNSUPPORTED);
+    DHAUG_CHECK(ksteps <= 16 && N <= 256, DHAUG_EUNSUPPORTED);
     const long long total = (long long)nslices * ksteps * 512;
     long long blocks = (total + 255) / 256;
     if (blocks > 1024) blocks = 1024;
@@ -567,6 +599,9 @@ int dhaug_pack_wfrag_f16x2(const float* W, int64_t ldw, uint16_t* dst, int64_t N
     return dhaug_launch_status();
 }
 
+/* The planner: the units address three virtual buffers (include/dhaug.h); the kernel has ONE image and a two-region global
+ * workspace.  Walk the program, track where every buffer's current value lives, and annotate the GEMM units; a program in
+ * which a value would be needed from a place it is not in is DHAUG_EUNSUPPORTED. */
 int dhaug_mlp_forward_x3(const dhaug_mlp_unit* units, int nunits, int64_t M, void* stream) {
     DHAUG_CHECK(nunits >= 1 && nunits <= X3_MAX_UNITS && M >= 0, DHAUG_EINVAL);
     DHAUG_CHECK_PTR(units);
@@ -574,42 +609,115 @@ int dhaug_mlp_forward_x3(const dhaug_mlp_unit* units, int nunits, int64_t M, voi
     Program prog;
     prog.nunits = nunits;
     auto okbuf = [](int b) { return b >= 0 && b <= 2; };
-    auto pitch = [](int b) { return b == 2 ? P2 : P01; };
+    auto is_out = [](const dhaug_mlp_unit& t) { return t.kind == U_GEMM && (t.flags & F_OUT_F32) != 0; };
+    auto map_of = [](int n) { const int nsl = (n + 31) / 32; return nsl > 4 ? MAP_2x4 : (nsl > 2 ? MAP_1x4 : (nsl == 2 ? MAP_1x2 : MAP_1x1)); };
+    // how buffer b's CURRENT value is read after unit i, until the buffer is written again: 1 as a source, 2 as a residual
+    auto uses = [&](int b, int i) {
+        int m = 0;
+        for (int j = i + 1; j < nunits; ++j) {
+            const dhaug_mlp_unit& t = units[j];
+            if (t.kind == U_GEMM) {
+                if (t.src == b) m |= 1;
+                if (t.res == b) m |= 2;
+                if (t.dst == b && !is_out(t)) break;
+            } else if (t.dst == b) {
+                break;
+            }
+        }
+        return m;
+    };
+    const void* ws = nullptr;                                       /* the workspace: g of the GEMM units that are not outputs */
+    for (int i = 0; i < nunits; ++i)
+        if (units[i].kind == U_GEMM && !is_out(units[i]) && units[i].g != nullptr) { ws = units[i].g; break; }
+    DHAUG_CHECK(ws == nullptr || dhaug_aligned16(ws), DHAUG_EALIGN);
+    int img = -1;                                                   /* the virtual buffer whose value the image holds */
+    int r0 = -1, r0_map = -1, r1 = -1, r1_map = -1;                 /* ... region 0 (a copy for a residual), region 1 (parked) */
     for (int i = 0; i < nunits; ++i) {
         const dhaug_mlp_unit& s = units[i];
         Unit& u = prog.u[i];
-        u.kind = s.kind; u.flags = s.flags; u.src = s.src; u.dst = s.dst; u.res = s.res; u.src2 = s.src2; u.ksteps2 = s.ksteps2;
-        u.ksteps = s.ksteps; u.N = s.n; u.act = s.act; u.slope = s.slope; u.cols = s.cols; u.ld = s.ld; u.g = s.g;
-        u.w = static_cast<const _Float16*>(s.w); u.w2 = static_cast<const _Float16*>(s.w2); u.bias = s.bias;
+        u.kind = s.kind; u.flags = s.flags; u.ksteps = s.ksteps; u.N = s.n; u.act = s.act; u.slope = s.slope; u.cols = s.cols;
+        u.ld = s.ld; u.g = s.g; u.w = static_cast<const _Float16*>(s.w); u.bias = s.bias;
         u.plan = 0;
         DHAUG_CHECK(u.kind == U_LOAD_F32 || u.kind == U_GEMM || u.kind == U_LOAD_KCS, DHAUG_EUNSUPPORTED);
         if (u.kind == U_GEMM) {
-            DHAUG_CHECK(okbuf(u.src) && u.ksteps >= 1 && u.ksteps <= X3_MAX_KSTEPS && u.N >= 1 && u.N <= 256, DHAUG_EUNSUPPORTED);
-            DHAUG_CHECK(((u.ksteps + 3) / 4) * 64 <= pitch(u.src), DHAUG_EUNSUPPORTED);
+            DHAUG_CHECK(okbuf(s.src) && u.ksteps >= 1 && u.ksteps <= 16 && u.N >= 1 && u.N <= 256, DHAUG_EUNSUPPORTED);
+            DHAUG_CHECK(s.ksteps2 == 0, DHAUG_EUNSUPPORTED);              /* (a concatenation is two units: see fused.py) */
             DHAUG_CHECK(u.w != nullptr && dhaug_aligned16(u.w) && u.bias != nullptr && dhaug_aligned16(u.bias), DHAUG_EALIGN);
-            DHAUG_CHECK(u.ksteps2 >= 0 && u.ksteps2 <= X3_MAX_KSTEPS, DHAUG_EUNSUPPORTED);
             DHAUG_CHECK((u.flags & ~F_OUT_F32) == 0, DHAUG_EUNSUPPORTED);
-            if (u.ksteps2 > 0) {
-                DHAUG_CHECK(okbuf(u.src2) && ((u.ksteps2 + 3) / 4) * 64 <= pitch(u.src2) && u.ksteps % 4 == 0, DHAUG_EUNSUPPORTED);
-                DHAUG_CHECK(u.w2 != nullptr && dhaug_aligned16(u.w2), DHAUG_EALIGN);
+            DHAUG_CHECK(s.src == img, DHAUG_EUNSUPPORTED);                /* the source must be what the image holds */
+            const int chunks = (u.ksteps + 3) / 4;
+            DHAUG_CHECK(chunks == 1 || chunks == 2 || chunks == 4, DHAUG_EUNSUPPORTED);
+            const int map = map_of(u.N);
+            const int lg = map == MAP_1x1 ? 0 : (map == MAP_1x2 ? 1 : 2);      /* log2(slice groups) */
+            int pf = 0;
+            if (s.res >= 0) {
+                DHAUG_CHECK(okbuf(s.res) && s.res != s.src, DHAUG_EINVAL);
+                if (s.res == r0) {
+                    DHAUG_CHECK(r0_map == map, DHAUG_EUNSUPPORTED);      /* (written and read back lane by lane) */
+                    pf |= PF_ADD_R0;
+                } else {
+                    DHAUG_CHECK(s.res == r1 && r1_map == map, DHAUG_EUNSUPPORTED);
+                    pf |= PF_ADD_R1;
+                    r1 = -1;
+                }
             }
-            const int c1 = (u.ksteps + 3) / 4, c2 = (u.ksteps2 + 3) / 4, sh = (c1 + c2) * 16 + c1;
-            DHAUG_CHECK(sh == 17 || sh == 34 || sh == 33 || sh == 68 || sh == 66 || sh == 132, DHAUG_EUNSUPPORTED);
-            if (u.flags & F_OUT_F32) {
+            const bool out = is_out(s);
+            const int mdst = out ? 0 : uses(s.dst, i);
+            const bool park = !out && (mdst & 2) && !(mdst & 1);
+            if (!park) {
+                /* the image is overwritten at this unit's epilogue: nobody may read the source from it afterwards, and
+                   whoever adds it later must find it in the workspace */
+                const int m = uses(s.src, i);
+                DHAUG_CHECK(!(m & 1) && (!(m & 2) || s.src == r0 || s.src == r1), DHAUG_EUNSUPPORTED);
+            }
+            if (out) {
                 DHAUG_CHECK(u.g != nullptr && u.ld >= u.N && u.N <= 64, DHAUG_EUNSUPPORTED);
-                DHAUG_CHECK((u.dst == 0 || u.dst == 1) && u.dst != u.src && (u.ksteps2 == 0 || u.dst != u.src2), DHAUG_EINVAL);
+                img = -1;                                                  /* the image becomes the staging area */
+                if (pf) { DHAUG_CHECK(ws != nullptr, DHAUG_EINVAL); }
             } else {
-                DHAUG_CHECK(okbuf(u.dst) && u.dst != u.src && (u.ksteps2 == 0 || u.dst != u.src2), DHAUG_EINVAL);
-                DHAUG_CHECK(((u.N + 31) / 32) * 32 <= pitch(u.dst), DHAUG_EUNSUPPORTED);
-                DHAUG_CHECK(u.res < 0 || (okbuf(u.res) && u.res != u.src && (u.ksteps2 == 0 || u.res != u.src2)), DHAUG_EINVAL);
-                DHAUG_CHECK(u.res < 0 || ((u.N + 31) / 32) * 32 <= pitch(u.res), DHAUG_EUNSUPPORTED);
+                DHAUG_CHECK(okbuf(s.dst) && s.dst != s.src, DHAUG_EINVAL);
+                const int m = mdst;
+                if (park) {
+                    /* nobody reads the result as a source before it is added somewhere: it waits in region 1 and the image
+                       keeps the source */
+                    DHAUG_CHECK(r1 < 0, DHAUG_EUNSUPPORTED);
+                    pf |= PF_TO_PARK;
+                    r1 = s.dst; r1_map = map;
+                    if (r0 == s.dst) r0 = -1;
+                } else {
+                    if (m & 2) {
+                        /* read as a source AND added later: image + a copy in region 0, whose old content must be dead */
+                        DHAUG_CHECK(r0 < 0 || r0 == s.dst || !(uses(r0, i) & 2), DHAUG_EUNSUPPORTED);
+                        pf |= PF_COPY_R0;
+                        r0 = s.dst; r0_map = map;
+                    } else if (r0 == s.dst) {
+                        r0 = -1;                                           /* (the copy is of the old value) */
+                    }
+                    if (r1 == s.dst) r1 = -1;
+                    img = s.dst;
+                }
+                u.g = ws;
+                if (pf) { DHAUG_CHECK(ws != nullptr, DHAUG_EINVAL); }
             }
-            u.plan = (sh << 16) | (((u.N + 31) >> 5) << 24);                  // bits 0..7: index + 1 of the next GEMM unit (below)
-        } else if (u.kind == U_LOAD_KCS) {
-            DHAUG_CHECK(okbuf(u.dst) && u.g != nullptr && u.ld >= 48 && 64 <= pitch(u.dst), DHAUG_EINVAL);
+            if (out && pf) {
+                /* an output that adds a residual reads the workspace through g, which holds the output: not supported */
+                return DHAUG_EUNSUPPORTED;
+            }
+            u.plan = (lg << 8) | (map << 12) | (chunks << 16) | (pf << 20);   // bits 0..7: index + 1 of the next GEMM unit (below)
         } else {
-            DHAUG_CHECK(okbuf(u.dst) && u.g != nullptr && u.cols >= 2 && ((u.cols + 63) & ~63) <= pitch(u.dst), DHAUG_EINVAL);
-            DHAUG_CHECK(u.cols % 2 == 0 && u.ld % 2 == 0 && u.ld >= u.cols && (reinterpret_cast<uintptr_t>(u.g) & 7u) == 0, DHAUG_EALIGN);
+            if (u.kind == U_LOAD_KCS) {
+                DHAUG_CHECK(okbuf(s.dst) && u.g != nullptr && u.ld >= 48, DHAUG_EINVAL);
+            } else {
+                DHAUG_CHECK(okbuf(s.dst) && u.g != nullptr && u.cols >= 2 && ((u.cols + 63) & ~63) <= 256, DHAUG_EINVAL);
+                DHAUG_CHECK(u.cols % 2 == 0 && u.ld % 2 == 0 && u.ld >= u.cols && (reinterpret_cast<uintptr_t>(u.g) & 7u) == 0, DHAUG_EALIGN);
+            }
+            if (img >= 0 && img != s.dst) {                                /* what the image held: dead, or safe in the workspace */
+                const int m = uses(img, i);
+                DHAUG_CHECK(!(m & 1) && (!(m & 2) || img == r0 || img == r1), DHAUG_EUNSUPPORTED);
+            }
+            if (r0 == s.dst) r0 = -1;
+            if (r1 == s.dst) r1 = -1;
+            img = s.dst;
         }
     }
     prog.first_gemm = -1;
@@ -635,7 +743,7 @@ int dhaug_mlp_forward_x3(const dhaug_mlp_unit* units, int nunits, int64_t M, voi
 
 #ifdef X3_TIMING
 int dhaug_debug_mlp_stamps(long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x3_stamps), sizeof(long long) * (n < 4 * X3_MAX_UNITS ? n : 4 * X3_MAX_UNITS));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x3_stamps), sizeof(long long) * (n < 8 * X3_MAX_UNITS ? n : 8 * X3_MAX_UNITS));
 }
 #endif
 }  // extern "C"

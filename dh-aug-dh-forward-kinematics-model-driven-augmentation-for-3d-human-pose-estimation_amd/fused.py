@@ -20,6 +20,7 @@ _vp = ctypes.c_void_p
 # (dhaug_mlp_forward_x3: operands as fp16 hi + lo pairs, three MFMA terms, fp32-grade -- the mode that meets the path's
 # 1e-4 logit tolerance against the fp32 reference)
 MODES = ("bf16", "f16x3")
+X3_WORKSPACE_BYTES = 2 * 256 * 4 * 64 * 128 * 4               # DHAUG_MLP_X3_WORKSPACE_BYTES of include/dhaug.h
 SIGN_BITS = os.environ.get("DHAUG_NO_SIGN_BITS") is None      # forward-with-save also emits (y > 0) bit arrays of its run layers
 
 
@@ -195,6 +196,15 @@ class FusedNet:
 
 
 def launch(units, M, mode):
+    if mode == "f16x3":
+        # residuals and parked partial sums wait in a global workspace (DHAUG_MLP_X3_WORKSPACE_BYTES, include/dhaug.h).  One per
+        # launch from the caching allocator, i.e. stream-ordered: launches on different streams never share one, and a
+        # hipGraph capture gets its own from the graph's pool.
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ws = torch.empty(X3_WORKSPACE_BYTES, dtype=torch.uint8, device=dev)
+        for u in units:
+            if u.kind == GEMM and not (u.flags & F_OUT_F32):
+                u.g = ws.data_ptr()
     arr = (_lib.MlpUnit * len(units))(*units)
     _lib.call("dhaug_mlp_forward" if mode == "bf16" else "dhaug_mlp_forward_x3", arr, len(units), M, ops._stream())
 
@@ -288,6 +298,7 @@ def _d3_program(D, L, inputs, M):
     # images the pose branch needs, so its share of the merge layer's pre-activation (W[:, :D] kcs_out + bias, 100 wide)
     # waits in buffer 2 as bf16 and the pose branch's share is added to it as a residual (one extra bf16 rounding of a
     # partial sum; the alternative was a 33.5 MB round trip through L2)
+    # (f16x3: that share waits in the launch's global workspace instead -- see launch())
     u.append(_unit(GEMM, src=0, dst=2, ksteps=mp.ksteps[0], n=mp.N, act=ACT_NONE, w=mp.w[0], bias=mp.bias))
     u += [_unit(LOAD_BF16 if x.dtype == torch.bfloat16 else LOAD_F32, dst=1, cols=48, ld=x.stride(0), g=x),
           _gemm(L["previous.0"], 1, 0, ACT_RELU)]

@@ -403,13 +403,19 @@ int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* 
 /* Parity-grade variant of the same programs: every operand is an fp16 pair x = hi + lo (22 mantissa bits), a product is
  * Whi Xhi + Whi Xlo + Wlo Xhi on v_mfma_f32_32x32x16_f16 with fp32 accumulation -- fp32-grade results (the reference's
  * layers are fp32 nn.Linear: R/models_Fk_GAN/Fk_discriminator.py:180-201,253-266, R/models_Fk_GAN/Fk_generator.py:115-119;
- * tolerance 1e-4 relative on the logits) at three matrix instructions per k-step.  64-row batch tiles, activations as
- * hi / lo planes in LDS.  Differences from dhaug_mlp_forward: weights come from dhaug_pack_wfrag_f16x2; only LOAD_F32
- * (cols and ld even, 8-byte aligned base) and GEMM units; no F_DOT_OUT (a 1-wide logit layer is an OUT_F32 unit).
+ * tolerance 1e-4 relative on the logits) at three matrix instructions per k-step.  128-row batch tiles; the activation lives
+ * in ONE hi / lo image in LDS that every layer updates in place, so the three buffer ids of a program are virtual: the
+ * library checks that every value a unit reads is where the kernel can find it (the image for a source, the workspace for a
+ * residual) and returns DHAUG_EUNSUPPORTED otherwise.  Values that a later unit adds as a RESIDUAL wait in a global workspace
+ * (fp32, written and read back by the same lane): a program with residuals passes g = a 16-byte aligned buffer of
+ * DHAUG_MLP_X3_WORKSPACE_BYTES, shared with no concurrent launch, in its GEMM units that are not outputs (any content).
+ * Differences from dhaug_mlp_forward: weights come from dhaug_pack_wfrag_f16x2; only LOAD_F32 (cols and ld even, 8-byte
+ * aligned base), LOAD_KCS and GEMM units; no second source; no F_DOT_OUT (a 1-wide logit layer is an OUT_F32 unit).
  * dhaug_pack_wfrag_f16x2: dst[(((slice*ksteps + ks)*2 + piece)*64 + lane)*8 + j] = piece(W[32 slice + (lane&31)][k0 + 16 ks +
  * 8 (lane>>5) + j]), piece 0 = fp16(w), piece 1 = fp16(w - piece 0); 8 slices, k-steps padded to multiples of 4, i.e.
  * 2 * 8 * ksteps * 512 fp16 values. */
 int dhaug_pack_wfrag_f16x2(const float* W, int64_t ldw, uint16_t* dst, int64_t N, int64_t K, int64_t k0, void* stream);
+#define DHAUG_MLP_X3_WORKSPACE_BYTES (2 * 256 * 4 * 64 * 128 * 4)   /* regions x workgroups x waves x lanes x values x 4 */
 int dhaug_mlp_forward_x3(const dhaug_mlp_unit* units, int nunits, int64_t M, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------

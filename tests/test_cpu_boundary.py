@@ -46,6 +46,9 @@ def test_scratch_sizes_mirror_the_header(built):
     from dhaug_amd import ops
     hdr = open(os.path.join(ROOT, "include", "dhaug.h")).read()
     assert int(re.search(r"#define\s+DHAUG_CRITIC_SCALARS_SCRATCH\s+(\d+)", hdr).group(1)) == ops.CRITIC_SCALARS_SCRATCH
+    from dhaug_amd import fused
+    expr = re.search(r"#define\s+DHAUG_MLP_X3_WORKSPACE_BYTES\s+\(([0-9 *]+)\)", hdr).group(1)
+    assert eval(expr) == fused.X3_WORKSPACE_BYTES
 
 
 def test_argument_errors_are_returned_not_thrown(built):

@@ -13,19 +13,21 @@ x3 = torch.randn(B, 48, device="cuda") * 0.3
 kcs = ops.kcs_forward(x3, True, f32=True)[0]
 L = _lib.lib()
 L.dhaug_debug_mlp_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
-buf = (ctypes.c_longlong * 128)()
+buf = (ctypes.c_longlong * 256)()
 with torch.no_grad():
     for _ in range(20):
         fused.critic3d(D3, x3, kcs=kcs, mode="f16x3")
     torch.cuda.synchronize()
-    L.dhaug_debug_mlp_stamps(buf, 128)
-st = [buf[i] for i in range(128)]
+    L.dhaug_debug_mlp_stamps(buf, 256)
+st = [buf[i] for i in range(256)]
 base = st[0]
-prev_end = base
 for u in range(32):
-    s0, s1, s2, s3 = st[4 * u:4 * u + 4]
+    s0, s1, s2, s3, s4, s5 = st[8 * u:8 * u + 6]
     if not s0:
         continue
-    print("unit %2d: start +%6d | k loop %6s | epilogue %6s | barrier %5d | total %6d" %
-          (u, s0 - base, (s1 - s0) if s1 else "-", (s2 - s1) if s1 else (s2 - s0), s3 - s2, s3 - s0))
+    if s1:
+        print("unit %2d: start +%6d | k loop %6d | prefetch issue %5d | barrier A %5s | epilogue %6s | barrier B %5d | total %6d" %
+              (u, s0 - base, s1 - s0, s4 - s1, (s5 - s4) if s5 else "-", (s2 - s5) if s5 else (s2 - s4), s3 - s2, s3 - s0))
+    else:
+        print("unit %2d: start +%6d | load %6d | barrier %5d" % (u, s0 - base, s2 - s0, s3 - s2))
 print("tile total", max(st) - base)
