@@ -10,32 +10,39 @@
 // MFMA runs at the BF16 rate, so this mode costs 3 matrix instructions per k-step instead of 1 -- its roofline is a third
 // of the dense peak in ALGORITHMIC flops.  Range: |x| < 65 504 (fp16); values below 2^-14 keep an ABSOLUTE error of 2^-25.
 //
-// Structure (round 4; the round-3 kernel -- 64-row tiles, two images, eight waves -- stood at 0.35 of the matrix peak because
+// Structure (round 4).  The round-3 kernel -- 64-row tiles, two images, eight waves -- stood at 0.35 of the matrix peak because
 // per 256 -> 256 layer and tile its three resources were of equal size: 6 144 clocks of matrix issue, 4 096 of the 64 B/clk
 // vector-memory path for 256 KB of weight fragments, 4 096 of LDS fragment reads; what had to shrink was the fragment bytes
-// PER ROW):
+// PER ROW.  Now:
 //   * 128-row batch tiles: a layer's hi + lo weight fragments (256 KB, streamed from L2) serve twice the rows -- the
 //     vector-memory path drops to a third of the matrix time.  B = 65 536 is exactly two tiles per CU;
 //   * ONE activation image per tile, updated IN PLACE: hi / lo planes [128][256] fp16 = 128 KB of the 160 KB (two images do
 //     not fit).  A layer reads the image through its whole k loop, all waves meet at a barrier, then every lane writes the
-//     elements it owns.  What a later layer adds as a residual is therefore NOT in LDS any more when it is needed, and the
-//     register file has no room for it either (128 accumulators + 128 residual values + fragments: hipcc spills from ~330
-//     live registers of the 512): the layer that PRODUCES such a value also writes it, fp32, into a per-workgroup global
-//     workspace (region 0; 16 bytes per lane and register quad, in accumulator order -- written and read back by the same
-//     lane, it never leaves L2 / the Infinity Cache), and the layer that adds it requests it tile by tile in its epilogue,
-//     two accumulator tiles ahead;
-//   * a partial result that has to wait while ANOTHER branch uses the image (the 3D critic's KCS half of the merge layer,
-//     fused.py `_d3_program`) is parked the same way (region 1), no longer in a third LDS buffer;
-//   * four waves (one per SIMD, 512 registers): wave w owns 64 features x 128 rows of a 256-wide layer = 128 accumulator
-//     registers, 24 matrix instructions per k-step and 4 KB of weights + 8 KB of LDS fragment reads for them (round 3:
-//     6 per 2 KB + 4 KB), fragments of the next k-step(s) always in flight.  Narrow layers are dealt as (slices x row tiles)
-//     blocks so that every wave has work: 1 x 4 (N <= 128), 1 x 2 (N <= 64), 1 x 1 (N <= 32);
+//     elements it owns (16-byte chunks after one half-wave exchange: whole_chunk) and a second barrier opens the next layer;
+//   * eight waves (two per SIMD, 256 registers; X3_NWAVES = 4 builds the one-wave-per-SIMD variant, measured slower:
+//     363 us against 331 for the 3D critic): wave w owns feature slice w for all 128 rows = 64 accumulator registers,
+//     12 matrix instructions per k-step for 2 KB of weights and 8 KB of LDS fragment reads, the k-step walked in two
+//     row-tile pairs so that only 32 registers of fragments are in flight.  Narrow layers are dealt as (slice x row tiles)
+//     blocks so that every wave has work: 1 x 2 (N <= 128), 1 x 1 (N <= 64);
+//   * what a later layer adds as a RESIDUAL is not in LDS any more when it is needed (the image has been overwritten twice):
+//     the lane that produced it is the lane that will add it, so it keeps the packed hi / lo pairs it has just stored in 64
+//     REGISTERS (`stash`) across the layer in between.  (Through a global workspace -- the first form of this kernel, still
+//     what the four-wave build does -- the same values cost 65 us of the 3D critic's 339: 4 MB per XCD of residuals evict
+//     the weight fragments from the 4 MB L2 they are streamed from; ablation X3_ABL_NOWS.)
+//   * a partial result that has to wait while ANOTHER branch uses the image and the stash (the 3D critic's KCS half of the
+//     merge layer, fused.py `_d3_program`) is parked in a per-workgroup global workspace (region 1: fp32, written and read
+//     back by the same lane, 64 KB per tile), no longer in a third LDS buffer;
 //   * the virtual three-buffer programs of include/dhaug.h are kept: the host planner below proves that a program can run on
-//     one image (every value is either in the image or in the workspace when it is read) and annotates its units;
+//     one image (every value is in the image, the stash or the workspace when it is read) and annotates its units;
 //   * weights: pre-split and pre-packed in A-fragment order (dhaug_pack_wfrag_f16x2); MFMA issued swapped (A = weights,
 //     B = activations): a lane owns one batch row and 4 consecutive features per register quad;
-//   * per output element the order of summation is the round-3 kernel's (k ascending, per k-step Wlo Xhi, Whi Xlo, Whi Xhi,
-//     bias as the accumulator seed, residual added last) -- the residual itself is now the exact fp32 value, not hi + lo.
+//   * per output element the arithmetic is the round-3 kernel's (k ascending, per k-step Wlo Xhi, Whi Xlo, Whi Xhi, bias as
+//     the accumulator seed, the residual added last as hi + lo): the generator's head and the 2D critic's logits are the same
+//     bits, the 3D critic's differ by the parked half (fp32 now, an fp16 pair then).
+// Measured (MI355X, B = 65 536, D = 256, same box, tools/time_x3.py): G 152 us (184), D3 309 (384), D2 103 (128).  Where a
+// 256 -> 256 layer's ~19 000 clocks per tile go (phase stamps, tools/stamp_x3.py): both waves' k loops 13 400 (12 288 of matrix
+// issue), the next layer's first fragments 450, barrier 400, epilogue 5 000 -- its 128 KB of LDS stores, not its arithmetic
+// (halving the VALU work, fencing or not fencing its phases, 8- or 16-byte stores: no change) -- barrier 150.
 #include "dhaug_common.h"
 #include "dhaug_fk_math.h"
 
@@ -51,7 +58,10 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int X3_BM = 128;                                           // batch rows per tile
 constexpr int X3_MT = X3_BM / 32;
-constexpr int X3_NW = 4;                                             // waves per workgroup (one per SIMD)
+#ifndef X3_NWAVES
+#define X3_NWAVES 8
+#endif
+constexpr int X3_NW = X3_NWAVES;                                     // waves per workgroup: 4 (one per SIMD, 512 registers) or 8
 constexpr int X3_THREADS = 64 * X3_NW;
 constexpr int X3_MAX_UNITS = 32;
 constexpr int PITCHB = 512;                                          // bytes per image row and plane (256 fp16)
@@ -61,8 +71,11 @@ constexpr int OUT_PITCH = 68;                                        // floats p
 #ifndef X3_SPREAD
 #define X3_SPREAD 1
 #endif
-constexpr int RING = 3;                                              // weight k-steps in registers (two requested ahead)
-constexpr int WS_FLOATS_PER_WAVE = 64 * 128;                         // 64 lanes x (2 x 4 x 16) accumulator values
+#ifndef X3_RING
+#define X3_RING 3
+#endif
+constexpr int RING = X3_RING;                                              // weight k-steps in registers (two requested ahead)
+constexpr int WS_FLOATS_PER_WAVE = 64 * 128 * 4 / X3_NW;              // 64 lanes x the wave's accumulator values (2 x 4 x 16 of four waves)
 constexpr int WS_REGION_FLOATS = 256 * X3_NW * WS_FLOATS_PER_WAVE;   // one region: every workgroup's tile, 32 MB
 
 enum { U_LOAD_F32 = 0, U_GEMM = 3, U_LOAD_KCS = 5 };
@@ -111,6 +124,17 @@ __device__ long long g_x3_stamps[8 * X3_MAX_UNITS + 8];
 
 typedef f16x8 WRing[RING][2][2];                  // [k-step % RING][slice of the wave][piece]
 typedef f32x16 Seed[2];                           // bias of the wave's slice(s) in accumulator order
+// Eight waves: a value that a later layer adds as a residual stays in REGISTERS (one slice x four row tiles = 64 per lane: the
+// lane that produced it is the lane that adds it) -- through the workspace the same values cost 65 us of the 3D critic's 339
+// (they fill the L2 the weight fragments are served from; ablation X3_ABL_NOWS).  Four waves have no room (128 + 128
+// accumulators and residuals of 512: hipcc spills from ~330 live), they go through workspace region 0.
+#ifndef X3_REG_STASH
+#define X3_REG_STASH 1
+#endif
+constexpr bool REG_STASH = X3_NW == 8 && X3_REG_STASH;
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef u32x16 Stash[X3_MT];                      // per row tile: the 8 packed hi pairs, then the 8 packed lo pairs, of the lane's 16 values
+constexpr int RQN = X3_NW == 8 ? 2 : 4;              // tiles of a workspace value in flight in the epilogue that adds it
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const _Float16* w, int slice0, int kt) {
     // a slice holds kt k-steps of (hi, lo) 1 KB blocks
@@ -124,6 +148,23 @@ __device__ __forceinline__ f16x8 load_frag(__amdgpu_buffer_rsrc_t rs, int lane16
 __device__ __forceinline__ float* ws_base(const void* g, int wave, int lane, int region) {
     return static_cast<float*>(const_cast<void*>(g)) + (long long)region * WS_REGION_FLOATS +
            ((long long)blockIdx.x * X3_NW + wave) * WS_FLOATS_PER_WAVE + lane * 4;
+}
+#ifndef X3_WS_NT
+#define X3_WS_NT 0           // (non-temporal workspace accesses: measured, 370 us against 344 -- off)
+#endif
+__device__ __forceinline__ f32x4 ws_load(const float* p) {
+#if X3_WS_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#else
+    return *reinterpret_cast<const f32x4*>(p);
+#endif
+}
+__device__ __forceinline__ void ws_store(float* p, f32x4 v) {
+#if X3_WS_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+    *reinterpret_cast<f32x4*>(p) = v;
+#endif
 }
 __device__ __forceinline__ void load_ws_tile(const float* src, int t, f32x16& x) {
 #pragma unroll
@@ -185,21 +226,63 @@ __device__ __forceinline__ uint32_t split_lo(float x0, float x1, uint32_t hi) {
     return lo;
 }
 
+// Register quads g (even) and g + 1 of a lane are the first / second 8 bytes of chunk g for the lane's h = 0 partner and of
+// chunk g + 1 for the h = 1 partner: one half exchange per dword (v_permlane32_swap: lanes 32..63 of the first operand swap
+// with lanes 0..31 of the second) leaves every lane with ONE whole 16-byte chunk -- chunk g + h of its row.  The image is then
+// written with ds_write_b128, which the chunk swizzle keeps conflict-free (8 lanes = 8 rows = 8 different chunks = 32 banks);
+// the 8-byte stores hit every bank pair twice (chunks p and p + 8 of a 16-lane group) and took ~3 000 clocks per layer.
+__device__ __forceinline__ uint4 whole_chunk(uint2 a, uint2 b) {
+    const auto rx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+    const auto ry = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+    return uint4{rx[0], ry[0], rx[1], ry[1]};
+}
+
+// (four waves: the epilogue's phases are fenced -- a lone wave must be kept from chaining dependent instructions and from copying
+// every accumulator out of the AGPRs first; eight waves: the partner covers the stalls and the scheduler may interleave the LDS
+// stores of one tile with the arithmetic of the next)
+#ifndef X3_EPI_FENCE
+#define X3_EPI_FENCE (X3_NWAVES == 4)
+#endif
+#if X3_EPI_FENCE
+#define EPI_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define EPI_FENCE()
+#endif
+
+// What a later layer adds as a residual is the value the IMAGE holds, hi + lo (22 bits), as in every other use of an
+// activation in this arithmetic -- and as the round-3 kernel added it, so the golden-test figures stay what they were.  The
+// producer keeps the packed pairs it has just written (no instruction); the adding layer turns a pair into hi + lo with one
+// v_fma_mix_f32 (float(hi) * 1.0 + float(lo), exact in fp32).
+__device__ __forceinline__ void keep_tile(u32x16& st, const uint2 (&oh)[4], const uint2 (&ol)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        st[2 * g] = oh[g].x; st[2 * g + 1] = oh[g].y;
+        st[8 + 2 * g] = ol[g].x; st[8 + 2 * g + 1] = ol[g].y;
+    }
+}
+__device__ __forceinline__ float stash_value(const u32x16& st, int i) {           // value i (0..15) of the tile
+    const uint32_t h = st[i >> 1], l = st[8 + (i >> 1)];
+    float x;
+    if (i & 1) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(x) : "v"(h), "v"(l));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(x) : "v"(h), "v"(l));
+    return x;
+}
+
 // The epilogue of one layer for the wave's SW x RW accumulator tiles, one tile (16 values per lane) at a time:
 //   v = act(acc [+ what waits in the workspace at `rin`, four tiles in flight]);  [v -> workspace at `rout`: a later layer's residual];
 //   v -> (hi, lo) -> this lane's elements of the image  |  v -> the fp32 staging image of a network output  |  nothing (PARK)
 enum { EP_IMAGE = 0, EP_OUT = 1, EP_PARK = 2 };
-template <int SW, int RW, int MODE, bool COPY, bool ADD>
-__device__ __forceinline__ void epilogue(f32x16 (&acc)[SW][RW], f32x4 (&rq)[4][4], const float* rin, float* rout, unsigned char* img, int row0,
-                                         int slice0, int h, float neg) {
+template <int SW, int RW, int MODE, bool COPY, int ADD>
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[SW][RW], f32x4 (&rq)[RQN][4], const float* rin, float* rout, unsigned char* img, int row0,
+                                         int slice0, int h, float neg, Stash& stash, bool keep) {
     constexpr int G = SW * RW;
     // the lane's image addresses: one per slice and register quad (row tiles and the lo plane are constants away)
-    int oaddr[SW][4];
+    int oaddr[SW][2];                                // (chunk 2 j + h of the slice: see whole_chunk)
     if (MODE == EP_IMAGE) {
 #pragma unroll
         for (int s = 0; s < SW; ++s)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) oaddr[s][g] = chunk_off(row0, 4 * (slice0 + s) + g) + (h << 3);
+            for (int j = 0; j < 2; ++j) oaddr[s][j] = chunk_off(row0, 4 * (slice0 + s) + 2 * j + h);
     }
 #pragma unroll
     for (int t = 0; t < G; ++t) {
@@ -210,24 +293,25 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[SW][RW], f32x4 (&rq)[4][4
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[g][e] = ADD ? acc[s][mt][4 * g + e] + rq[t % 4][g][e] : acc[s][mt][4 * g + e];
-        __builtin_amdgcn_sched_barrier(0);
-        if (ADD && t + 4 < G) {                      // the tile's residual registers are free: request tile t + 4 into them
+            for (int e = 0; e < 4; ++e)
+                v[g][e] = ADD == 1 ? acc[s][mt][4 * g + e] + rq[t % RQN][g][e] : (ADD == 2 ? acc[s][mt][4 * g + e] + stash_value(stash[t % X3_MT], 4 * g + e) : acc[s][mt][4 * g + e]);
+        EPI_FENCE();
+        if (ADD == 1 && t + RQN < G) {                 // the tile's residual registers are free: request tile t + 4 into them
 #pragma unroll
-            for (int g = 0; g < 4; ++g) rq[t % 4][g] = *reinterpret_cast<const f32x4*>(rin + ((t + 4) * 4 + g) * 256);
+            for (int g = 0; g < 4; ++g) rq[t % RQN][g] = ws_load(rin + ((t + RQN) * 4 + g) * 256);
         }
         f32x4 w[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) w[g] = v[g] * neg;
-        __builtin_amdgcn_sched_barrier(0);
+        EPI_FENCE();
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], w[g][e]);
-        __builtin_amdgcn_sched_barrier(0);
+        EPI_FENCE();
         if (COPY || MODE == EP_PARK) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(rout + (t * 4 + g) * 256) = v[g];
+            for (int g = 0; g < 4; ++g) ws_store(rout + (t * 4 + g) * 256, v[g]);
         }
         if (MODE == EP_OUT) {
 #pragma unroll
@@ -248,28 +332,90 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[SW][RW], f32x4 (&rq)[4][4
                 oh[g].x = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v[g][0], v[g][1]}, f16x2));
                 oh[g].y = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v[g][2], v[g][3]}, f16x2));
             }
-            __builtin_amdgcn_sched_barrier(0);
+            EPI_FENCE();
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 ol[g].x = split_lo(v[g][0], v[g][1], oh[g].x);
                 ol[g].y = split_lo(v[g][2], v[g][3], oh[g].y);
             }
 #endif
-            __builtin_amdgcn_sched_barrier(0);
+            EPI_FENCE();
+            if (REG_STASH && SW == 1 && keep) keep_tile(stash[t % X3_MT], oh, ol);      // (wave-uniform)
 #ifdef X3_ABL_NOWRITE
 #pragma unroll
             for (int g = 0; g < 4; ++g) asm volatile("" :: "v"(oh[g].x), "v"(oh[g].y), "v"(ol[g].x), "v"(ol[g].y));
 #else
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                unsigned char* o = img + oaddr[s][g] + mt * 32 * PITCHB;
-                *reinterpret_cast<uint2*>(o) = oh[g];
-                *reinterpret_cast<uint2*>(o + PLANE) = ol[g];
+            for (int g = 0; g < 4; g += 2) {
+                unsigned char* o = img + oaddr[s][g >> 1] + mt * 32 * PITCHB;
+                *reinterpret_cast<uint4*>(o) = whole_chunk(oh[g], oh[g + 1]);
+                *reinterpret_cast<uint4*>(o + PLANE) = whole_chunk(ol[g], ol[g + 1]);
             }
 #endif
         }
         // (one accumulator tile at a time: left alone the scheduler copies all 128 accumulators out of the AGPRs first)
-        __builtin_amdgcn_sched_barrier(0);
+        EPI_FENCE();
+    }
+}
+
+// The image epilogue in two stages for the waves that finish their k loop FIRST (eight waves: the older wave of a SIMD pair
+// takes the matrix pipe and is done ~6 000 clocks before its partner, phase stamps): stage 1 -- residual, activation, copy,
+// hi / lo split into registers -- needs nothing from the other waves and runs under the partner's matrix instructions;
+// stage 2, behind the layer's barrier, is the LDS stores alone.
+template <int SW, int RW, bool COPY, int ADD>
+__device__ __forceinline__ void epilogue_stage1(f32x16 (&acc)[SW][RW], f32x4 (&rq)[RQN][4], const float* rin, float* rout, float neg,
+                                                uint4 (&pk)[SW * RW][2][2], Stash& stash, bool keep) {
+    constexpr int G = SW * RW;
+#pragma unroll
+    for (int t = 0; t < G; ++t) {
+        const int s = t / RW, mt = t % RW;
+        f32x4 v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                v[g][e] = ADD == 1 ? acc[s][mt][4 * g + e] + rq[t % RQN][g][e] : (ADD == 2 ? acc[s][mt][4 * g + e] + stash_value(stash[t % X3_MT], 4 * g + e) : acc[s][mt][4 * g + e]);
+        if (ADD == 1 && t + RQN < G) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rq[t % RQN][g] = ws_load(rin + ((t + RQN) * 4 + g) * 256);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 w = v[g] * neg;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], w[e]);
+        }
+        if (COPY) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ws_store(rout + (t * 4 + g) * 256, v[g]);
+        }
+        uint2 oh[4], ol[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            oh[g].x = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v[g][0], v[g][1]}, f16x2));
+            oh[g].y = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v[g][2], v[g][3]}, f16x2));
+            ol[g].x = split_lo(v[g][0], v[g][1], oh[g].x);
+            ol[g].y = split_lo(v[g][2], v[g][3], oh[g].y);
+        }
+        if (REG_STASH && SW == 1 && keep) keep_tile(stash[t % X3_MT], oh, ol);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            pk[t][j][0] = whole_chunk(oh[2 * j], oh[2 * j + 1]);
+            pk[t][j][1] = whole_chunk(ol[2 * j], ol[2 * j + 1]);
+        }
+    }
+}
+template <int SW, int RW>
+__device__ __forceinline__ void epilogue_stage2(const uint4 (&pk)[SW * RW][2][2], unsigned char* img, int row0, int slice0, int h) {
+#pragma unroll
+    for (int t = 0; t < SW * RW; ++t) {
+        const int s = t / RW, mt = t % RW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned char* o = img + chunk_off(row0, 4 * (slice0 + s) + 2 * j + h) + mt * 32 * PITCHB;
+            *reinterpret_cast<uint4*>(o) = pk[t][j][0];
+            *reinterpret_cast<uint4*>(o + PLANE) = pk[t][j][1];
+        }
     }
 }
 
@@ -296,13 +442,17 @@ __device__ __forceinline__ void spread_requests() {
 // does ((W y + b) + x; starting the accumulators from x instead moved the generator's head error from 8.3e-7 to 9.5e-7 on the
 // second golden set -- 1.55e-5 m of pose through the 10 tanh root); the first four tiles are requested under the last two
 // k-steps, the others as registers come free.
-template <int KT, int SW, int RW, bool ADD>
+template <int KT, int SW, int RW, int ADD>
 __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned char* smem, int wave, int lane, WRing& ring, Seed& seed,
-                                           int ui) {
+                                           Stash& stash, int ui) {
     asm volatile("" : "+v"(lane));                   // lane-derived constants are recomputed per unit, not parked across units
     const int r31 = lane & 31, h = lane >> 5, lane16 = lane << 4;
     const int plan = u->plan;
+#ifdef X3_ABL_NOWS
+    const int lg = (plan >> 8) & 15, pf = (plan >> 20) & PF_TO_PARK;
+#else
     const int lg = (plan >> 8) & 15, pf = plan >> 20;
+#endif
     const int sg = wave & ((1 << lg) - 1), rg = wave >> lg;
     const bool active = rg * RW < X3_MT;             // wave-uniform
     const int slice0 = sg * SW, row0 = rg * RW * 32 + r31;
@@ -314,82 +464,102 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned cha
     }
     f32x16 acc[SW][RW];
     const float* rin = ws_base(u->g, wave, lane, (pf & PF_ADD_R1) ? 1 : 0);
-    f32x4 rq[4][4];                                  // (ADD) tiles of what the epilogue adds, four in flight
+    f32x4 rq[RQN][4];                                // (ADD == 1) tiles of what the epilogue adds, RQN in flight
     {
         const __amdgpu_buffer_rsrc_t rs = weight_rsrc(u->w, slice0, KT);
-        f16x8 fx[2][RW][2];                          // activation fragments (hi, lo) of the wave's row tiles, one k-step ahead
+        // activation fragments (hi, lo): the k-step is walked in row-tile groups of HR, the next group's fragments in flight while
+        // this group's matrix instructions issue (two buffers of HR x 2 fragments: 32 registers at HR = 2 instead of the 64 of
+        // whole k-steps -- what makes room for the residual stash beside the accumulators)
+        constexpr int HR = (X3_NW == 8 && RW == 4) ? 2 : RW, NH = RW / HR;
+        f16x8 fx[2][HR][2];
         // one address per k-step: row 32 mt + r has r's swizzle (32 % 16 == 0) and the lo plane is a constant away
         const int frag_row = row0 * PITCHB, frag_sw = r31 & 15;
-        auto read_frags = [&](int k, f16x8 (&f)[RW][2]) {
-            const unsigned char* a = img + frag_row + (((2 * k + h) ^ frag_sw) << 4);
+        auto read_frags = [&](int step, f16x8 (&f)[HR][2]) {
+            const int k = step / NH, hf = step % NH;
+            const unsigned char* a = img + frag_row + (((2 * k + h) ^ frag_sw) << 4) + hf * HR * 32 * PITCHB;
 #pragma unroll
-            for (int mt = 0; mt < RW; ++mt) {
+            for (int mt = 0; mt < HR; ++mt) {
                 f[mt][0] = *reinterpret_cast<const f16x8*>(a + mt * 32 * PITCHB);
                 f[mt][1] = *reinterpret_cast<const f16x8*>(a + mt * 32 * PITCHB + PLANE);
             }
         };
         read_frags(0, fx[0]);
 #pragma unroll
-        for (int k = 0; k < KT; ++k) {
+        for (int step = 0; step < KT * NH; ++step) {
+            const int k = step / NH, hf = step % NH;
 #ifndef X3_ABL_NOREAD
-            if (k + 1 < KT) read_frags(k + 1, fx[(k + 1) & 1]);
+            if (step + 1 < KT * NH) read_frags(step + 1, fx[(step + 1) & 1]);
 #endif
+            bool wl0 = false, wl1 = false, rl = false;
+            if (hf == 0) {
 #ifndef X3_ABL_NOWLOAD
-            if (k == 0) {                            // (the prefetch brought k-step 0 only)
+                if (k == 0) {                        // (the prefetch brought k-step 0 only)
 #pragma unroll
-                for (int s = 0; s < SW; ++s)
+                    for (int d = 1; d < RING - 1; ++d)
+                        if (d < KT) {
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) ring[1][s][p] = load_frag(rs, lane16, KT, s, 1, p);
-            }
-            if (k + 2 < KT) {                        // two k-steps ahead, into the entry k-step k - 1 just left
+                            for (int s = 0; s < SW; ++s)
 #pragma unroll
-                for (int s = 0; s < SW; ++s)
+                                for (int p = 0; p < 2; ++p) ring[d][s][p] = load_frag(rs, lane16, KT, s, d, p);
+                        }
+                    wl0 = true;
+                }
+                if (k + RING - 1 < KT) {             // RING - 1 k-steps ahead, into the entry k-step k - 1 just left
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) ring[(k + 2) % RING][s][p] = load_frag(rs, lane16, KT, s, k + 2, p);
-            }
+                    for (int s = 0; s < SW; ++s)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) ring[(k + RING - 1) % RING][s][p] = load_frag(rs, lane16, KT, s, k + RING - 1, p);
+                    wl1 = true;
+                }
 #endif
-            if (ADD && k == KT - 2) {                // what the epilogue adds: its first tiles travel under the last two k-steps
+                if (ADD == 1 && k == KT - 2) {       // what the epilogue adds: its first tiles travel under the last two k-steps
 #pragma unroll
-                for (int t = 0; t < (SW * RW < 4 ? SW * RW : 4); ++t)
+                    for (int t = 0; t < (SW * RW < RQN ? SW * RW : RQN); ++t)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) rq[t][g] = *reinterpret_cast<const f32x4*>(rin + (t * 4 + g) * 256);
+                        for (int g = 0; g < 4; ++g) rq[t][g] = ws_load(rin + (t * 4 + g) * 256);
+                    rl = true;
+                }
             }
-#if X3_SPREAD
-            // the k-step's requests are dealt out between its matrix instructions: a lone wave that computes right behind its
-            // own read burst pays for the burst (MI355X_MICROARCH.md, two waves per SIMD, item 7)
-#else
+#if !X3_SPREAD
             __builtin_amdgcn_sched_barrier(0);
 #endif
             // small terms first, then hi * hi (the order of the round-3 kernel)
 #pragma unroll
             for (int s = 0; s < SW; ++s)
 #pragma unroll
-                for (int mt = 0; mt < RW; ++mt)
-                    acc[s][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[k % RING][s][1], fx[k & 1][mt][0], k == 0 ? seed[s] : acc[s][mt], 0, 0, 0);
+                for (int m = 0; m < HR; ++m)
+                    acc[s][hf * HR + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[k % RING][s][1], fx[step & 1][m][0], k == 0 ? seed[s] : acc[s][hf * HR + m], 0, 0, 0);
 #pragma unroll
             for (int s = 0; s < SW; ++s)
 #pragma unroll
-                for (int mt = 0; mt < RW; ++mt)
-                    acc[s][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[k % RING][s][0], fx[k & 1][mt][1], acc[s][mt], 0, 0, 0);
+                for (int m = 0; m < HR; ++m)
+                    acc[s][hf * HR + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[k % RING][s][0], fx[step & 1][m][1], acc[s][hf * HR + m], 0, 0, 0);
 #pragma unroll
             for (int s = 0; s < SW; ++s)
 #pragma unroll
-                for (int mt = 0; mt < RW; ++mt)
-                    acc[s][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[k % RING][s][0], fx[k & 1][mt][0], acc[s][mt], 0, 0, 0);
+                for (int m = 0; m < HR; ++m)
+                    acc[s][hf * HR + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[k % RING][s][0], fx[step & 1][m][0], acc[s][hf * HR + m], 0, 0, 0);
 #if X3_SPREAD
-            if (k == 0) spread_requests<3 * SW * RW, 2 * RW, 4 * SW>();
-            else if (k + 2 < KT) spread_requests<3 * SW * RW, 2 * RW, 2 * SW>();
-            else if (k + 1 < KT) spread_requests<3 * SW * RW, 2 * RW, ADD ? (SW * RW < 4 ? SW * RW : 4) * 4 : 0>();
+            // the step's requests are dealt out between its matrix instructions: a wave that computes right behind its own
+            // read burst pays for the burst (MI355X_MICROARCH.md, two waves per SIMD, item 7)
+            {
+                constexpr int NM = 3 * SW * HR, ND = 2 * HR;
+                const bool rd = step + 1 < KT * NH;
+                if (rd && wl0 && wl1) spread_requests<NM, ND, 2 * SW * (RING - 1)>();
+                else if (rd && wl1) spread_requests<NM, ND, 2 * SW>();
+                else if (rd && rl) spread_requests<NM, ND, (SW * RW < RQN ? SW * RW : RQN) * 4>();
+                else if (rd) spread_requests<NM, ND, 0>();
+            }
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (ui >= 0) { X3_STAMP(8 * ui + 1) }
-    if (ADD && KT < 2) {
+    if (ADD == 1 && KT < 2) {
 #pragma unroll
-        for (int t = 0; t < (SW * RW < 4 ? SW * RW : 4); ++t)
+        for (int t = 0; t < (SW * RW < RQN ? SW * RW : RQN); ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) rq[t][g] = *reinterpret_cast<const f32x4*>(rin + (t * 4 + g) * 256);
+            for (int g = 0; g < 4; ++g) rq[t][g] = ws_load(rin + (t * 4 + g) * 256);
     }
     // the ring and the seed are dead: the next layer's first fragments travel during the epilogue and the barrier
     if (next != nullptr) prefetch_layer(next, wave, lane, ring, seed);
@@ -397,24 +567,37 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned cha
     const float neg = act_neg(u->act, u->slope);
     // this lane owns row (row0 + 32 mt), features 32 (slice0 + s) + 8 g + 4 h .. + 3 of the result
     float* rout = ws_base(u->g, wave, lane, (pf & PF_TO_PARK) ? 1 : 0);
-    const bool copy = (pf & PF_COPY_R0) != 0;
+    const bool copy = !REG_STASH && (pf & PF_COPY_R0) != 0, keep = REG_STASH && (pf & PF_COPY_R0) != 0;
     if (pf & PF_TO_PARK) {                           // (no barrier: the image is not touched)
-        epilogue<SW, RW, EP_PARK, false, ADD>(acc, rq, rin, rout, img, row0, slice0, h, neg);
+        epilogue<SW, RW, EP_PARK, false, ADD>(acc, rq, rin, rout, img, row0, slice0, h, neg, stash, false);
         return;
     }
-    // All waves finish their k loops at about the same time (one per SIMD, same work), so the barrier comes FIRST and the
-    // conversion is fused with the stores behind it: nothing but the accumulators waits across the barrier.
+#ifndef X3_AB_SPLIT
+#define X3_AB_SPLIT 0         // (measured: no gain -- the LDS stores, not the arithmetic, are what the layer ends with -- and 64 more live registers)
+#endif
+    if (X3_AB_SPLIT && X3_NW == 8 && wave < 4 && !(u->flags & F_OUT_F32)) {
+        // the first-finishing half: everything but the stores happens BEFORE the barrier, under the partners' k loops
+        uint4 pk[SW * RW][2][2];
+        if (copy) epilogue_stage1<SW, RW, true, ADD>(acc, rq, rin, rout, neg, pk, stash, keep);
+        else epilogue_stage1<SW, RW, false, ADD>(acc, rq, rin, rout, neg, pk, stash, keep);
+        lds_barrier();                               // every wave has read the image for the last time
+        if (ui >= 0) { X3_STAMP(8 * ui + 5) }
+        epilogue_stage2<SW, RW>(pk, img, row0, slice0, h);
+        return;
+    }
+    // The waves that finish LAST (four waves: every wave -- one per SIMD, same work): the barrier comes first and the conversion
+    // is fused with the stores behind it; nothing but the accumulators waits across the barrier.
     lds_barrier();                                   // every wave has read the image for the last time
     if (ui >= 0) { X3_STAMP(8 * ui + 5) }
     if (u->flags & F_OUT_F32) {                      // the image becomes the fp32 staging area of the network's output
-        epilogue<SW, RW, EP_OUT, false, ADD>(acc, rq, rin, rout, img, row0, slice0, h, neg);
+        epilogue<SW, RW, EP_OUT, false, ADD>(acc, rq, rin, rout, img, row0, slice0, h, neg, stash, false);
         return;
     }
 #ifdef X3_ABL_NOEPI
     if (u->slope != 12345.f) return;
 #endif
-    if (copy) epilogue<SW, RW, EP_IMAGE, true, ADD>(acc, rq, rin, rout, img, row0, slice0, h, neg);
-    else epilogue<SW, RW, EP_IMAGE, false, ADD>(acc, rq, rin, rout, img, row0, slice0, h, neg);
+    if (copy) epilogue<SW, RW, EP_IMAGE, true, ADD>(acc, rq, rin, rout, img, row0, slice0, h, neg, stash, keep);
+    else epilogue<SW, RW, EP_IMAGE, false, ADD>(acc, rq, rin, rout, img, row0, slice0, h, neg, stash, keep);
 }
 
 // LOAD: global fp32 (M, ld) columns [0, cols) -> hi / lo planes of the image, zero-filled up to the next multiple of 64
@@ -500,7 +683,7 @@ __device__ __forceinline__ void store_output(UnitPtr u, unsigned char* smem, lon
     }
 }
 
-__global__ __launch_bounds__(X3_THREADS, 1) void fused_mlp_x3_kernel(Program prog, long long M) {
+__global__ __launch_bounds__(X3_THREADS, X3_NW / 4) void fused_mlp_x3_kernel(Program prog, long long M) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -512,6 +695,7 @@ __global__ __launch_bounds__(X3_THREADS, 1) void fused_mlp_x3_kernel(Program pro
     const int first_gemm = *(const int __attribute__((address_space(4)))*)(ka + __builtin_offsetof(Program, first_gemm));
     WRing ring;
     Seed seed;
+    Stash stash;
     if ((long long)blockIdx.x < ntiles) prefetch_layer(units + first_gemm, wave, lane, ring, seed);
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long m0 = tile * X3_BM;
@@ -532,21 +716,35 @@ __global__ __launch_bounds__(X3_THREADS, 1) void fused_mlp_x3_kernel(Program pro
                 const int nx = plan & 255;
                 UnitPtr next = nx != 0 ? units + (nx - 1) : (more ? units + first_gemm : (UnitPtr) nullptr);
 #define X3_CASE(CH, MAP, SW, RW) \
-    case (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, false>(u, next, smem, wave, lane, ring, seed, si); break;
+    case (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, 0>(u, next, smem, wave, lane, ring, seed, stash, si); break;
 #define X3_CASE_ADD(CH, MAP, SW, RW) \
-    case 256 + (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, true>(u, next, smem, wave, lane, ring, seed, si); break;
-                /* (chunks, map, adds something): validated on the host */
-                switch (((plan >> 12) & 255) | ((plan & ((PF_ADD_R0 | PF_ADD_R1) << 20)) ? 256 : 0)) {
+    case 256 + (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, 1>(u, next, smem, wave, lane, ring, seed, stash, si); break;
+#define X3_CASE_STASH(CH, MAP, SW, RW) \
+    case 512 + (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, 2>(u, next, smem, wave, lane, ring, seed, stash, si); break;
+                /* (chunks, map, what it adds: nothing | from the workspace | from the register stash): validated on the host */
+                const int addsel = (plan & (PF_ADD_R1 << 20)) ? 256 : ((plan & (PF_ADD_R0 << 20)) ? (REG_STASH ? 512 : 256) : 0);
+#ifdef X3_ABL_NOWS
+                switch ((plan >> 12) & 255) {
+#else
+                switch (((plan >> 12) & 255) | addsel) {
+#endif
+#if X3_NWAVES == 4
                     X3_CASE(1, MAP_2x4, 2, 4) X3_CASE(2, MAP_2x4, 2, 4) X3_CASE(4, MAP_2x4, 2, 4)
+                    X3_CASE_ADD(1, MAP_2x4, 2, 4) X3_CASE_ADD(2, MAP_2x4, 2, 4) X3_CASE_ADD(4, MAP_2x4, 2, 4)
+#else
+                    X3_CASE_STASH(1, MAP_1x4, 1, 4) X3_CASE_STASH(2, MAP_1x4, 1, 4) X3_CASE_STASH(4, MAP_1x4, 1, 4)
+                    X3_CASE_STASH(1, MAP_1x2, 1, 2) X3_CASE_STASH(2, MAP_1x2, 1, 2) X3_CASE_STASH(4, MAP_1x2, 1, 2)
+                    X3_CASE_STASH(1, MAP_1x1, 1, 1) X3_CASE_STASH(2, MAP_1x1, 1, 1) X3_CASE_STASH(4, MAP_1x1, 1, 1)
+#endif
                     X3_CASE(1, MAP_1x4, 1, 4) X3_CASE(2, MAP_1x4, 1, 4) X3_CASE(4, MAP_1x4, 1, 4)
                     X3_CASE(1, MAP_1x2, 1, 2) X3_CASE(2, MAP_1x2, 1, 2) X3_CASE(4, MAP_1x2, 1, 2)
                     X3_CASE(1, MAP_1x1, 1, 1) X3_CASE(2, MAP_1x1, 1, 1) X3_CASE(4, MAP_1x1, 1, 1)
-                    X3_CASE_ADD(1, MAP_2x4, 2, 4) X3_CASE_ADD(2, MAP_2x4, 2, 4) X3_CASE_ADD(4, MAP_2x4, 2, 4)
                     X3_CASE_ADD(1, MAP_1x4, 1, 4) X3_CASE_ADD(2, MAP_1x4, 1, 4) X3_CASE_ADD(4, MAP_1x4, 1, 4)
                     X3_CASE_ADD(1, MAP_1x2, 1, 2) X3_CASE_ADD(2, MAP_1x2, 1, 2) X3_CASE_ADD(4, MAP_1x2, 1, 2)
                     X3_CASE_ADD(1, MAP_1x1, 1, 1) X3_CASE_ADD(2, MAP_1x1, 1, 1) X3_CASE_ADD(4, MAP_1x1, 1, 1)
                     default: break;
                 }
+#undef X3_CASE_STASH
 #undef X3_CASE_ADD
 #undef X3_CASE
                 if (u->flags & F_OUT_F32) {
@@ -610,7 +808,11 @@ int dhaug_mlp_forward_x3(const dhaug_mlp_unit* units, int nunits, int64_t M, voi
     prog.nunits = nunits;
     auto okbuf = [](int b) { return b >= 0 && b <= 2; };
     auto is_out = [](const dhaug_mlp_unit& t) { return t.kind == U_GEMM && (t.flags & F_OUT_F32) != 0; };
-    auto map_of = [](int n) { const int nsl = (n + 31) / 32; return nsl > 4 ? MAP_2x4 : (nsl > 2 ? MAP_1x4 : (nsl == 2 ? MAP_1x2 : MAP_1x1)); };
+    auto map_of = [](int n) {
+        const int nsl = (n + 31) / 32;
+        if (X3_NW == 8) return nsl > 4 ? MAP_1x4 : (nsl > 2 ? MAP_1x2 : MAP_1x1);
+        return nsl > 4 ? MAP_2x4 : (nsl > 2 ? MAP_1x4 : (nsl == 2 ? MAP_1x2 : MAP_1x1));
+    };
     // how buffer b's CURRENT value is read after unit i, until the buffer is written again: 1 as a source, 2 as a residual
     auto uses = [&](int b, int i) {
         int m = 0;
@@ -648,7 +850,9 @@ int dhaug_mlp_forward_x3(const dhaug_mlp_unit* units, int nunits, int64_t M, voi
             const int chunks = (u.ksteps + 3) / 4;
             DHAUG_CHECK(chunks == 1 || chunks == 2 || chunks == 4, DHAUG_EUNSUPPORTED);
             const int map = map_of(u.N);
-            const int lg = map == MAP_1x1 ? 0 : (map == MAP_1x2 ? 1 : 2);      /* log2(slice groups) */
+            const int nsl_ = (u.N + 31) / 32;
+            const int lg = X3_NW == 8 ? (nsl_ > 4 ? 3 : (nsl_ > 2 ? 2 : (nsl_ == 2 ? 1 : 0)))
+                                      : (map == MAP_1x1 ? 0 : (map == MAP_1x2 ? 1 : 2));      /* log2(slice groups) */
             int pf = 0;
             if (s.res >= 0) {
                 DHAUG_CHECK(okbuf(s.res) && s.res != s.src, DHAUG_EINVAL);
