@@ -98,6 +98,9 @@ def test_bench_gpus_flag_launches_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["max_over_ranks"] == 2.0 and line["backend"] == "gloo"
+    # who took part: the collective library saw 2 ranks (with RCCL this is where its version and the devices appear)
+    d = line["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and len(d["rank_devices"]) == 2 and d["rccl_version"] is None
     # a mismatch between --gpus and an externally set WORLD_SIZE is an error, never a silent n_gpus = 1
     env2 = dict(env, WORLD_SIZE="1", RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env2,
@@ -123,6 +126,6 @@ def test_bench_gan_step_dry_run_reports_the_exchange():
     # 436 771 / 881 585 / 271 873 parameters at DenseDim 256
     assert by == {"G": 4 * 436771, "d3d": 4 * 881585, "d2d": 4 * 271873}
     assert line["optimizer_steps_per_iteration"] == {"d3d": 2, "d2d": 2, "G": 0.2}
-    for k in ("value_gan_step", "allreduce_us_per_optimizer_step", "allreduce_share_of_gan_step_upper_bound"):
+    for k in ("value_gan_step", "allreduce_us_per_optimizer_step", "allreduce_share_of_gan_step_upper_bound", "dist", "graph_calibration"):
         assert k in line["multi_rank_fields"]
     assert "segmented" in line["hip_graph"]
