@@ -324,7 +324,8 @@ def kcs_features(pose16, with_lengths=True):
 
 # ----------------------------------------------------------------------------------------------
 # Dense layers.  precision: 'fp32' (reference arithmetic) or 'bf16' (emulates the build's choice:
-# bf16-rounded operands, fp32 accumulate, activations stored as bf16 between layers).
+# bf16-rounded operands, fp32 accumulate, activations stored as bf16 between layers); 'bf16_fused': the same with the one
+# extra rounding point of the build's one-launch 3D-critic program (d3_forward).
 # ----------------------------------------------------------------------------------------------
 def _rb(x):
     return x.to(torch.bfloat16).to(torch.float32)
@@ -332,13 +333,16 @@ def _rb(x):
 
 def _linear(x, sd, key, precision):
     w, b = sd[key + ".weight"], sd[key + ".bias"]
-    if precision == "bf16":
+    if precision in ("bf16", "bf16_fused"):
         return F.linear(_rb(x), _rb(w)) + b
     return F.linear(x, w, b)
 
 
 def _store(x, precision):
-    return _rb(x) if precision == "bf16" else x
+    # (autograd through the dtype round trip casts the COTANGENT to bf16 as well -- the gradient of a bf16 tensor is bf16 -- so a
+    # backward / double backward through this forward rounds cotangents and tangents where the build's explicit training step
+    # stores them in bf16 buffers)
+    return _rb(x) if precision in ("bf16", "bf16_fused") else x
 
 
 def resblock(x, sd, key, precision="fp32"):
@@ -415,8 +419,16 @@ def d3_forward(x, sd, precision="fp32"):
     p = _store(torch.relu(_linear(_store(x, precision), sd, "previous.0", precision)), precision)
     for n in ("block1", "block2", "block3"):
         p = resblock(p, sd, n, precision)
-    m = torch.cat([k, p], dim=-1)
-    m = _store(torch.relu(_linear(m, sd, "merge_previous.0", precision)), precision)
+    if precision == "bf16_fused":
+        # the build's FUSED bf16 programs (one launch per network; the layer-by-layer path is precision 'bf16') compute the merge layer in two halves: the KCS branch's share (with the bias) waits as
+        # bf16 while the pose branch runs -- one more rounding point than the concatenated product (fused.py _d3_program)
+        w, b = sd["merge_previous.0.weight"], sd["merge_previous.0.bias"]
+        Dk = k.shape[-1]
+        half = _rb(F.linear(_rb(k), _rb(w[:, :Dk])) + b)
+        m = _store(torch.relu(half + F.linear(_rb(p), _rb(w[:, Dk:]))), precision)
+    else:
+        m = torch.cat([k, p], dim=-1)
+        m = _store(torch.relu(_linear(m, sd, "merge_previous.0", precision)), precision)
     m = resblock(m, sd, "merge_block1", precision)
     return _linear(m, sd, "output", precision)
 

@@ -3,6 +3,8 @@
 
   gan_loop_D32.npz         GAN_solutions_FK_generator, 5 iterations (G step on the 5th), flip on
                            (R/models_Fk_GAN/model_fk_gan_train.py:236-511) -- SURVEY.md section 8(c) item 8
+  gan_loop_D256.npz        the same loop at DenseDim 256 (the width of the reference's README command and of the benchmark;
+                           `python make_golden_loops.py gan_loop_D256`): weights / gradients as compact records
   video_loop_D32.npz       video_mode_GAN_solutions_FK_generator, R = 9, 5 iterations, motion critics on, playback and
                            flip on (R/models_Fk_GAN/video_GAN_fun.py:79-601) incl. the (-1, R, 32) view of quirk q6
   motion_step_m{3,2}_D32   one train_Fk_discriminator call on each motion critic in the mode the video loop uses for it
@@ -125,19 +127,38 @@ def scalars(writer):
     return out
 
 
-def single_frame_loop(M):
+def single_frame_loop(M, D=32):
+    """D = 32: every tensor whole (gan_loop_D32).  D = 256 -- the width of the reference's README command and of the benchmark
+    (gan_loop_D256): the networks have 0.44 / 0.88 / 0.27 M parameters, so weights and gradients are kept as compact records of
+    their CHANGE from the seeded initial weights (golden_util.compact: strided samples + seeded +-1 projections; biases and
+    narrow layers whole)."""
     train, gen, dis, fkm, h36m = M["train"], M["gen"], M["dis"], M["fkm"], M["h36m"]
     import utils.utils as ru
-    B, D, ITERS = 64, 32, 5
+    import golden_util as GU
+    B, ITERS = 64, 5
+    small = D == 32
     args = RI.make_args(batch_size=B, Gen_DenseDim=D, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D, flip_GAN_model_input=True)
     train.torch = cpu_torch_proxy()
     fk = fkm.Forward_Kinematics_DH_Model(args, ["S1", "S5"], None)
     G = gen.Fk_Generator(fk, args, "cpu")
     D3 = dis.Fk_3D_Discriminator("cpu", args)
     D2 = dis.Fk_2D_Discriminator(args, 16)
-    seeds = dict(G=1100, D3=1200, D2=1300)
-    for net, s in ((G, seeds["G"]), (D3, seeds["D3"]), (D2, seeds["D2"])):
+    seeds = dict(G=1100, D3=1200, D2=1300) if small else dict(G=1150, D3=1250, D2=1350)
+    init = {}
+    for tag, net, s in (("G", G, seeds["G"]), ("d3", D3, seeds["D3"]), ("d2", D2, seeds["D2"])):
         net.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=s))
+        init[tag] = {k: v.detach().clone() for k, v in net.state_dict().items()}
+
+    def records(prefix, tag, tensors, delta):
+        """whole tensors (D = 32) or compact records of (tensor - initial weight) / of the tensor (gradients)"""
+        if small:
+            return {prefix + k: v.detach().clone() for k, v in tensors.items()}
+        out = {}
+        for i, (k, v) in enumerate(tensors.items()):
+            t = (v.detach() - init[tag][k]) if delta else v.detach()
+            for part, r in GU.compact(t, 100 + i).items():
+                out["%s%s__%s" % (prefix, part, k)] = r
+        return out
     d = dict(model_G=G, model_d3d=D3, model_d2d=D2, optimizer_G=adam(G), optimizer_d3d=adam(D3), optimizer_d2d=adam(D2))
     cp = torch.tensor(cam_param_rows(h36m, B))
     real3d = [synth_pose16(B, seed=800 + i) + torch.tensor([0.1, -0.2, 4.5]) for i in range(ITERS)]
@@ -149,15 +170,20 @@ def single_frame_loop(M):
     writer = M["Writer"]()
     gstep = {}
 
-    def at_g_step():
-        gstep.update(sd_arrays("gstep_d3__", D3.state_dict()))
-        gstep.update(sd_arrays("gstep_d2__", D2.state_dict()))
-        gstep.update({"gstep_grad__" + k: p.grad.detach().clone() for k, p in G.named_parameters()})
+    raw = {}
+
+    def at_g_step():                                  # (raw copies: compact() draws its signs with torch.randint, which is being recorded)
+        raw["d3"] = {k: v.detach().clone() for k, v in D3.state_dict().items()}
+        raw["d2"] = {k: v.detach().clone() for k, v in D2.state_dict().items()}
+        raw["grad"] = {k: p.grad.detach().clone() for k, p in G.named_parameters()}
     hook_step(d["optimizer_G"], at_g_step)
     np.random.seed(4242)
     torch.manual_seed(777)
     with Recorder() as rec:
         train.GAN_solutions_FK_generator(args, d, data, torch.nn.Linear(1, 1), summary, writer, ["S1", "S5"])
+    gstep.update(records("gstep_d3__", "d3", raw["d3"], True))
+    gstep.update(records("gstep_d2__", "d2", raw["d2"], True))
+    gstep.update(records("gstep_grad__", "G", raw["grad"], False))
     np.random.seed(4242)
     cams = np.array([[np.random.randint(0, 2), np.random.randint(0, 4)] for _ in range(ITERS)])
     ds = data["train_fake2d3d_loader"].dataset
@@ -168,12 +194,12 @@ def single_frame_loop(M):
                seeds=np.array([seeds["G"], seeds["D3"], seeds["D2"]]), iters=np.array(summary.train_iter_num))
     assert out["noise"].shape[0] == ITERS + 1 and out["alpha"].shape[0] == 4 * ITERS and out["scaler"].shape[0] == ITERS + 1
     out.update(chosen_cameras(h36m, ["S1", "S5"], cams))
-    out.update(sd_arrays("final_G__", G.state_dict()))
-    out.update(sd_arrays("final_d3__", D3.state_dict()))
-    out.update(sd_arrays("final_d2__", D2.state_dict()))
+    out.update(records("final_G__", "G", G.state_dict(), True))
+    out.update(records("final_d3__", "d3", D3.state_dict(), True))
+    out.update(records("final_d2__", "d2", D2.state_dict(), True))
     out.update(gstep)
     out.update(scalars(writer))
-    save("gan_loop_D32", **out)
+    save("gan_loop_D%d" % D, **out)
 
 
 def motion_shapes(net):
@@ -314,6 +340,10 @@ def main():
     M = RI.load_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "video_D1000":
         video_D1000(M)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "gan_loop_D256":
+        torch.set_num_threads(8)
+        single_frame_loop(M, 256)
         return
     single_frame_loop(M)
     video_loop(M)

@@ -78,8 +78,24 @@ def video_state_dicts(g, D=32, R=9):
                 m2=GU.seeded_state_dict(m2, sm2))
 
 
-def replay_single_oracle(g):
-    sdG, sd3, sd2 = single_state_dicts(g)
+def compact_record(g, prefix, k):
+    """the compact record (golden_util.compact) stored for tensor k under `prefix` (gan_loop_D256: weights as their change
+    from the seeded initial values, gradients as they are)"""
+    return {part: g["%s%s__%s" % (prefix, part, k)] for part in ("full", "sample", "proj") if "%s%s__%s" % (prefix, part, k) in g}
+
+
+def compact_names(g, prefix):
+    """parameter names, in state-dict order, that have a compact record under `prefix`"""
+    out = []
+    for key in g:
+        for part in ("full__", "sample__"):
+            if key.startswith(prefix + part):
+                out.append(key[len(prefix + part):])
+    return out
+
+
+def replay_single_oracle(g, D=32):
+    sdG, sd3, sd2 = single_state_dicts(g, D)
     G = O.Net(sdG, lambda z, p, bl, sc: O.generator_forward(z, p, bl, sc)[0])
     D3, D2 = O.Net(sd3, O.d3_forward), O.Net(sd2, O.d2_forward)
     iters = g["real3d"].shape[0]

@@ -144,6 +144,40 @@ def test_explicit_step_vs_reference_at_dense_dim_256(M, golden, tag):
     assert min(cos) > 0.95, cos
 
 
+@pytest.mark.parametrize("tag,D,B", [("d3", 256, 304), ("d2", 256, 304)])
+def test_bf16_explicit_step_vs_bf16_emulated_oracle(M, tag, D, B):
+    """The TIMED arithmetic (bf16 operands, fp32 accumulate, bf16 activations and cotangents) against the oracle's emulation of
+    it element by element: the oracle's forward rounds where the kernels round (operands and stored activations to bf16:
+    dhaug_oracle._linear / _store) and autograd through that dtype round trip rounds the cotangents and tangents to bf16 as well
+    (the gradient of a bf16 tensor is bf16) -- where the explicit step stores them; what is left is summation order.  Every gradient
+    element within 2e-2 of its tensor's scale (a dropped skip term or a wrong mask in one of the 17 layers moves whole
+    tensors by O(1)); cosine > 0.95 was all the earlier test asked of this path."""
+    args = _args(B, D)
+    shapes = GU.shapes_d3(D) if tag == "d3" else GU.shapes_d2(D)
+    sd = GU.seeded_state_dict(shapes, 950 + D)
+    data = _data(tag, B, 77 + D)
+    Wb, Cb, gb, _ = _run(M, tag, args, sd, "bf16", data, True)
+    f32 = O.d3_forward if tag == "d3" else O.d2_forward
+    # ('bf16_fused': at DenseDim 256 the step's forward sweep is the one-launch program, whose 3D critic parks half of its merge
+    # layer as bf16 -- one rounding point more than the layer path)
+    ref = O.critic_step(lambda x, p: f32(x, p, precision="bf16_fused"), sd, data[0], data[1], data[2])
+    assert abs(Wb - ref["Wasserstein_D"].item()) <= 2e-3 * max(1.0, abs(Wb)) and abs(Cb - ref["D_cost"].item()) <= 1e-2 * max(1.0, abs(Cb))
+    worst = {1: 0.0, 2: 0.0}
+    for k, r in ref["grads"].items():
+        scale = r.abs().max().item()
+        if scale == 0.0:
+            assert gb[k].abs().max().item() == 0.0, k
+            continue
+        e = (gb[k].double() - r.double()).abs().max().item() / scale
+        worst[r.dim()] = max(worst[r.dim()], e)
+        # weight gradients: 2e-2 of the tensor's scale.  A bias gradient is the DIFFERENCE of two column sums of equal size (the
+        # real rows' cotangents carry -1/B, the fake rows' +1/B): its scale is a residue of that cancellation, so the same
+        # absolute noise is a larger share of it -- 4e-2
+        assert e <= (2e-2 if r.dim() == 2 else 4e-2), (k, e, scale)
+    print("bf16 explicit %s step vs bf16-emulated oracle: worst element error %.2e (weights) / %.2e (biases) of the tensor's scale"
+          % (tag, worst[2], worst[1]))
+
+
 def test_gradient_penalty_dead_rows(M):
     """A row whose input gradient is exactly zero (every ReLU unit behind the merge layer dead): the reference's
     gradients.norm(2, dim=1) back-propagates 0 there (torch's norm subgradient at 0), the penalty term is (0 - 1)^2.  The

@@ -116,6 +116,108 @@ def test_single_frame_loop_vs_reference(M, golden):
     print("single-frame loop: worst weight error D3 %.2e D2 %.2e G %.2e" % tuple(worst))
 
 
+def _run_single_loop(M, g, D, precision):
+    iters, B = g["real3d"].shape[0], g["real3d"].shape[1]
+    args = _args(batch_size=B, flip_GAN_model_input=True, Gen_DenseDim=D, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D)
+    fk = M.fkm.Forward_Kinematics_DH_Model(args, ["S1", "S5"], None)
+    d = M.train.my_get_poseFk_model(args, None, fk)
+    for key, sd in zip(("model_G", "model_d3d", "model_d2d"), LU.single_state_dicts(g, D)):
+        d[key].load_state_dict(sd)
+        d[key].precision = precision
+    w, s = Writer(), Summary()
+    p3, p2 = [], []
+    for i in range(iters):
+        last = i == iters - 1
+        draws = M.train.Draws(noise=[g["noise"][i]] + ([g["noise"][iters]] if last else []),
+                              scaler=[g["scaler"][i]] + ([g["scaler"][iters]] if last else []),
+                              alpha=[g["alpha"][4 * i + j] for j in range(4)])
+        cam = (g["cam_quat"][i].tolist(), g["cam_trans"][i].tolist(), g["buf_cam"][i * B].tolist())
+        r = M.train.gan_iteration(args, d, g["real3d"][i], g["cam_param"], g["real2d"][i], ["S1", "S5"], s, w,
+                                  do_g_step=last, camera=cam, draws=draws)
+        assert not any(draws.q.values()), "recorded draws left over"
+        p3.append(r["pos_3d_cam"]); p2.append(r["pos_2d"])
+        s.train_iter_num += 1
+    return d, w, p3, p2, r
+
+
+@pytest.mark.parametrize("precision", ["bf16x6", "bf16"])
+def test_single_frame_loop_vs_reference_at_dense_dim_256(M, golden, precision):
+    """The reference's own five-iteration loop at the width of its README command and of the benchmark (gan_loop_D256).  At
+    DenseDim 256 the iteration runs the kernels the timed training step runs -- the fused forward-with-save programs, the
+    two-layer block kernel, the sign-bit masks, the grouped weight gradients, the explicit G step -- which the DenseDim-32
+    loop never enters.
+      bf16x6 (fp32-grade, layer by layer): pairs, scalars, G-step gradients and all weights at the DenseDim-32 tolerances;
+      bf16 (the TIMED arithmetic): the pairs of the first iterations are the bf16 generator's (no golden tolerance), the
+      scalars of all twenty critic steps within 5e-2, the G-step gradients and the weight changes by direction and size."""
+    g = golden("gan_loop_D256")
+    D = 256
+    d, w, p3, p2, r = _run_single_loop(M, g, D, precision)
+    ref = LU.scalar_series(g)
+    assert set(ref) == set(w.s)
+    init = dict(zip(("model_G", "model_d3d", "model_d2d"), LU.single_state_dicts(g, D)))
+    if precision == "bf16x6":
+        # pairs: the generator's 256-wide trunk in six bf16 terms per product is ~1e-6 in the head; the root is 10 tanh(head) and
+        # the projection divides by the camera depth, so the pairs are held to 1e-4 m / 3e-4 (measured: see the print)
+        e3, e2 = maxabs(torch.cat(p3), g["buf_p3"]), maxabs(torch.cat(p2), g["buf_p2"])
+        print("bf16x6 loop at D = 256: pairs differ by %.2e m (3D) / %.2e (2D)" % (e3, e2))
+        assert e3 <= 1e-4 and e2 <= 3e-4, (e3, e2)
+        scalars_close(w, g, 2e-4)
+        worst = 0.0
+        for i, (k, p) in enumerate(d["model_G"].named_parameters()):
+            rec = LU.compact_record(g, "gstep_grad__", k)
+            kk = "full" if "full" in rec else "sample"
+            got = GU.compact(p.grad.detach().float().cpu(), 100 + i)
+            worst = max(worst, (got[kk].double() - rec[kk].double()).abs().max().item() / rec[kk].abs().max().item())
+        # (the critics the G step differentiates through have taken 9 - 10 Adam steps of lr * g / (|g| + eps): the elements whose
+        # gradient is within rounding of zero have stepped +-lr either way, and the G-step gradient sees those critics)
+        print("bf16x6 loop at D = 256: worst G-step gradient element error %.2e of its tensor's scale" % worst)
+        for i, (k, p) in enumerate(d["model_G"].named_parameters()):
+            GU.compact_close(p.grad.detach().float().cpu(), LU.compact_record(g, "gstep_grad__", k), 100 + i, 1e-7, 1.5e-2, k)
+        for key, prefix, steps in (("model_d3d", "final_d3__", 10), ("model_d2d", "final_d2__", 10), ("model_G", "final_G__", 1)):
+            for i, (k, p) in enumerate(d[key].named_parameters()):
+                rec = LU.compact_record(g, prefix, k)
+                got = GU.compact(p.detach().float().cpu() - init[key][k], 100 + i)
+                kk = "full" if "full" in rec else "sample"
+                e = (got[kk].double() - rec[kk].double()).abs()
+                assert e.max().item() <= 1.05 * 2 * steps * 1e-4, (key, k, e.max().item())
+                if e.numel() >= 64:
+                    assert torch.quantile(e, 0.98).item() <= 2e-5, (key, k, torch.quantile(e, 0.98).item())
+        return
+    # ---- bf16: the arithmetic bench.py times ------------------------------------------------------------------------
+    for name, rr in ref.items():
+        got = torch.tensor(w.s[name], dtype=torch.float64)
+        assert got.shape == rr.shape, name
+        assert maxabs(got, rr) <= 5e-2 * max(1.0, rr.abs().max().item()), (name, maxabs(got, rr))
+    # generated pairs: the bf16 trunk's poses (3e-2 m of +-10 m roots is what a bf16 head gives; the FK itself is fp32)
+    # (the projection divides by the camera depth: a pose next to the camera plane turns centimetres into units, so the 2D pairs are
+    # compared by quantile)
+    e2 = (torch.cat(p2).detach().double().cpu() - g["buf_p2"].double()).abs().reshape(-1)
+    assert maxabs(torch.cat(p3), g["buf_p3"]) <= 0.15 and torch.quantile(e2, 0.99).item() <= 0.15, torch.quantile(e2, 0.99).item()
+    cs = torch.nn.functional.cosine_similarity
+    worst = 1.0
+    for i, (k, p) in enumerate(d["model_G"].named_parameters()):
+        rec = LU.compact_record(g, "gstep_grad__", k)
+        kk = "full" if "full" in rec else "sample"
+        a, b = GU.compact(p.grad.detach().float().cpu(), 100 + i)[kk].double(), rec[kk].double()
+        if b.abs().max() > 0:
+            c = cs(a, b, dim=0).item()
+            worst = min(worst, c)
+            assert c > 0.9, (k, c)
+            assert abs(a.norm().item() / b.norm().item() - 1.0) <= 0.15, (k, a.norm().item(), b.norm().item())
+    # ten Adam steps per critic: where the reference moved a weight by (nearly) the full 10 x lr, the bf16 run moved it the same way
+    for key, prefix in (("model_d3d", "final_d3__"), ("model_d2d", "final_d2__")):
+        agree, total = 0, 0
+        for i, (k, p) in enumerate(d[key].named_parameters()):
+            rec = LU.compact_record(g, prefix, k)
+            kk = "full" if "full" in rec else "sample"
+            got = GU.compact(p.detach().float().cpu() - init[key][k], 100 + i)[kk].double()
+            big = rec[kk].double().abs() >= 8e-4
+            agree += int((torch.sign(got[big]) == torch.sign(rec[kk].double()[big])).sum())
+            total += int(big.sum())
+        assert total > 1000 and agree >= 0.97 * total, (key, agree, total)
+    print("bf16 loop at D = 256: worst G-step gradient cosine %.4f" % worst)
+
+
 def test_video_loop_vs_reference(M, golden):
     g = golden("video_loop_D32")
     iters, B, R = g["real3d"].shape[0], g["real3d"].shape[1], g["real3d"].shape[2]

@@ -34,6 +34,34 @@ def test_single_frame_loop_golden(golden):
             assert maxabs(net.state()[k], g[tag + k]) <= 5e-6, (tag, k)
 
 
+def test_single_frame_loop_golden_at_dense_dim_256(golden):
+    """the same loop at the width of the reference's README command and of the benchmark (gan_loop_D256: weights and gradients
+    as compact records -- strided samples + seeded +-1 projections -- of their change from the seeded initial weights)"""
+    g = golden("gan_loop_D256")
+    D = 256
+    r = LU.replay_single_oracle(g, D)
+    assert maxabs(r["buf_p3"], g["buf_p3"]) <= 5e-6 and maxabs(r["buf_p2"], g["buf_p2"]) <= 5e-6
+    for name, ref in LU.scalar_series(g).items():
+        got = torch.tensor(r["scalars"][name], dtype=torch.float64)
+        assert got.shape == ref.shape, name
+        assert maxabs(got, ref) <= 5e-5 * max(1.0, ref.abs().max().item()), name
+    init = dict(zip(("G", "d3", "d2"), LU.single_state_dicts(g, D)))
+    names = {t: list(init[t]) for t in init}
+    for i, k in enumerate(names["G"]):
+        ref = LU.compact_record(g, "gstep_grad__", k)
+        GU.compact_close(r["g_grads"][k], ref, 100 + i, 1e-7, 5e-4, "gstep_grad " + k)
+    # weights: the CHANGE over the loop (10 Adam steps of 1e-4 for the critics, 1 for the generator); an element whose gradient
+    # is within rounding of zero may step the other way (lr * g / (|g| + eps)), hence the hard bound of (steps x lr)
+    for tag, net, prefix, steps in (("G", r["G"], "final_G__", 1), ("d3", r["D3"], "final_d3__", 10), ("d2", r["D2"], "final_d2__", 10)):
+        for i, k in enumerate(names[tag]):
+            ref = LU.compact_record(g, prefix, k)
+            got = GU.compact(net.state()[k] - init[tag][k], 100 + i)
+            key = "full" if "full" in ref else "sample"
+            e = (got[key].double() - ref[key].double()).abs()
+            assert e.max().item() <= 2.05 * steps * 1e-4, (tag, k, e.max().item())
+            assert torch.quantile(e, 0.98).item() <= 2e-5, (tag, k, torch.quantile(e, 0.98).item())
+
+
 def test_video_loop_golden(golden):
     g = golden("video_loop_D32")
     r = LU.replay_video_oracle(g)
