@@ -268,13 +268,17 @@ __device__ __forceinline__ float stash_value(const u32x16& st, int i) {         
     return x;
 }
 
+#ifndef X3_WRITE128
+#define X3_WRITE128 1
+#endif
+
 // The epilogue of one layer for the wave's SW x RW accumulator tiles, one tile (16 values per lane) at a time:
 //   v = act(acc [+ what waits in the workspace at `rin`, four tiles in flight]);  [v -> workspace at `rout`: a later layer's residual];
 //   v -> (hi, lo) -> this lane's elements of the image  |  v -> the fp32 staging image of a network output  |  nothing (PARK)
 enum { EP_IMAGE = 0, EP_OUT = 1, EP_PARK = 2 };
-template <int SW, int RW, int MODE, bool COPY, int ADD>
+template <int SW, int RW, int MODE, bool COPY, int ADD, bool RELU, bool KEEP>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[SW][RW], f32x4 (&rq)[RQN][4], const float* rin, float* rout, unsigned char* img, int row0,
-                                         int slice0, int h, float neg, Stash& stash, bool keep) {
+                                         int slice0, int h, float neg, Stash& stash) {
     constexpr int G = SW * RW;
     // the lane's image addresses: one per slice and register quad (row tiles and the lo plane are constants away)
     int oaddr[SW][2];                                // (chunk 2 j + h of the slice: see whole_chunk)
@@ -300,14 +304,28 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[SW][RW], f32x4 (&rq)[RQN]
 #pragma unroll
             for (int g = 0; g < 4; ++g) rq[t % RQN][g] = ws_load(rin + ((t + RQN) * 4 + g) * 256);
         }
-        f32x4 w[4];
+        if (RELU) {
+            // ReLU as ONE instruction per value: a signed-integer max with 0 on the bit pattern (negative floats are negative
+            // integers; +NaN passes, -NaN becomes 0 -- the fused bf16 kernels' convention).  The epilogue's arithmetic, not its
+            // LDS stores, is what it takes time for: ~110 vector instructions per 16-value tile at ~4.5 clocks each
 #pragma unroll
-        for (int g = 0; g < 4; ++g) w[g] = v[g] * neg;
-        EPI_FENCE();
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+                for (int e = 0; e < 4; ++e) {
+                    const float f = v[g][e];             // (a copy: bit_cast of a vector ELEMENT reads element 0)
+                    const int b = __builtin_bit_cast(int, f);
+                    v[g][e] = __builtin_bit_cast(float, b > 0 ? b : 0);
+                }
+        } else {
+            f32x4 w[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], w[g][e]);
+            for (int g = 0; g < 4; ++g) w[g] = v[g] * neg;
+            EPI_FENCE();
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], w[g][e]);
+        }
         EPI_FENCE();
         if (COPY || MODE == EP_PARK) {
 #pragma unroll
@@ -340,17 +358,26 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[SW][RW], f32x4 (&rq)[RQN]
             }
 #endif
             EPI_FENCE();
-            if (REG_STASH && SW == 1 && keep) keep_tile(stash[t % X3_MT], oh, ol);      // (wave-uniform)
+            if (REG_STASH && SW == 1 && KEEP) keep_tile(stash[t % X3_MT], oh, ol);
 #ifdef X3_ABL_NOWRITE
 #pragma unroll
             for (int g = 0; g < 4; ++g) asm volatile("" :: "v"(oh[g].x), "v"(oh[g].y), "v"(ol[g].x), "v"(ol[g].y));
 #else
+#if X3_WRITE128
 #pragma unroll
             for (int g = 0; g < 4; g += 2) {
                 unsigned char* o = img + oaddr[s][g >> 1] + mt * 32 * PITCHB;
                 *reinterpret_cast<uint4*>(o) = whole_chunk(oh[g], oh[g + 1]);
                 *reinterpret_cast<uint4*>(o + PLANE) = whole_chunk(ol[g], ol[g + 1]);
             }
+#else
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned char* o = img + chunk_off(row0, 4 * (slice0 + s) + g) + (h << 3) + mt * 32 * PITCHB;
+                *reinterpret_cast<uint2*>(o) = oh[g];
+                *reinterpret_cast<uint2*>(o + PLANE) = ol[g];
+            }
+#endif
 #endif
         }
         // (one accumulator tile at a time: left alone the scheduler copies all 128 accumulators out of the AGPRs first)
@@ -442,7 +469,7 @@ __device__ __forceinline__ void spread_requests() {
 // does ((W y + b) + x; starting the accumulators from x instead moved the generator's head error from 8.3e-7 to 9.5e-7 on the
 // second golden set -- 1.55e-5 m of pose through the 10 tanh root); the first four tiles are requested under the last two
 // k-steps, the others as registers come free.
-template <int KT, int SW, int RW, int ADD>
+template <int KT, int SW, int RW, int ADD, bool KEEP>
 __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned char* smem, int wave, int lane, WRing& ring, Seed& seed,
                                            Stash& stash, int ui) {
     asm volatile("" : "+v"(lane));                   // lane-derived constants are recomputed per unit, not parked across units
@@ -567,9 +594,9 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned cha
     const float neg = act_neg(u->act, u->slope);
     // this lane owns row (row0 + 32 mt), features 32 (slice0 + s) + 8 g + 4 h .. + 3 of the result
     float* rout = ws_base(u->g, wave, lane, (pf & PF_TO_PARK) ? 1 : 0);
-    const bool copy = !REG_STASH && (pf & PF_COPY_R0) != 0, keep = REG_STASH && (pf & PF_COPY_R0) != 0;
+    const bool copy = !REG_STASH && (pf & PF_COPY_R0) != 0;
     if (pf & PF_TO_PARK) {                           // (no barrier: the image is not touched)
-        epilogue<SW, RW, EP_PARK, false, ADD>(acc, rq, rin, rout, img, row0, slice0, h, neg, stash, false);
+        epilogue<SW, RW, EP_PARK, false, ADD, false, false>(acc, rq, rin, rout, img, row0, slice0, h, neg, stash);
         return;
     }
 #ifndef X3_AB_SPLIT
@@ -578,8 +605,8 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned cha
     if (X3_AB_SPLIT && X3_NW == 8 && wave < 4 && !(u->flags & F_OUT_F32)) {
         // the first-finishing half: everything but the stores happens BEFORE the barrier, under the partners' k loops
         uint4 pk[SW * RW][2][2];
-        if (copy) epilogue_stage1<SW, RW, true, ADD>(acc, rq, rin, rout, neg, pk, stash, keep);
-        else epilogue_stage1<SW, RW, false, ADD>(acc, rq, rin, rout, neg, pk, stash, keep);
+        if (copy) epilogue_stage1<SW, RW, true, ADD>(acc, rq, rin, rout, neg, pk, stash, KEEP);
+        else epilogue_stage1<SW, RW, false, ADD>(acc, rq, rin, rout, neg, pk, stash, KEEP);
         lds_barrier();                               // every wave has read the image for the last time
         if (ui >= 0) { X3_STAMP(8 * ui + 5) }
         epilogue_stage2<SW, RW>(pk, img, row0, slice0, h);
@@ -590,14 +617,16 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned cha
     lds_barrier();                                   // every wave has read the image for the last time
     if (ui >= 0) { X3_STAMP(8 * ui + 5) }
     if (u->flags & F_OUT_F32) {                      // the image becomes the fp32 staging area of the network's output
-        epilogue<SW, RW, EP_OUT, false, ADD>(acc, rq, rin, rout, img, row0, slice0, h, neg, stash, false);
+        epilogue<SW, RW, EP_OUT, false, ADD, false, false>(acc, rq, rin, rout, img, row0, slice0, h, neg, stash);
         return;
     }
 #ifdef X3_ABL_NOEPI
     if (u->slope != 12345.f) return;
 #endif
-    if (copy) epilogue<SW, RW, EP_IMAGE, true, ADD>(acc, rq, rin, rout, img, row0, slice0, h, neg, stash, keep);
-    else epilogue<SW, RW, EP_IMAGE, false, ADD>(acc, rq, rin, rout, img, row0, slice0, h, neg, stash, keep);
+    const bool relu = u->act == DHAUG_ACT_RELU;      // (wave-uniform)
+    if (copy) epilogue<SW, RW, EP_IMAGE, true, ADD, false, false>(acc, rq, rin, rout, img, row0, slice0, h, neg, stash);
+    else if (relu) epilogue<SW, RW, EP_IMAGE, false, ADD, true, KEEP>(acc, rq, rin, rout, img, row0, slice0, h, neg, stash);
+    else epilogue<SW, RW, EP_IMAGE, false, ADD, false, KEEP>(acc, rq, rin, rout, img, row0, slice0, h, neg, stash);
 }
 
 // LOAD: global fp32 (M, ld) columns [0, cols) -> hi / lo planes of the image, zero-filled up to the next multiple of 64
@@ -715,14 +744,18 @@ __global__ __launch_bounds__(X3_THREADS, X3_NW / 4) void fused_mlp_x3_kernel(Pro
                 // the next tile then starts over at the first)
                 const int nx = plan & 255;
                 UnitPtr next = nx != 0 ? units + (nx - 1) : (more ? units + first_gemm : (UnitPtr) nullptr);
+// (KEEP: the layer's result is a later layer's residual and stays in the register stash -- a template parameter, not a run-time
+// select per value: layers that add something always keep (a result nobody adds later is overwritten by the next keeper))
 #define X3_CASE(CH, MAP, SW, RW) \
-    case (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, 0>(u, next, smem, wave, lane, ring, seed, stash, si); break;
+    case (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, 0, false>(u, next, smem, wave, lane, ring, seed, stash, si); break; \
+    case 1024 + (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, 0, true>(u, next, smem, wave, lane, ring, seed, stash, si); break;
 #define X3_CASE_ADD(CH, MAP, SW, RW) \
-    case 256 + (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, 1>(u, next, smem, wave, lane, ring, seed, stash, si); break;
+    case 256 + (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, 1, true>(u, next, smem, wave, lane, ring, seed, stash, si); break;
 #define X3_CASE_STASH(CH, MAP, SW, RW) \
-    case 512 + (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, 2>(u, next, smem, wave, lane, ring, seed, stash, si); break;
+    case 512 + (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, 2, true>(u, next, smem, wave, lane, ring, seed, stash, si); break;
                 /* (chunks, map, what it adds: nothing | from the workspace | from the register stash): validated on the host */
-                const int addsel = (plan & (PF_ADD_R1 << 20)) ? 256 : ((plan & (PF_ADD_R0 << 20)) ? (REG_STASH ? 512 : 256) : 0);
+                int addsel = (plan & (PF_ADD_R1 << 20)) ? 256 : ((plan & (PF_ADD_R0 << 20)) ? (REG_STASH ? 512 : 256) : 0);
+                if (addsel == 0 && REG_STASH && (plan & (PF_COPY_R0 << 20))) addsel = 1024;
 #ifdef X3_ABL_NOWS
                 switch ((plan >> 12) & 255) {
 #else
