@@ -391,7 +391,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[SW][RW], f32x4 (&rq)[RQN]
 // stage 2, behind the layer's barrier, is the LDS stores alone.
 template <int SW, int RW, bool COPY, int ADD>
 __device__ __forceinline__ void epilogue_stage1(f32x16 (&acc)[SW][RW], f32x4 (&rq)[RQN][4], const float* rin, float* rout, float neg,
-                                                uint4 (&pk)[SW * RW][2][2], Stash& stash, bool keep) {
+                                                Stash& stash, bool keep) {
     constexpr int G = SW * RW;
 #pragma unroll
     for (int t = 0; t < G; ++t) {
@@ -425,23 +425,28 @@ __device__ __forceinline__ void epilogue_stage1(f32x16 (&acc)[SW][RW], f32x4 (&r
             ol[g].y = split_lo(v[g][2], v[g][3], oh[g].y);
         }
         if (REG_STASH && SW == 1 && keep) keep_tile(stash[t % X3_MT], oh, ol);
+        // the tile's 16 packed dwords take the place of its 16 accumulators (no second register array across the barrier)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            pk[t][j][0] = whole_chunk(oh[2 * j], oh[2 * j + 1]);
-            pk[t][j][1] = whole_chunk(ol[2 * j], ol[2 * j + 1]);
+            const uint4 ch = whole_chunk(oh[2 * j], oh[2 * j + 1]), cl = whole_chunk(ol[2 * j], ol[2 * j + 1]);
+            acc[s][mt][8 * j + 0] = __builtin_bit_cast(float, ch.x); acc[s][mt][8 * j + 1] = __builtin_bit_cast(float, ch.y);
+            acc[s][mt][8 * j + 2] = __builtin_bit_cast(float, ch.z); acc[s][mt][8 * j + 3] = __builtin_bit_cast(float, ch.w);
+            acc[s][mt][8 * j + 4] = __builtin_bit_cast(float, cl.x); acc[s][mt][8 * j + 5] = __builtin_bit_cast(float, cl.y);
+            acc[s][mt][8 * j + 6] = __builtin_bit_cast(float, cl.z); acc[s][mt][8 * j + 7] = __builtin_bit_cast(float, cl.w);
         }
     }
 }
 template <int SW, int RW>
-__device__ __forceinline__ void epilogue_stage2(const uint4 (&pk)[SW * RW][2][2], unsigned char* img, int row0, int slice0, int h) {
+__device__ __forceinline__ void epilogue_stage2(const f32x16 (&acc)[SW][RW], unsigned char* img, int row0, int slice0, int h) {
 #pragma unroll
     for (int t = 0; t < SW * RW; ++t) {
         const int s = t / RW, mt = t % RW;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             unsigned char* o = img + chunk_off(row0, 4 * (slice0 + s) + 2 * j + h) + mt * 32 * PITCHB;
-            *reinterpret_cast<uint4*>(o) = pk[t][j][0];
-            *reinterpret_cast<uint4*>(o + PLANE) = pk[t][j][1];
+            const f32x16 a = acc[s][mt];
+            *reinterpret_cast<f32x4*>(o) = f32x4{a[8 * j], a[8 * j + 1], a[8 * j + 2], a[8 * j + 3]};
+            *reinterpret_cast<f32x4*>(o + PLANE) = f32x4{a[8 * j + 4], a[8 * j + 5], a[8 * j + 6], a[8 * j + 7]};
         }
     }
 }
@@ -469,7 +474,7 @@ __device__ __forceinline__ void spread_requests() {
 // does ((W y + b) + x; starting the accumulators from x instead moved the generator's head error from 8.3e-7 to 9.5e-7 on the
 // second golden set -- 1.55e-5 m of pose through the 10 tanh root); the first four tiles are requested under the last two
 // k-steps, the others as registers come free.
-template <int KT, int SW, int RW, int ADD, bool KEEP>
+template <int KT, int SW, int RW, int ADD, bool KEEP, bool EARLY>
 __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned char* smem, int wave, int lane, WRing& ring, Seed& seed,
                                            Stash& stash, int ui) {
     asm volatile("" : "+v"(lane));                   // lane-derived constants are recomputed per unit, not parked across units
@@ -602,14 +607,13 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned cha
 #ifndef X3_AB_SPLIT
 #define X3_AB_SPLIT 0         // (measured: no gain -- the LDS stores, not the arithmetic, are what the layer ends with -- and 64 more live registers)
 #endif
-    if (X3_AB_SPLIT && X3_NW == 8 && wave < 4 && !(u->flags & F_OUT_F32)) {
+    if (EARLY && !(u->flags & F_OUT_F32)) {
         // the first-finishing half: everything but the stores happens BEFORE the barrier, under the partners' k loops
-        uint4 pk[SW * RW][2][2];
-        if (copy) epilogue_stage1<SW, RW, true, ADD>(acc, rq, rin, rout, neg, pk, stash, KEEP);
-        else epilogue_stage1<SW, RW, false, ADD>(acc, rq, rin, rout, neg, pk, stash, KEEP);
+        if (copy) epilogue_stage1<SW, RW, true, ADD>(acc, rq, rin, rout, neg, stash, KEEP);
+        else epilogue_stage1<SW, RW, false, ADD>(acc, rq, rin, rout, neg, stash, KEEP);
         lds_barrier();                               // every wave has read the image for the last time
         if (ui >= 0) { X3_STAMP(8 * ui + 5) }
-        epilogue_stage2<SW, RW>(pk, img, row0, slice0, h);
+        epilogue_stage2<SW, RW>(acc, img, row0, slice0, h);
         return;
     }
     // The waves that finish LAST (four waves: every wave -- one per SIMD, same work): the barrier comes first and the conversion
@@ -747,15 +751,21 @@ __global__ __launch_bounds__(X3_THREADS, X3_NW / 4) void fused_mlp_x3_kernel(Pro
 // (KEEP: the layer's result is a later layer's residual and stays in the register stash -- a template parameter, not a run-time
 // select per value: layers that add something always keep (a result nobody adds later is overwritten by the next keeper))
 #define X3_CASE(CH, MAP, SW, RW) \
-    case (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, 0, false>(u, next, smem, wave, lane, ring, seed, stash, si); break; \
-    case 1024 + (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, 0, true>(u, next, smem, wave, lane, ring, seed, stash, si); break;
+    case (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, 0, false, ROLE>(u, next, smem, wave, lane, ring, seed, stash, si); break; \
+    case 1024 + (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, 0, true, ROLE>(u, next, smem, wave, lane, ring, seed, stash, si); break;
 #define X3_CASE_ADD(CH, MAP, SW, RW) \
-    case 256 + (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, 1, true>(u, next, smem, wave, lane, ring, seed, stash, si); break;
+    case 256 + (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, 1, true, ROLE>(u, next, smem, wave, lane, ring, seed, stash, si); break;
 #define X3_CASE_STASH(CH, MAP, SW, RW) \
-    case 512 + (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, 2, true>(u, next, smem, wave, lane, ring, seed, stash, si); break;
+    case 512 + (CH) * 16 + (MAP): gemm_layer<4 * (CH), SW, RW, 2, true, ROLE>(u, next, smem, wave, lane, ring, seed, stash, si); break;
                 /* (chunks, map, what it adds: nothing | from the workspace | from the register stash): validated on the host */
                 int addsel = (plan & (PF_ADD_R1 << 20)) ? 256 : ((plan & (PF_ADD_R0 << 20)) ? (REG_STASH ? 512 : 256) : 0);
                 if (addsel == 0 && REG_STASH && (plan & (PF_COPY_R0 << 20))) addsel = 1024;
+#if X3_AB_SPLIT && X3_NWAVES == 8
+                // the waves that finish their k loop first (the older wave of every SIMD pair) run the bodies whose epilogue does its
+                // arithmetic BEFORE the layer's barrier; the two roles are separate instantiations, so neither carries the other's
+                // epilogue (as one body with a run-time role the register allocator spilled 160 registers)
+                if (wave < 4) {
+#define ROLE true
 #ifdef X3_ABL_NOWS
                 switch ((plan >> 12) & 255) {
 #else
@@ -777,6 +787,57 @@ __global__ __launch_bounds__(X3_THREADS, X3_NW / 4) void fused_mlp_x3_kernel(Pro
                     X3_CASE_ADD(1, MAP_1x1, 1, 1) X3_CASE_ADD(2, MAP_1x1, 1, 1) X3_CASE_ADD(4, MAP_1x1, 1, 1)
                     default: break;
                 }
+#undef ROLE
+                } else {
+#define ROLE false
+#ifdef X3_ABL_NOWS
+                switch ((plan >> 12) & 255) {
+#else
+                switch (((plan >> 12) & 255) | addsel) {
+#endif
+#if X3_NWAVES == 4
+                    X3_CASE(1, MAP_2x4, 2, 4) X3_CASE(2, MAP_2x4, 2, 4) X3_CASE(4, MAP_2x4, 2, 4)
+                    X3_CASE_ADD(1, MAP_2x4, 2, 4) X3_CASE_ADD(2, MAP_2x4, 2, 4) X3_CASE_ADD(4, MAP_2x4, 2, 4)
+#else
+                    X3_CASE_STASH(1, MAP_1x4, 1, 4) X3_CASE_STASH(2, MAP_1x4, 1, 4) X3_CASE_STASH(4, MAP_1x4, 1, 4)
+                    X3_CASE_STASH(1, MAP_1x2, 1, 2) X3_CASE_STASH(2, MAP_1x2, 1, 2) X3_CASE_STASH(4, MAP_1x2, 1, 2)
+                    X3_CASE_STASH(1, MAP_1x1, 1, 1) X3_CASE_STASH(2, MAP_1x1, 1, 1) X3_CASE_STASH(4, MAP_1x1, 1, 1)
+#endif
+                    X3_CASE(1, MAP_1x4, 1, 4) X3_CASE(2, MAP_1x4, 1, 4) X3_CASE(4, MAP_1x4, 1, 4)
+                    X3_CASE(1, MAP_1x2, 1, 2) X3_CASE(2, MAP_1x2, 1, 2) X3_CASE(4, MAP_1x2, 1, 2)
+                    X3_CASE(1, MAP_1x1, 1, 1) X3_CASE(2, MAP_1x1, 1, 1) X3_CASE(4, MAP_1x1, 1, 1)
+                    X3_CASE_ADD(1, MAP_1x4, 1, 4) X3_CASE_ADD(2, MAP_1x4, 1, 4) X3_CASE_ADD(4, MAP_1x4, 1, 4)
+                    X3_CASE_ADD(1, MAP_1x2, 1, 2) X3_CASE_ADD(2, MAP_1x2, 1, 2) X3_CASE_ADD(4, MAP_1x2, 1, 2)
+                    X3_CASE_ADD(1, MAP_1x1, 1, 1) X3_CASE_ADD(2, MAP_1x1, 1, 1) X3_CASE_ADD(4, MAP_1x1, 1, 1)
+                    default: break;
+                }
+#undef ROLE
+                }
+#else
+#define ROLE false
+#ifdef X3_ABL_NOWS
+                switch ((plan >> 12) & 255) {
+#else
+                switch (((plan >> 12) & 255) | addsel) {
+#endif
+#if X3_NWAVES == 4
+                    X3_CASE(1, MAP_2x4, 2, 4) X3_CASE(2, MAP_2x4, 2, 4) X3_CASE(4, MAP_2x4, 2, 4)
+                    X3_CASE_ADD(1, MAP_2x4, 2, 4) X3_CASE_ADD(2, MAP_2x4, 2, 4) X3_CASE_ADD(4, MAP_2x4, 2, 4)
+#else
+                    X3_CASE_STASH(1, MAP_1x4, 1, 4) X3_CASE_STASH(2, MAP_1x4, 1, 4) X3_CASE_STASH(4, MAP_1x4, 1, 4)
+                    X3_CASE_STASH(1, MAP_1x2, 1, 2) X3_CASE_STASH(2, MAP_1x2, 1, 2) X3_CASE_STASH(4, MAP_1x2, 1, 2)
+                    X3_CASE_STASH(1, MAP_1x1, 1, 1) X3_CASE_STASH(2, MAP_1x1, 1, 1) X3_CASE_STASH(4, MAP_1x1, 1, 1)
+#endif
+                    X3_CASE(1, MAP_1x4, 1, 4) X3_CASE(2, MAP_1x4, 1, 4) X3_CASE(4, MAP_1x4, 1, 4)
+                    X3_CASE(1, MAP_1x2, 1, 2) X3_CASE(2, MAP_1x2, 1, 2) X3_CASE(4, MAP_1x2, 1, 2)
+                    X3_CASE(1, MAP_1x1, 1, 1) X3_CASE(2, MAP_1x1, 1, 1) X3_CASE(4, MAP_1x1, 1, 1)
+                    X3_CASE_ADD(1, MAP_1x4, 1, 4) X3_CASE_ADD(2, MAP_1x4, 1, 4) X3_CASE_ADD(4, MAP_1x4, 1, 4)
+                    X3_CASE_ADD(1, MAP_1x2, 1, 2) X3_CASE_ADD(2, MAP_1x2, 1, 2) X3_CASE_ADD(4, MAP_1x2, 1, 2)
+                    X3_CASE_ADD(1, MAP_1x1, 1, 1) X3_CASE_ADD(2, MAP_1x1, 1, 1) X3_CASE_ADD(4, MAP_1x1, 1, 1)
+                    default: break;
+                }
+#undef ROLE
+#endif
 #undef X3_CASE_STASH
 #undef X3_CASE_ADD
 #undef X3_CASE
