@@ -100,6 +100,7 @@ SIGNATURES["dhaug_pack_wfrag"] = [_vp, _i64, _vp, _i64, _i64, _i64, _vp]
 SIGNATURES["dhaug_pack_wfrag_batch"] = [_vp, _i32, _vp]
 SIGNATURES["dhaug_mlp_forward"] = [ctypes.POINTER(MlpUnit), _i32, _i64, _vp]
 SIGNATURES["dhaug_pack_wfrag_f16x2"] = [_vp, _i64, _vp, _i64, _i64, _i64, _vp]
+SIGNATURES["dhaug_pack_wfrag_f16x2_t16"] = [_vp, _i64, _vp, _i64, _i64, _i64, _vp]
 SIGNATURES["dhaug_mlp_forward_x3"] = [ctypes.POINTER(MlpUnit), _i32, _i64, _vp]
 
 ERRORS = {-1: "DHAUG_EINVAL (bad argument)", -2: "DHAUG_EALIGN (alignment contract violated)",

@@ -61,6 +61,9 @@ constexpr int X3_MT = X3_BM / 32;
 #ifndef X3_NWAVES
 #define X3_NWAVES 8
 #endif
+// both matrix-instruction shapes are built (eight waves); a program says which one its weights are packed for
+// (DHAUG_MLP_F_T16 on its GEMM units: dhaug_pack_wfrag_f16x2_t16)
+#define X3_SHAPE16 (X3_NWAVES == 8)
 constexpr int X3_NW = X3_NWAVES;                                     // waves per workgroup: 4 (one per SIMD, 512 registers) or 8
 constexpr int X3_THREADS = 64 * X3_NW;
 constexpr int X3_MAX_UNITS = 32;
@@ -79,7 +82,7 @@ constexpr int WS_FLOATS_PER_WAVE = 64 * 128 * 4 / X3_NW;              // 64 lane
 constexpr int WS_REGION_FLOATS = 256 * X3_NW * WS_FLOATS_PER_WAVE;   // one region: every workgroup's tile, 32 MB
 
 enum { U_LOAD_F32 = 0, U_GEMM = 3, U_LOAD_KCS = 5 };
-enum { F_OUT_F32 = 4 };
+enum { F_OUT_F32 = 4, F_T16 = 32 };
 // what the planner found out about a GEMM unit (plan bits 20..)
 enum { PF_ADD_R0 = 1,          // epilogue: + the values waiting in workspace region 0 (a residual)
        PF_ADD_R1 = 2,          // epilogue: + the values waiting in region 1 (a parked partial result)
@@ -633,6 +636,233 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, UnitPtr next, unsigned cha
     else epilogue<SW, RW, EP_IMAGE, false, ADD, false, KEEP>(acc, rq, rin, rout, img, row0, slice0, h, neg, stash);
 }
 
+#if X3_SHAPE16
+// ======================================================================================================================
+// The layer body on v_mfma_f32_16x16x32_f16.  Same image, same programs, same waves (eight: slice w x 128 rows); a wave's
+// 32 x 128 block is 2 feature tiles x 8 row tiles of 16 x 16, a k-step covers 32 k.  Why: at equal cycles per flop the
+// chip holds a higher clock on this shape -- tools/ubench/mfma_shape.hip, fragments re-read from LDS, two waves per SIMD, random
+// data: 2 010 TFLOP/s against 1 690 for 32 x 32 x 16 (1.19 x; 1.93 against 1.62 GHz).
+//   A operand (weights): lane l holds W[16 ft + (l & 15)][32 ks + 8 (l >> 4) + j];  blob [slice][ft][ks][piece][lane][8]
+//   B operand (image):   lane l holds X[32 ks + 8 (l >> 4) + j][row 16 rt + (l & 15)] = chunk 4 ks + (l >> 4) of that row
+//   accumulator tile (ft, rt): lane l, register e = feature 16 ft + 4 (l >> 4) + e of row 16 rt + (l & 15)
+// A lane's register quad is 8 bytes of a chunk whose other half sits 16 lanes away: one v_permlane16_swap per dword over a PAIR
+// of row tiles gives the even quarter-waves the whole chunk of the first tile, the odd ones that of the second.
+typedef f16x8 WRing16[2][2][2];                   // [k-step & 1][feature tile][piece]
+typedef f32x4 Seed16[2];                          // bias of the two feature tiles in accumulator order
+typedef u32x16 Stash16[4];                        // tile t = ft * NT + rt: dwords 4 (t & 3) .. + 3 of [t >> 2] = hi pair, hi pair, lo pair, lo pair
+constexpr int RQ16 = 4;                           // 16 x 16 tiles of a workspace value in flight
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc16(const _Float16* w, int slice, int kt) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(w) + (long long)slice * kt * 2048, 0, 0x7fffffff, 0x27000);
+}
+__device__ __forceinline__ f16x8 load_frag16(__amdgpu_buffer_rsrc_t rs, int lane16, int kt, int ft, int ks, int p) {
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, ((ft * kt + ks) * 2 + p) * 1024, 0));
+}
+__device__ __forceinline__ void prefetch_layer16(UnitPtr u, int wave, int lane, WRing16& ring, Seed16& seed) {
+    const int plan = u->plan;
+    const int lg = (plan >> 8) & 15, kt = ((plan >> 16) & 15) * 2;           // (32-k steps)
+    const int slice = wave & ((1 << lg) - 1);
+    const __amdgpu_buffer_rsrc_t rs = weight_rsrc16(u->w, slice, kt);
+    const int lane16 = lane << 4, q = lane >> 4;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) ring[0][ft][p] = load_frag16(rs, lane16, kt, ft, 0, p);
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) seed[ft] = *reinterpret_cast<const f32x4*>(u->bias + 32 * slice + 16 * ft + 4 * q);
+}
+__device__ __forceinline__ uint4 whole_chunk16(uint2 a, uint2 b) {
+    const auto rx = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+    const auto ry = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+    return uint4{rx[0], ry[0], rx[1], ry[1]};
+}
+__device__ __forceinline__ float stash_value16(const Stash16& st, int t, int e) {
+    const uint32_t h = st[t >> 2][4 * (t & 3) + (e >> 1)], l = st[t >> 2][4 * (t & 3) + 2 + (e >> 1)];
+    float x;
+    if (e & 1) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(x) : "v"(h), "v"(l));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(x) : "v"(h), "v"(l));
+    return x;
+}
+
+// NT = row tiles of 16 of the wave's block (8, 4 or 2)
+template <int NT, int MODE, int ADD, bool RELU, bool KEEP>
+__device__ __forceinline__ void epilogue16(f32x4 (&acc)[2][NT], f32x4 (&rq)[RQ16], const float* rin, float* rout, unsigned char* img, int row0,
+                                           int slice, int q, float neg, Stash16& stash) {
+    constexpr int G = 2 * NT;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int p = 0; p < NT / 2; ++p) {
+            uint2 oh[2], ol[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rt = 2 * p + j, t = ft * NT + rt;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = ADD == 1 ? acc[ft][rt][e] + rq[t % RQ16][e] : (ADD == 2 ? acc[ft][rt][e] + stash_value16(stash, t, e) : acc[ft][rt][e]);
+                if (ADD == 1 && t + RQ16 < G) rq[t % RQ16] = ws_load(rin + (t + RQ16) * 256);
+                if (RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float f = v[e];
+                        const int b = __builtin_bit_cast(int, f);
+                        v[e] = __builtin_bit_cast(float, b > 0 ? b : 0);
+                    }
+                } else {
+                    const f32x4 w = v * neg;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], w[e]);
+                }
+                if (MODE == EP_PARK) ws_store(rout + t * 256, v);
+                if (MODE == EP_OUT) {
+                    if (slice < 2)                                                  // (N <= 64)
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(img) + (row0 + 16 * rt) * OUT_PITCH + 32 * slice + 16 * ft + 4 * q) = v;
+                } else if (MODE == EP_IMAGE) {
+                    oh[j].x = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v[0], v[1]}, f16x2));
+                    oh[j].y = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v[2], v[3]}, f16x2));
+                    ol[j].x = split_lo(v[0], v[1], oh[j].x);
+                    ol[j].y = split_lo(v[2], v[3], oh[j].y);
+                    if (KEEP) {
+                        stash[t >> 2][4 * (t & 3) + 0] = oh[j].x; stash[t >> 2][4 * (t & 3) + 1] = oh[j].y;
+                        stash[t >> 2][4 * (t & 3) + 2] = ol[j].x; stash[t >> 2][4 * (t & 3) + 3] = ol[j].y;
+                    }
+                }
+            }
+            if (MODE == EP_IMAGE) {
+                // even quarter-waves hold the chunk of row tile 2 p, odd ones that of 2 p + 1
+                unsigned char* o = img + chunk_off(row0 + 16 * (2 * p + (q & 1)), 4 * slice + 2 * ft + (q >> 1));
+                *reinterpret_cast<uint4*>(o) = whole_chunk16(oh[0], oh[1]);
+                *reinterpret_cast<uint4*>(o + PLANE) = whole_chunk16(ol[0], ol[1]);
+            }
+        }
+}
+
+template <int NM, int ND, int NV>
+__device__ __forceinline__ void spread_requests16() {
+    constexpr int PER = NM / ND;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (i < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (i + ND < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    if (NM - PER * ND > 0) __builtin_amdgcn_sched_group_barrier(0x008, NM - PER * ND, 0);
+}
+
+// KT: 32-k steps (2, 4 or 8); RW: 32-row groups of the wave's block (4, 2 or 1)
+template <int KT, int RW, int ADD, bool KEEP>
+__device__ __forceinline__ void gemm_layer16(UnitPtr u, UnitPtr next, unsigned char* smem, int wave, int lane, WRing16& ring, Seed16& seed,
+                                             Stash16& stash, int ui) {
+    asm volatile("" : "+v"(lane));
+    constexpr int NT = 2 * RW, NP = RW;              // row tiles of 16; PAIRS of row tiles = steps per k-step
+    const int c = lane & 15, q = lane >> 4, lane16 = lane << 4;
+    const int plan = u->plan;
+#ifdef X3_ABL_NOWS
+    const int lg = (plan >> 8) & 15, pf = (plan >> 20) & PF_TO_PARK;
+#else
+    const int lg = (plan >> 8) & 15, pf = plan >> 20;
+#endif
+    const int slice = wave & ((1 << lg) - 1), rg = wave >> lg;
+    const bool active = rg * RW < X3_MT;
+    const int row0 = rg * RW * 32 + c;
+    unsigned char* img = smem;
+    if (!active) {
+        if (next != nullptr) prefetch_layer16(next, wave, lane, ring, seed);
+        if (!(pf & PF_TO_PARK)) lds_barrier();
+        return;
+    }
+    f32x4 acc[2][NT];
+    const float* rin = ws_base(u->g, wave, lane, (pf & PF_ADD_R1) ? 1 : 0);
+    f32x4 rq[RQ16];
+    {
+        const __amdgpu_buffer_rsrc_t rs = weight_rsrc16(u->w, slice, KT);
+        f16x8 fx[2][2][2];                           // [buffer][row tile of the pair][plane]
+        const int frag_row = row0 * PITCHB;
+        auto read_frags = [&](int step, f16x8 (&f)[2][2]) {
+            const int ks = step / NP, pr = step % NP;
+            const unsigned char* a = img + frag_row + (((4 * ks + q) ^ c) << 4) + pr * 32 * PITCHB;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f[j][0] = *reinterpret_cast<const f16x8*>(a + j * 16 * PITCHB);
+                f[j][1] = *reinterpret_cast<const f16x8*>(a + j * 16 * PITCHB + PLANE);
+            }
+        };
+        read_frags(0, fx[0]);
+#pragma unroll
+        for (int step = 0; step < KT * NP; ++step) {
+            const int ks = step / NP, pr = step % NP;
+#ifndef X3_ABL_NOREAD
+            if (step + 1 < KT * NP) read_frags(step + 1, fx[(step + 1) & 1]);
+#endif
+            bool wl = false, rl = false;
+            if (pr == 0) {
+#ifndef X3_ABL_NOWLOAD
+                if (ks + 1 < KT) {                   // one 32-k step ahead, into the entry step ks - 1 just left
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) ring[(ks + 1) & 1][ft][p] = load_frag16(rs, lane16, KT, ft, ks + 1, p);
+                    wl = true;
+                }
+#endif
+                if (ADD == 1 && ks == KT - 1) {
+#pragma unroll
+                    for (int t = 0; t < (2 * NT < RQ16 ? 2 * NT : RQ16); ++t) rq[t] = ws_load(rin + t * 256);
+                    rl = true;
+                }
+            }
+            // small terms first, then hi * hi
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ft][2 * pr + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[ks & 1][ft][1], fx[step & 1][j][0], ks == 0 ? seed[ft] : acc[ft][2 * pr + j], 0, 0, 0);
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ft][2 * pr + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[ks & 1][ft][0], fx[step & 1][j][1], acc[ft][2 * pr + j], 0, 0, 0);
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ft][2 * pr + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[ks & 1][ft][0], fx[step & 1][j][0], acc[ft][2 * pr + j], 0, 0, 0);
+#if X3_SPREAD
+            {
+                const bool rd = step + 1 < KT * NP;
+                if (rd && wl) spread_requests16<12, 4, 4>();
+                else if (rd && rl) spread_requests16<12, 4, (2 * NT < RQ16 ? 2 * NT : RQ16)>();
+                else if (rd) spread_requests16<12, 4, 0>();
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (ui >= 0) { X3_STAMP(8 * ui + 1) }
+    if (next != nullptr) prefetch_layer16(next, wave, lane, ring, seed);
+    if (ui >= 0) { X3_STAMP(8 * ui + 4) }
+    const float neg = act_neg(u->act, u->slope);
+    float* rout = ws_base(u->g, wave, lane, 1);
+    if (pf & PF_TO_PARK) {
+        epilogue16<NT, EP_PARK, ADD, false, false>(acc, rq, rin, rout, img, row0, slice, q, neg, stash);
+        return;
+    }
+    lds_barrier();                                   // every wave has read the image for the last time
+    if (ui >= 0) { X3_STAMP(8 * ui + 5) }
+    if (u->flags & F_OUT_F32) {
+        epilogue16<NT, EP_OUT, ADD, false, false>(acc, rq, rin, rout, img, row0, slice, q, neg, stash);
+        return;
+    }
+#ifdef X3_ABL_NOEPI
+    if (u->slope != 12345.f) return;
+#endif
+    if (u->act == DHAUG_ACT_RELU) epilogue16<NT, EP_IMAGE, ADD, true, KEEP>(acc, rq, rin, rout, img, row0, slice, q, neg, stash);
+    else epilogue16<NT, EP_IMAGE, ADD, false, KEEP>(acc, rq, rin, rout, img, row0, slice, q, neg, stash);
+}
+#endif  // X3_SHAPE16
+
 // LOAD: global fp32 (M, ld) columns [0, cols) -> hi / lo planes of the image, zero-filled up to the next multiple of 64
 // columns and below row M.  cols and ld even: a thread moves column pairs (8-byte loads, 4-byte LDS writes).
 __device__ __forceinline__ void load_unit(UnitPtr u, unsigned char* smem, long long m0, long long M, int tid) {
@@ -716,6 +946,7 @@ __device__ __forceinline__ void store_output(UnitPtr u, unsigned char* smem, lon
     }
 }
 
+template <bool S16>
 __global__ __launch_bounds__(X3_THREADS, X3_NW / 4) void fused_mlp_x3_kernel(Program prog, long long M) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -726,10 +957,21 @@ __global__ __launch_bounds__(X3_THREADS, X3_NW / 4) void fused_mlp_x3_kernel(Pro
     UnitPtr units = (UnitPtr)(ka + __builtin_offsetof(Program, u));
     const int nunits = *(const int __attribute__((address_space(4)))*)(ka + __builtin_offsetof(Program, nunits));
     const int first_gemm = *(const int __attribute__((address_space(4)))*)(ka + __builtin_offsetof(Program, first_gemm));
+#if X3_SHAPE16
+    WRing16 ring16;
+    Seed16 seed16;
+    Stash16 stash16;
+#endif
     WRing ring;
     Seed seed;
     Stash stash;
-    if ((long long)blockIdx.x < ntiles) prefetch_layer(units + first_gemm, wave, lane, ring, seed);
+    if ((long long)blockIdx.x < ntiles) {
+#if X3_SHAPE16
+        if (S16) prefetch_layer16(units + first_gemm, wave, lane, ring16, seed16);
+        else
+#endif
+            prefetch_layer(units + first_gemm, wave, lane, ring, seed);
+    }
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long m0 = tile * X3_BM;
         const bool more = tile + gridDim.x < ntiles;
@@ -748,6 +990,29 @@ __global__ __launch_bounds__(X3_THREADS, X3_NW / 4) void fused_mlp_x3_kernel(Pro
                 // the next tile then starts over at the first)
                 const int nx = plan & 255;
                 UnitPtr next = nx != 0 ? units + (nx - 1) : (more ? units + first_gemm : (UnitPtr) nullptr);
+#if X3_SHAPE16
+                if (S16) {
+                // (chunks of 64 k, block map, what the layer adds: nothing | workspace | stash; whether its result is kept)
+#define X3_B16(CH, MAP, RW) \
+    case (CH) * 16 + (MAP): gemm_layer16<2 * (CH), RW, 0, false>(u, next, smem, wave, lane, ring16, seed16, stash16, si); break; \
+    case 1024 + (CH) * 16 + (MAP): gemm_layer16<2 * (CH), RW, 0, true>(u, next, smem, wave, lane, ring16, seed16, stash16, si); break; \
+    case 256 + (CH) * 16 + (MAP): gemm_layer16<2 * (CH), RW, 1, true>(u, next, smem, wave, lane, ring16, seed16, stash16, si); break; \
+    case 512 + (CH) * 16 + (MAP): gemm_layer16<2 * (CH), RW, 2, true>(u, next, smem, wave, lane, ring16, seed16, stash16, si); break;
+                int addsel = (plan & (PF_ADD_R1 << 20)) ? 256 : ((plan & (PF_ADD_R0 << 20)) ? 512 : 0);
+                if (addsel == 0 && (plan & (PF_COPY_R0 << 20))) addsel = 1024;
+#ifdef X3_ABL_NOWS
+                addsel = 0;
+#endif
+                switch (((plan >> 12) & 255) | addsel) {
+                    X3_B16(1, MAP_1x4, 4) X3_B16(2, MAP_1x4, 4) X3_B16(4, MAP_1x4, 4)
+                    X3_B16(1, MAP_1x2, 2) X3_B16(2, MAP_1x2, 2) X3_B16(4, MAP_1x2, 2)
+                    X3_B16(1, MAP_1x1, 1) X3_B16(2, MAP_1x1, 1) X3_B16(4, MAP_1x1, 1)
+                    default: break;
+                }
+#undef X3_B16
+                } else
+#endif
+                {
 // (KEEP: the layer's result is a later layer's residual and stays in the register stash -- a template parameter, not a run-time
 // select per value: layers that add something always keep (a result nobody adds later is overwritten by the next keeper))
 #define X3_CASE(CH, MAP, SW, RW) \
@@ -841,6 +1106,7 @@ __global__ __launch_bounds__(X3_THREADS, X3_NW / 4) void fused_mlp_x3_kernel(Pro
 #undef X3_CASE_STASH
 #undef X3_CASE_ADD
 #undef X3_CASE
+                }
                 if (u->flags & F_OUT_F32) {
                     lds_barrier();
                     store_output(u, smem, m0, M, tid);
@@ -857,13 +1123,20 @@ __global__ __launch_bounds__(X3_THREADS, X3_NW / 4) void fused_mlp_x3_kernel(Pro
 // weights -> hi / lo fp16 fragments.  dst[(((slice*ksteps + ks)*2 + piece)*64 + lane)*8 + j] =
 //   piece(W[32 slice + (lane&31)][k0 + 16 ks + 8 (lane>>5) + j])
 __global__ __launch_bounds__(256) void pack_wfrag_f16x2_kernel(const float* __restrict__ W, long long ldw, _Float16* __restrict__ dst,
-                                                               int N, int K, int k0, int ksteps, int nslices) {
+                                                               int N, int K, int k0, int ksteps, int nslices, int t16) {
     const long long total = (long long)nslices * ksteps * 64 * 8;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
         const long long blk = i >> 9;
-        const int ks = (int)(blk % ksteps), s = (int)(blk / ksteps);
-        const int n = 32 * s + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+        int n, k;
+        if (t16) {
+            // [slice][feature tile][32-k step][piece][lane][8]: blk = (slice * 2 + ft) * (ksteps / 2) + ks32
+            const int kt = ksteps / 2, ks = (int)(blk % kt), ft = (int)((blk / kt) & 1), s = (int)(blk / (2 * kt));
+            n = 32 * s + 16 * ft + (lane & 15); k = 32 * ks + 8 * (lane >> 4) + j;
+        } else {
+            const int ks = (int)(blk % ksteps), s = (int)(blk / ksteps);
+            n = 32 * s + (lane & 31); k = 16 * ks + 8 * (lane >> 5) + j;
+        }
         const float w = (n < N && k < K) ? W[(long long)n * ldw + k0 + k] : 0.0f;
         const _Float16 hi = (_Float16)w, lo = (_Float16)(w - (float)hi);
         const long long o = ((blk * 2) * 64 + lane) * 8 + j;
@@ -876,8 +1149,7 @@ __global__ __launch_bounds__(256) void pack_wfrag_f16x2_kernel(const float* __re
 
 extern "C" {
 
-/* see include/dhaug.h */
-int dhaug_pack_wfrag_f16x2(const float* W, int64_t ldw, uint16_t* dst, int64_t N, int64_t K, int64_t k0, void* stream) {
+static int pack_wfrag_f16x2_impl(const float* W, int64_t ldw, uint16_t* dst, int64_t N, int64_t K, int64_t k0, int t16, void* stream) {
     DHAUG_CHECK(N >= 1 && K >= 1 && k0 >= 0 && ldw >= k0 + K, DHAUG_EINVAL);
     DHAUG_CHECK_PTR(W); DHAUG_CHECK_PTR(dst);
     DHAUG_CHECK(dhaug_aligned16(dst), DHAUG_EALIGN);
@@ -887,8 +1159,16 @@ int dhaug_pack_wfrag_f16x2(const float* W, int64_t ldw, uint16_t* dst, int64_t N
     long long blocks = (total + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(pack_wfrag_f16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, W, (long long)ldw,
-                       reinterpret_cast<_Float16*>(dst), (int)N, (int)K, (int)k0, ksteps, nslices);
+                       reinterpret_cast<_Float16*>(dst), (int)N, (int)K, (int)k0, ksteps, nslices, t16);
     return dhaug_launch_status();
+}
+
+/* see include/dhaug.h */
+int dhaug_pack_wfrag_f16x2(const float* W, int64_t ldw, uint16_t* dst, int64_t N, int64_t K, int64_t k0, void* stream) {
+    return pack_wfrag_f16x2_impl(W, ldw, dst, N, K, k0, 0, stream);
+}
+int dhaug_pack_wfrag_f16x2_t16(const float* W, int64_t ldw, uint16_t* dst, int64_t N, int64_t K, int64_t k0, void* stream) {
+    return pack_wfrag_f16x2_impl(W, ldw, dst, N, K, k0, 1, stream);
 }
 
 /* The planner: the units address three virtual buffers (include/dhaug.h); the kernel has ONE image and a two-region global
@@ -927,6 +1207,7 @@ int dhaug_mlp_forward_x3(const dhaug_mlp_unit* units, int nunits, int64_t M, voi
         if (units[i].kind == U_GEMM && !is_out(units[i]) && units[i].g != nullptr) { ws = units[i].g; break; }
     DHAUG_CHECK(ws == nullptr || dhaug_aligned16(ws), DHAUG_EALIGN);
     int img = -1;                                                   /* the virtual buffer whose value the image holds */
+    int t16 = -1;                                                   /* which matrix instruction the program's weights are packed for */
     int r0 = -1, r0_map = -1, r1 = -1, r1_map = -1;                 /* ... region 0 (a copy for a residual), region 1 (parked) */
     for (int i = 0; i < nunits; ++i) {
         const dhaug_mlp_unit& s = units[i];
@@ -939,7 +1220,10 @@ int dhaug_mlp_forward_x3(const dhaug_mlp_unit* units, int nunits, int64_t M, voi
             DHAUG_CHECK(okbuf(s.src) && u.ksteps >= 1 && u.ksteps <= 16 && u.N >= 1 && u.N <= 256, DHAUG_EUNSUPPORTED);
             DHAUG_CHECK(s.ksteps2 == 0, DHAUG_EUNSUPPORTED);              /* (a concatenation is two units: see fused.py) */
             DHAUG_CHECK(u.w != nullptr && dhaug_aligned16(u.w) && u.bias != nullptr && dhaug_aligned16(u.bias), DHAUG_EALIGN);
-            DHAUG_CHECK((u.flags & ~F_OUT_F32) == 0, DHAUG_EUNSUPPORTED);
+            DHAUG_CHECK((u.flags & ~(F_OUT_F32 | F_T16)) == 0, DHAUG_EUNSUPPORTED);
+            if (t16 < 0) t16 = (u.flags & F_T16) ? 1 : 0;
+            DHAUG_CHECK(t16 == ((u.flags & F_T16) ? 1 : 0), DHAUG_EINVAL);            /* one fragment layout per program */
+            u.flags &= ~F_T16;
             DHAUG_CHECK(s.src == img, DHAUG_EUNSUPPORTED);                /* the source must be what the image holds */
             const int chunks = (u.ksteps + 3) / 4;
             DHAUG_CHECK(chunks == 1 || chunks == 2 || chunks == 4, DHAUG_EUNSUPPORTED);
@@ -1026,16 +1310,28 @@ int dhaug_mlp_forward_x3(const dhaug_mlp_unit* units, int nunits, int64_t M, voi
             prog.first_gemm = i;
         }
     DHAUG_CHECK(prog.first_gemm >= 0, DHAUG_EINVAL);
+#if !X3_SHAPE16
+    DHAUG_CHECK(t16 != 1, DHAUG_EUNSUPPORTED);
+#endif
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_x3_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_x3_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
+#if X3_SHAPE16
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                X3_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+#endif
         configured = true;
     }
     const long long ntiles = (M + X3_BM - 1) / X3_BM;
     const unsigned grid = dhaug_persistent_grid(ntiles);           // one persistent workgroup per CU
-    hipLaunchKernelGGL(fused_mlp_x3_kernel, dim3(grid), dim3(X3_THREADS), X3_LDS_BYTES, (hipStream_t)stream, prog, (long long)M);
+#if X3_SHAPE16
+    if (t16 == 1) hipLaunchKernelGGL(fused_mlp_x3_kernel<true>, dim3(grid), dim3(X3_THREADS), X3_LDS_BYTES, (hipStream_t)stream, prog, (long long)M);
+    else
+#endif
+        hipLaunchKernelGGL(fused_mlp_x3_kernel<false>, dim3(grid), dim3(X3_THREADS), X3_LDS_BYTES, (hipStream_t)stream, prog, (long long)M);
     return dhaug_launch_status();
 }
 

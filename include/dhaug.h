@@ -415,6 +415,14 @@ int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* 
  * 8 (lane>>5) + j]), piece 0 = fp16(w), piece 1 = fp16(w - piece 0); 8 slices, k-steps padded to multiples of 4, i.e.
  * 2 * 8 * ksteps * 512 fp16 values. */
 int dhaug_pack_wfrag_f16x2(const float* W, int64_t ldw, uint16_t* dst, int64_t N, int64_t K, int64_t k0, void* stream);
+/* The same pair of pieces in the fragment order of v_mfma_f32_16x16x32_f16 (same size): per slice of 32 features two feature
+ * tiles of 16, k-steps of 32 -- dst[((((slice*2 + ft)*(ksteps/2) + ks)*2 + piece)*64 + lane)*8 + j] = piece(W[32 slice + 16 ft +
+ * (lane&15)][k0 + 32 ks + 8 (lane>>4) + j]).  A program whose GEMM units carry DHAUG_MLP_F_T16 (all of them or none) runs its
+ * layers on that instruction: same image, same results to rounding (k is summed 32 at a time), and -- measured, MI355X,
+ * tools/ubench/mfma_shape.hip -- 1.19 x the FLOP/s of the 32 x 32 x 16 form at equal cycles, because the chip holds a higher
+ * clock on it. */
+#define DHAUG_MLP_F_T16      32
+int dhaug_pack_wfrag_f16x2_t16(const float* W, int64_t ldw, uint16_t* dst, int64_t N, int64_t K, int64_t k0, void* stream);
 #define DHAUG_MLP_X3_WORKSPACE_BYTES (2 * 256 * 4 * 64 * 128 * 4)   /* regions x workgroups x waves x lanes x values x 4 */
 int dhaug_mlp_forward_x3(const dhaug_mlp_unit* units, int nunits, int64_t M, void* stream);
 
