@@ -66,6 +66,47 @@ def test_argument_errors_are_returned_not_thrown(built):
         dhaug_amd._lib.check(-2, "x")
 
 
+def test_parity_program_planner_refuses_what_one_image_cannot_hold(built):
+    """dhaug_mlp_forward_x3 plans the three virtual buffers of a program onto ONE in-place LDS image (+ registers + a workspace)
+    on the host, before any launch: a program that reads a value from where it no longer is comes back DHAUG_EUNSUPPORTED, mixed
+    fragment layouts and a parked result without a workspace DHAUG_EINVAL -- checked here without a GPU."""
+    import dhaug_amd
+    from dhaug_amd import _lib
+    L = _lib.lib()
+    buf = (ctypes.c_float * 4096)()
+    base = ctypes.addressof(buf)
+    base += (-base) % 16
+    ptr = ctypes.c_void_p(base)
+
+    def unit(kind, **kw):
+        u = _lib.MlpUnit()
+        u.kind, u.src, u.dst, u.res, u.src2 = kind, -1, -1, -1, -1
+        for k, v in kw.items():
+            setattr(u, k, v)
+        return u
+
+    def run(units):
+        arr = (_lib.MlpUnit * len(units))(*units)
+        return L.dhaug_mlp_forward_x3(arr, len(units), 128, None)
+
+    LOAD, GEMM, OUT, T16 = 0, 3, 4, 32
+    load = lambda dst: unit(LOAD, dst=dst, cols=64, ld=64, g=ptr)
+    gemm = lambda src, dst, **kw: unit(GEMM, src=src, dst=dst, ksteps=4, n=256, w=ptr, bias=ptr, **kw)
+    # the source must be what the image holds: buffer 0 was never written
+    assert run([load(1), gemm(0, 1)]) == -3
+    # buffer 1 is read again as a SOURCE after the layer in between has overwritten the image
+    assert run([load(1), gemm(1, 0), gemm(1, 0)]) == -3
+    # one fragment layout per program
+    assert run([load(1), gemm(1, 0, flags=T16), gemm(0, 1)]) == -1
+    # a result that waits while another branch uses the image needs the workspace (g of the GEMM units that are not outputs)
+    parked = [load(1), gemm(1, 0), unit(GEMM, src=0, dst=2, ksteps=16, n=100, w=ptr, bias=ptr), load(1), gemm(1, 0),
+              unit(GEMM, src=0, dst=2, res=2, ksteps=16, n=100, w=ptr, bias=ptr)]
+    assert run(parked) == -1
+    # a second source (a concatenation in one unit) is not a unit of this kernel
+    assert run([load(1), unit(GEMM, src=1, dst=0, src2=0, ksteps2=4, ksteps=4, n=256, w=ptr, w2=ptr, bias=ptr)]) == -3
+    assert run([]) == -1
+
+
 def test_ops_refuse_cpu_tensors(built):
     from dhaug_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
