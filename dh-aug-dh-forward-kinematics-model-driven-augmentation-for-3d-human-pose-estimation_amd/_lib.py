@@ -50,6 +50,7 @@ SIGNATURES = {
     "dhaug_counter_add": [_vp, _i32, _vp],
     "dhaug_frame_diff": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     "dhaug_repack_weights": [_vp, _i32, _vp],
+    "dhaug_adam_repack_step": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _f32, _vp, _i32, _i64, _vp, _i32, _vp],
     "dhaug_gp_assemble": [_vp, _vp, _vp, _vp, _i64, _i64, _vp],
     "dhaug_gp_penalty": [_vp, _vp, _vp, _i64, _i64, _f32, _vp],
     "dhaug_critic_scalars": [_vp, _i64, _vp, _i64, _i64, _f32, _vp, _vp, _vp],
@@ -76,6 +77,11 @@ class WfragDesc(ctypes.Structure):
 class RepackDesc(ctypes.Structure):
     """struct dhaug_repack_desc (include/dhaug.h)"""
     _fields_ = [("W", _vp), ("nt", _vp), ("nn", _vp), ("N", _i32), ("K", _i32), ("Kp", _i32), ("Np", _i32)]
+
+
+class AdamDesc(ctypes.Structure):
+    """struct dhaug_adam_desc (include/dhaug.h)"""
+    _fields_ = [("off", _i64), ("len", _i64), ("nt", _vp), ("N", _i32), ("K", _i32), ("Kp", _i32), ("pad_", _i32), ("item0", _i64)]
 
 
 class TnLayer(ctypes.Structure):

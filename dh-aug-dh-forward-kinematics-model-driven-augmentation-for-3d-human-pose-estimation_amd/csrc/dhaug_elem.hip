@@ -239,6 +239,124 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
 }
 __global__ void counter_add_kernel(int* p, int v) { *p += v; }
 
+// The optimizer step of a whole network as TWO streaming launches (before: counter_add + adam_dev + repack_nt + repack_nn, the
+// copies re-reading every fp32 parameter twice, in 128-byte pieces):
+//   adam_nt_kernel   count, Adam, and the bf16 copy nt (N, Kp) of every weight written from the updated values while they are in
+//                    registers.  nt has W's row order, so the launch walks nt's index space in 4 096-element pieces -- every
+//                    access of a wave is one contiguous run (element e of nt = W[e / Kp][e % Kp], zero for e % Kp >= K);
+//                    everything that is not a weight (biases) in 4 096-element pieces of the flat vector.
+//   nn_from_nt_kernel  nn (K, Np) = nt^T through 64 x 64 LDS tiles: reads 2 bytes per parameter instead of 4.
+// (A single launch that also transposed -- 64 x 64 tiles of W, Adam on the tile, both copies from LDS -- was written first:
+// bit-identical, and 450 us against 275 for the four launches on the 25 M parameters of a DenseDim-1000 motion critic: reading
+// four fp32 arrays in 256-byte row pieces ran at 1.4 TB/s.)
+// The step count: adam_nt_kernel reads *state and uses *state + 1; the launch behind it (nn_from_nt_kernel, or the counter kernel
+// for a network without weights) stores the new count -- stream order is the synchronisation.  (A "last workgroup out" ticket
+// counter was measured first: 8 192 returning atomics on ONE address execute one after the other at the memory side, ~65 ns
+// each -- the launch took 540 us for 140 us of traffic.)
+__global__ __launch_bounds__(256) void adam_nt_kernel(float* __restrict__ P, const float* __restrict__ G, float* __restrict__ Mo,
+                                                      float* __restrict__ Vo, float lr, float b1, float b2, float eps,
+                                                      const int* __restrict__ state, float gscale,
+                                                      const dhaug_adam_desc* __restrict__ descs, int ndesc, long long nitems) {
+    const int tid = threadIdx.x;
+    const int step = state[0] + 1;
+    __shared__ float s_bc[2];                                   // the bias corrections: double-precision pow, once per workgroup
+    if (tid == 0) {
+        s_bc[0] = (float)(1.0 - pow((double)b1, (double)step));
+        s_bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)step));
+    }
+    __syncthreads();
+    const float bc1 = s_bc[0], bc2_sqrt = s_bc[1];
+    auto adam = [&](float pi, float graw, float mo, float vo, float& mi, float& vi) -> float {   // (adam_dev_kernel's arithmetic,
+        const float gi = graw * gscale;                                                          //  expression for expression)
+        mi = mo + (gi - mo) * (1.0f - b1);
+        vi = vo * b2 + gi * gi * (1.0f - b2);
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        return pi - (lr / bc1) * (mi / denom);
+    };
+    for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
+        int lo = 0, hi = ndesc - 1;                                           // the last descriptor with item0 <= item
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (descs[mid].item0 <= item) lo = mid; else hi = mid - 1;
+        }
+        const dhaug_adam_desc d = descs[lo];
+        const long long e0 = (item - d.item0) * 4096;
+        const bool mat = d.N != 0;
+        const long long total = mat ? (long long)d.N * d.Kp : d.len;
+        // (a pointer read from a descriptor is a generic one: stores through it are FLAT instructions, and the compiler drains
+        // the memory counter around every one of them -- as a global pointer the copy's stores travel with the others)
+        typedef uint32_t __attribute__((address_space(1))) * GlobalU32;
+        const GlobalU32 nt32 = (GlobalU32)(uintptr_t)d.nt;
+        const unsigned kp = mat ? (unsigned)d.Kp : 1u;
+        // sixteen elements per thread, four at a time: their sixteen loads are requested before the first value is used
+        // (unconditional, from a clamped index: a load behind a branch is waited for right there)
+#pragma unroll 1
+        for (int b4 = 0; b4 < 4; ++b4) {
+            float pv[4], gv[4], mv[4], vv[4];
+            long long idx[4];
+            bool live[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long long e = e0 + (b4 * 4 + q) * 256 + tid;
+                long long i = e;                                              // index into the flat vectors, relative to d.off
+                live[q] = e < total;
+                if (mat) {
+                    const unsigned r = (unsigned)(e < total ? e : 0) / kp, c = (unsigned)(e < total ? e : 0) - r * kp;
+                    live[q] = live[q] && c < (unsigned)d.K;
+                    i = (long long)r * d.K + c;
+                }
+                idx[q] = d.off + (live[q] ? i : 0);
+                pv[q] = P[idx[q]]; gv[q] = G[idx[q]]; mv[q] = Mo[idx[q]]; vv[q] = Vo[idx[q]];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long long e = e0 + (b4 * 4 + q) * 256 + tid;
+                float a = 0.0f;
+                if (live[q]) {
+                    float mi, vi;
+                    a = adam(pv[q], gv[q], mv[q], vv[q], mi, vi);
+                    Mo[idx[q]] = mi; Vo[idx[q]] = vi; P[idx[q]] = a;
+                }
+                if (mat) {                                                    // (wave-uniform) even lanes store their pair: e is even there
+                    const unsigned h = dhaug_f32_to_bf16(a);
+                    const unsigned hn = (unsigned)__shfl_xor((int)h, 1);
+                    if (!(tid & 1) && e < total) nt32[e >> 1] = h | (hn << 16);
+                }
+            }
+        }
+    }
+}
+
+// nn (K, Np) = nt^T (nt: (N, Kp) bf16), zero for columns >= N; blockIdx.y = weight.  One thread advances the step count.
+__global__ __launch_bounds__(256) void nn_from_nt_kernel(const dhaug_repack_desc* __restrict__ descs, int* __restrict__ state) {
+    __shared__ uint16_t t[64][66];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *state += 1;
+    const dhaug_repack_desc d = descs[blockIdx.y];
+    typedef uint32_t __attribute__((address_space(1))) * GlobalU32;          // (global, not generic: see adam_nt_kernel)
+    const GlobalU32 nt32 = (GlobalU32)(uintptr_t)d.nt, nn32 = (GlobalU32)(uintptr_t)d.nn;
+    const int tid = threadIdx.x;
+    const int tiles_r = (d.Np + 63) >> 6, tiles_c = (d.K + 63) >> 6;
+    for (int tile = blockIdx.x; tile < tiles_r * tiles_c; tile += gridDim.x) {
+        const int r0 = (tile / tiles_c) * 64, c0 = (tile % tiles_c) * 64;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {                                // rows of nt, two columns per lane
+            const int rr = pass * 8 + (tid >> 5), c2 = 2 * (tid & 31);
+            const int r = r0 + rr, c = c0 + c2;
+            const uint32_t v = (r < d.N && c < d.Kp) ? nt32[((long long)r * d.Kp + c) >> 1] : 0u;
+            *reinterpret_cast<uint32_t*>(&t[rr][c2]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {                                // rows of nn = columns of nt, two per lane
+            const int cc = pass * 8 + (tid >> 5), rr = 2 * (tid & 31);
+            const int c = c0 + cc, r = r0 + rr;
+            if (c < d.K && r < d.Np)
+                nn32[((long long)c * d.Np + r) >> 1] = (uint32_t)t[rr][cc] | ((uint32_t)t[rr + 1][cc] << 16);
+        }
+        __syncthreads();
+    }
+}
+
 // rows [0,B) = real, [B,2B) = fake, [2B,3B) = alpha*real + (1-alpha)*fake: the batch one critic step scores
 // (R/models_Fk_GAN/model_fk_gan_train.py:186-198, R/models_Fk_GAN/Fk_discriminator.py:210-216)
 __global__ __launch_bounds__(256) void gp_assemble_kernel(const float* __restrict__ real, const float* __restrict__ fake,
@@ -531,6 +649,24 @@ int dhaug_adam_step_dev(float* param, const float* grad, float* exp_avg, float* 
     hipLaunchKernelGGL(adam_dev_kernel, dim3(grid1d(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, (long long)n, lr, beta1, beta2, eps, step_dev, grad_scale);
     return dhaug_launch_status();
+}
+
+int dhaug_adam_repack_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
+                           float eps, int* state, float grad_scale, const dhaug_adam_desc* descs_device, int ndesc, int64_t nitems,
+                           const dhaug_repack_desc* weights_device, int nweights, void* stream) {
+    DHAUG_CHECK(ndesc >= 0 && nitems >= 0 && nweights >= 0 && nweights <= 65535, DHAUG_EINVAL);
+    DHAUG_CHECK_PTR(state);
+    if (ndesc == 0 || nitems == 0) return dhaug_counter_add(state, 1, stream);      // nothing to update: the count still advances
+    DHAUG_CHECK_PTR(param); DHAUG_CHECK_PTR(grad); DHAUG_CHECK_PTR(exp_avg); DHAUG_CHECK_PTR(exp_avg_sq); DHAUG_CHECK_PTR(descs_device);
+    const unsigned grid = (unsigned)(nitems < 8192 ? nitems : 8192);
+    hipLaunchKernelGGL(adam_nt_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, lr, beta1,
+                       beta2, eps, state, grad_scale, descs_device, ndesc, (long long)nitems);
+    if (nweights > 0) {
+        DHAUG_CHECK_PTR(weights_device);
+        hipLaunchKernelGGL(nn_from_nt_kernel, dim3(64, (unsigned)nweights), dim3(256), 0, (hipStream_t)stream, weights_device, state);
+        return dhaug_launch_status();
+    }
+    return dhaug_counter_add(state, 1, stream);
 }
 
 int dhaug_repack_weights(const dhaug_repack_desc* descs_device, int nparams, void* stream) {

@@ -6,11 +6,18 @@ and .grad tensors are views into them), so that an optimizer step is
 With world_size > 1 (torch.distributed initialised, backend "nccl" = RCCL on ROCm, or "gloo" in the CPU tests)
 the all-reduce sums the replicas' gradients and the kernel scales by 1/world_size.  No activation, parameter or
 optimizer state crosses the fabric."""
+import os
+
 import torch
 import torch.distributed as dist
 
 from . import autograd_ops as A
 from . import ops
+
+
+# the optimizer step as two streaming launches (count + Adam + the weights' nt copies | nn = nt^T); DHAUG_NO_FUSED_ADAM=1: the four
+# launches they replace (kept for the A/B and the equality test)
+FUSED_STEP = os.environ.get("DHAUG_NO_FUSED_ADAM") is None
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -140,12 +147,23 @@ class FusedAdam(torch.optim.Optimizer):
 
     def _apply(self, ws):
         g = self.param_groups[0]
-        ops.adam_step_dev(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_dev, g["lr"],
-                          tuple(g["betas"]), g["eps"], 1.0 / ws)
         # the packed copies of THIS network's weights are stale (other networks keep theirs); the bf16 operand copies the
-        # training path reads are rebuilt right here, all layers in two launches
+        # training path reads are rebuilt right here
         for p in self._params:
             p._dhaug_epoch = getattr(p, "_dhaug_epoch", 0) + 1
+        if FUSED_STEP:
+            # count + Adam + the weights' nt copies in one streaming launch, nn = nt^T in a second (dhaug_adam_repack_step)
+            from . import _lib
+            arena, dev, views, adam_dev, ndesc, nitems = self._ensure_packs()
+            b = tuple(g["betas"])
+            _lib.call("dhaug_adam_repack_step", self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                      self.exp_avg_sq.data_ptr(), g["lr"], b[0], b[1], g["eps"], self.step_dev.data_ptr(), 1.0 / ws,
+                      adam_dev.data_ptr(), ndesc, nitems, dev.data_ptr(), len(views), ops._stream())
+            for p, nt, nn in views:
+                A.install_packed(p, nt, nn)
+            return
+        ops.adam_step_dev(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_dev, g["lr"],
+                          tuple(g["betas"]), g["eps"], 1.0 / ws)
         self._repack()
 
     def _ensure_packs(self):
@@ -168,12 +186,30 @@ class FusedAdam(torch.optim.Optimizer):
                 descs[i].N, descs[i].K, descs[i].Kp, descs[i].Np = N, K, Kp, Np
                 views.append((p, nt, nn))
             dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.flat_param.device)
-            self._packs = (arena, dev, views)
+            # the same weights, and everything between them, as the work list of the one-launch step (ascending item0)
+            by_ptr = {p.data_ptr(): (nt, nn) for p, nt, nn in views}
+            ad, item0, base = [], 0, self.flat_param.data_ptr()
+            for p in self._params:
+                e = _lib.AdamDesc()
+                e.off, e.len, e.item0 = (p.data_ptr() - base) // 4, p.numel(), item0
+                if p.data_ptr() in by_ptr and p.dim() == 2:
+                    nt, nn = by_ptr[p.data_ptr()]
+                    e.N, e.K, e.Kp = p.shape[0], p.shape[1], c16(p.shape[1])
+                    e.nt = nt.data_ptr()
+                    item0 += (e.N * e.Kp + 4095) // 4096
+                else:
+                    e.N = e.K = e.Kp = 0
+                    e.nt = None
+                    item0 += (p.numel() + 4095) // 4096
+                ad.append(e)
+            arr = (_lib.AdamDesc * max(1, len(ad)))(*ad)
+            adam_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.flat_param.device)
+            self._packs = (arena, dev, views, adam_dev, len(ad), item0)
         return self._packs
 
     def _repack(self):
         from . import _lib
-        arena, dev, views = self._ensure_packs()
+        arena, dev, views = self._ensure_packs()[:3]
         if views:
             _lib.call("dhaug_repack_weights", dev.data_ptr(), len(views), ops._stream())
             for p, nt, nn in views:

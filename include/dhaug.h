@@ -469,6 +469,24 @@ typedef struct dhaug_repack_desc {
 } dhaug_repack_desc;
 int dhaug_repack_weights(const dhaug_repack_desc* descs_device, int nparams, void* stream);
 
+/* The optimizer step of a whole network as two streaming launches (replaces dhaug_counter_add + dhaug_adam_step_dev +
+ * dhaug_repack_weights; same arithmetic, torch.optim.Adam.step at R/models_Fk_GAN/model_fk_gan_train.py:218,470): Adam on the flat
+ * vectors with the bf16 copy nt of every weight written from the updated values, then nn = nt^T.
+ * descs_device (device memory, ndesc entries, ascending item0, together covering every element of the flat vectors exactly once):
+ * a weight W (N, K) at element offset `off` with its copy nt (N, Kp) as in dhaug_repack_desc, items = ceil(N * Kp / 4096); or
+ * N = 0: `len` plain elements at `off`, items = ceil(len / 4096).  nitems = the sum.  weights_device: the dhaug_repack_desc of the
+ * same weights (nweights of them), for the transposed copies.  state: the step count in device memory; the call uses count + 1
+ * for the bias corrections and leaves count + 1 there -- a captured hipGraph replays it. */
+typedef struct dhaug_adam_desc {
+    long long off, len;
+    void* nt;
+    int N, K, Kp, pad_;
+    long long item0;
+} dhaug_adam_desc;
+int dhaug_adam_repack_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
+                           float eps, int* state, float grad_scale, const dhaug_adam_desc* descs_device, int ndesc, int64_t nitems,
+                           const dhaug_repack_desc* weights_device, int nweights, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * WGAN-GP critic step arithmetic (R/models_Fk_GAN/Fk_discriminator.py:205-231, model_fk_gan_train.py:186-221)
  * ---------------------------------------------------------------------------------------------------- */

@@ -435,6 +435,55 @@ def test_colsum_actbwd_adam(ops):
     assert maxabs(pg, pr.detach()) <= 2e-7
 
 
+def test_two_launch_optimizer_step_equals_the_four_launches(ops):
+    """dhaug_adam_repack_step (count + Adam + the nt copies of every weight in one streaming launch, nn = nt^T in a second) against
+    dhaug_counter_add + dhaug_adam_step_dev + dhaug_repack_weights on a network of ragged shapes: parameters, moments, packed
+    copies (pad included) and the device step count bit for bit over several steps, and torch.optim.Adam within rounding"""
+    from dhaug_amd import optim
+
+    def build():
+        torch.manual_seed(11)
+        return torch.nn.Sequential(torch.nn.Linear(225, 100), torch.nn.Linear(100, 257), torch.nn.Linear(257, 64),
+                                   torch.nn.Linear(64, 1), torch.nn.Linear(1000, 130)).cuda()
+    nets = [build(), build(), build()]
+    ref = torch.optim.Adam(nets[2].parameters(), lr=1e-4, betas=(0.5, 0.9))
+    opts = []
+    for fused, net in ((True, nets[0]), (False, nets[1])):
+        old = optim.FUSED_STEP
+        optim.FUSED_STEP = fused
+        try:
+            opts.append(optim.FusedAdam(net.parameters(), lr=1e-4, betas=(0.5, 0.9)))
+        finally:
+            optim.FUSED_STEP = old
+    gen = torch.Generator().manual_seed(12)
+    for step in range(1, 5):
+        grads = [torch.randn(p.shape, generator=gen).cuda() * 0.1 for p in nets[0].parameters()]
+        for fused, opt, net in ((True, opts[0], nets[0]), (False, opts[1], nets[1])):
+            opt.zero_grad()
+            for p, g in zip(net.parameters(), grads):
+                p.grad.copy_(g)
+            old = optim.FUSED_STEP
+            optim.FUSED_STEP = fused
+            try:
+                opt.step()
+            finally:
+                optim.FUSED_STEP = old
+        for p, g in zip(nets[2].parameters(), grads):
+            p.grad = g.clone()
+        ref.step()
+        a, b = opts
+        assert int(a.step_dev.item()) == step == int(b.step_dev.item())
+        for name in ("flat_param", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (step, name)
+        for (_, nta, nna), (_, ntb, nnb) in zip(a._packs[2], b._packs[2]):   # the copies, their zero pads included
+            assert torch.equal(nta, ntb) and torch.equal(nna, nnb), step
+        for (pa, nta, nna), pr in zip(a._packs[2], [p for p in nets[2].parameters() if p.dim() == 2]):
+            N, K = pa.shape
+            assert maxabs(pa, pr.detach()) <= 3e-7
+            assert torch.equal(nta[:, :K], pa.detach().to(torch.bfloat16)) and nta[:, K:].abs().sum() == 0
+            assert torch.equal(nna[:, :N], pa.detach().t().to(torch.bfloat16)) and nna[:, N:].abs().sum() == 0
+
+
 def test_random_bl_aug_golden(ops, golden):
     """next row N3: bone-length swap + per-sample projection against the reference's own output"""
     from dhaug_amd.function_aug.dataloader_update import random_bl_aug, BL_TEMPLATES
