@@ -691,6 +691,15 @@ def main():
                 cpu = cpu_baseline(a.workload, D, sd(G), sd(D3), sd(D2), quat, trans, cam9, Bs=B)
                 out["cpu_baseline_faithful"] = cpu_baseline(a.workload, D, sd(G), sd(D3), sd(D2), quat, trans, cam9, faithful=True,
                                                             Bs=B, seconds=10.0)
+                # the same pair at the reference's own CPU-runnable batch (BASELINE.json configs[0]: 1 024): there the op-by-op FK
+                # is dispatch-bound (7 035 small ops per call), so the ratio of the two shows what op fusion alone buys on the
+                # CPU -- at 65 536 both are memory-bound and the ratio drowns in the noise
+                small = {}
+                for key, faithful in (("batched", False), ("faithful", True)):
+                    r = cpu_baseline(a.workload, D, sd(G), sd(D3), sd(D2), quat, trans, cam9, faithful=faithful, Bs=1024, seconds=4.0)
+                    small[key] = {k: r[k] for k in ("value", "unit", "cores", "sample")}
+                small["fusion_ratio"] = small["batched"]["value"] / small["faithful"]["value"]
+                out["cpu_baseline_b1024"] = small
         out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if world > 1:

@@ -98,7 +98,7 @@ class Block2(ctypes.Structure):
 
 BLOCK2_MAX = 3
 SIGNATURES["dhaug_gemm_block2_stack_bf16"] = [_vp, _i64, ctypes.POINTER(Block2), _i32, _i32, _f32, _i64, _vp]
-TN_GROUP_MAX = 44
+TN_GROUP_MAX = 42
 TN_GROUP_WORKSPACE_FLOATS = 256 * (256 * 256 + 256)
 SIGNATURES["dhaug_gemm_tn_group_bf16"] = [ctypes.POINTER(TnLayer), _i32, _vp, _vp]
 SIGNATURES["dhaug_gemm_tn_group_bf16_phase"] = [ctypes.POINTER(TnLayer), _i32, _vp, _i32, _vp]

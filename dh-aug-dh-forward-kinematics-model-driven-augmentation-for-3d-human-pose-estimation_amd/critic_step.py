@@ -194,15 +194,11 @@ class _Math:
             M = gb.shape[0]
             cr = M if colsum_rows is None else colsum_rows
             if TN_GROUP and ops.tn_group_ok(M, min(N, 256), min(K, 256), cr):
-                # joins the step's grouped launch, as 256 x 256 blocks of the gradient (a DenseDim-1000 layer is 4 x 4 of them;
-                # the bias sums ride with the first column block of every row block)
-                for n0 in range(0, N, 256):
-                    nn = min(256, N - n0)
-                    for k0 in range(0, K, 256):
-                        kk = min(256, K - k0)
-                        cs = bslot[n0:] if (bslot is not None and not narrow and k0 == 0) else None
-                        self.tn.append((gb[:, n0:], xb[:, k0:], nn, kk, wslot[n0:, k0:], cs, cr if cs is not None else 0, True, M,
-                                        None, None))
+                # joins the step's grouped launch (a DenseDim-1000 layer is 4 x 4 blocks of 256 x 256: ops.gemm_tn_group hands it
+                # over whole where the group has blocks enough to fill the card, block by block otherwise; the bias sums ride
+                # with the first column block of every row block)
+                cs = bslot if (bslot is not None and not narrow) else None
+                self.tn.append((gb, xb, N, K, wslot, cs, cr if cs is not None else 0, True, M, None, None))
             else:
                 ops.gemm_tn(gb, xb, N, K, colsum=bslot if (bslot is not None and not narrow) else None, out=wslot, accumulate=True,
                             colsum_rows=colsum_rows)

@@ -21,6 +21,7 @@
 //     16 zero bytes (every lane of every copy stays active: the vmcnt arithmetic is the same in every wave);
 //   * fragments leave the row-major stage through the hardware transpose read (ds_read_b64_tr_b16).
 #include <cstdlib>
+#include <algorithm>
 #include "dhaug_common.h"
 
 namespace {
@@ -44,13 +45,17 @@ struct TnLayer {
     long long lda, ldb, ldc;
     long long cs_rows;              // column sums over rows [0, cs_rows): a multiple of 32
     int nst;                        // 32-row stages of the layer (M / 32)
-    int n1, n2;
-    int wg0, nwg;                   // workgroups [wg0, wg0 + nwg) work on this layer
+    int n1, n2;                     // whole layer: a layer wider than 256 is a grid of 256 x 256 blocks, (n2 + 255) / 256 per row
+    int wg0, nwg;                   // workgroups [wg0, wg0 + nwg) work on this layer: `split` per block, block-major
     int accumulate;
+    int split;                      // 1: the block's one workgroup adds its result into C / colsum itself (no partial, no sum)
+    int ws0;                        // split > 1: the layer's partial results start at workspace slot ws0
 };
 struct TnGroup {
     int nlayers;
-    int abl;                        // development: 1 no partial stores, 2 no fragment reads / MFMAs, 4 no copies (timing only)
+    int abl;                        // development: 1 no partial stores, 2 no fragment reads / MFMAs, 4 no copies (timing only);
+                                    // bit 8 (set by the host for the two-phase form): a block's only workgroup writes a partial
+                                    // result too -- in that form only the summing launch may touch the gradient slots
     float* ws;
     TnLayer L[T2_MAX_LAYERS];
 };
@@ -104,15 +109,18 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(TnGroup grp_by_va
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w1 = wave >> 1, w2 = wave & 1;
-    const int j = (int)blockIdx.x - L->wg0, nwg = L->nwg;
-    if (j >= nwg) return;
-    const int s0 = (int)((long long)L->nst * j / nwg), s1 = (int)((long long)L->nst * (j + 1) / nwg);
-    const int nst = s1 - s0;                                      // >= 1: the host gives a layer at most one workgroup per stage
+    const int jw = (int)blockIdx.x - L->wg0;
+    if (jw >= L->nwg) return;
+    // the workgroup's 256 x 256 block of the layer, and its slice of the batch
+    const int split = L->split, blk = jw / split, j = jw - blk * split;
+    const int nbj = (L->n2 + 255) >> 8, bi = blk / nbj, bj = blk - bi * nbj;
+    const int s0 = (int)((long long)L->nst * j / split), s1 = (int)((long long)L->nst * (j + 1) / split);
+    const int nst = s1 - s0;                                      // >= 1: the host gives a block at most one workgroup per stage
     const long long ms = (long long)s0 * T2_ROWS;
-    const uint16_t* A = L->A;
-    const uint16_t* B = L->B;
+    const uint16_t* A = L->A + 256 * bi;
+    const uint16_t* B = L->B + 256 * bj;
     const long long lda = L->lda, ldb = L->ldb, cs_rows = L->cs_rows;
-    const int n1 = L->n1, n2 = L->n2;
+    const int n1 = L->n1 - 256 * bi < 256 ? L->n1 - 256 * bi : 256, n2 = L->n2 - 256 * bj < 256 ? L->n2 - 256 * bj : 256;
     const int ca = (n1 + 7) >> 3, cb = (n2 + 7) >> 3;             // live 16-byte chunks per row
     const t2_lds_ptr lds0 = (t2_lds_ptr)tsm;
 
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(TnGroup grp_by_va
         }
     }
     const bool live = 64 * w1 < n1 && 128 * w2 < n2 && !(abl & 2);       // this wave's quadrant holds part of the result
-    const bool do_cs = L->colsum != nullptr && cs_rows > 0 && w2 == 0 && live;
+    const bool do_cs = L->colsum != nullptr && bj == 0 && cs_rows > 0 && w2 == 0 && live;
     const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
     const int grp = lane >> 4;                                    // 16-lane group: columns 16 (grp & 1), k half grp >> 1
 #pragma unroll
@@ -173,9 +181,39 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(TnGroup grp_by_va
         }
     }
     if (!live || (abl & 1)) return;
-    // this workgroup's partial result: plain stores (D[n1][n2]: the lane owns column n2 = lane & 31 of its tile, rows
-    // n1 = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)); only the tiles that hold part of the N1 x N2 result
-    float* part = ws + (long long)blockIdx.x * T2_WS_STRIDE;
+    // (D[n1][n2]: the lane owns column n2 = lane & 31 of its tile, rows n1 = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+    if (split == 1 && !(abl & 8)) {
+        // the block's only workgroup: its result IS the block's -- added into (or stored to) the gradient slot right here,
+        // 128-byte row pieces; no partial result, nothing for the summing launch to do
+        float* C = L->C + (long long)256 * bi * L->ldc + 256 * bj;
+        const long long ldc = L->ldc;
+        const int accm = L->accumulate;
+        float* csum = (L->colsum != nullptr && bj == 0) ? L->colsum + 256 * bi : nullptr;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (64 * w1 + 32 * t >= n1) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int r1 = 64 * w1 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (r1 >= n1) continue;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c1 = 128 * w2 + 32 * u + (lane & 31);
+                    if (c1 < n2) {
+                        float* d = C + r1 * ldc + c1;
+                        *d = accm ? *d + acc[t][u][r] : acc[t][u][r];
+                    }
+                }
+                if (csum != nullptr && w2 == 0 && (lane & 31) == 0) {
+                    const float sv = cs_rows > 0 ? accs[t][r] : 0.0f;
+                    csum[r1] = accm ? csum[r1] + sv : sv;
+                }
+            }
+        }
+        return;
+    }
+    // this workgroup's partial result: plain stores; only the tiles that hold part of the N1 x N2 result
+    float* part = ws + (long long)(L->ws0 + jw) * T2_WS_STRIDE;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         if (64 * w1 + 32 * t >= n1) continue;
@@ -198,8 +236,10 @@ __global__ __launch_bounds__(256) void tn_group_reduce_kernel(TnGroup g) {
     float* ws = *(float* const __attribute__((address_space(4)))*)(ka + __builtin_offsetof(TnGroup, ws));
     LayerPtr L = (LayerPtr)(ka + __builtin_offsetof(TnGroup, L)) + blockIdx.y;
     (void)g;
-    const int n1 = L->n1, n2 = L->n2, nwg = L->nwg, acc = L->accumulate;
-    const float* p0 = ws + (long long)L->wg0 * T2_WS_STRIDE;
+    const int abl = *(const int __attribute__((address_space(4)))*)(ka + __builtin_offsetof(TnGroup, abl));
+    if (L->split == 1 && !(abl & 8)) return;                      // (its workgroups wrote the gradient slot themselves)
+    const int n1 = L->n1, n2 = L->n2, nwg = L->nwg, acc = L->accumulate;   // (split > 1: a single block, n1, n2 <= 256)
+    const float* p0 = ws + (long long)L->ws0 * T2_WS_STRIDE;
     float* C = L->C;
     const long long ldc = L->ldc;
     // one element per thread, eight partials per trip: the partials are read once, from HBM / MALL -- a dependent chain of
@@ -234,6 +274,7 @@ __global__ __launch_bounds__(256) void tn_group_reduce_kernel(TnGroup g) {
 extern "C" {
 
 static_assert(DHAUG_TN_GROUP_WORKSPACE_FLOATS == (long long)T2_MAX_WG * T2_WS_STRIDE, "workspace size");
+static_assert(sizeof(TnGroup) <= 4096, "the group travels as a kernel argument");
 
 /* see include/dhaug.h */
 int dhaug_gemm_tn_group_bf16_phase(const dhaug_tn_layer* layers, int n, float* workspace, int phase, void* stream);
@@ -253,12 +294,14 @@ int dhaug_gemm_tn_group_bf16_phase(const dhaug_tn_layer* layers, int n, float* w
     g.abl = getenv("DHAUG_TN256_ABL") ? atoi(getenv("DHAUG_TN256_ABL")) : 0;
     g.ws = workspace;
     double weight[T2_MAX_LAYERS], total = 0.0, bytes2 = 0.0;
-    long long stages = 0;
+    long long stages = 0, blocks = 0;
+    int nblk[T2_MAX_LAYERS];
+    bool wide = false;
     static const int floor_cols = getenv("DHAUG_TN_FLOOR") ? atoi(getenv("DHAUG_TN_FLOOR")) : 448;
     for (int i = 0; i < n; ++i) {
         const dhaug_tn_layer& s = layers[i];
         DHAUG_CHECK(s.M >= T2_ROWS && s.M % T2_ROWS == 0 && s.M / T2_ROWS < (1LL << 30), DHAUG_EUNSUPPORTED);
-        DHAUG_CHECK(s.N1 >= 1 && s.N1 <= 256 && s.N2 >= 1 && s.N2 <= 256, DHAUG_EUNSUPPORTED);
+        DHAUG_CHECK(s.N1 >= 1 && s.N1 <= 4096 && s.N2 >= 1 && s.N2 <= 4096, DHAUG_EUNSUPPORTED);
         DHAUG_CHECK(s.colsum_rows >= 0 && s.colsum_rows <= s.M && s.colsum_rows % T2_ROWS == 0, DHAUG_EUNSUPPORTED);
         DHAUG_CHECK_PTR(s.A); DHAUG_CHECK_PTR(s.B); DHAUG_CHECK_PTR(s.C);
         DHAUG_CHECK(s.ldc >= s.N2, DHAUG_EINVAL);
@@ -269,8 +312,12 @@ int dhaug_gemm_tn_group_bf16_phase(const dhaug_tn_layer* layers, int n, float* w
         L.A = s.A; L.B = s.B; L.C = s.C; L.colsum = s.colsum_a;
         L.lda = s.lda; L.ldb = s.ldb; L.ldc = s.ldc; L.cs_rows = s.colsum_a != nullptr ? s.colsum_rows : 0;
         L.nst = (int)(s.M / T2_ROWS); L.n1 = s.N1; L.n2 = s.N2; L.accumulate = s.accumulate;
-        const int cols = ((s.N1 + 7) & ~7) + ((s.N2 + 7) & ~7);                   // operand bytes / 2 per row
-        bytes2 += (double)s.M * cols;
+        nblk[i] = ((s.N1 + 255) / 256) * ((s.N2 + 255) / 256);
+        wide = wide || nblk[i] > 1;
+        blocks += nblk[i];
+        // (per 256 x 256 block of the layer)
+        const int cols = ((std::min(s.N1, 256) + 7) & ~7) + ((std::min(s.N2, 256) + 7) & ~7);   // operand bytes / 2 per row
+        bytes2 += (double)s.M * cols * nblk[i];
         // what a row COSTS its workgroup: its bytes at the workgroup's share of HBM (13 B/clk), but never less than the
         // stage's fixed work -- four LDS-DMA instructions per wave fill 32 KB at ~32 B/clk whatever the layer's width, plus
         // the barrier.  Measured (tools/time_tn_group.py, the 3D critic's 19 contractions, 3.16 GB): floor 0 (bytes alone) 1 027 us, 224 693, 320 649, 448 583 = 5.4 TB/s, 512+ (rows alone) 605.  Dealt by bytes alone, the few workgroups of
@@ -278,38 +325,51 @@ int dhaug_gemm_tn_group_bf16_phase(const dhaug_tn_layer* layers, int n, float* w
         // pole: 704 us of stage floor against 356 us for a 256 x 256 layer's workgroups.
         weight[i] = (double)s.M * (cols > floor_cols ? cols : floor_cols);
         total += weight[i];
-        stages += L.nst;
+        stages += (long long)L.nst * nblk[i];
     }
     // deal the workgroups (one per CU) out in proportion to that cost: at least one, at most one per stage
     // (a short batch leaves little to read per layer: every workgroup costs a 256 KB partial result to write and to sum, so
     // the group gets about one workgroup per 768 KB of operands, at least one per layer, at most one per CU)
-    long long want = (long long)(bytes2 * 2.0 / (768.0 * 1024.0)) + 1;
+    static const double per_wg = getenv("DHAUG_TN_BYTES_PER_WG") ? atof(getenv("DHAUG_TN_BYTES_PER_WG")) : 768.0 * 1024.0;
+    long long want = (long long)(bytes2 * 2.0 / per_wg) + 1;
     if (want < n) want = n;
     int cap = layers[0].max_workgroups > 0 && layers[0].max_workgroups < T2_MAX_WG ? layers[0].max_workgroups : T2_MAX_WG;
     if ((int)dhaug_persistent_grid(T2_MAX_WG) < cap) cap = (int)dhaug_persistent_grid(T2_MAX_WG);
     if (want > cap) want = cap;
     const int budget = (int)(stages < want ? stages : want);
-    // every layer one workgroup, then the next one always to the layer whose slowest workgroup finishes last: its time is
-    // (stages per workgroup, rounded UP) x (cost of a stage) -- the rounding matters, a layer's 6 144 stages over 17 or 18
-    // workgroups differ by a whole 6 %
-    int used = 0;
+    // every block of every layer one workgroup (`split` = 1: it adds its result into the gradient slot itself); then, while
+    // workgroups are left, one more PER BLOCK to the layer whose slowest workgroup finishes last: its time is (stages per
+    // workgroup, rounded UP) x (cost of a stage) -- the rounding matters, a layer's 6 144 stages over 17 or 18 workgroups differ
+    // by a whole 6 %.  A group with more blocks than workgroups (the DenseDim-1000 layers of a video step: 16 blocks each) is
+    // launched as it is: no block is split, nothing is written twice, the launch runs in waves of one workgroup per CU.
+    long long used = 0;
     double stage_cost[T2_MAX_LAYERS];
     for (int i = 0; i < n; ++i) {
-        g.L[i].nwg = 1;
+        g.L[i].split = 1;
         stage_cost[i] = weight[i] / g.L[i].nst;
-        ++used;
+        used += nblk[i];
     }
-    DHAUG_CHECK(used <= T2_MAX_WG, DHAUG_EUNSUPPORTED);
-    auto finish = [&](int i) { return (double)((g.L[i].nst + g.L[i].nwg - 1) / g.L[i].nwg) * stage_cost[i]; };
+    DHAUG_CHECK(used <= 65535, DHAUG_EUNSUPPORTED);
+    auto finish = [&](int i) { return (double)((g.L[i].nst + g.L[i].split - 1) / g.L[i].split) * stage_cost[i]; };
     while (used < budget) {
         int b = -1;
         for (int i = 0; i < n; ++i)
-            if (g.L[i].nwg < g.L[i].nst && (b < 0 || finish(i) > finish(b))) b = i;
+            if (nblk[i] == 1 && g.L[i].split < g.L[i].nst && used + 1 <= budget && (b < 0 || finish(i) > finish(b))) b = i;
         if (b < 0) break;
-        ++g.L[b].nwg; ++used;
+        ++g.L[b].split; used += nblk[b];
     }
-    int wg = 0;
-    for (int i = 0; i < n; ++i) { g.L[i].wg0 = wg; wg += g.L[i].nwg; }
+    // (a wide layer that is split keeps one summing pass per BLOCK: not built -- its callers hand over wide layers only where
+    // the group has blocks enough without splitting; a long batch of few wide layers goes block by block)
+    int wg = 0, slot = 0;
+    for (int i = 0; i < n; ++i) {
+        DHAUG_CHECK(nblk[i] == 1 || phase == 0, DHAUG_EUNSUPPORTED);      // (a wide layer's blocks have no summing pass)
+        g.L[i].wg0 = wg; g.L[i].nwg = nblk[i] * g.L[i].split; wg += g.L[i].nwg;
+        g.L[i].ws0 = slot;
+        if (g.L[i].split > 1 || phase != 0) slot += g.L[i].nwg;
+    }
+    if (phase != 0) g.abl |= 8;
+    DHAUG_CHECK(slot <= T2_MAX_WG, DHAUG_EUNSUPPORTED);
+    (void)wide; (void)blocks;
     hipStream_t s = (hipStream_t)stream;
     static bool configured = false;
     if (!configured) {

@@ -416,12 +416,33 @@ def tn_group_ok(M, N1, N2, colsum_rows):
     return M >= 1024 and M % 32 == 0 and colsum_rows % 32 == 0 and 1 <= N1 <= 256 and 1 <= N2 <= 256
 
 
+TN_WIDE_MIN_BLOCKS = int(os.environ.get("DHAUG_TN_WIDE_MIN_BLOCKS", "128"))
+
+
 def gemm_tn_group(items, max_workgroups=0, phase=0, workspace=None):
     """items: [(A, B, N1, N2, out, colsum | None, colsum_rows, accumulate, M | None, lda | None, ldb | None)] -- the weight
     gradients C_i (+)= A_i^T B_i of several layers in one launch (+ one that sums the partial results).
     max_workgroups: leave CUs to kernels running beside this launch (0: one workgroup per CU).
     phase 1: the contractions only (partial results into `workspace`); phase 2: only their sums into the outputs (same items,
     same workspace; one chunk of at most TN_GROUP_MAX items); 0: both."""
+    # layers wider than 256: whole ("wide": one workgroup per 256 x 256 block, which adds into the gradient slot itself) where the
+    # chunk they travel in has blocks enough to fill the card without splitting any over the batch; as 256 x 256 blocks, each an
+    # item of its own, otherwise (a long batch of few wide layers: the blocks are split over the batch and summed)
+    nblk = lambda it: ((it[2] + 255) // 256) * ((it[3] + 255) // 256)
+    if any(nblk(it) > 1 for it in items):
+        flat = []
+        for i0 in range(0, len(items), _lib.TN_GROUP_MAX):
+            chunk = items[i0:i0 + _lib.TN_GROUP_MAX]
+            if phase == 0 and sum(nblk(it) for it in chunk) >= TN_WIDE_MIN_BLOCKS:
+                flat.extend(chunk)
+                continue
+            for (A, B, N1, N2, out, cs, cr, accumulate, M, la, lb) in chunk:
+                for n0 in range(0, N1, 256):
+                    for k0 in range(0, N2, 256):
+                        c = cs[n0:] if (cs is not None and k0 == 0) else None
+                        flat.append((A[:, n0:], B[:, k0:], min(256, N1 - n0), min(256, N2 - k0), out[n0:, k0:], c,
+                                     cr if c is not None else 0, accumulate, A.shape[0] if M is None else M, la, lb))
+        items = flat
     assert phase == 0 or (len(items) <= _lib.TN_GROUP_MAX and workspace is not None)
     for i0 in range(0, len(items), _lib.TN_GROUP_MAX):
         chunk = items[i0:i0 + _lib.TN_GROUP_MAX]

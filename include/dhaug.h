@@ -277,15 +277,17 @@ int dhaug_gemm_tn_bf16_rows(const uint16_t* A, int64_t lda, const uint16_t* B, i
 
 /* The weight / bias gradients of ALL layers of a critic step in one launch (+ one small launch that sums the partial
  * results): layer i computes C[N1,N2] (+)= A[M,N1]^T * B[M,N2] and colsum_a[N1] (+)= column sums of A over rows
- * [0, colsum_rows), with N1, N2 <= 256, M and colsum_rows multiples of 32, operands bf16 with rows readable up to ceil8(N)
- * columns.  One workgroup per CU owns a layer's WHOLE output over its slice of the batch (every operand byte crosses
+ * [0, colsum_rows), M and colsum_rows multiples of 32, operands bf16 with rows readable up to ceil8(N) columns (of every
+ * 256-column block).  N1, N2 <= 256, or "wide" (up to 4096: a grid of 256 x 256 blocks, one workgroup each, phase 0 only -- for
+ * groups that have blocks enough to fill the card without splitting any over the batch: the DenseDim-1000 layers of a video step).
+ * A block that ends up with ONE workgroup adds its result into C / colsum_a itself (no partial result, no sum).  One workgroup per CU owns a layer's WHOLE output over its slice of the batch (every operand byte crosses
  * L2 -> LDS once; the 64 x 64-tile kernel behind dhaug_gemm_tn_bf16 re-reads each row four times); the workgroups are dealt
  * out to the layers by what their 32-row stages cost (operand bytes, with a floor for narrow layers), so a step leaves 256
  * partial results in total, not per layer.
  * `layers`: host array (read during the call).  `workspace`: DHAUG_TN_GROUP_WORKSPACE_FLOATS fp32 values owned by the
  * caller, any content (calls sharing it must be ordered on one stream).
  * Replaces the parameter-gradient half of loss.backward() in R/models_Fk_GAN/model_fk_gan_train.py:191-214. */
-#define DHAUG_TN_GROUP_MAX 44
+#define DHAUG_TN_GROUP_MAX 42
 #define DHAUG_TN_GROUP_WORKSPACE_FLOATS (256LL * (256 * 256 + 256))
 typedef struct dhaug_tn_layer {
     const uint16_t* A; int64_t lda;

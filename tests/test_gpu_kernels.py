@@ -392,6 +392,45 @@ def test_gemm_tn_group(ops):
             assert maxabs(cs, csr) <= 1e-4 * max(1.0, csr.abs().max().item()) + 1e-3, (N1, N2)
 
 
+def test_gemm_tn_group_wide_layers(ops, monkeypatch):
+    """layers wider than 256 handed over whole (a grid of 256 x 256 blocks, one workgroup each, adding into the gradient slot
+    itself): the DenseDim-1000 shapes of a video step -- 1000 x 1000, the 100 x 4000 merge layer, a 1000 x 135 input layer, a
+    classic 256-wide layer in the same group -- against a float64 product and against the block-by-block form"""
+    gen = torch.Generator().manual_seed(78)
+    M = 1536
+    c16 = lambda n: (n + 15) // 16 * 16
+    shapes = [(1000, 1000, 1024, True), (1000, 1000, 0, False), (100, 4000, 1024, True), (1000, 135, 1024, False),
+              (256, 256, 1024, True), (1000, 1000, 1536, True), (300, 700, 512, False), (1000, 1000, 1024, True)] + [(1000, 1000, 0, True)] * 3
+
+    def build():
+        g = torch.Generator().manual_seed(79)
+        items, refs = [], []
+        for (N1, N2, cr, acc) in shapes:
+            A = torch.zeros(M, c16(N1)); A[:, :N1] = torch.randn(M, N1, generator=g)
+            B = torch.zeros(M, c16(N2)); B[:, :N2] = torch.randn(M, N2, generator=g) * 0.5
+            A, B = _bf(A).cuda(), _bf(B).cuda()
+            out = torch.full((N1, N2), 2.0, device="cuda")
+            cs = torch.full((N1,), -1.0, device="cuda") if cr else None
+            items.append((A, B, N1, N2, out, cs, cr, acc, None, None, None))
+            ref = A[:, :N1].float().cpu().double().t() @ B[:, :N2].float().cpu().double()
+            csr = A[:cr, :N1].float().cpu().double().sum(0)
+            refs.append((ref + (2.0 if acc else 0.0), csr + (-1.0 if acc else 0.0)))
+        return items, refs
+    items, refs = build()
+    monkeypatch.setattr(ops, "TN_WIDE_MIN_BLOCKS", 1)
+    ops.gemm_tn_group(items)
+    for (A, B, N1, N2, out, cs, cr, acc, _, _, _), (ref, csr) in zip(items, refs):
+        assert maxabs(out, ref) <= 1e-4 * max(1.0, ref.abs().max().item()), (N1, N2)
+        if cs is not None:
+            assert maxabs(cs, csr) <= 1e-4 * max(1.0, csr.abs().max().item()) + 1e-3, (N1, N2)
+    blocks, _ = build()
+    monkeypatch.setattr(ops, "TN_WIDE_MIN_BLOCKS", 10 ** 9)
+    ops.gemm_tn_group(blocks)
+    for a, b in zip(items, blocks):                  # (the blocks are split over the batch there: another summation order)
+        assert maxabs(a[4], b[4]) <= 2e-6 * a[4].abs().max().item(), a[2:4]
+        assert a[5] is None or maxabs(a[5], b[5]) <= 2e-6 * max(1.0, a[5].abs().max().item()), a[2:4]
+
+
 def test_pack_kernels(ops):
     gen = torch.Generator().manual_seed(4)
     W = torch.randn(100, 30, generator=gen)
