@@ -55,14 +55,14 @@ constexpr int BK = 64;
 // its columns is loaded once, and the residual / mask values of RB rows are requested together before the first of them is
 // used.  (The first version re-loaded eight bias scalars and waited for its row's residual in every iteration: 16 dependent
 // memory round trips per thread for a 128 x 256 tile -- 36 us of the big-tile kernel's 87 us at 13 824 x 1000 x 1000.)
-template <int BM, int BN>
+template <int BM, int BN, int NT = 256>
 __device__ __forceinline__ void nt_store_tile(const GemmArgs& p, const float* sC, long long m0, long long n0, int tid) {
     constexpr int CS = BN + 4;
     constexpr int PPR = BN / 8;                                  // pieces per row
-    constexpr int RSTEP = 256 / PPR;                             // rows per step of the workgroup
+    constexpr int RSTEP = NT / PPR;                              // rows per step of the workgroup (NT threads)
     constexpr int NIT = BM / RSTEP;                              // rows per thread
     constexpr int RB = NIT >= 4 ? 4 : NIT;                       // rows whose global operands travel together
-    static_assert(256 % PPR == 0 && BM % RSTEP == 0 && NIT % RB == 0, "tile shape");
+    static_assert(NT % PPR == 0 && BM % RSTEP == 0 && NIT % RB == 0, "tile shape");
     const int pc = tid % PPR, r0 = tid / PPR;
     const long long n = n0 + pc * 8;
     const bool any_out = n < p.N || (p.cb != nullptr && n < p.npad);
@@ -489,6 +489,130 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_big_kernel(GemmArgs p) {
     }
     p_lds_barrier();
     nt_store_tile<G_BM, G_BN>(p, sC, m0, n0, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 256 x 256 tiles for the wide layers (DenseDim 1000) *(r4)*.  The 128 x 256 kernel above runs ONE wave per SIMD: every k-step
+// waits for its six fragment reads before its eight matrix instructions, and two 48 KB stages in flight feed it 48 KB per
+// ~1 us: measured 31 us per workgroup of 128 x 256 x 1000 = 0.22 of the CU's matrix peak.  Here eight waves (two per SIMD: one
+// wave's fragment reads run under the other's matrix instructions) own 128 x 64 each; a k-tile is 32 wide, so a stage is
+// 32 KB and FIVE fit: four in flight = 128 KB per CU; 128 flop per staged byte instead of 85.  Same stage mechanics (global ->
+// LDS without registers, exact vmcnt waits, LDS-only barriers); 64-byte stage rows, 16-byte chunk c of row r at position
+// c ^ ((r >> 2) & 3): the sixteen rows a quarter-wave reads cover all 64 banks.  The epilogue goes through the fp32 C image in
+// two passes of 128 rows (nt_store_tile: bias, residual, activation, mask, bf16 / fp32 stores -- coalesced).
+// *(measured, 13 824 x 1000 x 1000, 216 workgroups)* 48 us against 62 (576 TFLOP/s): the k loop 32 us -- the copies alone take 22
+// (1 MB per workgroup at 47 GB/s per CU = 10 TB/s of L2 -> LDS over the card: the LDS-DMA path's rate, not HBM's), the matrix
+// instructions alone 22 --, the epilogue 10, the launch 5.  A workgroup's time does not shrink with the batch: below ~160
+// workgroups the 128 x 256 kernel's smaller tiles win (4 608 rows: 31 us against 43), and grouping the four 1 536-row branch
+// layers of a motion critic into one launch of these tiles (96 workgroups, 45 us) buys nothing over four launches of 64 x 64 tiles
+// (13 us each) -- that launch form was written, measured and removed.
+// ---------------------------------------------------------------------------------------------------
+constexpr int W_BM = 256, W_BN = 256, W_BK = 32, W_NSTG = 5;
+constexpr int W_STG = (W_BM + W_BN) * W_BK * 2;                              // 32 768 bytes per stage
+constexpr int W_LDS = W_NSTG * W_STG;                                        // 163 840: all of the CU's LDS
+constexpr int W_CS = W_BN + 4;
+static_assert(128 * W_CS * 4 <= W_LDS, "C image");
+
+__global__ __launch_bounds__(512, 1) void gemm_nt_wide_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+    float* sC = reinterpret_cast<float*>(wsm);                  // [128][W_CS], reuses the staging buffers
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                    // 2 x 4 waves: rows [128 wm, +128), columns [64 wn, +64)
+    const long long ntn = (p.W + W_BN - 1) / W_BN;
+    const long long m0 = (long long)(blockIdx.x / ntn) * W_BM;
+    const long long n0 = (long long)(blockIdx.x % ntn) * W_BN;
+    const int nkt = (int)((p.K + W_BK - 1) / W_BK);
+    constexpr int NCP = 4;                                      // copies per lane and stage: rows 16 (8 i + wave) .. + 16 of the image
+    const uint16_t* pg[NCP];
+    int rowoff[NCP];
+#pragma unroll
+    for (int i = 0; i < NCP; ++i) {
+        const int row0 = (8 * i + wave) * 16, row = row0 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+        if (i < 2) {
+            const long long gm = m0 + row;
+            pg[i] = p.A + (gm < p.M ? gm : p.M - 1) * p.lda + c * 8;
+        } else {
+            const long long gn = n0 + row - W_BM;
+            pg[i] = p.B + (gn < p.N ? gn : p.N - 1) * p.ldb + c * 8;
+        }
+        rowoff[i] = row0 * (W_BK * 2);
+    }
+    auto copy_stage = [&](int kt) {
+        unsigned char* base = wsm + (kt % W_NSTG) * W_STG;
+        long long k0 = (long long)kt * W_BK;
+        if (k0 + W_BK > p.K) k0 = p.K - W_BK > 0 ? p.K - W_BK : 0;       // short last stage: the last full window (K >= 32)
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) p_copy16(pg[i] + k0, base + rowoff[i]);
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+#pragma unroll
+    for (int s2 = 0; s2 < W_NSTG - 1; ++s2)
+        if (s2 < nkt && !(p.abl & 4)) copy_stage(s2);
+    const int r31 = lane & 31, h = lane >> 5;
+    for (int kt = 0; kt < nkt; ++kt) {
+        // stage kt must have landed; younger: stages kt+1 .. kt+3 (4 copies each) where they exist
+        const int younger = nkt - 1 - kt;
+        if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p_lds_barrier();                                        // stage kt is in LDS for everybody, stage kt-1 is released
+        if (kt + W_NSTG - 1 < nkt && !(p.abl & 4)) copy_stage(kt + W_NSTG - 1);
+        if (p.abl & 2) continue;
+        const unsigned char* bufA = wsm + (kt % W_NSTG) * W_STG;
+        const unsigned char* bufB = bufA + W_BM * W_BK * 2;
+        const long long kbeg = (long long)kt * W_BK;
+        int ks0 = 0;
+        if (kbeg + W_BK > p.K && p.K >= W_BK) ks0 = (int)((kbeg - (p.K - W_BK)) >> 4);
+        const int ks1 = p.K >= W_BK ? 2 : (int)(p.K >> 4);
+        for (int ks = ks0; ks < ks1; ++ks) {
+            const int chunk = 2 * ks + h;
+            bf16x8 fx[4], fw[2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int row = 128 * wm + 32 * a + r31;
+                fx[a] = *reinterpret_cast<const bf16x8*>(bufA + row * (W_BK * 2) + ((chunk ^ ((row >> 2) & 3)) << 4));
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int row = 64 * wn + 32 * b + r31;
+                fw[b] = *reinterpret_cast<const bf16x8*>(bufB + row * (W_BK * 2) + ((chunk ^ ((row >> 2) & 3)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b], fx[a], acc[a][b], 0, 0, 0);
+        }
+    }
+    if (p.abl & 1) return;
+    p_lds_barrier();                                            // the staging buffers become the C image
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {                               // rows [128 r, +128) of the tile: the waves with wm == r hold them
+        if (wm == r) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int m = 32 * a + r31;
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = 64 * wn + 32 * b + 8 * g + 4 * h;
+                        f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(sC + m * W_CS + n) = v;
+                    }
+            }
+        }
+        p_lds_barrier();
+        nt_store_tile<128, W_BN, 512>(p, sC, m0 + 128 * r, n0, tid);
+        if (r == 0) p_lds_barrier();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1811,6 +1935,18 @@ int launch_nt(Kern kern, long long grid, size_t lds, hipStream_t s, const GemmAr
 
 extern "C" {
 
+static int launch_wide(hipStream_t s, const GemmArgs& p) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    const long long grid = ((p.M + W_BM - 1) / W_BM) * ((p.W + W_BN - 1) / W_BN);
+    hipLaunchKernelGGL(gemm_nt_wide_kernel, dim3((unsigned)grid), dim3(512), W_LDS, s, p);
+    return dhaug_launch_status();
+}
+
 static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias,
                           const uint16_t* residual, int64_t ld_res, const float* residual_f32, int64_t ld_res_f32,
                           uint16_t* c_bf16, int64_t ldc_bf16, int64_t n_pad_zero,
@@ -1872,6 +2008,12 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
             case 16: return launch_ws<16>(s, p);
             default: break;
         }
+    }
+    if (width >= 512 && ((M + W_BM - 1) / W_BM) * ((width + W_BN - 1) / W_BN) >= 160 && K >= 64 && lda >= 64 && ldb >= 64 &&
+        getenv("DHAUG_GEMM_NOWIDE") == nullptr && getenv("DHAUG_GEMM_NOBIG") == nullptr && getenv("DHAUG_GEMM_NOPIPE") == nullptr) {
+        // long batch, wide layer, tiles enough for most of the card: 256 x 256 tiles, eight waves
+        p.abl = getenv("DHAUG_BIG_ABL") ? atoi(getenv("DHAUG_BIG_ABL")) : 0;   // (development: timing only)
+        return launch_wide(s, p);
     }
     if (width >= 512 && M >= 4096 && K >= 64 && lda >= 64 && ldb >= 64 && getenv("DHAUG_GEMM_NOBIG") == nullptr &&
         getenv("DHAUG_GEMM_NOPIPE") == nullptr) {
