@@ -50,6 +50,7 @@ SIGNATURES = {
     "dhaug_counter_add": [_vp, _i32, _vp],
     "dhaug_frame_diff": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     "dhaug_repack_weights": [_vp, _i32, _vp],
+    "dhaug_gemm_bf16_dmask_f32": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _f32, _vp, _i64, _i64, _i64, _i64, _vp],
     "dhaug_adam_repack_step": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _f32, _vp, _i32, _i64, _vp, _i32, _vp],
     "dhaug_gp_assemble": [_vp, _vp, _vp, _vp, _i64, _i64, _vp],
     "dhaug_gp_penalty": [_vp, _vp, _vp, _i64, _i64, _f32, _vp],

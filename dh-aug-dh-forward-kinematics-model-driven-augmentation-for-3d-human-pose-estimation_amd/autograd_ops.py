@@ -167,14 +167,17 @@ def _raw_linear_t(g, W, prec, out_f32):
     return cf
 
 
-def _raw_outer(g, x, N, K, prec, colsum=None, out=None):
+def _raw_outer(g, x, N, K, prec, colsum=None, out=None, split=None):
     if prec == "bf16":
         gb = _operand(g, ceil16(N)) if g.dtype != BF16 else g
         xb = _operand(x, ceil16(K)) if x.dtype != BF16 else x
         return ops.gemm_tn(gb, xb, N, K, colsum=colsum, out=out, accumulate=out is not None)
     Np, Kp, T = ceil16(N), ceil16(K), TERMS[prec]
-    g3 = ops.split_bf16(g, 0, T, Np)          # activation-side layout: hi / mid / lo live in fixed segments
-    x3 = ops.split_bf16(x, 0, T, Kp)
+    if split is not None:                      # (the caller holds the operands' splits already: critic_step._Math)
+        g3, x3 = split
+    else:
+        g3 = ops.split_bf16(g, 0, T, Np)      # activation-side layout: hi / mid / lo live in fixed segments
+        x3 = ops.split_bf16(x, 0, T, Kp)
     M = g.shape[0]
     for a, b in _PAIRS[T]:                     # (a given `out` is accumulated into from the first term on)
         ga = g3[:, _SEG[T][a] * Np:]

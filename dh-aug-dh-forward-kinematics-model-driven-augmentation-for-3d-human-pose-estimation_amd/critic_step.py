@@ -52,6 +52,9 @@ TN_SIDE_WGS = int(os.environ.get("DHAUG_TN_SIDE_WGS", "128"))
 TN_PHASED = os.environ.get("DHAUG_TN_PHASED") is not None
 TN_MAIN_WGS = int(os.environ.get("DHAUG_TN_MAIN_WGS", "0"))  # workgroups of the second part (0: one per CU)
 
+# split-operand arithmetic: one activation-side split per tensor and step (_Math.split0); DHAUG_NO_SPLIT_CACHE=1: one per use
+SPLIT_CACHE = os.environ.get("DHAUG_NO_SPLIT_CACHE") is None
+
 BF16 = torch.bfloat16
 NONE, RELU, LRELU = A.ACT_NONE, A.ACT_RELU, A.ACT_LRELU
 ceil16 = A.ceil16
@@ -82,6 +85,7 @@ class _Math:
         self.prec, self.bf16 = prec, prec == "bf16"
         self.T = 1 if self.bf16 else A.TERMS[prec]
         self.tn = []                                 # weight-gradient contractions waiting for the grouped launch (flush)
+        self._splits = []                            # split-operand arithmetic: (address, rows, cols, source, split) of this step
 
     def width(self, n):
         return ceil16(n) if self.bf16 else n
@@ -93,7 +97,26 @@ class _Math:
         """activation-side operand of a (fp32 (M,k) network input / bf16 hidden / fp32 hidden)"""
         if self.bf16:
             return a if a.dtype == BF16 else ops.cast_pad_bf16(a, ceil16(k))
-        return ops.split_bf16(a if a.is_contiguous() else a.contiguous(), 0, self.T, ceil16(k))
+        return self.split0(a, k)
+
+    def split0(self, a, k):
+        """the activation-side split of fp32 a (rows, k) -- made ONCE per tensor and step: a layer's input, cotangent and tangent
+        are each an operand of one sweep AND of sweep 4 (there as row ranges of the same tensor), and a split moves 3.5 x the
+        bytes of the tensor it splits (the splits were 29 of the step's 95 ms).  The sources are kept referenced until flush()
+        (no address is reused inside a step); nothing in the schedule writes a tensor after it was an operand."""
+        if not a.is_contiguous():
+            return ops.split_bf16(a.contiguous(), 0, self.T, ceil16(k))
+        p, rows, cols = a.data_ptr(), a.shape[0], a.shape[1]
+        if SPLIT_CACHE and cols == k:
+            for bp, brows, bcols, _, sp in self._splits:
+                if bcols == cols and p >= bp and (p - bp) % (4 * cols) == 0:
+                    r0 = (p - bp) // (4 * cols)
+                    if r0 + rows <= brows:
+                        return sp if (r0 == 0 and rows == brows) else sp[r0:r0 + rows]
+        sp = ops.split_bf16(a, 0, self.T, ceil16(k))
+        if SPLIT_CACHE and cols == k:
+            self._splits.append((p, rows, cols, a, sp))
+        return sp
 
     def mm(self, a, W, orient, bias=None, res=None, act=NONE, slope=0.0, mask=None, mask_act=NONE, out=None, out_f32=False):
         """(a @ W^T if orient == 'nt' else a @ W) + bias + res, then act(.) or, with `mask`, * mask_act'(mask)."""
@@ -126,6 +149,9 @@ class _Math:
         if res is not None and not res.is_contiguous():
             res = res.contiguous()
         masked = mask is not None and mask_act != NONE
+        if masked and bias is None and act == NONE and mask.dtype == torch.float32 and mask.stride(1) == 1 and (out is None or out.stride(1) == 1):
+            # the mask rides the GEMM's epilogue (fp32 mask from the producing layer's activation): one launch, not two
+            return ops.gemm_nt_dmask_f32(a_op, Bop, n, self.T * kp, mask, mask_act, slope, res_f32=res, out=out)
         direct = out is not None and not (masked and not out.is_contiguous())
         _, cf = ops.gemm_nt(a_op, Bop, n, self.T * kp, bias=bias, res_f32=res, act=act, slope=slope, out_f32=True,
                             c_f32=out if direct else None)
@@ -151,6 +177,7 @@ class _Math:
         if self.tn:
             ops.gemm_tn_group(self.tn)
             self.tn = []
+        self._splits = []
 
     def flush_side(self):
         """the same on a side stream of the current one (join() / flush() makes the current stream wait for it): the
@@ -205,8 +232,8 @@ class _Math:
             if bslot is not None and narrow:
                 ops.colsum(gb if colsum_rows is None else gb[:colsum_rows], N=N, out=bslot, accumulate=True)
             return
-        A._raw_outer(g if g.is_contiguous() else g.contiguous(), x if x.is_contiguous() else x.contiguous(), N, K, self.prec,
-                     out=wslot)
+        gc, xc = g if g.is_contiguous() else g.contiguous(), x if x.is_contiguous() else x.contiguous()
+        A._raw_outer(gc, xc, N, K, self.prec, out=wslot, split=(self.split0(gc, N), self.split0(xc, K)))
         if bslot is not None:
             ops.colsum(g if g.is_contiguous() else g.contiguous(), N=N, out=bslot, accumulate=True)
 

@@ -53,26 +53,43 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
 //   terms 6 ("bf16x6", x = hi + mid + lo):     activation side [hi|hi|mid|mid|hi|lo], weight side [hi|mid|hi|mid|lo|hi]
 // so that A' B'^T = hi*hi + hi*mid + mid*hi (+ mid*mid + hi*lo + lo*hi): every product term down to 2^-16 (2^-24)
 // relative.  Each segment is pad_cols wide, zero padded.
+// (eight columns per thread: one or two 16-byte loads, `terms` 16-byte stores -- the first version stored 2 bytes per lane and
+// segment and ran at the store instruction rate, 66 us for a 196 608 x 256 operand; pad_cols is a multiple of 8)
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ src, long long ld_src,
                                                     uint16_t* __restrict__ dst, long long rows, long long cols,
                                                     long long pad_cols, int mode, int terms) {
-    const long long total = rows * pad_cols;
+    const long long ppr = pad_cols >> 3, total = rows * ppr;
+    const bool vec = (ld_src & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long r = i / pad_cols, c = i - r * pad_cols;
-        const float x = c < cols ? src[r * ld_src + c] : 0.0f;
-        const uint16_t hi = dhaug_f32_to_bf16(x);
-        const float r1 = x - dhaug_bf16_to_f32(hi);
-        const uint16_t mid = dhaug_f32_to_bf16(r1);
-        const uint16_t lo = dhaug_f32_to_bf16(r1 - dhaug_bf16_to_f32(mid));
-        uint16_t* row = dst + r * terms * pad_cols + c;
-        if (terms == 3) {
-            row[0] = hi;
-            row[pad_cols] = mode == 0 ? hi : mid;
-            row[2 * pad_cols] = mode == 0 ? mid : hi;
+        const long long r = i / ppr, c = (i - r * ppr) * 8;
+        float x[8];
+        if (vec && c + 8 <= cols) {
+            const float4 a = *reinterpret_cast<const float4*>(src + r * ld_src + c), b = *reinterpret_cast<const float4*>(src + r * ld_src + c + 4);
+            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
         } else {
-            const uint16_t a[6] = {hi, hi, mid, mid, hi, lo}, b[6] = {hi, mid, hi, mid, lo, hi};
 #pragma unroll
-            for (int t = 0; t < 6; ++t) row[t * pad_cols] = mode == 0 ? a[t] : b[t];
+            for (int e = 0; e < 8; ++e) x[e] = c + e < cols ? src[r * ld_src + c + e] : 0.0f;
+        }
+        uint32_t hi[4], mid[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint16_t h = dhaug_f32_to_bf16(x[e]);
+            const float r1 = x[e] - dhaug_bf16_to_f32(h);
+            const uint16_t m = dhaug_f32_to_bf16(r1);
+            const uint16_t l = dhaug_f32_to_bf16(r1 - dhaug_bf16_to_f32(m));
+            if (e & 1) { hi[e >> 1] |= (uint32_t)h << 16; mid[e >> 1] |= (uint32_t)m << 16; lo[e >> 1] |= (uint32_t)l << 16; }
+            else { hi[e >> 1] = h; mid[e >> 1] = m; lo[e >> 1] = l; }
+        }
+        const uint4 H = make_uint4(hi[0], hi[1], hi[2], hi[3]), Mi = make_uint4(mid[0], mid[1], mid[2], mid[3]),
+                    L = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        uint16_t* row = dst + r * terms * pad_cols + c;
+        auto put = [&](int t, const uint4& v) { *reinterpret_cast<uint4*>(row + t * pad_cols) = v; };
+        if (terms == 3) {
+            put(0, H); put(1, mode == 0 ? H : Mi); put(2, mode == 0 ? Mi : H);
+        } else if (mode == 0) {
+            put(0, H); put(1, H); put(2, Mi); put(3, Mi); put(4, H); put(5, L);
+        } else {
+            put(0, H); put(1, Mi); put(2, H); put(3, Mi); put(4, L); put(5, H);
         }
     }
 }
@@ -595,7 +612,8 @@ int dhaug_split_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ro
     DHAUG_CHECK(terms == 3 || terms == 6, DHAUG_EINVAL);
     if (rows == 0) return DHAUG_OK;
     DHAUG_CHECK_PTR(src); DHAUG_CHECK_PTR(dst);
-    hipLaunchKernelGGL(split_kernel, dim3(grid1d(rows * pad_cols, 256)), dim3(256), 0, (hipStream_t)stream, src,
+    DHAUG_CHECK(pad_cols % 8 == 0 && dhaug_aligned16(dst), DHAUG_EALIGN);
+    hipLaunchKernelGGL(split_kernel, dim3(grid1d(rows * (pad_cols / 8), 256)), dim3(256), 0, (hipStream_t)stream, src,
                        (long long)ld_src, dst, (long long)rows, (long long)cols, (long long)pad_cols, mode, terms);
     return dhaug_launch_status();
 }

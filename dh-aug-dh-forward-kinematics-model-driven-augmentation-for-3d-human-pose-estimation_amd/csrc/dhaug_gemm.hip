@@ -40,6 +40,8 @@ struct GemmArgs {
     const uint32_t* dbits;                                   // the same mask as a sign-bit array (dhaug_mlp_unit.bits layout)
     const uint32_t* dbits2;                                  // ... of output columns 256..511 (gemm_nt_ws_kernel: a layer whose output is two 256-wide blocks)
     int abl;                                                 // development (big-tile kernel): 1 no epilogue, 2 no reads / MFMAs, 4 no copies
+    const float* dmaskf; long long ld_dmaskf;                // the same mask from an fp32 activation (split-operand arithmetic): kernels
+                                                             // whose epilogue is nt_store_tile
 };
 
 // branch-free activation: v > 0 ? v : v * neg, neg = 0 (ReLU) / slope (LeakyReLU) / 1 (identity)
@@ -144,6 +146,21 @@ __device__ __forceinline__ void nt_store_tile(const GemmArgs& p, const float* sC
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
                         if (full || n + e < p.N) v[e] = (short)p.dmask[gm * p.ld_dmask + n + e] > 0 ? v[e] : v[e] * p.dneg;
+                }
+            }
+            if (p.dmaskf != nullptr) {
+                const float* mrow = p.dmaskf + gm * p.ld_dmaskf + n;
+                if (full && (p.ld_dmaskf & 3) == 0 && (reinterpret_cast<uintptr_t>(p.dmaskf) & 15) == 0) {
+                    const f32x4 m0v = *reinterpret_cast<const f32x4*>(mrow), m1v = *reinterpret_cast<const f32x4*>(mrow + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = m0v[e] > 0.0f ? v[e] : v[e] * p.dneg;
+                        v[4 + e] = m1v[e] > 0.0f ? v[4 + e] : v[4 + e] * p.dneg;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < p.N) v[e] = mrow[e] > 0.0f ? v[e] : v[e] * p.dneg;
                 }
             }
             if (p.cb != nullptr) {
@@ -1951,7 +1968,8 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
                           const uint16_t* residual, int64_t ld_res, const float* residual_f32, int64_t ld_res_f32,
                           uint16_t* c_bf16, int64_t ldc_bf16, int64_t n_pad_zero,
                           float* c_f32, int64_t ldc_f32, int64_t M, int64_t N, int64_t K, int act, float slope,
-                          const uint16_t* dmask, int64_t ld_dmask, float dneg, bool* mask_done, void* stream) {
+                          const uint16_t* dmask, int64_t ld_dmask, float dneg, bool* mask_done, void* stream,
+                          const float* dmaskf = nullptr, int64_t ld_dmaskf = 0) {
     DHAUG_CHECK(M >= 0 && N >= 1 && K >= 16, DHAUG_EINVAL);
     DHAUG_CHECK(act >= DHAUG_ACT_NONE && act <= DHAUG_ACT_LRELU, DHAUG_EINVAL);
     if (M == 0) return DHAUG_OK;
@@ -1969,8 +1987,12 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
     hipStream_t s = (hipStream_t)stream;
     const long long width = (c_bf16 && p.npad > N) ? p.npad : N;
     p.W = width;
+    if (dmaskf != nullptr) {                                     // (fp32 mask: applied by nt_store_tile -- the kernels that have it)
+        DHAUG_CHECK(dmask == nullptr && ld_dmaskf >= N, DHAUG_EINVAL);
+        p.dmaskf = dmaskf; p.ld_dmaskf = ld_dmaskf; p.dneg = dneg;
+    }
     // the training path's 256-wide layers
-    if (N == 256 && width == 256 && K <= 256 && M % F_BM == 0 && c_bf16 != nullptr && c_f32 == nullptr && residual_f32 == nullptr &&
+    if (dmaskf == nullptr && N == 256 && width == 256 && K <= 256 && M % F_BM == 0 && c_bf16 != nullptr && c_f32 == nullptr && residual_f32 == nullptr &&
         (bias == nullptr || dhaug_aligned16(bias)) && getenv("DHAUG_GEMM_GENERIC") == nullptr && getenv("DHAUG_GEMM_NO256") == nullptr) {
         if (getenv("DHAUG_NT256_SINGLE") == nullptr) {                        // two-role kernel (default): mask in its own LDS image
             if (dmask != nullptr && (K == 128 || K == 256)) {
@@ -1997,7 +2019,7 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
         p.dmask = dmask; p.ld_dmask = ld_dmask; p.dneg = dneg;
         *mask_done = true;
     }
-    if (width > 64 && K <= 256 && getenv("DHAUG_GEMM_GENERIC") == nullptr) {
+    if (dmaskf == nullptr && width > 64 && K <= 256 && getenv("DHAUG_GEMM_GENERIC") == nullptr) {
         switch (K / 16) {
             case 1: return launch_ws<1>(s, p);
             case 2: return launch_ws<2>(s, p);
@@ -2009,9 +2031,10 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
             default: break;
         }
     }
-    if (width >= 512 && ((M + W_BM - 1) / W_BM) * ((width + W_BN - 1) / W_BN) >= 160 && K >= 64 && lda >= 64 && ldb >= 64 &&
+    if (width >= 256 && ((M + W_BM - 1) / W_BM) * ((width + W_BN - 1) / W_BN) >= 160 && K >= 64 && lda >= 64 && ldb >= 64 &&
         getenv("DHAUG_GEMM_NOWIDE") == nullptr && getenv("DHAUG_GEMM_NOBIG") == nullptr && getenv("DHAUG_GEMM_NOPIPE") == nullptr) {
-        // long batch, wide layer, tiles enough for most of the card: 256 x 256 tiles, eight waves
+        // long batch, tiles enough for most of the card: 256 x 256 tiles, eight waves (the DenseDim-1000 layers of the frame
+        // critics; the 256-wide layers of the split-operand parity arithmetic, K' = 3 K or 6 K)
         p.abl = getenv("DHAUG_BIG_ABL") ? atoi(getenv("DHAUG_BIG_ABL")) : 0;   // (development: timing only)
         return launch_wide(s, p);
     }
@@ -2073,6 +2096,17 @@ int dhaug_gemm_bf16_dmask_pad(const uint16_t* A, int64_t lda, const uint16_t* B,
     bool done = false;
     return gemm_bf16_impl(A, lda, B, ldb, nullptr, residual, ld_res, nullptr, 0, c_bf16, ldc_bf16, n_pad_zero > N ? n_pad_zero : N,
                           nullptr, 0, M, N, K, DHAUG_ACT_NONE, 0.0f, dmask, ld_dmask, dneg, &done, stream);
+}
+
+/* see include/dhaug.h */
+int dhaug_gemm_bf16_dmask_f32(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* residual_f32, int64_t ld_res_f32,
+                              const float* dmask, int64_t ld_dmask, int dmask_act, float dmask_slope, float* c_f32, int64_t ldc_f32,
+                              int64_t M, int64_t N, int64_t K, void* stream) {
+    DHAUG_CHECK(dmask_act == DHAUG_ACT_RELU || dmask_act == DHAUG_ACT_LRELU, DHAUG_EINVAL);
+    DHAUG_CHECK_PTR(c_f32); DHAUG_CHECK_PTR(dmask);
+    bool done = false;
+    return gemm_bf16_impl(A, lda, B, ldb, nullptr, nullptr, 0, residual_f32, ld_res_f32, nullptr, 0, 0, c_f32, ldc_f32, M, N, K,
+                          DHAUG_ACT_NONE, 0.0f, nullptr, 0, dmask_act == DHAUG_ACT_RELU ? 0.0f : dmask_slope, &done, stream, dmask, ld_dmask);
 }
 
 int dhaug_gemm_bf16_dmask(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* residual,

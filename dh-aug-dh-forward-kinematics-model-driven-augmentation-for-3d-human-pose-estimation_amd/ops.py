@@ -323,6 +323,20 @@ def gemm_nt_dmask(A, B, N, K, dmask, dmask_act, dmask_slope=0.0, res_bf16=None, 
     return out
 
 
+def gemm_nt_dmask_f32(A, B, N, K, dmask, dmask_act, dmask_slope=0.0, res_f32=None, out=None):
+    """(A[M,K] B[N,K]^T + res) * act'(dmask) in the split-operand arithmetic: fp32 result / residual / mask (M, N), A and B the
+    operands split_bf16 makes (K = terms * padded width)."""
+    assert A.dtype == BF16 and B.dtype == BF16 and dmask.dtype == torch.float32 and dmask.stride(1) == 1
+    M = A.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    assert out.dtype == torch.float32 and out.stride(1) == 1 and out.shape[0] == M and out.shape[1] >= N
+    assert res_f32 is None or (res_f32.dtype == torch.float32 and res_f32.stride(1) == 1)
+    _lib.call("dhaug_gemm_bf16_dmask_f32", _p(A), A.stride(0), _p(B), B.stride(0), _p(res_f32), 0 if res_f32 is None else res_f32.stride(0),
+              _p(dmask), dmask.stride(0), dmask_act, float(dmask_slope), _p(out), out.stride(0), M, N, K, _stream())
+    return out
+
+
 DBITS = os.environ.get("DHAUG_NO_DBITS") is None          # consume sign-bit masks where a saved activation carries one
 BLOCK2 = os.environ.get("DHAUG_NO_BLOCK2") is None        # the two layers of a residual block's backward / tangent step in one launch
 

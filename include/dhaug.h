@@ -195,6 +195,13 @@ int dhaug_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t l
                     float* c_f32, int64_t ldc_f32,
                     int64_t M, int64_t N, int64_t K, int act, float slope, void* stream);
 
+/* The split-operand ("bf16x3" / "bf16x6") form of the same step: fp32 result, fp32 residual, and the mask read from the producing
+ * layer's fp32 activation: c_f32 = (A B^T + residual_f32) * dmask_act'(dmask), dmask (M, >= N) fp32 (ReLU / LeakyReLU only).  A, B:
+ * the operands dhaug_split_bf16 makes (K = terms * padded width).  One launch instead of the GEMM + dhaug_act_backward_f32. */
+int dhaug_gemm_bf16_dmask_f32(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* residual_f32, int64_t ld_res_f32,
+                              const float* dmask, int64_t ld_dmask, int dmask_act, float dmask_slope, float* c_f32, int64_t ldc_f32,
+                              int64_t M, int64_t N, int64_t K, void* stream);
+
 /* Input gradient of a layer whose input came out of an activation, in one pass:
  *   c_bf16[M,N] = ( A[M,K] * B[N,K]^T + residual[M,N] ) * act'(dmask[M,N])      act'(y) = y > 0 ? 1 : (ReLU 0 | LeakyReLU slope)
  * i.e. LinearT followed by the activation backward of the producing layer (the `loss.backward()` of
