@@ -109,8 +109,9 @@ def _w_nt(W, Kp, prec):
     return d[key]
 
 
-def _w_nn(W, prec):
-    """B operand of g W (= g (W^T)^T): (K, Np) bf16, or (K, 3Np)."""
+def _w_nn(W, prec, mode=1):
+    """B operand of g W (= g (W^T)^T): (K, Np) bf16, or (K, 3Np).  mode 0: the split in the ACTIVATION-side layout, for a g that
+    comes in the weight-side layout (the product pairs are symmetric in the two layouts: critic_step._Math.mm)."""
     ent = _pack(W)
     if prec == "bf16":
         if ent.nn is None:
@@ -118,9 +119,9 @@ def _w_nn(W, prec):
         return ent.nn
     if ent.nn3 is None:
         ent.nn3 = {}
-    if prec not in ent.nn3:
-        ent.nn3[prec] = ops.split_bf16(W.detach().t().contiguous(), 1, TERMS[prec])
-    return ent.nn3[prec]
+    if (prec, mode) not in ent.nn3:
+        ent.nn3[(prec, mode)] = ops.split_bf16(W.detach().t().contiguous(), mode, TERMS[prec])
+    return ent.nn3[(prec, mode)]
 
 
 def clear_weight_cache():
@@ -173,17 +174,18 @@ def _raw_outer(g, x, N, K, prec, colsum=None, out=None, split=None):
         xb = _operand(x, ceil16(K)) if x.dtype != BF16 else x
         return ops.gemm_tn(gb, xb, N, K, colsum=colsum, out=out, accumulate=out is not None)
     Np, Kp, T = ceil16(N), ceil16(K), TERMS[prec]
-    if split is not None:                      # (the caller holds the operands' splits already: critic_step._Math)
-        g3, x3 = split
-    else:
-        g3 = ops.split_bf16(g, 0, T, Np)      # activation-side layout: hi / mid / lo live in fixed segments
-        x3 = ops.split_bf16(x, 0, T, Kp)
     M = g.shape[0]
-    for a, b in _PAIRS[T]:                     # (a given `out` is accumulated into from the first term on)
-        ga = g3[:, _SEG[T][a] * Np:]
-        xb = x3[:, _SEG[T][b] * Kp:]
-        out = ops.gemm_tn(ga, xb, N, K, out=out, accumulate=out is not None, M=M, lda=T * Np, ldb=T * Kp)
-    return out
+    # ONE contraction over T * M rows: a split is (M, T * pad) with the terms side by side, i.e. -- the same memory -- a
+    # (T * M, pad) matrix whose row T m + t holds term t of row m.  With g in the weight-side layout and x in the activation-side
+    # layout, row T m + t of the two carries exactly the t-th product pair (dhaug_split_bf16: [hi|mid|hi|mid|lo|hi] against
+    # [hi|hi|mid|mid|hi|lo]), so sum_{m,t} g''[Tm+t]^T x''[Tm+t] is the six-term (three-term) product.  (Before: one contraction
+    # per pair on column blocks of two activation-side splits -- six launches, six partial sums.)
+    if split is not None:                      # (the caller holds the operands' splits already: critic_step._Math)
+        g1, x3 = split
+    else:
+        g1 = ops.split_bf16(g, 1, T, Np)
+        x3 = ops.split_bf16(x, 0, T, Kp)
+    return ops.gemm_tn(g1.view(T * M, Np), x3.view(T * M, Kp), N, K, out=out, accumulate=out is not None)
 
 
 # ---------------------------------------------------------------------------------------------------

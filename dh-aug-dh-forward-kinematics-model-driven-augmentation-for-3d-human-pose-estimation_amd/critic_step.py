@@ -85,7 +85,7 @@ class _Math:
         self.prec, self.bf16 = prec, prec == "bf16"
         self.T = 1 if self.bf16 else A.TERMS[prec]
         self.tn = []                                 # weight-gradient contractions waiting for the grouped launch (flush)
-        self._splits = []                            # split-operand arithmetic: (address, rows, cols, source, split) of this step
+        self._splits, self._split_src = [], []       # split-operand arithmetic: (address, rows, cols, mode, split) of this step
 
     def width(self, n):
         return ceil16(n) if self.bf16 else n
@@ -99,23 +99,24 @@ class _Math:
             return a if a.dtype == BF16 else ops.cast_pad_bf16(a, ceil16(k))
         return self.split0(a, k)
 
-    def split0(self, a, k):
+    def split0(self, a, k, mode=0):
         """the activation-side split of fp32 a (rows, k) -- made ONCE per tensor and step: a layer's input, cotangent and tangent
         are each an operand of one sweep AND of sweep 4 (there as row ranges of the same tensor), and a split moves 3.5 x the
         bytes of the tensor it splits (the splits were 29 of the step's 95 ms).  The sources are kept referenced until flush()
         (no address is reused inside a step); nothing in the schedule writes a tensor after it was an operand."""
         if not a.is_contiguous():
-            return ops.split_bf16(a.contiguous(), 0, self.T, ceil16(k))
+            return ops.split_bf16(a.contiguous(), mode, self.T, ceil16(k))
         p, rows, cols = a.data_ptr(), a.shape[0], a.shape[1]
         if SPLIT_CACHE and cols == k:
-            for bp, brows, bcols, _, sp in self._splits:
-                if bcols == cols and p >= bp and (p - bp) % (4 * cols) == 0:
+            for bp, brows, bcols, bmode, sp in self._splits:
+                if bmode == mode and bcols == cols and p >= bp and (p - bp) % (4 * cols) == 0:
                     r0 = (p - bp) // (4 * cols)
                     if r0 + rows <= brows:
                         return sp if (r0 == 0 and rows == brows) else sp[r0:r0 + rows]
-        sp = ops.split_bf16(a, 0, self.T, ceil16(k))
+        sp = ops.split_bf16(a, mode, self.T, ceil16(k))
         if SPLIT_CACHE and cols == k:
-            self._splits.append((p, rows, cols, a, sp))
+            self._splits.append((p, rows, cols, mode, sp))
+            self._split_src.append(a)                # (referenced until flush: no address is reused inside a step)
         return sp
 
     def mm(self, a, W, orient, bias=None, res=None, act=NONE, slope=0.0, mask=None, mask_act=NONE, out=None, out_f32=False):
@@ -123,8 +124,11 @@ class _Math:
         N, K = W.shape
         n, k = (N, K) if orient == "nt" else (K, N)
         kp = ceil16(k)
-        Bop = A._w_nt(W, kp, self.prec) if orient == "nt" else A._w_nn(W, self.prec)
-        a_op = self._a(a, k)
+        # split-operand arithmetic, backward chain (orient "nn"): the cotangent is split ONCE, in the weight-side layout -- the
+        # layout sweep 4 contracts it in (autograd_ops._raw_outer) -- and meets the weights in the activation-side layout
+        swap = (not self.bf16) and orient == "nn" and SPLIT_CACHE
+        Bop = A._w_nt(W, kp, self.prec) if orient == "nt" else A._w_nn(W, self.prec, 0 if swap else 1)
+        a_op = self.split0(a, k, 1) if swap else self._a(a, k)
         if (self.bf16 and RANK1 and orient == "nn" and N == 1 and a.dtype == BF16 and res is None and bias is None
                 and mask is not None and mask_act != NONE and not out_f32 and mask.stride(0) % 8 == 0 and mask.shape[1] >= ceil16(K)
                 and ceil16(K) <= 1024):
@@ -177,7 +181,7 @@ class _Math:
         if self.tn:
             ops.gemm_tn_group(self.tn)
             self.tn = []
-        self._splits = []
+        self._splits, self._split_src = [], []
 
     def flush_side(self):
         """the same on a side stream of the current one (join() / flush() makes the current stream wait for it): the
@@ -233,7 +237,7 @@ class _Math:
                 ops.colsum(gb if colsum_rows is None else gb[:colsum_rows], N=N, out=bslot, accumulate=True)
             return
         gc, xc = g if g.is_contiguous() else g.contiguous(), x if x.is_contiguous() else x.contiguous()
-        A._raw_outer(gc, xc, N, K, self.prec, out=wslot, split=(self.split0(gc, N), self.split0(xc, K)))
+        A._raw_outer(gc, xc, N, K, self.prec, out=wslot, split=(self.split0(gc, N, 1), self.split0(xc, K)))
         if bslot is not None:
             ops.colsum(g if g.is_contiguous() else g.contiguous(), N=N, out=bslot, accumulate=True)
 
