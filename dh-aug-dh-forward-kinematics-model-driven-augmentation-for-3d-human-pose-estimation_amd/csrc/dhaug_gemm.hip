@@ -317,59 +317,73 @@ __device__ __forceinline__ void p_copy16(const void* g, unsigned char* lds_wave_
 // first version), which serialises the stages again.  A stage is [64 rows][64 k] bf16 per operand, rows contiguous (the
 // copy fixes a lane's LDS slot), 16-byte chunk c of row r at position c ^ ((r >> 1) & 7) (applied on the global side).
 // Rows beyond M / N read a valid row (their results are never stored); the K tail is cut in the k-step loop.
-__global__ __launch_bounds__(256, 2) void gemm_nt_pipe_kernel(GemmArgs p) {
-    constexpr int BM = 64, BN = 64, NSTG = 4;
+// *(r4, measured with `tools/time_nt_graph.py`: fifty launches replayed as one hipGraph -- the host issues a C-ABI call in ~10 us, a
+// timing loop of these launches measures the host)*  1 536 x 1000 x 1000 (the motion critics' branch layers, 435 launches per video
+// iteration): 13.3 us; without the epilogue 10.5, without fragment reads / matrix instructions 9.8, without copies 10.2, copies
+// alone 7.1 -- the phases of a stage do not overlap inside a workgroup (wait for the stage, barrier, issue the copy three stages on,
+// compute), and with 1.5 workgroups per CU little overlaps across them.  The template's other instantiation, 64 x 128 tiles with six
+// stages (one workgroup per CU, all 192 resident at once), is SLOWER (17.5 us) and is not dispatched; requesting a stage's eight
+// fragment reads before its four matrix instructions and alternating two accumulator sets (the whole-stage path below) bought 3 %.
+template <int BN, int NSTG>
+__global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void gemm_nt_pipe_kernel(GemmArgs p) {
+    constexpr int BM = 64;
+    constexpr int TN = BN / 64;                                              // 32-column MFMA tiles per wave
     constexpr int CS = BN + 4;
-    constexpr int STG = (BM + BN) * BK * 2;                                  // 16 384 bytes per stage
-    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[NSTG * STG];
+    constexpr int STG = (BM + BN) * BK * 2;                                  // bytes per stage: 16 384 / 24 576
+    constexpr int NCP = (BM + BN) / 32;                                      // copies per lane and stage: 4 / 6
+    static_assert(NSTG * STG >= BM * CS * 4, "C tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* sC = reinterpret_cast<float*>(smem_raw);             // [BM][CS], reuses the staging buffers
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;                    // 2 x 2 waves, one 32 x 32 MFMA tile each
+    const int wm = wave >> 1, wn = wave & 1;                    // 2 x 2 waves: rows [32 wm, +32), columns [BN / 2 wn, + BN / 2)
     const long long ntn = (p.W + BN - 1) / BN;
     const long long m0 = (long long)(blockIdx.x / ntn) * BM;
     const long long n0 = (long long)(blockIdx.x % ntn) * BN;
     const int nkt = (int)((p.K + BK - 1) / BK);
 
-    // this lane's two rows per operand and its swizzled chunk
-    const uint16_t* pa[2];
-    const uint16_t* pb[2];
-    int rowoff[2];
+    // copy i of wave w moves rows [8 (4 i + w), +8) of the stage image (A rows first, then B rows): 8 lanes per row
+    const uint16_t* pg[NCP];
+    int rowoff[NCP];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row0 = (wave * 2 + i) * 8, row = row0 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
-        const long long gm = m0 + row, gn = n0 + row;
-        pa[i] = p.A + (gm < p.M ? gm : p.M - 1) * p.lda + c * 8;
-        pb[i] = p.B + (gn < p.N ? gn : p.N - 1) * p.ldb + c * 8;
+    for (int i = 0; i < NCP; ++i) {
+        const int row0 = (4 * i + wave) * 8, row = row0 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+        if (i < BM / 32) {
+            const long long gm = m0 + row;
+            pg[i] = p.A + (gm < p.M ? gm : p.M - 1) * p.lda + c * 8;
+        } else {
+            const long long gn = n0 + row - BM;
+            pg[i] = p.B + (gn < p.N ? gn : p.N - 1) * p.ldb + c * 8;
+        }
         rowoff[i] = row0 * (BK * 2);
     }
-    auto copy_stage = [&](int kt) {                             // 4 copies per lane
+    auto copy_stage = [&](int kt) {
         unsigned char* base = smem_raw + (kt % NSTG) * STG;
         long long k0 = (long long)kt * BK;
         if (k0 + BK > p.K) k0 = p.K - BK > 0 ? p.K - BK : 0;   // short last stage: re-read the last full window (K >= 64) ...
-        const long long shift = (long long)kt * BK - k0;       // ... and skip its first `shift` columns in the k-step loop
-        (void)shift;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            p_copy16(pa[i] + k0, base + rowoff[i]);
-            p_copy16(pb[i] + k0, base + BM * BK * 2 + rowoff[i]);
-        }
+#pragma unroll                                                 // ... and skip its first columns in the k-step loop
+        for (int i = 0; i < NCP; ++i) p_copy16(pg[i] + k0, base + rowoff[i]);
     };
-    f32x16 acc;
+    f32x16 acc[TN], acc2[TN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int u = 0; u < TN; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[u][r] = 0.0f; acc2[u][r] = 0.0f; }
 #pragma unroll
     for (int s = 0; s < NSTG - 1; ++s)
-        if (s < nkt) copy_stage(s);
-    const int rowb = wn * 32 + (lane & 31), rowa = wm * 32 + (lane & 31);
+        if (s < nkt && !(p.abl & 4)) copy_stage(s);
+    const int rowa = wm * 32 + (lane & 31);
     for (int kt = 0; kt < nkt; ++kt) {
-        // stage kt must have landed; younger: stages kt+1, kt+2 (4 copies each) where they exist
+        // stage kt must have landed; younger: stages kt+1 .. kt+NSTG-2 (NCP copies each) where they exist
         const int younger = nkt - 1 - kt;
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (NSTG >= 6 && younger >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NCP) : "memory");
+        else if (NSTG >= 5 && younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NCP) : "memory");
+        else if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCP) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCP) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         p_lds_barrier();                                        // everybody's copies of stage kt are in LDS, stage kt-1 is released
-        if (kt + NSTG - 1 < nkt) copy_stage(kt + NSTG - 1);
+        if (kt + NSTG - 1 < nkt && !(p.abl & 4)) copy_stage(kt + NSTG - 1);
+        if (p.abl & 2) continue;
         const unsigned char* bufA = smem_raw + (kt % NSTG) * STG;
         const unsigned char* bufB = bufA + BM * BK * 2;
         // k-steps of this stage: a short last stage was loaded as the last full 64-wide window, its first columns belong
@@ -378,22 +392,59 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_pipe_kernel(GemmArgs p) {
         int ks0 = 0;
         if (kbeg + BK > p.K && p.K >= BK) ks0 = (int)((kbeg - (p.K - BK)) >> 4);
         const int ks1 = p.K >= BK ? 4 : (int)(p.K >> 4);
+        if (ks0 == 0 && ks1 == 4) {
+            // a whole stage (all but a K tail): every fragment read is requested before the first matrix instruction, and the
+            // k-steps alternate between two accumulator sets.  The loop below, with its run-time bounds, is compiled as read ->
+            // wait -> MFMA per k-step on one accumulator: four LDS latencies plus four dependent matrix instructions per stage
+            // -- *(measured, hipGraph replay, 512 x 1000 x 1000: one workgroup per CU)* 9.2 us of a 10.1 us launch with the copies
+            // switched off.
+            bf16x8 fx[4], fw[4][TN];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int chunk = 2 * ks + (lane >> 5);
+                fx[ks] = *reinterpret_cast<const bf16x8*>(bufA + rowa * (BK * 2) + ((chunk ^ ((rowa >> 1) & 7)) << 4));
+#pragma unroll
+                for (int u = 0; u < TN; ++u) {
+                    const int rowb = wn * (BN / 2) + 32 * u + (lane & 31);
+                    fw[ks][u] = *reinterpret_cast<const bf16x8*>(bufB + rowb * (BK * 2) + ((chunk ^ ((rowb >> 1) & 7)) << 4));
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int u = 0; u < TN; ++u) {
+                    if (ks & 1) acc2[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks][u], fx[ks], acc2[u], 0, 0, 0);
+                    else acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks][u], fx[ks], acc[u], 0, 0, 0);
+                }
+            continue;
+        }
         for (int ks = ks0; ks < ks1; ++ks) {
             const int chunk = 2 * ks + (lane >> 5);
-            const bf16x8 fw = *reinterpret_cast<const bf16x8*>(bufB + rowb * (BK * 2) + ((chunk ^ ((rowb >> 1) & 7)) << 4));
             const bf16x8 fx = *reinterpret_cast<const bf16x8*>(bufA + rowa * (BK * 2) + ((chunk ^ ((rowa >> 1) & 7)) << 4));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fx, acc, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < TN; ++u) {
+                const int rowb = wn * (BN / 2) + 32 * u + (lane & 31);
+                const bf16x8 fw = *reinterpret_cast<const bf16x8*>(bufB + rowb * (BK * 2) + ((chunk ^ ((rowb >> 1) & 7)) << 4));
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fx, acc[u], 0, 0, 0);
+            }
         }
     }
+#pragma unroll
+    for (int u = 0; u < TN; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] += acc2[u][r];
+    if (p.abl & 1) return;
     p_lds_barrier();                                            // the staging buffers become the C tile
     {
         const int m = wm * 32 + (lane & 31);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = wn * 32 + 8 * g + 4 * (lane >> 5);
-            f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-            *reinterpret_cast<f32x4*>(sC + m * CS + n) = v;
-        }
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = wn * (BN / 2) + 32 * u + 8 * g + 4 * (lane >> 5);
+                f32x4 v = {acc[u][4 * g], acc[u][4 * g + 1], acc[u][4 * g + 2], acc[u][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(sC + m * CS + n) = v;
+            }
     }
     p_lds_barrier();
     nt_store_tile<BM, BN>(p, sC, m0, n0, tid);
@@ -2055,7 +2106,8 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
     }
     if (width > 64 && K >= 64 && lda >= 64 && ldb >= 64 && getenv("DHAUG_GEMM_NOPIPE") == nullptr) {
         const long long grid = ((M + 63) / 64) * ((width + 63) / 64);
-        hipLaunchKernelGGL(gemm_nt_pipe_kernel, dim3((unsigned)grid), dim3(256), 0, s, p);
+        p.abl = getenv("DHAUG_BIG_ABL") ? atoi(getenv("DHAUG_BIG_ABL")) : 0;   // (development: timing only)
+        hipLaunchKernelGGL((gemm_nt_pipe_kernel<64, 4>), dim3((unsigned)grid), dim3(256), 4 * (64 + 64) * BK * 2, s, p);
         return dhaug_launch_status();
     }
     if (width > 64) {
