@@ -571,7 +571,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_big_kernel(GemmArgs p) {
 // *(measured, 13 824 x 1000 x 1000, 216 workgroups)* 48 us against 62 (576 TFLOP/s): the k loop 32 us -- the copies alone take 22
 // (1 MB per workgroup at 47 GB/s per CU = 10 TB/s of L2 -> LDS over the card: the LDS-DMA path's rate, not HBM's), the matrix
 // instructions alone 22 --, the epilogue 10, the launch 5.  A workgroup's time does not shrink with the batch: below ~160
-// workgroups the 128 x 256 kernel's smaller tiles win (4 608 rows: 31 us against 43), and grouping the four 1 536-row branch
+// workgroups the 128 x 256 kernel's smaller tiles win (4 608 rows: 31 us against 43).  (The copies' 47 GB/s per CU is this
+// kernel's pipeline, not the path: tools/ubench/fill_rate.hip moves 145-150 GB/s per CU from L2 into LDS with the same row-strided
+// requests, by LDS-DMA or through registers alike, once 48 KB per workgroup are in flight and nothing waits in between.  Tried:
+// one dword load per wave and stage, eight stages ahead, to warm L2 -- 64 lines per instruction: 45 -> 61 us.)  Grouping the four 1 536-row branch
 // layers of a motion critic into one launch of these tiles (96 workgroups, 45 us) buys nothing over four launches of 64 x 64 tiles
 // (13 us each) -- that launch form was written, measured and removed.
 // ---------------------------------------------------------------------------------------------------
