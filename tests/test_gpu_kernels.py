@@ -392,6 +392,28 @@ def test_gemm_tn_group(ops):
             assert maxabs(cs, csr) <= 1e-4 * max(1.0, csr.abs().max().item()) + 1e-3, (N1, N2)
 
 
+def test_gemm_split_operand_mask_in_the_epilogue(ops):
+    """dhaug_gemm_bf16_dmask_f32: (A B^T + res) * relu'(mask) with fp32 result / residual / mask on six-term split operands -- the
+    backward / tangent GEMM of the parity-grade training step -- against fp64 and against the GEMM + dhaug_act_backward_f32 pair it
+    replaces (long batch: the 256 x 256-tile kernel; short: the 64 x 64 one; a ragged width)"""
+    gen = torch.Generator().manual_seed(31)
+    for M, N, K in ((40960 + 24, 256, 256), (300, 100, 256), (4096, 1000, 48)):
+        a = torch.randn(M, K, generator=gen)
+        W = torch.randn(N, K, generator=gen) / K ** 0.5
+        res = torch.randn(M, N, generator=gen).cuda()
+        mask = torch.randn(M, N, generator=gen).cuda()
+        kp = (K + 15) // 16 * 16
+        a6, w6 = ops.split_bf16(a.cuda(), 0, 6, kp), ops.split_bf16(W.cuda(), 1, 6, kp)
+        for slope, act in ((0.0, 1), (0.01, 2)):
+            out = ops.gemm_nt_dmask_f32(a6, w6, N, 6 * kp, mask, act, slope, res_f32=res)
+            pre = a.double() @ W.double().t() + res.cpu().double()
+            ref = torch.where(mask.cpu() > 0, pre, pre * slope)
+            assert maxabs(out, ref) <= 3e-6 * max(1.0, ref.abs().max().item()), (M, N, K, act)
+            _, two = ops.gemm_nt(a6, w6, N, 6 * kp, res_f32=res, out_f32=True)
+            two = ops.act_backward(two, mask, act, slope)
+            assert maxabs(out, two) <= 1e-6 * max(1.0, ref.abs().max().item()), (M, N, K, act)
+
+
 def test_gemm_tn_group_wide_layers(ops, monkeypatch):
     """layers wider than 256 handed over whole (a grid of 256 x 256 blocks, one workgroup each, adding into the gradient slot
     itself): the DenseDim-1000 shapes of a video step -- 1000 x 1000, the 100 x 4000 merge layer, a 1000 x 135 input layer, a
