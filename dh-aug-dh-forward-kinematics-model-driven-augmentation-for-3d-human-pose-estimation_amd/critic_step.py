@@ -86,6 +86,7 @@ class _Math:
         self.T = 1 if self.bf16 else A.TERMS[prec]
         self.tn = []                                 # weight-gradient contractions waiting for the grouped launch (flush)
         self._splits, self._split_src = [], []       # split-operand arithmetic: (address, rows, cols, mode, split) of this step
+        self._casts = {}                             # bf16: the casts of fp32 inputs made in this step
 
     def width(self, n):
         return ceil16(n) if self.bf16 else n
@@ -96,8 +97,18 @@ class _Math:
     def _a(self, a, k):
         """activation-side operand of a (fp32 (M,k) network input / bf16 hidden / fp32 hidden)"""
         if self.bf16:
-            return a if a.dtype == BF16 else ops.cast_pad_bf16(a, ceil16(k))
+            return a if a.dtype == BF16 else self.cast(a, ceil16(k))
         return self.split0(a, k)
+
+    def cast(self, a, width):
+        """bf16 copy of an fp32 network input / tangent seed, made once per tensor and step (the tangent seeds of a branch are an
+        operand of the tangent sweep's first GEMM and of sweep 4)"""
+        key = (a.data_ptr(), tuple(a.shape), tuple(a.stride()), width)
+        hit = self._casts.get(key)
+        if hit is None:
+            hit = (ops.cast_pad_bf16(a, width), a)       # (the source stays referenced: no address is reused inside the step)
+            self._casts[key] = hit
+        return hit[0]
 
     def split0(self, a, k, mode=0):
         """the activation-side split of fp32 a (rows, k) -- made ONCE per tensor and step: a layer's input, cotangent and tangent
@@ -181,7 +192,7 @@ class _Math:
         if self.tn:
             ops.gemm_tn_group(self.tn)
             self.tn = []
-        self._splits, self._split_src = [], []
+        self._splits, self._split_src, self._casts = [], [], {}
 
     def flush_side(self):
         """the same on a side stream of the current one (join() / flush() makes the current stream wait for it): the
@@ -219,8 +230,8 @@ class _Math:
         """wslot (N,K) += g^T x;  bslot (N) += column sums of g over rows [0, colsum_rows) (all rows by default; through the
         pairing column-sum kernel when N < 16)"""
         if self.bf16:
-            gb = g if g.dtype == BF16 else ops.cast_pad_bf16(g, ceil16(N))
-            xb = x if x.dtype == BF16 else ops.cast_pad_bf16(x, ceil16(K))
+            gb = g if g.dtype == BF16 else self.cast(g, ceil16(N))
+            xb = x if x.dtype == BF16 else self.cast(x, ceil16(K))
             narrow = N < 16
             M = gb.shape[0]
             cr = M if colsum_rows is None else colsum_rows
