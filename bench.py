@@ -556,6 +556,28 @@ def main():
                 extra["gan_step_parity_error"] = repr(ex)[:200]
             set_precision("bf16")
         set_precision(main_prec)
+        if world == 1 and a.workload == "fwd" and D != 1000:
+            # the same forward at the reference's DEFAULT width (DenseDim 1000: R/function_aug/config.py:101-109), bf16, layer by
+            # layer (the fused programs cover 64 / 128 / 256): trunk of G + both critics on B poses
+            try:
+                a1k = synth_args(B, 1000)
+                m1k = T.my_get_poseFk_model(a1k, None, Forward_Kinematics_DH_Model(a1k, ["S1"], None))
+                g1k, d31k, d21k = m1k["model_G"], m1k["model_d3d"], m1k["model_d2d"]
+                x31k = torch.randn(B, 16, 3, device=dev) * 0.3
+                x21k = torch.rand(B, 16, 2, device=dev) - 0.5
+
+                def fwd1k():
+                    with torch.no_grad():
+                        g1k.trunk(z); d31k(x31k); d21k(x21k)
+                t1k, _ = timed(fwd1k, 10, 3)
+                mg, m3_, m2_ = mac_per_pose(1000, 1)
+                extra["fwd_D1000_ms_per_step"] = t1k / 10 * 1e3
+                extra["fwd_D1000_poses_per_s"] = B * 10 / t1k
+                extra["fwd_D1000_frac_of_mfma_peak"] = 2.0 * (mg + m3_ + m2_) * B * 10 / t1k / 2.5e15
+                extra["fwd_D1000_note"] = "G trunk + D3 + D2, DenseDim 1000, bf16, layer-by-layer GEMMs (256 x 256-tile kernel), eager"
+                del m1k, g1k, d31k, d21k
+            except Exception as ex:
+                extra["fwd_D1000_error"] = repr(ex)[:200]
     out["extra"] = extra
 
     gen_mac, d3_mac, d2_mac = mac_per_pose(D, R)

@@ -591,8 +591,18 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_wide_kernel(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;                    // 2 x 4 waves: rows [128 wm, +128), columns [64 wn, +64)
     const long long ntn = (p.W + W_BN - 1) / W_BN;
+    // Workgroups go to the eight XCDs round-robin, and every XCD has its own L2: the column tiles of ONE row block are given to
+    // workgroups b, b + 8, b + 16 ... (same XCD, started together), so the row block's operand rows come from beyond L2 once, not
+    // once per column tile.  (Row blocks are padded to a multiple of eight: a workgroup beyond the batch leaves at once.)
+#ifndef W_NO_XCD_MAP
+    const long long j = blockIdx.x >> 3;
+    const long long m0 = ((j / ntn) * 8 + (blockIdx.x & 7)) * W_BM;
+    const long long n0 = (j % ntn) * W_BN;
+    if (m0 >= p.M) return;
+#else
     const long long m0 = (long long)(blockIdx.x / ntn) * W_BM;
     const long long n0 = (long long)(blockIdx.x % ntn) * W_BN;
+#endif
     const int nkt = (int)((p.K + W_BK - 1) / W_BK);
     constexpr int NCP = 4;                                      // copies per lane and stage: rows 16 (8 i + wave) .. + 16 of the image
     const uint16_t* pg[NCP];
@@ -2013,7 +2023,7 @@ static int launch_wide(hipStream_t s, const GemmArgs& p) {
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    const long long grid = ((p.M + W_BM - 1) / W_BM) * ((p.W + W_BN - 1) / W_BN);
+    const long long grid = (((p.M + W_BM - 1) / W_BM + 7) / 8 * 8) * ((p.W + W_BN - 1) / W_BN);     // (row blocks padded to eight: XCD map)
     hipLaunchKernelGGL(gemm_nt_wide_kernel, dim3((unsigned)grid), dim3(512), W_LDS, s, p);
     return dhaug_launch_status();
 }
