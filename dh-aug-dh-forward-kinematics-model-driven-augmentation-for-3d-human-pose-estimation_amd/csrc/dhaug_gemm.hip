@@ -576,7 +576,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_big_kernel(GemmArgs p) {
 // requests, by LDS-DMA or through registers alike, once 48 KB per workgroup are in flight and nothing waits in between.  Tried:
 // one dword load per wave and stage, eight stages ahead, to warm L2 -- 64 lines per instruction: 45 -> 61 us.)  Grouping the four 1 536-row branch
 // layers of a motion critic into one launch of these tiles (96 workgroups, 45 us) buys nothing over four launches of 64 x 64 tiles
-// (13 us each) -- that launch form was written, measured and removed.
+// (13 us each) -- that launch form was written, measured and removed.  So was a four-wave form of this kernel (128 x 128 per wave: 0.5 KB
+// of fragment reads per matrix instruction instead of 0.75 -- LDS reads and the matrix pipe are both ~1 000 clocks per stage here):
+// 256 accumulator registers + two fragment sets leave hipcc 96 spilled registers inside the k loop, and scratch reloads are entries of
+// the memory counter the stage waits count.
 // ---------------------------------------------------------------------------------------------------
 constexpr int W_BM = 256, W_BN = 256, W_BK = 32, W_NSTG = 5;
 constexpr int W_STG = (W_BM + W_BN) * W_BK * 2;                              // 32 768 bytes per stage
