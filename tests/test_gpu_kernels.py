@@ -222,13 +222,14 @@ def test_gemm_nt_epilogues(ops, act, slope):
     assert maxabs(cf2, ref2) <= 3e-5 * ref2.abs().max().item()
 
 
-def test_gemm_nt_big_tiles_epilogues(ops):
-    """the 128 x 256-tile kernel with everything the DenseDim-1000 training layers ask of it: bias + bf16 residual + ReLU with a
-    zero-padded bf16 output (forward), and the masked input-gradient form (backward / tangent); against fp64 on the bf16
-    operands and against the 64 x 64-tile kernel it replaces for long batches"""
+@pytest.mark.parametrize("M", [4608 + 40, 10240 + 40])
+def test_gemm_nt_big_tiles_epilogues(ops, M):
+    """the 128 x 256-tile kernel (4 648 rows) and the 256 x 256-tile kernel (10 280 rows: 164 tiles) with everything the DenseDim-1000
+    training layers ask of them: bias + bf16 residual + ReLU with a zero-padded bf16 output (forward), and the masked input-gradient
+    form (backward / tangent); against fp64 on the bf16 operands and against the 64 x 64-tile kernel they replace for long batches"""
     import os
     gen = torch.Generator().manual_seed(5)
-    M, N, K, Kp = 4608 + 40, 1000, 1000, 1008
+    N, K, Kp = 1000, 1000, 1008
     A = torch.zeros(M, Kp); A[:, :K] = torch.randn(M, K, generator=gen) * 0.5
     W = torch.zeros(N, Kp); W[:, :K] = torch.randn(N, K, generator=gen) / K ** 0.5
     R = torch.zeros(M, Kp); R[:, :N] = torch.randn(M, N, generator=gen)
