@@ -324,6 +324,12 @@ __device__ __forceinline__ void p_copy16(const void* g, unsigned char* lds_wave_
 // compute), and with 1.5 workgroups per CU little overlaps across them.  The template's other instantiation, 64 x 128 tiles with six
 // stages (one workgroup per CU, all 192 resident at once), is SLOWER (17.5 us) and is not dispatched; requesting a stage's eight
 // fragment reads before its four matrix instructions and alternating two accumulator sets (the whole-stage path below) bought 3 %.
+#ifdef DHAUG_PIPE_TIMING
+__device__ long long g_pipe_stamps[256];
+#define PIPE_STAMP(i) if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 256) g_pipe_stamps[i] = (long long)__builtin_readcyclecounter();
+#else
+#define PIPE_STAMP(i)
+#endif
 template <int BN, int NSTG>
 __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void gemm_nt_pipe_kernel(GemmArgs p) {
     constexpr int BM = 64;
@@ -373,16 +379,21 @@ __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void gemm_nt_pipe_kernel(Gem
     for (int s = 0; s < NSTG - 1; ++s)
         if (s < nkt && !(p.abl & 4)) copy_stage(s);
     const int rowa = wm * 32 + (lane & 31);
+    PIPE_STAMP(0)
     for (int kt = 0; kt < nkt; ++kt) {
         // stage kt must have landed; younger: stages kt+1 .. kt+NSTG-2 (NCP copies each) where they exist
         const int younger = nkt - 1 - kt;
+        PIPE_STAMP(4 + 4 * kt)
         if (NSTG >= 6 && younger >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NCP) : "memory");
         else if (NSTG >= 5 && younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NCP) : "memory");
         else if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCP) : "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCP) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PIPE_STAMP(5 + 4 * kt)
         p_lds_barrier();                                        // everybody's copies of stage kt are in LDS, stage kt-1 is released
+        PIPE_STAMP(6 + 4 * kt)
         if (kt + NSTG - 1 < nkt && !(p.abl & 4)) copy_stage(kt + NSTG - 1);
+        PIPE_STAMP(7 + 4 * kt)
         if (p.abl & 2) continue;
         const unsigned char* bufA = smem_raw + (kt % NSTG) * STG;
         const unsigned char* bufB = bufA + BM * BK * 2;
@@ -409,6 +420,8 @@ __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void gemm_nt_pipe_kernel(Gem
                     fw[ks][u] = *reinterpret_cast<const bf16x8*>(bufB + rowb * (BK * 2) + ((chunk ^ ((rowb >> 1) & 7)) << 4));
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);                  // (left alone the scheduler sinks every read next to its MFMA,
+                                                                //  with a full lgkmcnt(0) in front of each)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -433,6 +446,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void gemm_nt_pipe_kernel(Gem
     for (int u = 0; u < TN; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[u][r] += acc2[u][r];
+    PIPE_STAMP(1)
     if (p.abl & 1) return;
     p_lds_barrier();                                            // the staging buffers become the C tile
     {
@@ -445,6 +459,123 @@ __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void gemm_nt_pipe_kernel(Gem
                 f32x4 v = {acc[u][4 * g], acc[u][4 * g + 1], acc[u][4 * g + 2], acc[u][4 * g + 3]};
                 *reinterpret_cast<f32x4*>(sC + m * CS + n) = v;
             }
+    }
+    p_lds_barrier();
+    PIPE_STAMP(2)
+    nt_store_tile<BM, BN>(p, sC, m0, n0, tid);
+    PIPE_STAMP(3)
+}
+
+// *(r4)* The same 64 x 64 tiles with the fragment reads taken out of the stage's critical path.  Phase stamps of the kernel above
+// (`tools/stamp_pipe.py`, one workgroup per CU): a stage is wait + barrier, ~300 clocks of copy issue, and ~600 of "read eight
+// fragments, wait for them, four matrix instructions" -- nothing of it overlaps.  Here the fragments of stage kt + 1 are requested
+// right behind the barrier that publishes them and travel under the matrix instructions of stage kt (two fragment sets, the k loop
+// unrolled by two); a stage's buffer is free as soon as its fragments are in registers, so the copy issued behind the barrier is
+// stage kt + 4's: FOUR stages buffered or in flight with the same four buffers.
+__global__ __launch_bounds__(256, 2) void gemm_nt_pipe2_kernel(GemmArgs p) {
+    constexpr int BM = 64, BN = 64, NSTG = 4, NCP = 4;
+    constexpr int CS = BN + 4;
+    constexpr int STG = (BM + BN) * BK * 2;                                  // 16 384 bytes per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* sC = reinterpret_cast<float*>(smem_raw);             // [BM][CS], reuses the staging buffers
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                    // 2 x 2 waves, one 32 x 32 MFMA tile each
+    const long long ntn = (p.W + BN - 1) / BN;
+    const long long m0 = (long long)(blockIdx.x / ntn) * BM;
+    const long long n0 = (long long)(blockIdx.x % ntn) * BN;
+    const int nkt = (int)((p.K + BK - 1) / BK);
+    const uint16_t* pg[NCP];
+    int rowoff[NCP];
+#pragma unroll
+    for (int i = 0; i < NCP; ++i) {
+        const int row0 = (4 * i + wave) * 8, row = row0 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+        if (i < BM / 32) {
+            const long long gm = m0 + row;
+            pg[i] = p.A + (gm < p.M ? gm : p.M - 1) * p.lda + c * 8;
+        } else {
+            const long long gn = n0 + row - BM;
+            pg[i] = p.B + (gn < p.N ? gn : p.N - 1) * p.ldb + c * 8;
+        }
+        rowoff[i] = row0 * (BK * 2);
+    }
+    auto copy_stage = [&](int kt) {
+        unsigned char* base = smem_raw + (kt % NSTG) * STG;
+        long long k0 = (long long)kt * BK;
+        if (k0 + BK > p.K) k0 = p.K - BK > 0 ? p.K - BK : 0;   // short last stage: the last full window (K >= 64)
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) p_copy16(pg[i] + k0, base + rowoff[i]);
+    };
+    const int rowa = wm * 32 + (lane & 31), rowb = wn * 32 + (lane & 31), hh = lane >> 5;
+    struct Frags { bf16x8 x[4], w[4]; };
+    auto read_frags = [&](int kt, Frags& f) {
+        const unsigned char* bufA = smem_raw + (kt % NSTG) * STG;
+        const unsigned char* bufB = bufA + BM * BK * 2;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int chunk = 2 * ks + hh;
+            f.x[ks] = *reinterpret_cast<const bf16x8*>(bufA + rowa * (BK * 2) + ((chunk ^ ((rowa >> 1) & 7)) << 4));
+            f.w[ks] = *reinterpret_cast<const bf16x8*>(bufB + rowb * (BK * 2) + ((chunk ^ ((rowb >> 1) & 7)) << 4));
+        }
+    };
+    f32x16 acc, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc2[r] = 0.0f; }
+#pragma unroll
+    for (int s = 0; s < NSTG; ++s)
+        if (s < nkt) copy_stage(s);
+    {
+        const int younger = nkt - 1 < 3 ? nkt - 1 : 3;           // stages 1 .. 3 may still fly
+        if (younger == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p_lds_barrier();
+    }
+    Frags f0, f1;
+    read_frags(0, f0);
+    auto step = [&](int kt, const Frags& cur, Frags& nxt) {
+        if (kt + 1 < nkt) {
+            // stage kt + 1 must have landed; issued so far: stages up to min(kt + 3, nkt - 1)
+            const int younger = nkt - 2 - kt < 2 ? nkt - 2 - kt : 2;
+            if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            p_lds_barrier();                                    // stage kt + 1 is in LDS for everybody; everybody holds stage kt's fragments
+            if (kt + NSTG < nkt) copy_stage(kt + NSTG);         // (into stage kt's buffer)
+            read_frags(kt + 1, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const long long kbeg = (long long)kt * BK;
+        int ks0 = 0;
+        if (kbeg + BK > p.K && p.K >= BK) ks0 = (int)((kbeg - (p.K - BK)) >> 4);
+        const int ks1 = p.K >= BK ? 4 : (int)(p.K >> 4);
+        if (ks0 == 0 && ks1 == 4) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.w[0], cur.x[0], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.w[1], cur.x[1], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.w[2], cur.x[2], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.w[3], cur.x[3], acc2, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                if (ks >= ks0 && ks < ks1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.w[ks], cur.x[ks], acc, 0, 0, 0);
+        }
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        step(kt, f0, f1);
+        if (kt + 1 < nkt) step(kt + 1, f1, f0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+    p_lds_barrier();                                            // the staging buffers become the C tile
+    {
+        const int m = wm * 32 + (lane & 31);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = wn * 32 + 8 * g + 4 * (lane >> 5);
+            f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            *reinterpret_cast<f32x4*>(sC + m * CS + n) = v;
+        }
     }
     p_lds_barrier();
     nt_store_tile<BM, BN>(p, sC, m0, n0, tid);
@@ -2123,6 +2254,10 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
     if (width > 64 && K >= 64 && lda >= 64 && ldb >= 64 && getenv("DHAUG_GEMM_NOPIPE") == nullptr) {
         const long long grid = ((M + 63) / 64) * ((width + 63) / 64);
         p.abl = getenv("DHAUG_BIG_ABL") ? atoi(getenv("DHAUG_BIG_ABL")) : 0;   // (development: timing only)
+        if (getenv("DHAUG_GEMM_PIPE1") == nullptr) {
+            hipLaunchKernelGGL(gemm_nt_pipe2_kernel, dim3((unsigned)grid), dim3(256), 4 * (64 + 64) * BK * 2, s, p);
+            return dhaug_launch_status();
+        }
         hipLaunchKernelGGL((gemm_nt_pipe_kernel<64, 4>), dim3((unsigned)grid), dim3(256), 4 * (64 + 64) * BK * 2, s, p);
         return dhaug_launch_status();
     }
@@ -2166,6 +2301,11 @@ int dhaug_gemm_bf16_dmask_pad(const uint16_t* A, int64_t lda, const uint16_t* B,
                           nullptr, 0, M, N, K, DHAUG_ACT_NONE, 0.0f, dmask, ld_dmask, dneg, &done, stream);
 }
 
+#ifdef DHAUG_PIPE_TIMING
+int dhaug_debug_pipe_stamps(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pipe_stamps), sizeof(long long) * (n < 256 ? n : 256));
+}
+#endif
 /* see include/dhaug.h */
 int dhaug_gemm_bf16_dmask_f32(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* residual_f32, int64_t ld_res_f32,
                               const float* dmask, int64_t ld_dmask, int dmask_act, float dmask_slope, float* c_f32, int64_t ldc_f32,
