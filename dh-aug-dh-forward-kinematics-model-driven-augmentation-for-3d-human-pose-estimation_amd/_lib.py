@@ -50,6 +50,7 @@ SIGNATURES = {
     "dhaug_counter_add": [_vp, _i32, _vp],
     "dhaug_frame_diff": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     "dhaug_repack_weights": [_vp, _i32, _vp],
+    "dhaug_gemm_bf16_group": [_vp, _i32, _vp],
     "dhaug_gemm_bf16_dmask_f32": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _f32, _vp, _i64, _i64, _i64, _i64, _vp],
     "dhaug_adam_repack_step": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _f32, _vp, _i32, _i64, _vp, _i32, _vp],
     "dhaug_gp_assemble": [_vp, _vp, _vp, _vp, _i64, _i64, _vp],
@@ -78,6 +79,14 @@ class WfragDesc(ctypes.Structure):
 class RepackDesc(ctypes.Structure):
     """struct dhaug_repack_desc (include/dhaug.h)"""
     _fields_ = [("W", _vp), ("nt", _vp), ("nn", _vp), ("N", _i32), ("K", _i32), ("Kp", _i32), ("Np", _i32)]
+
+
+class GemmDesc(ctypes.Structure):
+    """struct dhaug_gemm_desc (include/dhaug.h)"""
+    _fields_ = [("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("bias", _vp), ("residual", _vp), ("ld_res", _i64),
+                ("residual_f32", _vp), ("ld_res_f32", _i64), ("c_bf16", _vp), ("ldc_bf16", _i64), ("n_pad_zero", _i64),
+                ("c_f32", _vp), ("ldc_f32", _i64), ("M", _i64), ("N", _i64), ("K", _i64), ("act", _i32), ("slope", _f32),
+                ("dmask", _vp), ("ld_dmask", _i64), ("dmask_act", _i32), ("dmask_slope", _f32)]
 
 
 class AdamDesc(ctypes.Structure):

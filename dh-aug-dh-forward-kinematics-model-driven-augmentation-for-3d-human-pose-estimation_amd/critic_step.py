@@ -52,6 +52,11 @@ TN_SIDE_WGS = int(os.environ.get("DHAUG_TN_SIDE_WGS", "128"))
 TN_PHASED = os.environ.get("DHAUG_TN_PHASED") is not None
 TN_MAIN_WGS = int(os.environ.get("DHAUG_TN_MAIN_WGS", "0"))  # workgroups of the second part (0: one per CU)
 
+# the layers of independent branches at the same depth as ONE launch (_Math.mm_group, dhaug_gemm_bf16_group): DHAUG_NT_GROUP=1.  Off by
+# default *(measured)*: alone, four 1 536 x 1000 x 1000 branch layers take 35 us as one launch against 4 x 12.7 (four 512-row ones 14.5
+# against 4 x 9.1) -- but the video iteration runs its four critics on four streams, a 384-workgroup launch leaves a quarter of the
+# card's workgroup slots to the other critics' kernels and a 1 536-workgroup one does not: 17.2 ms per iteration against 15.4.
+NT_GROUP = os.environ.get("DHAUG_NT_GROUP") is not None
 # split-operand arithmetic: one activation-side split per tensor and step (_Math.split0); DHAUG_NO_SPLIT_CACHE=1: one per use
 SPLIT_CACHE = os.environ.get("DHAUG_NO_SPLIT_CACHE") is None
 
@@ -176,6 +181,36 @@ class _Math:
             out.copy_(cf)
             return out
         return cf
+
+    def mm_group(self, calls):
+        """The products of the SAME layer position in several independent branches: `calls` are keyword dicts for mm().  In bf16,
+        where every call is a plain or mask-fused generic GEMM of one shape, they are ONE launch (ops.gemm_nt_group: a motion
+        critic's four / two branch layers); otherwise they run one by one."""
+        if not (self.bf16 and NT_GROUP and 2 <= len(calls) <= ops.NT_GROUP_MAX):
+            return [self.mm(**kw) for kw in calls]
+        members, shape = [], None
+        for kw in calls:
+            a, W, orient = kw["a"], kw["W"], kw["orient"]
+            N, K = W.shape
+            n, k = (N, K) if orient == "nt" else (K, N)
+            kp = ceil16(k)
+            res, mask, mask_act = kw.get("res"), kw.get("mask"), kw.get("mask_act", NONE)
+            masked = mask is not None and mask_act != NONE
+            out = kw.get("out")
+            ok = (a.dtype == BF16 and (a.shape[1] == kp or (a.shape[1] == k and a.stride(0) >= kp)) and a.stride(1) == 1
+                  and not kw.get("out_f32", False) and (res is None or res.dtype == BF16)
+                  and n > 256 and kp > 256 and (out is None or (out.dtype == BF16 and out.stride(1) == 1))
+                  and (not masked or (kw.get("bias") is None and kw.get("act", NONE) == NONE and mask.dtype == BF16
+                                      and getattr(mask, "_dhaug_bits", None) is None and getattr(mask, "_dhaug_bits_cols", None) is None)))
+            sh = (a.shape[0], n, kp, masked)
+            if not ok or (shape is not None and sh != shape):
+                return [self.mm(**kw) for kw in calls]
+            shape = sh
+            Bop = A._w_nt(W, kp, self.prec) if orient == "nt" else A._w_nn(W, self.prec)
+            members.append(dict(A=a, B=Bop, N=n, K=kp, bias=kw.get("bias"), res_bf16=res, act=kw.get("act", NONE), slope=kw.get("slope", 0.0),
+                                dmask=mask if masked else None, dmask_act=mask_act if masked else NONE, dmask_slope=kw.get("slope", 0.0),
+                                out=out, n_pad=ceil16(n)))
+        return ops.gemm_nt_group(members)
 
     def flush(self):
         """launch the collected weight-gradient contractions (before the optimizer step reads the gradient bucket)"""
@@ -490,6 +525,56 @@ class _Branch:
         self.first, self.blocks = _Lin(first, RELU), [_Block(b) for b in blocks]
 
 
+def _layer_major(m, branches):
+    """wide branches of equal depth in bf16: their layers at the same depth run as one launch each (_Math.mm_group)"""
+    return (m.bf16 and NT_GROUP and len(branches) > 1 and branches[0].first.N > 256
+            and all(len(br.blocks) == len(branches[0].blocks) and br.first.N == branches[0].first.N for br in branches))
+
+
+def _fwd_layer_major(m, branches, F, cat, Dw):
+    """sweep 1 of the branches, depth by depth (same products as _Block.fwd, same buffers)"""
+    nb, nblk = len(branches), len(branches[0].blocks)
+    y = [[br.first.fwd(m, F[bi])] for bi, br in enumerate(branches)]
+    h = [[] for _ in range(nb)]
+    for i in range(nblk):
+        hh = m.mm_group([dict(a=y[bi][-1], W=br.blocks[i].fc1.W, orient="nt", bias=br.blocks[i].fc1.b, act=RELU) for bi, br in enumerate(branches)])
+        last = i == nblk - 1
+        yy = m.mm_group([dict(a=hh[bi], W=br.blocks[i].fc2.W, orient="nt", bias=br.blocks[i].fc2.b, res=y[bi][-1], act=RELU,
+                              out=cat[:, bi * Dw:(bi + 1) * Dw] if last else None) for bi, br in enumerate(branches)])
+        for bi in range(nb):
+            h[bi].append(hh[bi]); y[bi].append(yy[bi])
+    return y, h
+
+
+def _bwd_layer_major(m, branches, gcat, h, y, Dw):
+    """sweep 2 through the branches' blocks, depth by depth (same products as _Block.bwd's two-launch form)"""
+    nb, nblk = len(branches), len(branches[0].blocks)
+    a2 = [[None] * nblk + [gcat[:, bi * Dw:(bi + 1) * Dw]] for bi in range(nb)]
+    a1 = [[None] * nblk for _ in range(nb)]
+    for i in range(nblk - 1, -1, -1):
+        g1 = m.mm_group([dict(a=a2[bi][i + 1], W=br.blocks[i].fc2.W, orient="nn", mask=h[bi][i], mask_act=RELU) for bi, br in enumerate(branches)])
+        g2 = m.mm_group([dict(a=g1[bi], W=br.blocks[i].fc1.W, orient="nn", res=a2[bi][i + 1], mask=y[bi][i], mask_act=RELU)
+                         for bi, br in enumerate(branches)])
+        for bi in range(nb):
+            a1[bi][i], a2[bi][i] = g1[bi], g2[bi]
+    return a1, a2
+
+
+def _tan_layer_major(m, branches, u_first, hs, ys):
+    """sweep 3 through the branches' blocks, depth by depth, in place over the interpolated rows of hs / ys (as _Block.tan)"""
+    nb, nblk = len(branches), len(branches[0].blocks)
+    u = [[u_first[bi]] for bi in range(nb)]
+    uh = [[] for _ in range(nb)]
+    for i in range(nblk):
+        t1 = m.mm_group([dict(a=u[bi][-1], W=br.blocks[i].fc1.W, orient="nt", mask=hs[bi][i], mask_act=RELU, out=hs[bi][i])
+                         for bi, br in enumerate(branches)])
+        t2 = m.mm_group([dict(a=t1[bi], W=br.blocks[i].fc2.W, orient="nt", res=u[bi][-1], mask=ys[bi][i], mask_act=RELU, out=ys[bi][i])
+                         for bi, br in enumerate(branches)])
+        for bi in range(nb):
+            uh[bi].append(t1[bi]); u[bi].append(t2[bi])
+    return u, uh
+
+
 def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, input_grad, tangents, pen_view=None, fwd=None):
     """The four sweeps for a critic of the form  cat_b(branch_b(feat_b(x))) -> Linear(100)+ReLU -> myResNet(100) -> Linear(1).
     X (3*rows, W) fp32 = [real; fake; x_hat] (ops.gp_assemble); feats(X) -> one fp32 input per branch (3*rows each);
@@ -505,6 +590,12 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
     if fwd is not None:                                      # one fused launch that saves every layer's output (same buffers)
         r = fwd()
         cat, y, h, m0, mh, m1, logits = r["cat"], r["y"], r["h"], r["m0"], r["mh"], r["m1"], r["logits"]
+    elif _layer_major(m, branches):
+        cat = m.empty(M3, nb * Dw, dev)
+        y, h = _fwd_layer_major(m, branches, F, cat, Dw)
+        m0 = Lm.fwd(m, cat)
+        mh, m1 = Mb.fwd(m, m0)
+        logits = Lo.fwd(m, m1, out_f32=True)
     else:
         cat = m.empty(M3, nb * Dw, dev)
         y, h = [], []
@@ -526,7 +617,10 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
         cat._dhaug_bits_cols = [y[bi][-1]._dhaug_bits for bi in range(nb)]      # (the mask of column block bi: its branch's sign bits)
     gcat = Lm.bwd(m, gz_m0, cat, RELU, 0.0)                  # (3B, nb*D): cotangents at every branch's last fc2
     g1, g2, gin = [], [], []
-    for bi, br in enumerate(branches):
+    if _layer_major(m, branches):
+        g1, g2 = _bwd_layer_major(m, branches, gcat, h, y, Dw)
+        gin = [br.first.bwd(m, g2[bi][0][B2:], None, NONE, 0.0, out_f32=True) for bi, br in enumerate(branches)]
+    for bi, br in enumerate(branches if not gin else []):
         # a2[i]: cotangent at the pre-activation producing y[i]
         a1, a2 = stack_bwd(m, br.blocks, gcat[:, bi * Dw:(bi + 1) * Dw], h[bi], y[bi])
         g1.append(a1); g2.append(a2)
@@ -548,7 +642,11 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
     v, pen = ops.gp_penalty(gv, 2.0 * lam / gv.shape[0])
     T = tangents(v.reshape(g.shape))
     u, uh = [], []
-    for bi, br in enumerate(branches):
+    if _layer_major(m, branches):
+        u_first = [br.first.tan(m, T[bi], ops.tail_rows(y[bi][0], B2), inplace=True) for bi, br in enumerate(branches)]
+        u, uh = _tan_layer_major(m, branches, u_first, [[ops.tail_rows(t, B2) for t in h[bi]] for bi in range(nb)],
+                                 [[ops.tail_rows(t, B2) for t in y[bi][1:]] for bi in range(nb)])
+    for bi, br in enumerate(branches if not u else []):
         u_first = br.first.tan(m, T[bi], ops.tail_rows(y[bi][0], B2), inplace=True)
         uhs, uo = stack_tan(m, br.blocks, u_first, [ops.tail_rows(t, B2) for t in h[bi]], [ops.tail_rows(t, B2) for t in y[bi][1:]])
         u.append([u_first] + uo); uh.append(uhs)

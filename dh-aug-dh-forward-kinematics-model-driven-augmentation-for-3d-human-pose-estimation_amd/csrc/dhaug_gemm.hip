@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void gemm_nt_pipe_kernel(Gem
 // right behind the barrier that publishes them and travel under the matrix instructions of stage kt (two fragment sets, the k loop
 // unrolled by two); a stage's buffer is free as soon as its fragments are in registers, so the copy issued behind the barrier is
 // stage kt + 4's: FOUR stages buffered or in flight with the same four buffers.
-__global__ __launch_bounds__(256, 2) void gemm_nt_pipe2_kernel(GemmArgs p) {
+__device__ __forceinline__ void nt_pipe2_body(const GemmArgs& p, long long tile) {
     constexpr int BM = 64, BN = 64, NSTG = 4, NCP = 4;
     constexpr int CS = BN + 4;
     constexpr int STG = (BM + BN) * BK * 2;                                  // 16 384 bytes per stage
@@ -482,8 +482,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_pipe2_kernel(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;                    // 2 x 2 waves, one 32 x 32 MFMA tile each
     const long long ntn = (p.W + BN - 1) / BN;
-    const long long m0 = (long long)(blockIdx.x / ntn) * BM;
-    const long long n0 = (long long)(blockIdx.x % ntn) * BN;
+    const long long m0 = (tile / ntn) * BM;
+    const long long n0 = (tile % ntn) * BN;
     const int nkt = (int)((p.K + BK - 1) / BK);
     const uint16_t* pg[NCP];
     int rowoff[NCP];
@@ -579,6 +579,43 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_pipe2_kernel(GemmArgs p) {
     }
     p_lds_barrier();
     nt_store_tile<BM, BN>(p, sC, m0, n0, tid);
+}
+__global__ __launch_bounds__(256, 2) void gemm_nt_pipe2_kernel(GemmArgs p) { nt_pipe2_body(p, blockIdx.x); }
+
+// Up to eight independent GEMMs of ONE shape as one launch (blockIdx.y = member): the layers of a motion critic's four / two branches
+// at the same depth (dhaug_gemm_bf16_group).  A 1 536 x 1000 x 1000 layer is 384 of these tiles -- one and a half waves of the card's
+// 512 workgroup slots, behind a launch of its own; four of them are three full waves behind ONE launch.  The member's arguments are
+// read from the kernarg segment with scalar loads (a by-value array indexed dynamically would be copied to scratch).
+constexpr int NT_GROUP_MAX = 8;
+struct GemmGroupArgs { GemmArgs g[NT_GROUP_MAX]; };
+// Which member a workgroup takes: workgroups go to the eight XCDs round-robin and every XCD has its own 4 MB L2, so with 2, 4 or 8
+// members each member gets XCDs of its own (member = XCD * n / 8): an XCD's L2 then holds ONE member's weights (2 MB at DenseDim
+// 1000) beside the activation rows in flight.  *(measured, four 1 536 x 1000 x 1000 members)* dealt member by member the launch takes
+// 37.9 us -- 393 MB of stage fills at 10.4 TB/s, the rate of the Infinity Cache: four weight matrices thrash every L2 -- against
+// 12.7 us for one member alone.
+__global__ __launch_bounds__(256, 2) void gemm_nt_pipe2_group_kernel(GemmGroupArgs grp, int n, int tiles) {
+    (void)grp;
+    int member;
+    long long tile;
+    if (n == 2 || n == 4 || n == 8) {
+        const int per = 8 / n, xcd = blockIdx.x & 7;
+        member = xcd / per;
+        tile = (long long)(blockIdx.x >> 3) * per + (xcd % per);
+    } else {
+        member = blockIdx.x / tiles;
+        tile = blockIdx.x - member * tiles;
+    }
+    if (tile >= tiles || member >= n) return;
+    GemmArgs p;
+    {
+        static_assert(sizeof(GemmArgs) % 8 == 0, "copied as 8-byte words");
+        const unsigned long long __attribute__((address_space(4)))* src = (const unsigned long long __attribute__((address_space(4)))*)(
+            (const unsigned char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + member * sizeof(GemmArgs));
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(&p);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(GemmArgs) / 8); ++i) dst[i] = src[i];
+    }
+    nt_pipe2_body(p, tile);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2167,7 +2204,7 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
                           uint16_t* c_bf16, int64_t ldc_bf16, int64_t n_pad_zero,
                           float* c_f32, int64_t ldc_f32, int64_t M, int64_t N, int64_t K, int act, float slope,
                           const uint16_t* dmask, int64_t ld_dmask, float dneg, bool* mask_done, void* stream,
-                          const float* dmaskf = nullptr, int64_t ld_dmaskf = 0) {
+                          const float* dmaskf = nullptr, int64_t ld_dmaskf = 0, GemmArgs* collect = nullptr) {
     DHAUG_CHECK(M >= 0 && N >= 1 && K >= 16, DHAUG_EINVAL);
     DHAUG_CHECK(act >= DHAUG_ACT_NONE && act <= DHAUG_ACT_LRELU, DHAUG_EINVAL);
     if (M == 0) return DHAUG_OK;
@@ -2185,6 +2222,12 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
     hipStream_t s = (hipStream_t)stream;
     const long long width = (c_bf16 && p.npad > N) ? p.npad : N;
     p.W = width;
+    if (collect != nullptr) {                                    // a member of a group (dhaug_gemm_bf16_group): checked, not launched
+        DHAUG_CHECK(M > 0 && width > 64 && K >= 64 && lda >= 64 && ldb >= 64 && dmaskf == nullptr, DHAUG_EUNSUPPORTED);
+        if (dmask != nullptr) { p.dmask = dmask; p.ld_dmask = ld_dmask; p.dneg = dneg; *mask_done = true; }
+        *collect = p;
+        return DHAUG_OK;
+    }
     if (dmaskf != nullptr) {                                     // (fp32 mask: applied by nt_store_tile -- the kernels that have it)
         DHAUG_CHECK(dmask == nullptr && ld_dmaskf >= N, DHAUG_EINVAL);
         p.dmaskf = dmaskf; p.ld_dmaskf = ld_dmaskf; p.dneg = dneg;
@@ -2299,6 +2342,33 @@ int dhaug_gemm_bf16_dmask_pad(const uint16_t* A, int64_t lda, const uint16_t* B,
     bool done = false;
     return gemm_bf16_impl(A, lda, B, ldb, nullptr, residual, ld_res, nullptr, 0, c_bf16, ldc_bf16, n_pad_zero > N ? n_pad_zero : N,
                           nullptr, 0, M, N, K, DHAUG_ACT_NONE, 0.0f, dmask, ld_dmask, dneg, &done, stream);
+}
+
+/* see include/dhaug.h */
+int dhaug_gemm_bf16_group(const dhaug_gemm_desc* d, int n, void* stream) {
+    DHAUG_CHECK(n >= 1 && n <= NT_GROUP_MAX, DHAUG_EINVAL);
+    DHAUG_CHECK_PTR(d);
+    GemmGroupArgs ga;
+    for (int i = 0; i < n; ++i) {
+        const dhaug_gemm_desc& e = d[i];
+        DHAUG_CHECK(e.M == d[0].M && e.N == d[0].N && e.K == d[0].K && e.M > 0, DHAUG_EUNSUPPORTED);
+        DHAUG_CHECK(e.dmask_act >= DHAUG_ACT_NONE && e.dmask_act <= DHAUG_ACT_LRELU, DHAUG_EINVAL);
+        const uint16_t* dm = e.dmask_act == DHAUG_ACT_NONE ? nullptr : e.dmask;
+        if (dm) DHAUG_CHECK(e.ld_dmask >= e.N && (reinterpret_cast<uintptr_t>(dm) & 1u) == 0, DHAUG_EALIGN);
+        bool done = false;
+        const int rc = gemm_bf16_impl(e.A, e.lda, e.B, e.ldb, e.bias, e.residual, e.ld_res, e.residual_f32, e.ld_res_f32, e.c_bf16,
+                                      e.ldc_bf16, e.n_pad_zero, e.c_f32, e.ldc_f32, e.M, e.N, e.K, e.act, e.slope, dm, e.ld_dmask,
+                                      e.dmask_act == DHAUG_ACT_RELU ? 0.0f : e.dmask_slope, &done, stream, nullptr, 0, &ga.g[i]);
+        if (rc != DHAUG_OK) return rc;
+        DHAUG_CHECK(ga.g[i].W == ga.g[0].W, DHAUG_EUNSUPPORTED);
+    }
+    const GemmArgs& p = ga.g[0];
+    const long long tiles = ((p.M + 63) / 64) * ((p.W + 63) / 64);
+    long long grid = tiles * n;
+    if (n == 2 || n == 4 || n == 8) grid = (tiles + 8 / n - 1) / (8 / n) * 8;       // (XCD map: see the kernel)
+    DHAUG_CHECK(grid <= 0x7fffffffLL && tiles <= 0x7fffffffLL, DHAUG_EUNSUPPORTED);
+    hipLaunchKernelGGL(gemm_nt_pipe2_group_kernel, dim3((unsigned)grid), dim3(256), 4 * (64 + 64) * BK * 2, (hipStream_t)stream, ga, n, (int)tiles);
+    return dhaug_launch_status();
 }
 
 #ifdef DHAUG_PIPE_TIMING

@@ -323,6 +323,43 @@ def gemm_nt_dmask(A, B, N, K, dmask, dmask_act, dmask_slope=0.0, res_bf16=None, 
     return out
 
 
+NT_GROUP_MAX = 8
+
+
+def gemm_nt_group(members):
+    """Up to NT_GROUP_MAX independent GEMMs of one shape as ONE launch (dhaug_gemm_bf16_group).  members: dicts with A, B (bf16
+    operands), N, K and optionally bias, res_bf16, act, slope, dmask, dmask_act, dmask_slope, out (bf16 (M, >= N) view), n_pad.
+    Each computes act(A B^T + bias + res) * dmask_act'(dmask) like gemm_nt / gemm_nt_dmask; returns the outputs."""
+    assert 1 <= len(members) <= NT_GROUP_MAX
+    arr = (_lib.GemmDesc * len(members))()
+    outs, keep = [], []
+    for d, m in zip(arr, members):
+        A, B, N, K = m["A"], m["B"], m["N"], m["K"]
+        assert A.dtype == BF16 and B.dtype == BF16
+        M = A.shape[0]
+        out = m.get("out")
+        n_pad = m.get("n_pad", ceil_to(N, 16))
+        if out is None:
+            out = torch.empty((M, max(n_pad, ceil_to(N, 8))), dtype=BF16, device=A.device)
+        assert out.dtype == BF16 and out.stride(1) == 1 and out.shape[0] == M
+        n_pad = min(max(n_pad, N), out.shape[1])
+        res, dm, bias = m.get("res_bf16"), m.get("dmask"), m.get("bias")
+        d.A, d.lda, d.B, d.ldb = _p(A), A.stride(0), _p(B), B.stride(0)
+        d.bias = _p(bias)
+        d.residual, d.ld_res = _p(res), 0 if res is None else res.stride(0)
+        d.residual_f32, d.ld_res_f32 = None, 0
+        d.c_bf16, d.ldc_bf16, d.n_pad_zero = _p(out), out.stride(0), n_pad
+        d.c_f32, d.ldc_f32 = None, 0
+        d.M, d.N, d.K = M, N, K
+        d.act, d.slope = int(m.get("act", 0)), float(m.get("slope", 0.0))
+        d.dmask, d.ld_dmask = _p(dm), 0 if dm is None else dm.stride(0)
+        d.dmask_act, d.dmask_slope = int(m.get("dmask_act", 0)) if dm is not None else 0, float(m.get("dmask_slope", 0.0))
+        outs.append(out)
+        keep.append((A, B, res, dm, bias))
+    _lib.call("dhaug_gemm_bf16_group", arr, len(members), _stream())
+    return outs
+
+
 def gemm_nt_dmask_f32(A, B, N, K, dmask, dmask_act, dmask_slope=0.0, res_f32=None, out=None):
     """(A[M,K] B[N,K]^T + res) * act'(dmask) in the split-operand arithmetic: fp32 result / residual / mask (M, N), A and B the
     operands split_bf16 makes (K = terms * padded width)."""

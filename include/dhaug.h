@@ -282,6 +282,26 @@ int dhaug_gemm_tn_bf16_rows(const uint16_t* A, int64_t lda, const uint16_t* B, i
                             float* C, int64_t ldc, float* colsum_a, int64_t colsum_rows, int64_t M, int64_t N1, int64_t N2,
                             int accumulate, void* stream);
 
+/* n <= 8 independent GEMMs of the same (M, N, K) as ONE launch (64 x 64 tiles, blockIdx.y = member): member i computes what
+ * dhaug_gemm_bf16 (dmask == NULL or dmask_act == DHAUG_ACT_NONE) / dhaug_gemm_bf16_dmask_pad compute from the same fields --
+ * c = act(A B^T + bias + residual + residual_f32), then * dmask_act'(dmask).  For the branches of a motion critic
+ * (R/models_Fk_GAN/Fk_discriminator.py:381-587: four / two stacks of identical layers over different features): a 1 536 x 1000 x 1000
+ * layer alone is one and a half waves of the card's workgroup slots behind a launch of its own.  N > 64, K >= 64; everything else
+ * as dhaug_gemm_bf16. */
+typedef struct dhaug_gemm_desc {
+    const uint16_t* A; int64_t lda;
+    const uint16_t* B; int64_t ldb;
+    const float* bias;
+    const uint16_t* residual; int64_t ld_res;
+    const float* residual_f32; int64_t ld_res_f32;
+    uint16_t* c_bf16; int64_t ldc_bf16; int64_t n_pad_zero;
+    float* c_f32; int64_t ldc_f32;
+    int64_t M, N, K;
+    int32_t act; float slope;
+    const uint16_t* dmask; int64_t ld_dmask; int32_t dmask_act; float dmask_slope;
+} dhaug_gemm_desc;
+int dhaug_gemm_bf16_group(const dhaug_gemm_desc* members, int n, void* stream);
+
 /* The weight / bias gradients of ALL layers of a critic step in one launch (+ one small launch that sums the partial
  * results): layer i computes C[N1,N2] (+)= A[M,N1]^T * B[M,N2] and colsum_a[N1] (+)= column sums of A over rows
  * [0, colsum_rows), M and colsum_rows multiples of 32, operands bf16 with rows readable up to ceil8(N) columns (of every

@@ -281,6 +281,37 @@ def test_motion_critic_step_vs_reference(M, golden, tag):
             assert maxabs(p.detach().cpu()[well], g["new__" + k][well]) <= 3e-6, k
 
 
+@pytest.mark.parametrize("tag", ["m3", "m2"])
+def test_motion_critic_step_branch_layers_grouped_equals_layer_by_layer(M, tag, monkeypatch):
+    """DenseDim 1000, bf16: the layers of a motion critic's four / two branches at the same depth as ONE launch each
+    (critic_step._layer_major, dhaug_gemm_bf16_group) against one launch per layer -- same kernel body, same operands: scalars,
+    gradients and the weights after Adam bit for bit"""
+    from dhaug_amd import critic_step as CS
+    from dhaug_amd.models_Fk_GAN import Fk_discriminator as dis
+    B, R, D = 96, 9, 1000
+    args = _args(batch_size=B, single_or_multi_train_mode="multi", architecture="3,3", video_Dis_DenseDim_3D=D, video_Dis_DenseDim_2D=D)
+    cls = dis.Video_motion_Fk_3D_Discriminator if tag == "m3" else dis.Video_motion_Fk_2D_Discriminator
+    gen = torch.Generator().manual_seed(5)
+    w = 48 if tag == "m3" else 32
+    real = torch.randn(B, R, w, generator=gen) * 0.3
+    fake = real + 0.05 * torch.randn(B, R, w, generator=gen)
+    alpha = torch.rand(B if tag == "m3" else B * R, 1, generator=gen)
+    res = []
+    for grouped in (True, False):
+        monkeypatch.setattr(CS, "NT_GROUP", grouped)
+        torch.manual_seed(7)
+        net = cls("cuda", args, R)
+        net.precision = "bf16"
+        net = net.cuda()
+        opt = M.train.FusedAdam(net.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        W, C = M.train.train_Fk_discriminator(net, real.cuda(), fake.cuda(), Summary(), None, "motion_" + tag, opt, args,
+                                              dis_mode="motion" if tag == "m3" else "single", alpha=alpha.cuda())
+        res.append((W.item(), C.item(), opt.flat_grad.clone(), opt.flat_param.clone()))
+    a, b = res
+    assert a[0] == b[0] and a[1] == b[1] and torch.isfinite(a[2]).all()
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+
+
 # ------------------------------------------------------------------------------- BASELINE configs[4] widths (DenseDim 1000)
 def _video_nets(M, B, R, D, prec):
     from dhaug_amd.function_aug.config import synth_args

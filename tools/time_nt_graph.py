@@ -14,7 +14,9 @@ for M in (512, 1536, 4608):
     b = torch.zeros(N, device="cuda")
     y = (torch.randn(M, Kp, device="cuda") * 0.1).bfloat16()
     out = torch.empty(M, Kp, device="cuda", dtype=torch.bfloat16)
-    fns = dict(fwd=lambda: ops.gemm_nt(x, w, N, Kp, bias=b, act=1, out_bf16=True, n_pad=Kp, c_bf16=out),
+    xs = [x.clone() for _ in range(4)]; ws = [w.clone() for _ in range(4)]; os_ = [out.clone() for _ in range(4)]
+    grp = lambda n: (lambda: ops.gemm_nt_group([dict(A=xs[i], B=ws[i], N=N, K=Kp, bias=b, act=1, out=os_[i], n_pad=Kp) for i in range(n)]))
+    fns = dict(fwd=lambda: ops.gemm_nt(x, w, N, Kp, bias=b, act=1, out_bf16=True, n_pad=Kp, c_bf16=out), group2=grp(2), group4=grp(4),
                res=lambda: ops.gemm_nt(x, w, N, Kp, bias=b, res_bf16=y, act=1, out_bf16=True, n_pad=Kp, c_bf16=out),
                dmask=lambda: ops.gemm_nt_dmask(x, w, N, Kp, y, 1, 0.0, out=out))
     line = []
