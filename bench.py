@@ -519,7 +519,7 @@ def main():
                     te, ce = timed(steps[name], k, 5 if name == "gan_step" else 3)
                     if name == "gan_step" and world == 1 and a.graph == "auto":
                         # the same iterations as captured hipGraphs: the faster form is the one reported (as --workload gan_step
-                        # would pick it); which one wins depends on the box's host (eager issues 137 C-ABI calls per iteration)
+                        # would pick it); which one wins depends on the box's host (eager issues ~110-130 C-ABI calls per iteration)
                         try:
                             from dhaug_amd.graphs import GraphedGanIteration
                             gg = GraphedGanIteration(T.gan_iteration, args, models, ["S1"], summary)
