@@ -90,6 +90,7 @@ class _Math:
         self.prec, self.bf16 = prec, prec == "bf16"
         self.T = 1 if self.bf16 else A.TERMS[prec]
         self.tn = []                                 # weight-gradient contractions waiting for the grouped launch (flush)
+        self.tn2, self._tn_slots = [], set()         # split-operand arithmetic: second contributions to a slot already in self.tn
         self._splits, self._split_src = [], []       # split-operand arithmetic: (address, rows, cols, mode, split) of this step
         self._casts = {}                             # bf16: the casts of fp32 inputs made in this step
 
@@ -227,6 +228,9 @@ class _Math:
         if self.tn:
             ops.gemm_tn_group(self.tn)
             self.tn = []
+        if self.tn2:
+            ops.gemm_tn_group(self.tn2)
+        self.tn2, self._tn_slots = [], set()
         self._splits, self._split_src, self._casts = [], [], {}
 
     def flush_side(self):
@@ -283,7 +287,22 @@ class _Math:
                 ops.colsum(gb if colsum_rows is None else gb[:colsum_rows], N=N, out=bslot, accumulate=True)
             return
         gc, xc = g if g.is_contiguous() else g.contiguous(), x if x.is_contiguous() else x.contiguous()
-        A._raw_outer(gc, xc, N, K, self.prec, out=wslot, split=(self.split0(gc, N, 1), self.split0(xc, K)))
+        g1, x3 = self.split0(gc, N, 1), self.split0(xc, K)
+        TM, Np, Kp = self.T * gc.shape[0], ceil16(N), ceil16(K)
+        if TN_GROUP and ops.tn_group_ok(TM, min(N, 256), min(K, 256), 0) and (wslot.data_ptr(), 2) not in self._tn_slots:
+            # the split-operand contraction (ONE contraction over T * M rows: autograd_ops._raw_outer) joins the step's grouped launch
+            # like a bf16 one.  A second contribution to the same gradient (the interpolated rows' part) waits for a second launch:
+            # the items of one launch are summed into their slots concurrently.
+            item = (g1.view(TM, Np), x3.view(TM, Kp), N, K, wslot, None, 0, True, TM, None, None)
+            key = wslot.data_ptr()
+            if key in self._tn_slots:
+                self.tn2.append(item)
+                self._tn_slots.add((key, 2))         # (a third contribution would run on its own, right away)
+            else:
+                self.tn.append(item)
+                self._tn_slots.add(key)
+        else:
+            A._raw_outer(gc, xc, N, K, self.prec, out=wslot, split=(g1, x3))
         if bslot is not None:
             ops.colsum(g if g.is_contiguous() else g.contiguous(), N=N, out=bslot, accumulate=True)
 
