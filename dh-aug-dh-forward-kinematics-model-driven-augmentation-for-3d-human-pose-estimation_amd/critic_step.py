@@ -121,8 +121,8 @@ class _Math:
         are each an operand of one sweep AND of sweep 4 (there as row ranges of the same tensor), and a split moves 3.5 x the
         bytes of the tensor it splits (the splits were 29 of the step's 95 ms).  The sources are kept referenced until flush()
         (no address is reused inside a step); nothing in the schedule writes a tensor after it was an operand."""
-        if not a.is_contiguous():
-            return ops.split_bf16(a.contiguous(), mode, self.T, ceil16(k))
+        if not a.is_contiguous():                    # (a column block: split where it lies, one per use)
+            return ops.split_bf16(a if (a.dim() == 2 and a.stride(1) == 1) else a.contiguous(), mode, self.T, ceil16(k))
         p, rows, cols = a.data_ptr(), a.shape[0], a.shape[1]
         if SPLIT_CACHE and cols == k:
             for bp, brows, bcols, bmode, sp in self._splits:
@@ -286,7 +286,8 @@ class _Math:
             if bslot is not None and narrow:
                 ops.colsum(gb if colsum_rows is None else gb[:colsum_rows], N=N, out=bslot, accumulate=True)
             return
-        gc, xc = g if g.is_contiguous() else g.contiguous(), x if x.is_contiguous() else x.contiguous()
+        rowm = lambda t: t if (t.dim() == 2 and t.stride(1) == 1) else t.contiguous()      # (row-major, any row pitch)
+        gc, xc = rowm(g), rowm(x)
         g1, x3 = self.split0(gc, N, 1), self.split0(xc, K)
         TM, Np, Kp = self.T * gc.shape[0], ceil16(N), ceil16(K)
         if TN_GROUP and ops.tn_group_ok(TM, min(N, 256), min(K, 256), 0) and (wslot.data_ptr(), 2) not in self._tn_slots:

@@ -248,11 +248,16 @@ def cast_transpose_bf16(src, pad_cols=None):
 def split_bf16(src, mode, terms, pad_cols=None):
     """fp32 (rows, cols) -> bf16 (rows, terms*pad): see dhaug_split_bf16 (mode 0 activation side, 1 weight side)."""
     s = _dev(src, torch.float32, "split_bf16")
-    s = s.reshape(-1, s.shape[-1])
+    if s.dim() == 2 and s.stride(1) == 1 and s.stride(0) >= s.shape[1]:
+        ld = s.stride(0)                              # a column block of a wider buffer is read where it lies
+    else:
+        s = s.reshape(-1, s.shape[-1])
+        s = s if s.is_contiguous() else s.contiguous()
+        ld = s.shape[1]
     rows, cols = s.shape
     pad_cols = ceil_to(cols, 16) if pad_cols is None else pad_cols
     dst = torch.empty((rows, terms * pad_cols), dtype=BF16, device=s.device)
-    _lib.call("dhaug_split_bf16", _p(s), cols, _p(dst), rows, cols, pad_cols, mode, terms, _stream())
+    _lib.call("dhaug_split_bf16", _p(s), ld, _p(dst), rows, cols, pad_cols, mode, terms, _stream())
     return dst
 
 
