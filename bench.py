@@ -110,13 +110,20 @@ def profile_stats(name, kernel_substr):
 
 
 def with_profile(block, name, kernel_substr, work):
-    """adds the tracked profile's durations to a roofline block and the fraction that follows from its MEAN (work = flops or
-    bytes per launch; block["peak"] in T or G units per second): `frac` stays the live HIP-event measurement of THIS run"""
+    """adds the tracked profile's durations to a roofline block (work = flops or bytes per launch; block["peak"] in T or G
+    units per second): `frac` / `achieved` become the figures that follow from the profile's MEAN launch duration (what a
+    reader recomputes from profiles/), the live HIP-event measurement of THIS run is kept as frac_events / achieved_events"""
     ps = profile_stats(name, kernel_substr)
+    block["frac_events"], block["achieved_events"], block["frac_source"] = block["frac"], block["achieved"], "HIP events of this run"
     if ps:
+        unit = 1e12 if block["unit"] == "TFLOP/s" else 1e9
         block.update(ps)
-        block["frac_profile_mean"] = work / (ps["profile_mean_us"] * 1e-6) / (1e12 if block["unit"] == "TFLOP/s" else 1e9) / block["peak"]
-        block["frac_profile_min"] = work / (ps["profile_min_us"] * 1e-6) / (1e12 if block["unit"] == "TFLOP/s" else 1e9) / block["peak"]
+        block["frac_profile_mean"] = work / (ps["profile_mean_us"] * 1e-6) / unit / block["peak"]
+        block["frac_profile_min"] = work / (ps["profile_min_us"] * 1e-6) / unit / block["peak"]
+        # the headline fraction is the one the TRACKED profile reproduces (its mean launch duration, clocks as under the
+        # profiler); the live HIP-event figure of this run stays beside it as frac_events / achieved_events / avg_us
+        block["frac"], block["achieved"] = block["frac_profile_mean"], work / (ps["profile_mean_us"] * 1e-6) / unit
+        block["frac_source"] = "mean launch duration in " + ps["profile_file"]
     return block
 
 
@@ -197,6 +204,9 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--reps", type=int, default=5,
+                    help="the block of --steps timed steps is repeated this many times (after ONE warm-up): `value` / `ms_per_step` "
+                         "are the MEDIAN block's, value_min / value_max the slowest / fastest block's")
     ap.add_argument("--prewarm", type=float, default=1.0,
                     help="seconds of the workload run before the W warmup steps, untimed: MI355X clocks take a few hundred ms "
                          "of load to leave their idle state (the same step measures 0.28 ms right after start-up, 0.25 ms warm)")
@@ -395,6 +405,16 @@ def main():
             t = tt.item()
         return t, calls
 
+    def timed_reps(fn, k, w, reps):
+        """`reps` blocks of exactly k steps, each bracketed like timed() (barrier + synchronize on both sides, MAX over ranks);
+        one warm-up in front of the first.  Returns (median block time, calls per step, sorted block times)."""
+        ts, calls = [], 0.0
+        for r in range(max(1, reps)):
+            t, calls = timed(fn, k, w if r == 0 else 0)
+            ts.append(t)
+        ts.sort()
+        return ts[len(ts) // 2], calls, ts
+
     def prewarm(fn, training):
         if a.prewarm <= 0:
             return
@@ -426,18 +446,34 @@ def main():
         it[0] = 0
         tc, _ = timed(steps[a.workload], 10, 5)
         cal["eager_ms"] = tc / 10 * 1e3
+        # (1) CAPTURE on every rank, no replay, no eager warm-up in front of it: the capture issues no collective (FusedAdam
+        #     records where its all-reduces go), so a rank that fails here leaves no peer waiting inside one;
+        # (2) every rank, unconditionally, joins ONE MIN all-reduce of the outcome -- the collective sequence is the same on
+        #     the failure path;
+        # (3) only if all ranks captured is the graph form (whose replay holds the all-reduces) run and timed.  A rank that
+        #     fails INSIDE a replay cannot be recovered from (its peers are in a collective): it reports and exits non-zero,
+        #     the launcher ends the others.  Nothing is re-executed in this process.
         ok = 1.0
         try:
-            mode["graph"] = True
-            it[0] = 0
-            tc, _ = timed(steps[a.workload], 10, 10)
-            cal["graph_ms"] = tc / 10 * 1e3
+            for gstep in (False, True):
+                graphed.prepare(vin3, cam_param, vin2, gstep, (quat, trans, cam9), warmup=0)
         except Exception as ex:                                   # noqa: BLE001
             cal["graph_error"] = repr(ex)[:300]
             ok = 0.0
         flag = torch.tensor([ok], device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = flag.item() > 0
+        cal["captured_on_every_rank"] = bool(ok)
+        if ok:
+            try:
+                mode["graph"] = True
+                it[0] = 0
+                tc, _ = timed(steps[a.workload], 10, 10)
+                cal["graph_ms"] = tc / 10 * 1e3
+            except Exception as ex:                               # noqa: BLE001
+                sys.stderr.write("bench.py rank %d: segmented-graph replay failed (%r); peers are inside a collective -- exiting\n" % (rank, ex))
+                sys.stderr.flush()
+                os._exit(4)
         mode["graph"] = bool(ok and cal.get("graph_ms", 1e30) <= cal["eager_ms"])
         cal["picked"] = "graph" if mode["graph"] else "eager"
         graph_calibration = cal
@@ -455,7 +491,7 @@ def main():
         mode["graph"] = cal["graph"] <= cal["eager"]
         graph_calibration = {"graph_ms": cal["graph"], "eager_ms": cal["eager"], "picked": "graph" if mode["graph"] else "eager"}
         it[0] = 0
-    t, calls = timed(steps[a.workload], a.steps, a.warmup)
+    t, calls, blocks = timed_reps(steps[a.workload], a.steps, a.warmup, a.reps)
     value = N * world * a.steps / t
     out = {"metric": "augmented poses/sec (FK+GAN step), 16-joint batch=65536", "value": value, "unit": "poses/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "prewarm_s": a.prewarm, "ms_per_step": t / a.steps * 1e3,
@@ -464,16 +500,20 @@ def main():
            "config": {"workload": WORKLOADS[a.workload], "batch_per_gpu": B, "frames": R, "poses_per_gpu_per_step": N,
                       "global_batch": N * world, "dense_dim": D, "preAngle": True, "fk_dtype": "f32",
                       "dense_dtype": "bf16 MFMA, fp32 accumulate" if main_prec == "bf16" else "3 x fp16 MFMA (hi+lo operands), fp32 accumulate"},
-           "c_abi_calls_per_step": calls, "hip_graph": bool(mode["graph"]), "graph_calibration": graph_calibration}
+           "c_abi_calls_per_step": calls, "hip_graph": bool(mode["graph"]), "graph_calibration": graph_calibration,
+           # spread of the timed blocks: `value` is the median block; the slowest / fastest block beside it
+           "reps": len(blocks), "value_min": N * world * a.steps / blocks[-1], "value_max": N * world * a.steps / blocks[0],
+           "ms_per_step_min": blocks[0] / a.steps * 1e3, "ms_per_step_max": blocks[-1] / a.steps * 1e3}
 
     # the forward workload in the OTHER arithmetic, same inputs (bf16 <-> parity), with its own step time
     if fwd_like:
         other = "bf16" if main_prec == "f16x3" else "f16x3"
         set_precision(other)
-        to, _ = timed(steps[a.workload], max(5, a.steps // 2), max(3, a.warmup // 2))
         k = max(5, a.steps // 2)
+        to, _, ob = timed_reps(steps[a.workload], k, max(3, a.warmup // 2), a.reps)
         key = "value_bf16" if other == "bf16" else "value_parity"
         out[key] = N * world * k / to
+        out[key + "_min"], out[key + "_max"] = N * world * k / ob[-1], N * world * k / ob[0]
         out[("ms_per_step_bf16" if other == "bf16" else "ms_per_step_parity")] = to / k * 1e3
         out["parity_mode"] = ("f16x3: logits <= 1e-4 rel / poses <= 1e-5 m vs the fp32 reference "
                               "(tests/test_gpu_models.py::test_fused_forward_vs_reference_golden)")
@@ -578,6 +618,55 @@ def main():
                 del m1k, g1k, d31k, d21k
             except Exception as ex:
                 extra["fwd_D1000_error"] = repr(ex)[:200]
+    if not a.no_extra and not video and world == 1 and a.workload == "fwd":
+        # the video iteration at BASELINE.json configs[4]'s per-GPU shape (B = 512 clips x R = 9 frames, DenseDim 1000, the two
+        # frame critics + the two motion critics, G step every fifth iteration): eager and as hipGraphs, ten iterations each
+        # (two G steps), so that the driver's default line carries it
+        try:
+            from dhaug_amd.graphs import GraphedGanIteration
+            Bv, Dv, Rv = 512, 1000, 9
+            Nv = Bv * Rv
+            av = synth_args(Bv, Dv, single_or_multi_train_mode="multi", architecture="3,3", video_Dis_DenseDim_3D=Dv,
+                            video_Dis_DenseDim_2D=Dv, single_dis_warmup_epoch=0)
+            mv = T.video_mode_my_get_poseFk_model(av, None, Forward_Kinematics_DH_Model(av, ["S1"], None), Rv)
+            angv = (torch.randn(Nv, 37, device=dev) * 40).clamp(-180, 180)
+            rwv = ops.fk_forward(angv, torch.rand(Nv, 15, device=dev) * 0.4 + 0.1, torch.randn(Nv, 3, device=dev).clamp(-10, 10) * 0.3)
+            rcv, r2v = ops.world_to_camera_project(rwv, quat, trans, cam9)
+            cpv = torch.zeros(Bv, 16, device=dev)
+            cpv[:, 9:13] = torch.tensor(quat, device=dev)
+            cpv[:, 13:16] = torch.tensor(trans, device=dev)
+            mv["model_G"].GAN_generator_get_bone_length(rcv)
+            v3, v2 = rcv.reshape(Bv, Rv, 16, 3), r2v.reshape(Bv, Rv, 16, 2)
+            sv = argparse.Namespace(epoch=10, train_iter_num=0)
+            gv = GraphedGanIteration(V.video_gan_iteration, av, mv, ["S1"], sv)
+            itv = [0]
+
+            def video_eager():
+                V.video_gan_iteration(av, mv, v3, cpv, v2, ["S1"], sv, None, do_g_step=itv[0] % 5 == 4, camera=(quat, trans, cam9))
+                itv[0] += 1
+
+            def video_graph():
+                gv(v3, cpv, v2, itv[0] % 5 == 4, (quat, trans, cam9))
+                itv[0] += 1
+            tve, cve = timed(video_eager, 10, 5)
+            itv[0] = 0
+            tvg, _ = timed(video_graph, 10, 10)
+            tvb = min(tve, tvg) / 10
+            extra["video_eager_ms_per_step"], extra["video_graph_ms_per_step"] = tve / 10 * 1e3, tvg / 10 * 1e3
+            extra["video_ms_per_step"], extra["video_hip_graph"] = tvb * 1e3, bool(tvg < tve)
+            extra["video_poses_per_s"] = Nv / tvb
+            extra["video_c_abi_calls_per_step_eager"] = cve
+            extra["video_config"] = {"batch_clips": Bv, "frames": Rv, "dense_dim": Dv, "critics": 4}
+            by_v = video_algorithmic_bytes(Dv, Dv, Dv, Bv, Rv)
+            trv = pmc_step_traffic("video")
+            out["roofline_video_step"] = {"kernel": "one video GAN iteration (B = 512 x R = 9, DenseDim 1000): 2 + 2 frame-critic and 4 + 4 motion-critic steps, sampling, G step every 5th",
+                                          "bound": "hbm", "achieved": by_v / tvb / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": by_v / tvb / 1e9 / HBM_PEAK_GBS, "traffic": trv, "traffic_source": pmc_stamp(),
+                                          "algorithmic_bytes_per_iteration": by_v, "traffic_over_algorithmic": (trv / by_v) if trv else None,
+                                          "ms_per_iteration": tvb * 1e3}
+            del gv, mv
+        except Exception as ex:                      # never lose the headline line to an optional measurement
+            extra["video_error"] = repr(ex)[:300]
     out["extra"] = extra
 
     gen_mac, d3_mac, d2_mac = mac_per_pose(D, R)
@@ -729,7 +818,7 @@ def main():
         dist.destroy_process_group()
 
 
-PROFILE_TAG = "r04" if os.path.exists(os.path.join(ROOT, "profiles", "r04_STAMP.txt")) else "r03"
+PROFILE_TAG = next((t for t in ("r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", t + "_STAMP.txt"))), "r03")
 
 
 def pmc_stamp():

@@ -32,6 +32,7 @@ SIGNATURES = {
     "dhaug_gemm_bf16_dbits": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _f32, _vp, _i64, _i64, _vp],
     "dhaug_gemm_block2_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _i64, _vp, _i64, _i64, _vp],
     "dhaug_set_workgroup_cap": [_i32],
+    "dhaug_set_nan_propagation": [_i32],
     "dhaug_rank1_bits_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _f32, _vp],
     "dhaug_gemm_bf16_dbits_wide": [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _i64, _i64, _i64, _i64, _vp],
     "dhaug_gemm_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i32,
@@ -139,6 +140,8 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = ctypes.c_int
+        if os.environ.get("DHAUG_NAN_PROPAGATION", "") in ("1", "true", "yes"):
+            L.dhaug_set_nan_propagation(1)         # fused inference programs: NaN / inf reach the logit (include/dhaug.h)
         _lib = L
     return _lib
 

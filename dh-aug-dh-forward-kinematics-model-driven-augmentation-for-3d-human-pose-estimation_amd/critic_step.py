@@ -215,7 +215,11 @@ class _Math:
 
     def flush(self):
         """launch the collected weight-gradient contractions (before the optimizer step reads the gradient bucket)"""
-        if self.tn and TN_PHASED and getattr(self, "_side", None) is not None and len(self.tn) <= ops._lib.TN_GROUP_MAX:
+        if (self.tn and TN_PHASED and getattr(self, "_side", None) is not None and len(self.tn) <= ops._lib.TN_GROUP_MAX
+                and all(it[2] <= 256 and it[3] <= 256 for it in self.tn) and not self.tn2
+                and len({it[4].data_ptr() for it in self.tn}) == len(self.tn)):
+            # (layers of at most 256 x 256 with distinct gradient slots only: a wide layer is several blocks of the launch, and
+            # the phased form takes one chunk)
             # both parts add into the same gradient slots -- but only their SUMS touch the slots: this part's contractions
             # start now, beside what is left of the side part, and only the sums wait for it
             ws = ops._tn_group_workspace(self.tn[0][0].device)
@@ -223,6 +227,8 @@ class _Math:
             self.join()
             ops.gemm_tn_group(self.tn, phase=2, workspace=ws, max_workgroups=TN_MAIN_WGS)
             self.tn = []
+            self.tn2, self._tn_slots = [], set()
+            self._splits, self._split_src, self._casts = [], [], {}
             return
         self.join()                          # (both parts accumulate into the same gradient slots: never concurrently)
         if self.tn:

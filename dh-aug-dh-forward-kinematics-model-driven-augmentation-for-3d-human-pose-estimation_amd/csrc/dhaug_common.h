@@ -6,6 +6,30 @@
 
 #define DHAUG_WAVE 64
 
+// Development switches (ablations: "timing only, results wrong"; phase stamps; structure variants of the fused kernels) exist in
+// these sources for tools/build_*_abl.sh.  A PRODUCT build defines none of them: any of the names below on the command line is a
+// compile error unless DHAUG_ABLATION_BUILD is defined as well (tools/ define it; __graft_entry__.build_lib never does unless the
+// environment asks for an ablation build by name) -- a stray -DX3_ABL_NOSPLIT cannot yield a library that loads, exports every
+// symbol and computes garbage (tests/test_cpu_boundary.py::test_ablation_switches_need_an_ablation_build).
+#if !defined(DHAUG_ABLATION_BUILD)
+#if defined(T4_ABL_NOSTORE) || defined(T4_ABL_NOCOMPUTE) || defined(ABL_NOWRITE) || defined(ABL_NOREAD) || defined(ABL_NOWLOAD) || \
+    defined(SAVE_ABL_TILE0) || defined(SAVE_ABL_NOSTORE) || defined(SAVE_ABL_NULLSTORES) || defined(MOVE_BATCH_OVERRIDE) || \
+    defined(DHAUG_MLP_TIMING) || defined(DHAUG_MLP_TIMING_UNITS) || defined(DHAUG_STAMP_TID) || defined(DHAUG_PIPE_TIMING) || \
+    defined(W_NO_XCD_MAP) || defined(X3_NWAVES) || defined(X3_SPREAD) || defined(X3_RING) || defined(X3_TIMING) || \
+    defined(X3_STAMP_TID) || defined(X3_REG_STASH) || defined(X3_WS_NT) || defined(X3_EPI_FENCE) || defined(X3_WRITE128) || \
+    defined(X3_ABL_NOSPLIT) || defined(X3_ABL_NOWRITE) || defined(X3_ABL_NOWS) || defined(X3_ABL_NOREAD) || \
+    defined(X3_ABL_NOWLOAD) || defined(X3_ABL_NOEPI) || defined(X3_AB_SPLIT) || defined(X3_PRIO_SEL)
+#error "a development / ablation switch is defined without -DDHAUG_ABLATION_BUILD: this would build a library with wrong results"
+#endif
+#endif
+// run-time ablation selectors (DHAUG_TN256_ABL, DHAUG_BIG_ABL: phases of a kernel switched off, results wrong) are read from the
+// environment in ablation builds only
+#if defined(DHAUG_ABLATION_BUILD)
+#define DHAUG_ABL_ENV(name) (getenv(name) ? atoi(getenv(name)) : 0)
+#else
+#define DHAUG_ABL_ENV(name) 0
+#endif
+
 #define DHAUG_CHECK_PTR(p)        do { if ((p) == nullptr) return DHAUG_EINVAL; } while (0)
 #define DHAUG_CHECK(cond, code)   do { if (!(cond)) return (code); } while (0)
 
@@ -19,6 +43,9 @@ static inline bool dhaug_aligned16(const void* p) { return (reinterpret_cast<uin
 // Workgroups a one-per-CU (persistent) launch may take: 256, or what dhaug_set_workgroup_cap() left it -- two chains of such
 // launches on two streams then run SIDE BY SIDE on disjoint sets of CUs instead of queueing for the whole card.
 extern "C" int dhaug_workgroup_cap_;
+// dhaug_set_nan_propagation(): the fused inference programs apply ReLU as max(v, v * 0) (NaN-propagating) instead of an integer
+// max on the bit pattern (which turns the matrix pipe's -NaN into 0)
+extern "C" int dhaug_nan_propagation_;
 static inline unsigned dhaug_persistent_grid(long long tiles) {
     const long long cap = dhaug_workgroup_cap_ > 0 && dhaug_workgroup_cap_ < 256 ? dhaug_workgroup_cap_ : 256;
     return (unsigned)(tiles < cap ? tiles : cap);

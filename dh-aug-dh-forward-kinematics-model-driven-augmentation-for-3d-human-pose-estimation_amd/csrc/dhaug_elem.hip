@@ -805,6 +805,15 @@ int dhaug_set_workgroup_cap(int n) {
     return old;
 }
 
+int dhaug_nan_propagation_ = 0;
+
+/* see include/dhaug.h */
+int dhaug_set_nan_propagation(int on) {
+    const int old = dhaug_nan_propagation_;
+    dhaug_nan_propagation_ = on != 0;
+    return old;
+}
+
 int dhaug_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
     DHAUG_CHECK(n >= 0, DHAUG_EINVAL);
     if (n == 0) return DHAUG_OK;

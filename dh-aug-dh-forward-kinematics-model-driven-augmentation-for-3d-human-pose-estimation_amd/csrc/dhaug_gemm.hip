@@ -2276,7 +2276,7 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
         getenv("DHAUG_GEMM_NOWIDE") == nullptr && getenv("DHAUG_GEMM_NOBIG") == nullptr && getenv("DHAUG_GEMM_NOPIPE") == nullptr) {
         // long batch, tiles enough for most of the card: 256 x 256 tiles, eight waves (the DenseDim-1000 layers of the frame
         // critics; the 256-wide layers of the split-operand parity arithmetic, K' = 3 K or 6 K)
-        p.abl = getenv("DHAUG_BIG_ABL") ? atoi(getenv("DHAUG_BIG_ABL")) : 0;   // (development: timing only)
+        p.abl = DHAUG_ABL_ENV("DHAUG_BIG_ABL");   // (development: timing only)
         return launch_wide(s, p);
     }
     if (width >= 512 && M >= 4096 && K >= 64 && lda >= 64 && ldb >= 64 && getenv("DHAUG_GEMM_NOBIG") == nullptr &&
@@ -2290,13 +2290,13 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
             configured = true;
         }
         const long long grid = ((M + G_BM - 1) / G_BM) * ((width + G_BN - 1) / G_BN);
-        p.abl = getenv("DHAUG_BIG_ABL") ? atoi(getenv("DHAUG_BIG_ABL")) : 0;
+        p.abl = DHAUG_ABL_ENV("DHAUG_BIG_ABL");
         hipLaunchKernelGGL(gemm_nt_big_kernel, dim3((unsigned)grid), dim3(256), G_LDS, s, p);
         return dhaug_launch_status();
     }
     if (width > 64 && K >= 64 && lda >= 64 && ldb >= 64 && getenv("DHAUG_GEMM_NOPIPE") == nullptr) {
         const long long grid = ((M + 63) / 64) * ((width + 63) / 64);
-        p.abl = getenv("DHAUG_BIG_ABL") ? atoi(getenv("DHAUG_BIG_ABL")) : 0;   // (development: timing only)
+        p.abl = DHAUG_ABL_ENV("DHAUG_BIG_ABL");   // (development: timing only)
         if (getenv("DHAUG_GEMM_PIPE1") == nullptr) {
             hipLaunchKernelGGL(gemm_nt_pipe2_kernel, dim3((unsigned)grid), dim3(256), 4 * (64 + 64) * BK * 2, s, p);
             return dhaug_launch_status();

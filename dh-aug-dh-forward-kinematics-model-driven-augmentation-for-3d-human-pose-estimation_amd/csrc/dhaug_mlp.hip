@@ -47,7 +47,7 @@ enum { U_LOAD_F32 = 0, U_LOAD_BF16 = 1, U_STORE_BF16 = 2, U_GEMM = 3 };
 // max(v, v * 0) in fp32 like the LeakyReLU layers' mul + max (NaN * 0 = NaN, max(NaN, NaN) = NaN), so a diverged network is
 // REPORTED by D_cost as the reference's ATen ops report it.  The inference unit keeps the integer max on the packed bf16
 // pair (v_pk_max_i16: +NaN passes, -NaN -- what the matrix pipe produces -- becomes 0).
-#ifdef DHAUG_MLP_SAVE_TU
+#if defined(DHAUG_MLP_SAVE_TU) || defined(DHAUG_MLP_NAN_SAFE)
 constexpr bool NAN_SAFE_TU = true;
 #else
 constexpr bool NAN_SAFE_TU = false;
@@ -1369,6 +1369,9 @@ int dhaug_mlp_forward(const dhaug_mlp_unit* units, int nunits, int64_t M, void* 
         u.kind = s.kind; u.flags = s.flags; u.src = s.src; u.dst = s.dst; u.res = s.res;
         u.src2 = s.src2; u.ksteps2 = s.ksteps2;
         u.ksteps = s.ksteps; u.N = s.n; u.act = s.act; u.slope = s.slope; u.cols = s.cols; u.ld = s.ld;
+        // dhaug_set_nan_propagation(1): ReLU runs as LeakyReLU with slope 0 -- max(v, v * 0) in fp32, the same value for every
+        // finite v, NaN for NaN / inf (the forward-with-save unit always does this: NAN_SAFE_TU)
+        if (dhaug_nan_propagation_ && s.kind == U_GEMM && s.act == DHAUG_ACT_RELU) { u.act = DHAUG_ACT_LRELU; u.slope = 0.0f; }
         u.g = s.g; u.w = static_cast<const uint16_t*>(s.w); u.w2 = static_cast<const uint16_t*>(s.w2); u.bias = s.bias;
         u.save = static_cast<uint16_t*>(s.save); u.save_ld = s.save_ld;
         u.save_rows = s.save_rows == 0 ? M : (s.save_rows < 0 ? 0 : (s.save_rows < M ? s.save_rows : M));

@@ -80,6 +80,7 @@ constexpr int OUT_PITCH = 68;                                        // floats p
 constexpr int RING = X3_RING;                                              // weight k-steps in registers (two requested ahead)
 constexpr int WS_FLOATS_PER_WAVE = 64 * 128 * 4 / X3_NW;              // 64 lanes x the wave's accumulator values (2 x 4 x 16 of four waves)
 constexpr int WS_REGION_FLOATS = 256 * X3_NW * WS_FLOATS_PER_WAVE;   // one region: every workgroup's tile, 32 MB
+static_assert(2LL * WS_REGION_FLOATS * 4 == DHAUG_MLP_X3_WORKSPACE_BYTES, "include/dhaug.h: DHAUG_MLP_X3_WORKSPACE_BYTES = two regions");
 
 enum { U_LOAD_F32 = 0, U_GEMM = 3, U_LOAD_KCS = 5 };
 enum { F_OUT_F32 = 4, F_T16 = 32 };
@@ -1215,6 +1216,9 @@ int dhaug_mlp_forward_x3(const dhaug_mlp_unit* units, int nunits, int64_t M, voi
         u.kind = s.kind; u.flags = s.flags; u.ksteps = s.ksteps; u.N = s.n; u.act = s.act; u.slope = s.slope; u.cols = s.cols;
         u.ld = s.ld; u.g = s.g; u.w = static_cast<const _Float16*>(s.w); u.bias = s.bias;
         u.plan = 0;
+        // dhaug_set_nan_propagation(1): ReLU as LeakyReLU with slope 0 (max(v, v * 0): NaN / inf reach the logit) instead of
+        // the one-instruction integer max
+        if (dhaug_nan_propagation_ && s.kind == U_GEMM && s.act == DHAUG_ACT_RELU) { u.act = DHAUG_ACT_LRELU; u.slope = 0.0f; }
         DHAUG_CHECK(u.kind == U_LOAD_F32 || u.kind == U_GEMM || u.kind == U_LOAD_KCS, DHAUG_EUNSUPPORTED);
         if (u.kind == U_GEMM) {
             DHAUG_CHECK(okbuf(s.src) && u.ksteps >= 1 && u.ksteps <= 16 && u.N >= 1 && u.N <= 256, DHAUG_EUNSUPPORTED);

@@ -291,7 +291,7 @@ int dhaug_gemm_tn_group_bf16_phase(const dhaug_tn_layer* layers, int n, float* w
     DHAUG_CHECK(dhaug_aligned16(workspace), DHAUG_EALIGN);
     TnGroup g;
     g.nlayers = n;
-    g.abl = getenv("DHAUG_TN256_ABL") ? atoi(getenv("DHAUG_TN256_ABL")) : 0;
+    g.abl = DHAUG_ABL_ENV("DHAUG_TN256_ABL");
     g.ws = workspace;
     double weight[T2_MAX_LAYERS], total = 0.0, bytes2 = 0.0;
     long long stages = 0, blocks = 0;
@@ -308,6 +308,10 @@ int dhaug_gemm_tn_group_bf16_phase(const dhaug_tn_layer* layers, int n, float* w
         // columns are fetched in 16-byte chunks: the operand rows must be readable up to ceil8(N)
         DHAUG_CHECK(s.lda % 8 == 0 && s.ldb % 8 == 0 && s.lda >= ((s.N1 + 7) & ~7) && s.ldb >= ((s.N2 + 7) & ~7), DHAUG_EALIGN);
         DHAUG_CHECK(dhaug_aligned16(s.A) && dhaug_aligned16(s.B), DHAUG_EALIGN);
+        // the layers of one launch are summed into their outputs concurrently (a block with one workgroup adds into C /
+        // colsum_a with a plain read-modify-write): the outputs of a launch must be distinct (include/dhaug.h)
+        for (int j = 0; j < i; ++j)
+            DHAUG_CHECK(layers[j].C != s.C && (s.colsum_a == nullptr || layers[j].colsum_a != s.colsum_a), DHAUG_EINVAL);
         TnLayer& L = g.L[i];
         L.A = s.A; L.B = s.B; L.C = s.C; L.colsum = s.colsum_a;
         L.lda = s.lda; L.ldb = s.ldb; L.ldc = s.ldc; L.cs_rows = s.colsum_a != nullptr ? s.colsum_rows : 0;

@@ -296,6 +296,13 @@ class GraphedGanIteration:
     def __call__(self, inputs_3d, cam_param, inputs_2d, do_g_step, camera, draws=None):
         """draws: None (the iteration draws on the device: graph-safe generator), or a ConstDraws whose DEVICE tensors are
         baked into the graph (it must outlive the graph and keep its values)."""
+        return self.prepare(inputs_3d, cam_param, inputs_2d, do_g_step, camera, draws)(inputs_3d, cam_param, inputs_2d)
+
+    def prepare(self, inputs_3d, cam_param, inputs_2d, do_g_step, camera, draws=None, warmup=2):
+        """the captured form of this call (captured now if it is not yet), WITHOUT replaying it.  warmup = 0: no eager
+        iteration in front of the capture -- with several ranks the capture then issues NO collective (FusedAdam only records
+        where its all-reduces go), so a rank on which the capture fails leaves no peer waiting inside one (bench.py's
+        calibration: every rank captures, all agree on the outcome, only then anything with a collective in it is replayed)."""
         key = (bool(do_g_step), tuple(camera[0]), tuple(camera[1]), tuple(camera[2]),
                tuple(inputs_3d.shape), tuple(cam_param.shape), tuple(inputs_2d.shape), id(draws))
         g = self.graphs.get(key)
@@ -312,7 +319,7 @@ class GraphedGanIteration:
             counts = [o.step_count for o in opts]
             multi = any(o.world_size() > 1 for o in opts)          # collectives between graph segments
             g = self.graphs[key] = (SegmentedCall if multi else (ForkedCall if FORKED else GraphedCall))(
-                run, (inputs_3d, cam_param, inputs_2d), prologue=lambda: [o._repack() for o in opts], state=state)
+                run, (inputs_3d, cam_param, inputs_2d), warmup=warmup, prologue=lambda: [o._repack() for o in opts], state=state)
             for o, c in zip(opts, counts):                     # (host-side bookkeeping of the warm-up calls)
                 o.step_count = c
-        return g(inputs_3d, cam_param, inputs_2d)
+        return g

@@ -247,12 +247,13 @@ def cast_transpose_bf16(src, pad_cols=None):
 
 def split_bf16(src, mode, terms, pad_cols=None):
     """fp32 (rows, cols) -> bf16 (rows, terms*pad): see dhaug_split_bf16 (mode 0 activation side, 1 weight side)."""
-    s = _dev(src, torch.float32, "split_bf16")
-    if s.dim() == 2 and s.stride(1) == 1 and s.stride(0) >= s.shape[1]:
-        ld = s.stride(0)                              # a column block of a wider buffer is read where it lies
+    if src.is_cuda and src.dtype == torch.float32 and src.dim() == 2 and src.stride(1) == 1 and src.stride(0) >= src.shape[1]:
+        # a column block of a wider buffer is read where it lies (no contiguous copy, no realignment: the kernel's vector
+        # path tests the base address and the row pitch itself and falls back to element loads)
+        s, ld = src, src.stride(0)
     else:
+        s = _dev(src, torch.float32, "split_bf16")
         s = s.reshape(-1, s.shape[-1])
-        s = s if s.is_contiguous() else s.contiguous()
         ld = s.shape[1]
     rows, cols = s.shape
     pad_cols = ceil_to(cols, 16) if pad_cols is None else pad_cols
@@ -467,6 +468,22 @@ class workgroup_cap:
             _lib.lib().dhaug_set_workgroup_cap(self.old)
 
 
+class nan_propagation:
+    """with nan_propagation(True): the fused INFERENCE programs launched inside apply ReLU as max(v, v * 0) -- a NaN / inf input
+    row reaches its logit, NaN weights reach every logit, as in the reference (dhaug_set_nan_propagation; process-wide default:
+    DHAUG_NAN_PROPAGATION=1 in the environment)"""
+
+    def __init__(self, on=True):
+        self.on = int(bool(on))
+
+    def __enter__(self):
+        self.old = _lib.lib().dhaug_set_nan_propagation(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.lib().dhaug_set_nan_propagation(self.old)
+
+
 def tn_group_ok(M, N1, N2, colsum_rows):
     """shapes dhaug_gemm_tn_group_bf16 takes (and where it pays: a long batch)"""
     return M >= 1024 and M % 32 == 0 and colsum_rows % 32 == 0 and 1 <= N1 <= 256 and 1 <= N2 <= 256
@@ -500,6 +517,24 @@ def gemm_tn_group(items, max_workgroups=0, phase=0, workspace=None):
                                      cr if c is not None else 0, accumulate, A.shape[0] if M is None else M, la, lb))
         items = flat
     assert phase == 0 or (len(items) <= _lib.TN_GROUP_MAX and workspace is not None)
+    # the items of ONE launch are summed into their outputs concurrently (a block that is left with one workgroup adds its
+    # result into C / colsum with a plain read-modify-write): two items with the same output must not share a launch
+    # (include/dhaug.h, dhaug_gemm_tn_group_bf16).  A later contribution to an output waits for a launch of its own.
+    seen, later = set(), []
+    first = []
+    for it in items:
+        keys = {("C", _p(it[4]))} | ({("s", _p(it[5]))} if it[5] is not None else set())
+        if keys & seen:
+            later.append(it)
+        else:
+            seen |= keys
+            first.append(it)
+    if later:
+        if phase != 0:
+            raise RuntimeError("gemm_tn_group: two items of a phased launch share an output")
+        gemm_tn_group(first, max_workgroups, 0, workspace)
+        gemm_tn_group(later, max_workgroups, 0, workspace)
+        return
     for i0 in range(0, len(items), _lib.TN_GROUP_MAX):
         chunk = items[i0:i0 + _lib.TN_GROUP_MAX]
         arr = (_lib.TnLayer * len(chunk))()

@@ -242,6 +242,17 @@ int dhaug_gemm_bf16_dbits_wide(const uint16_t* A, int64_t lda, const uint16_t* B
  * another stream's, and the two chains run side by side on disjoint sets of CUs instead of queueing for the whole card. */
 int dhaug_set_workgroup_cap(int n);
 
+/* Non-finite values in the fused INFERENCE programs (dhaug_mlp_forward without save targets, dhaug_mlp_forward_x3).  Default
+ * (0): their ReLU is an integer max on the bit pattern -- one instruction in the matrix pipe's shadow -- which lets +NaN pass
+ * and turns the matrix pipe's -NaN into 0: a NaN / inf input row or a NaN weight does NOT reach the logit through a ReLU
+ * layer (LeakyReLU layers, i.e. the 2D critic, always propagate).  on != 0: every ReLU is applied as max(v, v * 0) in fp32
+ * like the forward-with-save unit of the training steps does: a NaN / inf input row gives NaN in ITS logit (no other), NaN
+ * weights give NaN logits everywhere -- what R/models_Fk_GAN/Fk_discriminator.py:180-201 does through ATen (inf * 0 = NaN:
+ * an inf activation becomes NaN one layer earlier than in the reference, the logit is NaN either way).  Same results for
+ * finite values; measured cost on MI355X: bf16 programs +5 % (D3 114 -> 120 us at B = 65 536).  Process-wide, read at launch
+ * time; returns the previous value.  The Python package sets it from DHAUG_NAN_PROPAGATION=1 at load. */
+int dhaug_set_nan_propagation(int on);
+
 /* Two 256 -> 256 layers of a residual block in one launch (the backward step through myResNet,
  * R/models_Fk_GAN/special_operate.py:490-510 under loss.backward(), and its tangent twin in the gradient penalty's
  * double backward, R/models_Fk_GAN/Fk_discriminator.py:205-231):
@@ -313,6 +324,9 @@ int dhaug_gemm_bf16_group(const dhaug_gemm_desc* members, int n, void* stream);
  * partial results in total, not per layer.
  * `layers`: host array (read during the call).  `workspace`: DHAUG_TN_GROUP_WORKSPACE_FLOATS fp32 values owned by the
  * caller, any content (calls sharing it must be ordered on one stream).
+ * The outputs of ONE call must be distinct: no two layers may name the same C or the same colsum_a (they are summed
+ * concurrently, a one-workgroup block with a plain read-modify-write) -- DHAUG_EINVAL otherwise.  A second contribution
+ * to a gradient goes into a second call (stream order is the synchronisation).
  * Replaces the parameter-gradient half of loss.backward() in R/models_Fk_GAN/model_fk_gan_train.py:191-214. */
 #define DHAUG_TN_GROUP_MAX 42
 #define DHAUG_TN_GROUP_WORKSPACE_FLOATS (256LL * (256 * 256 + 256))

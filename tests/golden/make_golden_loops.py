@@ -9,6 +9,8 @@
                            flip on (R/models_Fk_GAN/video_GAN_fun.py:79-601) incl. the (-1, R, 32) view of quirk q6
   motion_step_m{3,2}_D32   one train_Fk_discriminator call on each motion critic in the mode the video loop uses for it
                            (M3: dis_mode='motion', GP over B clips; M2: default mode, GP over B*R frames -- :219-232,:341-346)
+  motion_step_m{3,2}_D1000 the same at DenseDim 1000 (the reference's default width, README video command), B = 16 clips:
+                           gradients and weight changes as compact records (`python make_golden_loops.py motion_step_D1000`)
 
 Build-container only (imports /root/reference through _ref_import.py).  The reference draws its random numbers from the
 global torch / numpy generators inside the loop; the draws are RECORDED here (torch.randn / rand / randint and the FK
@@ -336,8 +338,53 @@ def video_D1000(M):
     save("video_D1000", **out)
 
 
+def motion_steps_D1000(M):
+    """One train_Fk_discriminator call on each MOTION critic at the width of the reference's README video command (DenseDim 1000:
+    R/function_aug/config.py:101-109, 25.5 M / 12.5 M parameters), R = 9, B = 16 clips, in the mode the video loop uses for it
+    (M3: dis_mode='motion', penalty over B clips; M2: default mode, penalty over B*R frames): the training kernels of the video
+    path (1000-wide NT layers, wide grouped contractions, adam_nt) are pinned to the reference above DenseDim 32.  Gradients and
+    the weights' CHANGE are kept as compact records (golden_util.compact)."""
+    import golden_util as GU
+    train, dis = M["train"], M["dis"]
+    import utils.utils as ru
+    train.torch = cpu_torch_proxy()
+    B, R, D = 16, 9, 1000
+    args = RI.make_args(batch_size=B, video_Dis_DenseDim_3D=D, video_Dis_DenseDim_2D=D, single_or_multi_train_mode="multi",
+                        architecture="3,3", random_seed=7)
+    summary = ru.Summary("/tmp/dhaug_ref_summary")
+    for tag, mode, seed in (("m3", "motion", 4600), ("m2", "single", 4700)):
+        net = (dis.Video_motion_Fk_3D_Discriminator if tag == "m3" else dis.Video_motion_Fk_2D_Discriminator)("cpu", args, R)
+        sd = seeded_state_dict(motion_shapes(net), seed=seed)
+        net.load_state_dict(sd)
+        if tag == "m3":
+            xr = synth_pose16(B * R, seed=161); xr = (xr - xr[:, :1]).reshape(B * R, 48)
+            xf = synth_pose16(B * R, seed=162); xf = (xf - xf[:, :1]).reshape(B * R, 48)
+        else:
+            xr = ((torch.rand(B * R, 16, 2, generator=torch.Generator().manual_seed(163)) - 0.5) * 1.6)
+            xf = ((torch.rand(B * R, 16, 2, generator=torch.Generator().manual_seed(164)) - 0.5) * 1.6)
+        opt = adam(net)
+        one = torch.tensor(1, dtype=torch.float32)
+        grads = {}
+        hook_step(opt, lambda: grads.update({k: p.grad.detach().clone() for k, p in net.named_parameters()}))
+        torch.manual_seed(1999)
+        with Recorder() as rec:
+            kw = dict(dis_mode="motion") if mode == "motion" else {}
+            W, C = train.train_Fk_discriminator(net, xr.clone(), xf.clone(), summary, M["Writer"](), "motion_" + tag, opt,
+                                                args, one, one * -1, **kw)
+        out = dict(real=xr, fake=xf, alpha=rec.of("rand")[0], Wasserstein_D=W.detach(), D_cost=C.detach(), weight_seed=np.array(seed))
+        for i, (k, p) in enumerate(net.named_parameters()):
+            for kind, t in (("grad", grads[k]), ("delta", p.detach() - sd[k])):
+                for part, v in GU.compact(t, 100 + i).items():
+                    out["%s__%s__%s" % (kind, part, k)] = v
+        save("motion_step_%s_D1000" % tag, **out)
+
+
 def main():
     M = RI.load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "motion_step_D1000":
+        torch.set_num_threads(8)
+        motion_steps_D1000(M)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "video_D1000":
         video_D1000(M)
         return

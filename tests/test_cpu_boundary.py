@@ -51,6 +51,36 @@ def test_scratch_sizes_mirror_the_header(built):
     assert eval(expr) == fused.X3_WORKSPACE_BYTES
 
 
+def test_ablation_switches_need_an_ablation_build(tmp_path):
+    """a development switch ("timing only, results wrong") cannot reach a product library: every such -D is a compile error
+    without -DDHAUG_ABLATION_BUILD (csrc/dhaug_common.h), and build_lib ignores DHAUG_EXTRA_HIPFLAGS unless the environment
+    names an ablation build"""
+    import subprocess
+    import __graft_entry__ as G
+    assert G.ablation_flags({"DHAUG_EXTRA_HIPFLAGS": "-DX3_ABL_NOSPLIT"}) == []
+    assert G.ablation_flags({}) == []
+    assert G.ablation_flags({"DHAUG_ABLATION_BUILD": "1", "DHAUG_EXTRA_HIPFLAGS": "-DX3_ABL_NOSPLIT"}) == ["-DDHAUG_ABLATION_BUILD", "-DX3_ABL_NOSPLIT"]
+    src = tmp_path / "probe.cpp"
+    src.write_text('#include "dhaug_common.h"\nint main() { return 0; }\n')
+    base = [G.HIPCC, "-x", "hip", "--cuda-host-only", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), "-I" + G.CSRC]
+    ok = subprocess.run(base + [str(src)], capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    for d in ("X3_ABL_NOSPLIT", "ABL_NOWRITE", "SAVE_ABL_NULLSTORES", "T4_ABL_NOCOMPUTE", "X3_NWAVES=4", "DHAUG_MLP_TIMING"):
+        bad = subprocess.run(base + ["-D" + d, str(src)], capture_output=True, text=True)
+        assert bad.returncode != 0 and "DHAUG_ABLATION_BUILD" in bad.stderr, d
+        good = subprocess.run(base + ["-D" + d, "-DDHAUG_ABLATION_BUILD", str(src)], capture_output=True, text=True)
+        assert good.returncode == 0, (d, good.stderr[-2000:])
+    # the shipped sources name no switch the guard does not know: every *_ABL_* / X3_* / timing macro tested by an #if / #ifdef
+    guard = open(os.path.join(G.CSRC, "dhaug_common.h")).read()
+    known = set(re.findall(r"defined\((\w+)\)", guard))
+    internal = {"X3_SHAPE16", "X3_NW", "X3_MT", "X3_BM", "X3_B16", "X3_THREADS", "X3_LDS_BYTES", "X3_MAX_UNITS", "X3_CASE", "X3_CASE_ADD",
+                "X3_CASE_STASH", "X3_STAMP", "X3_WORKSPACE_BYTES"}                     # defined by the sources themselves, unconditionally
+    for path in sorted(p for p in os.listdir(G.CSRC) if p.endswith((".hip", ".h"))):
+        text = open(os.path.join(G.CSRC, path)).read()
+        for mac in set(re.findall(r"^\s*#\s*(?:if|ifdef|ifndef|elif)[^\n]*?\b((?:\w*_ABL_\w+|ABL_\w+|X3_\w+|\w*TIMING\w*|\w+_OVERRIDE|W_NO_\w+))\b", text, re.M)):
+            assert mac in known or mac in internal, (path, mac)
+
+
 def test_argument_errors_are_returned_not_thrown(built):
     """host-side validation happens before any launch, so it can be exercised without a GPU"""
     import dhaug_amd

@@ -117,6 +117,77 @@ def test_nan_in_the_fused_step_forward(ops):
     assert torch.isnan(l3d).all()
 
 
+def test_nonfinite_in_the_fused_inference_programs(ops):
+    """What the fused INFERENCE programs (fused_mlp_kernel<false>: bf16; fused_mlp_x3_kernel: f16x3 -- the sampling pass, the G
+    step's flipped evaluations, score_fake_pair) do with non-finite values, in both settings of dhaug_set_nan_propagation:
+    * default: their ReLU is an integer max on the bit pattern, which turns the matrix pipe's -NaN into 0 -- a NaN / +-inf input
+      row of the 3D critic or the generator trunk gives a FINITE logit / head (documented deviation, include/dhaug.h,
+      INTEGRATION.md), and a NaN weight of a ReLU network does not show in the output; the LeakyReLU 2D critic (mul + max in
+      fp32) propagates: NaN in that row's logit, NaN weights give NaN logits everywhere;
+    * nan_propagation(True): every network does what the reference's ATen ops do (R/models_Fk_GAN/Fk_discriminator.py:180-201,
+      253-266): the bad row's own logit / head row is NaN, NaN weights give NaN everywhere;
+    * in either setting no other row changes by a bit, and finite inputs give the same bits in both settings."""
+    from dhaug_amd import fused, autograd_ops as A
+    from dhaug_amd.models_Fk_GAN import Fk_discriminator as dis, Fk_generator as gen
+    from test_gpu_models import make_args
+    B, D = 512, 256
+    args = make_args(batch_size=B, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D, Gen_DenseDim=D)
+    torch.manual_seed(3)
+    D3, D2 = dis.Fk_3D_Discriminator("cuda", args).cuda(), dis.Fk_2D_Discriminator(args, 16).cuda()
+    G = gen.Fk_Generator(None, args, "cuda").cuda()
+    gsel = torch.Generator().manual_seed(8)
+    x3 = (torch.randn(B, 48, generator=gsel) * 0.3).cuda()
+    x2 = (torch.rand(B, 32, generator=gsel) - 0.5).cuda()
+    z = torch.randn(B, 128, generator=gsel).cuda()
+
+    def run(mode, x3, x2, z):
+        kf, kb = ops.kcs_forward(x3, True, f32=True, bf16_ld=32)
+        with torch.no_grad():
+            l3 = fused.critic3d(D3, x3 if mode == "f16x3" else x3.bfloat16(), kcs=kf if mode == "f16x3" else kb, mode=mode).float().reshape(-1).clone()
+            l2 = fused.critic2d(D2, x2 if mode == "f16x3" else x2.bfloat16(), mode=mode).float().reshape(-1).clone()
+            h = fused.generator_head(G, z, mode).float().clone()
+        return l3, l2, h
+
+    rows = torch.arange(B, device="cuda")
+    for mode in ("bf16", "f16x3"):
+        c3, c2, ch = run(mode, x3, x2, z)
+        assert torch.isfinite(c3).all() and torch.isfinite(c2).all() and torch.isfinite(ch).all()
+        with ops.nan_propagation(True):
+            p3, p2, ph = run(mode, x3, x2, z)
+        assert torch.equal(p3, c3) and torch.equal(p2, c2) and torch.equal(ph, ch), mode        # finite values: the same bits
+        for val in (float("nan"), float("inf"), float("-inf")):
+            a3, a2, az = x3.clone(), x2.clone(), z.clone()
+            a3[7, 20] = val; a2[11, 3] = val; az[5, 9] = val
+            for prop in (False, True):
+                with ops.nan_propagation(prop):
+                    l3, l2, h = run(mode, a3, a2, az)
+                assert torch.equal(l3[rows != 7], c3[rows != 7]) and torch.equal(l2[rows != 11], c2[rows != 11]), (mode, val, prop)
+                assert torch.equal(h[rows != 5], ch[rows != 5]), (mode, val, prop)
+                assert torch.isnan(l2[11]).item(), (mode, val, prop)                            # LeakyReLU: always propagates
+                if prop:
+                    assert torch.isnan(l3[7]).item() and torch.isnan(h[5]).all(), (mode, val)
+                else:
+                    assert torch.isfinite(l3[7]).item() and torch.isfinite(h[5]).all(), (mode, val)   # the documented deviation
+        # one NaN weight in each network's first layer
+        keep = [(m, m.weight[5, 9].item()) for m in (D3.previous[0], D2.pose_layer_1, G.preprocess[0])]
+        with torch.no_grad():
+            for m, _ in keep:
+                m.weight[5, 9] = float("nan")
+        A.bump_weight_epoch()
+        for prop in (False, True):
+            with ops.nan_propagation(prop):
+                l3, l2, h = run(mode, x3, x2, z)
+            assert torch.isnan(l2).all(), (mode, prop)
+            if prop:
+                assert torch.isnan(l3).all() and torch.isnan(h).all(), mode
+            else:
+                assert torch.isfinite(l3).all() and torch.isfinite(h).all(), mode                # the documented deviation
+        with torch.no_grad():
+            for m, w in keep:
+                m.weight[5, 9] = w
+        A.bump_weight_epoch()
+
+
 def test_fk_angles_far_outside_the_joint_range(ops):
     g = torch.Generator().manual_seed(9)
     N = 4096

@@ -393,6 +393,43 @@ def test_gemm_tn_group(ops):
             assert maxabs(cs, csr) <= 1e-4 * max(1.0, csr.abs().max().item()) + 1e-3, (N1, N2)
 
 
+def test_gemm_tn_group_same_output_twice(ops):
+    """two contributions to ONE gradient slot in one list (short batch: every block is left with one workgroup, which adds into
+    the slot itself): ops.gemm_tn_group serialises them into two launches; the C-ABI call refuses two layers with one output"""
+    import ctypes
+    lib = ops._lib
+    gen = torch.Generator().manual_seed(5)
+    M = 1024 + 32
+    A1, B1 = _bf(torch.randn(M, 256, generator=gen)).cuda(), _bf(torch.randn(M, 256, generator=gen) * 0.5).cuda()
+    A2, B2 = _bf(torch.randn(64, 256, generator=gen)).cuda(), _bf(torch.randn(64, 256, generator=gen) * 0.5).cuda()
+    out, cs = torch.zeros(256, 256, device="cuda"), torch.zeros(256, device="cuda")
+    items = [(A1, B1, 256, 256, out, cs, M, True, None, None, None), (A2, B2, 256, 256, out, cs, 64, True, None, None, None)]
+    ops.gemm_tn_group(items)
+    ref = A1.float().cpu().double().t() @ B1.float().cpu().double() + A2.float().cpu().double().t() @ B2.float().cpu().double()
+    csr = A1.float().cpu().double().sum(0) + A2.float().cpu().double().sum(0)
+    assert maxabs(out, ref) <= 1e-4 * ref.abs().max().item()
+    assert maxabs(cs, csr) <= 1e-4 * csr.abs().max().item() + 1e-3
+    arr = (lib.TnLayer * 2)()
+    for d, (A, B, N1, N2, o, c, cr, acc, _, _, _) in zip(arr, items):
+        d.A, d.lda, d.B, d.ldb, d.C, d.ldc, d.colsum_a, d.colsum_rows = A.data_ptr(), 256, B.data_ptr(), 256, o.data_ptr(), 256, c.data_ptr(), cr
+        d.M, d.N1, d.N2, d.accumulate, d.max_workgroups = A.shape[0], 256, 256, 1, 0
+    ws = ops._tn_group_workspace(out.device)
+    rc = lib.lib().dhaug_gemm_tn_group_bf16_phase(arr, 2, ctypes.c_void_p(ws.data_ptr()), 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc != 0
+
+
+def test_split_of_a_column_view_reads_it_in_place(ops):
+    """ops.split_bf16 on a column block of a wider fp32 buffer (row pitch > width, base not 16-byte aligned) = the split of its
+    contiguous copy"""
+    gen = torch.Generator().manual_seed(6)
+    wide = torch.randn(300, 100, generator=gen).cuda()
+    for c0, w in ((0, 48), (3, 30), (52, 48)):
+        v = wide[:, c0:c0 + w]
+        assert not v.is_contiguous()
+        for mode, T in ((0, 3), (1, 6)):
+            assert torch.equal(ops.split_bf16(v, mode, T), ops.split_bf16(v.contiguous(), mode, T))
+
+
 def test_gemm_split_operand_mask_in_the_epilogue(ops):
     """dhaug_gemm_bf16_dmask_f32: (A B^T + res) * relu'(mask) with fp32 result / residual / mask on six-term split operands -- the
     backward / tangent GEMM of the parity-grade training step -- against fp64 and against the GEMM + dhaug_act_backward_f32 pair it

@@ -282,6 +282,67 @@ def test_motion_critic_step_vs_reference(M, golden, tag):
 
 
 @pytest.mark.parametrize("tag", ["m3", "m2"])
+def test_motion_critic_step_vs_reference_at_dense_dim_1000(M, golden, tag):
+    """The video path's TRAINING kernels at the width of the reference's README video command (DenseDim 1000: the 1000-wide NT
+    layers, the wide grouped weight-gradient contractions, adam_nt) against the reference's own train_Fk_discriminator on B = 16
+    clips (tests/golden/make_golden_loops.py motion_step_D1000; compact records): (1) in the fp32-grade arithmetic at the golden
+    tolerances of the DenseDim-32 / 256 step tests; (2) in the TIMED bf16 arithmetic element-wise against the oracle's bf16
+    emulation (<= 2e-2 of every weight gradient's scale, biases 4e-2), whose fp32 form test_oracle_loops.py holds to the same
+    fixture on CPU."""
+    from dhaug_amd.models_Fk_GAN import Fk_discriminator as dis
+    from oracle import dhaug_oracle as O
+    g = golden("motion_step_%s_D1000" % tag)
+    B, R, D = 16, 9, 1000
+    args = _args(batch_size=B, single_or_multi_train_mode="multi", architecture="3,3", video_Dis_DenseDim_3D=D, video_Dis_DenseDim_2D=D)
+    cls = dis.Video_motion_Fk_3D_Discriminator if tag == "m3" else dis.Video_motion_Fk_2D_Discriminator
+    sd = GU.seeded_state_dict(LU.motion_shapes(D, R)[0 if tag == "m3" else 1], int(g["weight_seed"]))
+    rec = lambda kind, k: {part: g["%s__%s__%s" % (kind, part, k)] for part in ("full", "sample", "proj") if "%s__%s__%s" % (kind, part, k) in g}
+
+    def run(prec):
+        net = cls("cuda", args, R)
+        net.load_state_dict(sd)
+        net.precision = prec
+        net = net.cuda()
+        opt = M.train.FusedAdam(net.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        W, C = M.train.train_Fk_discriminator(net, g["real"].cuda(), g["fake"].cuda(), Summary(), None, "motion_" + tag, opt,
+                                              args, dis_mode="motion" if tag == "m3" else "single", alpha=g["alpha"].cuda())
+        return (W.item(), C.item(), {k: p.grad.detach().float().cpu() for k, p in net.named_parameters()},
+                {k: p.detach().float().cpu() for k, p in net.named_parameters()})
+    W, C, grads, params = run("bf16x6")
+    assert abs(W - g["Wasserstein_D"].item()) <= 2e-5 and abs(C - g["D_cost"].item()) <= 2e-4 * max(1.0, abs(g["D_cost"].item()))
+    for i, k in enumerate(sd):
+        GU.compact_close(grads[k], rec("grad", k), 100 + i, 2e-6, 5e-4, k)
+        ref, got = rec("delta", k), GU.compact(params[k] - sd[k], 100 + i)
+        key = "full" if "full" in ref else "sample"
+        gref = rec("grad", k)[key]
+        well = gref.abs() > max(1e-3 * gref.abs().max().item(), 1e-7)
+        if well.any():
+            assert (got[key].double() - ref[key].double())[well].abs().max().item() <= 3e-6, k
+        assert (got[key].double() - ref[key].double()).abs().max().item() <= 2.05e-4, k
+    # the timed arithmetic against the oracle's bf16 emulation (same rounding points: operands, stored activations, cotangents)
+    Wb, Cb, gb, _ = run("bf16")
+    fwd = (lambda x, p: O.motion_d3_forward(x, p, R, precision="bf16")) if tag == "m3" else (lambda x, p: O.motion_d2_forward(x, p, R, precision="bf16"))
+    rows = B if tag == "m3" else B * R
+    net = O.Net(sd, fwd)
+    net.zero_grad()
+    gp = O.gradient_penalty(net, g["real"].reshape(rows, -1), g["fake"].reshape(rows, -1), g["alpha"])
+    lr_, lf_ = net(g["real"]).mean(), net(g["fake"]).mean()
+    (lf_ - lr_ + gp).backward()
+    assert abs(Wb - (lr_ - lf_).item()) <= 3e-3 * max(1.0, abs(Wb)) and abs(Cb - (lf_ - lr_ + gp).item()) <= 2e-2 * max(1.0, abs(Cb))
+    worst = {1: 0.0, 2: 0.0}
+    for k, r in net.grads().items():
+        scale = r.abs().max().item()
+        if scale == 0.0:
+            assert gb[k].abs().max().item() == 0.0, k
+            continue
+        e = (gb[k].double() - r.double()).abs().max().item() / scale
+        worst[r.dim()] = max(worst[r.dim()], e)
+        assert e <= (2e-2 if r.dim() == 2 else 4e-2), (k, e, scale)
+    print("bf16 %s step at DenseDim 1000 vs bf16-emulated oracle: worst element error %.2e (weights) / %.2e (biases) of scale"
+          % (tag, worst[2], worst[1]))
+
+
+@pytest.mark.parametrize("tag", ["m3", "m2"])
 def test_motion_critic_step_branch_layers_grouped_equals_layer_by_layer(M, tag, monkeypatch):
     """DenseDim 1000, bf16: the layers of a motion critic's four / two branches at the same depth as ONE launch each
     (critic_step._layer_major, dhaug_gemm_bf16_group) against one launch per layer -- same kernel body, same operands: scalars,

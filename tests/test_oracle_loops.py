@@ -103,6 +103,37 @@ def test_motion_critic_step_golden(golden, tag):
         assert maxabs(v, g["new__" + k]) <= 2e-6, k
 
 
+@pytest.mark.parametrize("tag", ["m3", "m2"])
+def test_motion_critic_step_golden_at_dense_dim_1000(golden, tag):
+    """the same at the reference's DEFAULT width (DenseDim 1000, README video command; 25.5 M / 12.5 M parameters, B = 16 clips):
+    scalars, every gradient (compact records: strided samples + seeded +-1 projections) and the Adam update"""
+    g = golden("motion_step_%s_D1000" % tag)
+    B, R, D = 16, 9, 1000
+    shapes = LU.motion_shapes(D, R)[0 if tag == "m3" else 1]
+    sd = GU.seeded_state_dict(shapes, int(g["weight_seed"]))
+    fwd = (lambda x, p: O.motion_d3_forward(x, p, R)) if tag == "m3" else (lambda x, p: O.motion_d2_forward(x, p, R))
+    rows = B if tag == "m3" else B * R
+    assert g["alpha"].shape == (rows, 1)
+    net = O.Net(sd, fwd)
+    net.zero_grad()
+    gp = O.gradient_penalty(net, g["real"].reshape(rows, -1), g["fake"].reshape(rows, -1), g["alpha"])
+    (net(g["fake"]).mean() - net(g["real"]).mean() + gp).backward()
+    grads = net.grads()
+    net2 = O.Net(sd, fwd)
+    W, C = O.critic_step_net(net2, g["real"], g["fake"], g["alpha"], rows)
+    assert abs(W.item() - g["Wasserstein_D"].item()) <= 2e-6 and abs(C.item() - g["D_cost"].item()) <= 1e-5 * max(1.0, abs(g["D_cost"].item()))
+    rec = lambda kind, k: {part: g["%s__%s__%s" % (kind, part, k)] for part in ("full", "sample", "proj") if "%s__%s__%s" % (kind, part, k) in g}
+    for i, k in enumerate(sd):
+        GU.compact_close(grads[k], rec("grad", k), 100 + i, 1e-7, 2e-4, k)
+        ref, got = rec("delta", k), GU.compact(net2.state()[k] - sd[k], 100 + i)
+        key = "full" if "full" in ref else "sample"
+        gref = rec("grad", k)[key]
+        well = gref.abs() > max(1e-3 * gref.abs().max().item(), 1e-7)     # (Adam's first step is lr * sign-like: where |g| is not within rounding of 0)
+        if well.any():
+            assert (got[key].double() - ref[key].double())[well].abs().max().item() <= 2e-6, k
+        assert (got[key].double() - ref[key].double()).abs().max().item() <= 2.01e-4, k
+
+
 def test_video_D1000_forward_golden(golden):
     """BASELINE configs[4] widths (DenseDim 1000, R = 9): the oracle's video generator and four critics against the reference"""
     g = golden("video_D1000")

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 P=dh-aug-dh-forward-kinematics-model-driven-augmentation-for-3d-human-pose-estimation_amd
 O=tools/_timing
 mkdir -p $O
-F="--offload-arch=gfx950 -O3 -fPIC -ffp-contract=fast -fno-signed-zeros -ffinite-math-only -Iinclude -I$P/csrc"
+F="--offload-arch=gfx950 -DDHAUG_ABLATION_BUILD -O3 -fPIC -ffp-contract=fast -fno-signed-zeros -ffinite-math-only -Iinclude -I$P/csrc"
 VARIANTS=${VARIANTS:-"base: vform:-mllvm,-amdgpu-mfma-vgpr-form=1"}
 for v in $VARIANTS; do
   n=${v%%:*}; d=${v#*:}; d=${d//,/ }; d=${d//@/ }

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 P=dh-aug-dh-forward-kinematics-model-driven-augmentation-for-3d-human-pose-estimation_amd
 O=tools/_timing
 mkdir -p $O
-F="--offload-arch=gfx950 -O3 -fPIC -ffp-contract=fast -fno-signed-zeros -ffinite-math-only -mllvm -amdgpu-mfma-vgpr-form -Iinclude -I$P/csrc"
+F="--offload-arch=gfx950 -DDHAUG_ABLATION_BUILD -O3 -fPIC -ffp-contract=fast -fno-signed-zeros -ffinite-math-only -mllvm -amdgpu-mfma-vgpr-form -Iinclude -I$P/csrc"
 for v in "$@"; do
   n=${v%%:*}; d=${v#*:}
   /opt/rocm/bin/hipcc $F $d -c $P/csrc/dhaug_mlp_save.hip -o $O/save_$n.o &

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 P=dh-aug-dh-forward-kinematics-model-driven-augmentation-for-3d-human-pose-estimation_amd
 O=tools/_timing
 mkdir -p $O
-F="--offload-arch=gfx950 -O3 -fPIC -ffp-contract=fast -fno-signed-zeros -ffinite-math-only -Iinclude -I$P/csrc"
+F="--offload-arch=gfx950 -DDHAUG_ABLATION_BUILD -O3 -fPIC -ffp-contract=fast -fno-signed-zeros -ffinite-math-only -Iinclude -I$P/csrc"
 for v in base:"" nostore:-DT4_ABL_NOSTORE nocompute:-DT4_ABL_NOCOMPUTE neither:"-DT4_ABL_NOSTORE -DT4_ABL_NOCOMPUTE"; do
   n=${v%%:*}; d=${v#*:}
   /opt/rocm/bin/hipcc $F $d -c $P/csrc/dhaug_fk.hip -o $O/tail_$n.o &

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 P=dh-aug-dh-forward-kinematics-model-driven-augmentation-for-3d-human-pose-estimation_amd
 O=tools/_timing
 mkdir -p $O
-F="--offload-arch=gfx950 -O3 -fPIC -ffp-contract=fast -Iinclude -I$P/csrc"
+F="--offload-arch=gfx950 -DDHAUG_ABLATION_BUILD -O3 -fPIC -ffp-contract=fast -Iinclude -I$P/csrc"
 VARIANTS=${VARIANTS:-"prio0:-DX3_PRIO_SEL=0 prio1:-DX3_PRIO_SEL=1 prio2:-DX3_PRIO_SEL=2"}
 for v in $VARIANTS; do
   n=${v%%:*}; d=${v#*:}
