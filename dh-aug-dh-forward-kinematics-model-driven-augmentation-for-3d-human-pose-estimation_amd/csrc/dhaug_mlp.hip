@@ -470,12 +470,19 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 // KS < 16: the narrow layer that feeds a stack (K = 16 KS <= 128, no residual); its own fragments sit in `wlo`, and
 // BOTH halves of the following layer's are requested while it runs (tile 1: low, tile 2: high).
 // SAVE (forward-with-save): the layer also writes its INPUT image to global memory (`sv`: buffer resource of the 128-row
-// tile of the producer's save target, sv_ld bytes per row; zero records = nothing to save).  The activation fragments it reads
-// for the matrix pipe ARE the image, 16 bytes per lane: wave w stores the fragments of row tile w (one buffer store per
-// k-step behind a wave-uniform branch; rows beyond M fall outside the resource and are dropped by the range check) -- no
-// LDS read, no exposed copy loop between the layers.  (Issuing the stores from all four waves and letting the range check
-// drop three quarters of them cost more than the stores themselves: 448 us with every store nullified against 336 us
-// without the instructions, 3D critic at 3B = 196 608 rows.)
+// tile of the producer's save target, sv_ld bytes per row; zero records = nothing to save).  *(r5)* Wave w copies rows
+// [32 w, 32 w + 32) of the source image as whole rows: every fourth k-step one ds_read_b128 in which consecutive lanes take
+// consecutive 16-byte chunks (lane = 32 (row & 1) + chunk: two 512-byte rows per instruction), and two k-steps later one
+// buffer store of the same shape -- sixteen fully coalesced 1 KB stores per wave, layer and tile, dealt out evenly over the
+// layer's four row tiles (rows beyond M fall outside the resource and are dropped by the range check; the source image is
+// read-only while the layer runs).  The first form stored the activation FRAGMENTS the wave reads for the matrix pipe (no
+// LDS read): 16 bytes per lane of 32 different rows -- every quad of lanes four separate 16-byte accesses for the address
+// coalescer -- bunched in ONE row tile per wave.  tools/ubench/store_issue.hip (this kernel's operating point: one wave per
+// SIMD, 32 KB of weight fragments per wave and layer tile on the same vector-memory path, target resident in L2): the
+// fragment pattern takes a layer tile from 2.00 to 4.08 us, whole rows bunched 3.72, whole rows spread 2.41.
+// (tried, r5: v_maximum3_f32 v, 0, 0 -- gfx950's NaN-propagating maximum -- as the forward-with-save unit's ReLU in place of
+// max(v, v * neg): ONE instruction per element instead of two, and the 3D critic's forward-with-save launch went from 510 to
+// 717 us; the instruction is far from full rate on this part.  Removed.)
 template <bool LEAKY, int RESMODE, int KS = MLP_MAX_KSTEPS, bool SAVE = false, bool BITS = SAVE>
 __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc& nd, unsigned char* smem, int wave, int lane,
                                             const WHalf& wlo, WHalf& nlo, WHalf& whi, f32x16 (&seed)[MLP_NS],
@@ -585,14 +592,26 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
         __builtin_amdgcn_raw_buffer_store_b32((int)bacc, brs, ((mt * 4 + wave) * 64 + lane) * 4, 0, 0);
         bacc = 0;
     };
-    int sv_off[MLP_MT];                                                      // byte offset of the lane's chunk 0 of row tile mt, or out of range
-    if (SAVE && !LEAD) {
-#pragma unroll
-        for (int mt = 0; mt < MLP_MT; ++mt) sv_off[mt] = (32 * mt + r31) * sv_ld + (h << 4);
-    }
-#if defined(SAVE_ABL_TILE0)
-    const int sv_rot = (32 * wave + r31) * sv_ld + (h << 4);
+    // SAVE: the in-layer copy of the source image (see above).  Row pair p (0..15) of the wave: rows 32 wave + 2 p + h', the lane's
+    // chunk c = lane & 31, h' = lane >> 5.  The image swizzle c ^ (row & 15) = (c ^ h') ^ (2 p & 15): one XOR with a constant per read.
+    uint32_t cp_lds = 0;
+    int cp_goff = 0;
+    i32x4 cpv = {0, 0, 0, 0};
+    // No branch around the copy: a tile / layer with nothing to save (sv_ld = 0, zero records) still reads and issues stores that
+    // the range check drops -- 32 wave-uniform branches per layer and tile in the matrix-instruction stream cost more than that
+    // (SAVE_ABL_BRANCH builds the branching form for comparison).
+#if defined(SAVE_ABL_NOSTORE)
+    const bool sv_on = false;
+#elif defined(SAVE_ABL_BRANCH)
+    const bool sv_on = SAVE && !LEAD && sv_ld != 0;                          // (wave-uniform)
+#else
+    const bool sv_on = SAVE && !LEAD;
 #endif
+    if (SAVE && !LEAD) {
+        const int c = lane & 31, row = 32 * wave + h;
+        cp_lds = (uint32_t)(uintptr_t)(LdsPtr)src + (uint32_t)(row * (BUF01_PITCH * 2) + ((c ^ h) << 4));
+        cp_goff = row * sv_ld + (c << 4);
+    }
 #pragma unroll
     for (int mt = 0; mt < MLP_MT; ++mt) {
 #pragma unroll
@@ -631,16 +650,15 @@ __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc&
                     }
                 }
 #endif
-#if defined(SAVE_ABL_TILE0)            /* timing only (wrong rows): every wave stores during tile 0, no branch in the MFMA stream */
-                if (SAVE && !LEAD && t == 0 && mt == 0)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, fx[s & 3]), sv, sv_rot + 32 * k, 0, 0);
-                if (false)
-#elif !defined(SAVE_ABL_NOSTORE)
-                if (SAVE && !LEAD && t == 0 && mt == wave && sv_ld != 0) // chunk 2k+h of the lane's row: this k-step's fragment
-#else
-                if (false)
-#endif
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, fx[s & 3]), sv, sv_off[mt] + 32 * k, 0, 0);
+                if (SAVE && !LEAD && t == 0 && (k & 1) && sv_on) {           // row pair p = 4 mt + k / 4: read at k % 4 == 1, stored at k % 4 == 3
+                    constexpr int ROWP = 2 * BUF01_PITCH * 2;                // bytes of a row pair in the image
+                    const int p = 4 * mt + (k >> 2);
+                    if ((k & 3) == 1)
+                        cpv = *reinterpret_cast<const i32x4 __attribute__((address_space(3)))*>(
+                            (LdsPtr)(uintptr_t)(cp_lds ^ (uint32_t)(((2 * p) & 15) << 4)) + p * ROWP);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b128(cpv, sv, cp_goff, 2 * p * sv_ld, 0);
+                }
                 if (t == 1) {
                     if (!LEAD) {                                             // pairs 2(k-1), 2k are packed at odd k, stored at k+1
                         if (mt > 0 && (k & 1)) {

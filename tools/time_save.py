@@ -15,7 +15,9 @@ D3, D2 = d["model_d3d"], d["model_d2d"]
 x3 = torch.randn(M, 48, device="cuda") * .3
 x2 = torch.rand(M, 32, device="cuda") - .5
 kf, kb = ops.kcs_forward(x3, True, f32=True, bf16_ld=32)
+B2 = 2 * 65536
 fns = dict(D3save=lambda: fused.critic3d_forward_save(D3, x3, kb), D2save=lambda: fused.critic2d_forward_save(D2, x2),
+           D3save2B=lambda: fused.critic3d_forward_save(D3, x3, kb, save_rows=B2), D2save2B=lambda: fused.critic2d_forward_save(D2, x2, save_rows=B2),
            D3infer=lambda: fused.critic3d(D3, x3, kcs=kb), D2infer=lambda: fused.critic2d(D2, x2))
 with torch.no_grad():
     for _ in range(100):
