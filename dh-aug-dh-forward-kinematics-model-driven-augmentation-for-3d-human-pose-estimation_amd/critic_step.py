@@ -52,11 +52,12 @@ TN_SIDE_WGS = int(os.environ.get("DHAUG_TN_SIDE_WGS", "128"))
 TN_PHASED = os.environ.get("DHAUG_TN_PHASED") is not None
 TN_MAIN_WGS = int(os.environ.get("DHAUG_TN_MAIN_WGS", "0"))  # workgroups of the second part (0: one per CU)
 
-# the layers of independent branches at the same depth as ONE launch (_Math.mm_group, dhaug_gemm_bf16_group): DHAUG_NT_GROUP=1.  Off by
-# default *(measured)*: alone, four 1 536 x 1000 x 1000 branch layers take 35 us as one launch against 4 x 12.7 (four 512-row ones 14.5
-# against 4 x 9.1) -- but the video iteration runs its four critics on four streams, a 384-workgroup launch leaves a quarter of the
-# card's workgroup slots to the other critics' kernels and a 1 536-workgroup one does not: 17.2 ms per iteration against 15.4.
-NT_GROUP = os.environ.get("DHAUG_NT_GROUP") is not None
+# the layers of independent branches at the same depth as ONE launch (_Math.mm_group, dhaug_gemm_bf16_group): a motion critic's four /
+# two branch layers.  On by default since round 5 (DHAUG_NO_NT_GROUP=1: one launch per layer): the grouped launch runs on 128 x 128
+# tiles -- four 1 536 x 1000 x 1000 layers are 384 workgroups, ONE round of the card's slots, half the staged bytes of 64 x 64 tiles.
+# (Round 4's form, the same launch on 64 x 64 tiles = 1 536 workgroups: 35 us alone against 4 x 12.7, but 17.2 ms per video iteration
+# against 15.4 -- it left no slots to the other three critics' streams; DHAUG_NT_GROUP_TILE=64 still selects it.)
+NT_GROUP = os.environ.get("DHAUG_NO_NT_GROUP") is None
 # split-operand arithmetic: one activation-side split per tensor and step (_Math.split0); DHAUG_NO_SPLIT_CACHE=1: one per use
 SPLIT_CACHE = os.environ.get("DHAUG_NO_SPLIT_CACHE") is None
 

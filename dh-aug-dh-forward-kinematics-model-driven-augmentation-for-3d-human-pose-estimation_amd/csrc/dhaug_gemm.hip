@@ -618,6 +618,167 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_pipe2_group_kernel(GemmGroupAr
     nt_pipe2_body(p, tile);
 }
 
+// *(r5)* The grouped launch on 128 x 128 tiles (`gemm_nt_g128_group_kernel`).  With 64 x 64 tiles the four branch layers of a motion
+// critic are 1 536 workgroups -- three rounds of the card's 512 slots of this size, every slot of the card taken while the other
+// three critics' streams wait (measured in round 4: 35 us alone against 4 x 12.7, but the video iteration SLOWER, 17.2 against
+// 15.4 ms) -- and stage 393 MB.  A 128 x 128 tile stages half the bytes per output and the four layers are 384 workgroups: ONE
+// round at two workgroups per CU (four 16 KB stages of 32 k: 64 KB), a quarter of the card's slot-time, and the stream's chain is one
+// launch per depth instead of four.  Eight waves of 64 x 32 (three fragment reads feed two matrix instructions; four per SIMD, 128
+// registers each); the stage mechanics of the kernels above (global -> LDS without registers, exact vmcnt waits, LDS-only barriers;
+// 64-byte stage rows with chunk c of row r at c ^ ((r >> 2) & 3) as in the 256 x 256-tile kernel); the epilogue through the fp32
+// C image in two passes of 64 rows.  The k-steps are summed in `gemm_nt_pipe2_kernel`'s order (k-steps of its whole 64-wide stages
+// alternate between two accumulators, those of its short last stage go to the first, the two are added at the end): the result is
+// bit-identical to one launch per layer on that kernel, whatever the tiling (tests/test_gpu_loops.py, grouped against not).
+constexpr int Q_BM = 128, Q_BN = 128, Q_BK = 32, Q_NSTG = 4;
+constexpr int Q_STG = (Q_BM + Q_BN) * Q_BK * 2;                              // 16 384 bytes per stage
+constexpr int Q_LDS = Q_NSTG * Q_STG;                                        // 65 536: two workgroups per CU
+constexpr int Q_CS = Q_BN + 4;
+static_assert(64 * Q_CS * 4 <= Q_LDS, "C image of one pass");
+__device__ __forceinline__ void nt_g128_body(const GemmArgs& p, long long tile) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* sC = reinterpret_cast<float*>(smem_raw);             // [64][Q_CS], reuses the staging buffers
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                    // 2 x 4 waves: rows [64 wm, +64), columns [32 wn, +32)
+    const long long ntn = (p.W + Q_BN - 1) / Q_BN;
+    const long long m0 = (tile / ntn) * Q_BM;
+    const long long n0 = (tile % ntn) * Q_BN;
+    const int nkt = (int)((p.K + Q_BK - 1) / Q_BK);
+    constexpr int NCP = 2;                                      // copies per lane and stage: rows 16 (8 i + wave) .. + 16 of the image
+    const uint16_t* pg[NCP];
+    int rowoff[NCP];
+#pragma unroll
+    for (int i = 0; i < NCP; ++i) {
+        const int row0 = (8 * i + wave) * 16, row = row0 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+        if (i < 1) {
+            const long long gm = m0 + row;
+            pg[i] = p.A + (gm < p.M ? gm : p.M - 1) * p.lda + c * 8;
+        } else {
+            const long long gn = n0 + row - Q_BM;
+            pg[i] = p.B + (gn < p.N ? gn : p.N - 1) * p.ldb + c * 8;
+        }
+        rowoff[i] = row0 * (Q_BK * 2);
+    }
+    auto copy_stage = [&](int kt) {
+        unsigned char* base = smem_raw + (kt % Q_NSTG) * Q_STG;
+        long long k0 = (long long)kt * Q_BK;
+        if (k0 + Q_BK > p.K) k0 = p.K - Q_BK > 0 ? p.K - Q_BK : 0;       // short last stage: the last full window (K >= 32)
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) p_copy16(pg[i] + k0, base + rowoff[i]);
+    };
+    // two accumulator sets of 2 x 16 registers (the 64 x 64-tile kernel's even / odd k-steps): eight waves of 64 x 32.  (Four waves
+    // of 64 x 64 need 256 accumulator registers for the two sets -- all a wave has at two workgroups per CU; the two sets as two WAVES
+    // of a pair, each 64 x 64 on one k-step parity and four fragment reads for four matrix instructions, met in the C image: measured
+    // SLOWER, 36.4 against 28.9 us for four 1 536-row layers -- a stage's time is its barrier and the LDS fill, not its fragment reads.)
+    f32x16 acc[2], acc2[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[a][r] = 0.0f; acc2[a][r] = 0.0f; }
+#pragma unroll
+    for (int s2 = 0; s2 < Q_NSTG - 1; ++s2)
+        if (s2 < nkt) copy_stage(s2);
+    const int r31 = lane & 31, h = lane >> 5;
+    const int nfull = (int)(p.K / 64) * 4;                      // k-steps inside the 64 x 64-tile kernel's whole stages: they alternate accumulators
+    int fxo[2], fwo;                                            // the lane's fragment rows: byte offset, swizzle in bits 4..5
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int rx = 64 * wm + 32 * a + r31;
+        fxo[a] = rx * (Q_BK * 2) + (((rx >> 2) & 3) << 4);
+    }
+    {
+        const int rw = 32 * wn + r31;
+        fwo = Q_BM * Q_BK * 2 + rw * (Q_BK * 2) + (((rw >> 2) & 3) << 4);
+    }
+    // one stage: wait for it, publish it, refill the buffer released by the barrier, two k-steps.  `tail` (a constant at both call
+    // sites): the stages behind the 64 x 64-tile kernel's last whole stage, whose k-steps all go to the first accumulator set
+    auto stage = [&](int kt, const bool tail) {
+        // stage kt must have landed; younger: stages kt + 1, kt + 2 (2 copies each) where they exist
+        const int younger = nkt - 1 - kt;
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p_lds_barrier();                                        // stage kt is in LDS for everybody, stage kt - 1 is released
+        if (kt + Q_NSTG - 1 < nkt) copy_stage(kt + Q_NSTG - 1);
+        const unsigned char* buf = smem_raw + (kt % Q_NSTG) * Q_STG;
+        bf16x8 fx[2][2], fw[2];                                 // [k-step][row tile], [k-step]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int cs = (2 * ks + h) << 4;                   // (chunk ^ swizzle) << 4 == (chunk << 4) ^ (swizzle << 4)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) fx[ks][a] = *reinterpret_cast<const bf16x8*>(buf + ((fxo[a] & ~63) | ((fxo[a] & 48) ^ cs)));
+            fw[ks] = *reinterpret_cast<const bf16x8*>(buf + ((fwo & ~63) | ((fwo & 48) ^ cs)));
+        }
+        if (!tail) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[0], fx[0][a], acc[a], 0, 0, 0);
+                acc2[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[1], fx[1][a], acc2[a], 0, 0, 0);
+            }
+        } else {
+            const long long kbeg = (long long)kt * Q_BK;
+            int ks0 = 0;
+            if (kbeg + Q_BK > p.K && p.K >= Q_BK) ks0 = (int)((kbeg - (p.K - Q_BK)) >> 4);   // (the short last stage was copied as the last full window)
+            const int ks1 = p.K >= Q_BK ? 2 : (int)(p.K >> 4);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                if (ks >= ks0 && ks < ks1) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks], fx[ks][a], acc[a], 0, 0, 0);
+                }
+        }
+    };
+    const int nmain = nfull / 2 < nkt ? nfull / 2 : nkt;         // stages whose two k-steps alternate between the accumulator sets
+    for (int kt = 0; kt < nmain; ++kt) stage(kt, false);
+    for (int kt = nmain; kt < nkt; ++kt) stage(kt, true);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] += acc2[a][r];
+    p_lds_barrier();                                            // the staging buffers become the C image
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {                               // rows [64 r, +64) of the tile: the waves with wm == r hold them
+        if (wm == r) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int m = 32 * a + r31;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = 32 * wn + 8 * g + 4 * h;
+                    f32x4 v = {acc[a][4 * g], acc[a][4 * g + 1], acc[a][4 * g + 2], acc[a][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(sC + m * Q_CS + n) = v;
+                }
+            }
+        }
+        p_lds_barrier();
+        nt_store_tile<64, Q_BN, 512>(p, sC, m0 + 64 * r, n0, tid);
+        if (r == 0) p_lds_barrier();
+    }
+}
+__global__ __launch_bounds__(512, 4) void gemm_nt_g128_group_kernel(GemmGroupArgs grp, int n, int tiles) {
+    (void)grp;
+    int member;
+    long long tile;
+    if (n == 2 || n == 4 || n == 8) {                           // (members on XCDs of their own: see gemm_nt_pipe2_group_kernel)
+        const int per = 8 / n, xcd = blockIdx.x & 7;
+        member = xcd / per;
+        tile = (long long)(blockIdx.x >> 3) * per + (xcd % per);
+    } else {
+        member = blockIdx.x / tiles;
+        tile = blockIdx.x - member * tiles;
+    }
+    if (tile >= tiles || member >= n) return;
+    GemmArgs p;
+    {
+        const unsigned long long __attribute__((address_space(4)))* src = (const unsigned long long __attribute__((address_space(4)))*)(
+            (const unsigned char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + member * sizeof(GemmArgs));
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(&p);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(GemmArgs) / 8); ++i) dst[i] = src[i];
+    }
+    nt_g128_body(p, tile);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Long batches of the same generic shapes (the DenseDim-1000 layers of the frame critics' steps in the video configuration:
 // 3 x 4 608 rows).  The 64 x 64-tile kernel above issues ONE matrix instruction per two fragment reads and moves
@@ -2363,11 +2524,17 @@ int dhaug_gemm_bf16_group(const dhaug_gemm_desc* d, int n, void* stream) {
         DHAUG_CHECK(ga.g[i].W == ga.g[0].W, DHAUG_EUNSUPPORTED);
     }
     const GemmArgs& p = ga.g[0];
-    const long long tiles = ((p.M + 63) / 64) * ((p.W + 63) / 64);
+    // 128 x 128 tiles (half the staged bytes, a quarter of the workgroups) unless the group is too small to fill the card with them
+    // or DHAUG_NT_GROUP_TILE=64 asks for the 64 x 64 form
+    static const int tile_env = getenv("DHAUG_NT_GROUP_TILE") ? atoi(getenv("DHAUG_NT_GROUP_TILE")) : 0;
+    const bool big = tile_env != 64 && p.K >= 32 && p.M >= 128;
+    const int T = big ? 128 : 64;
+    const long long tiles = ((p.M + T - 1) / T) * ((p.W + T - 1) / T);
     long long grid = tiles * n;
-    if (n == 2 || n == 4 || n == 8) grid = (tiles + 8 / n - 1) / (8 / n) * 8;       // (XCD map: see the kernel)
+    if (n == 2 || n == 4 || n == 8) grid = (tiles + 8 / n - 1) / (8 / n) * 8;       // (XCD map: see the kernels)
     DHAUG_CHECK(grid <= 0x7fffffffLL && tiles <= 0x7fffffffLL, DHAUG_EUNSUPPORTED);
-    hipLaunchKernelGGL(gemm_nt_pipe2_group_kernel, dim3((unsigned)grid), dim3(256), 4 * (64 + 64) * BK * 2, (hipStream_t)stream, ga, n, (int)tiles);
+    if (big) hipLaunchKernelGGL(gemm_nt_g128_group_kernel, dim3((unsigned)grid), dim3(512), Q_LDS, (hipStream_t)stream, ga, n, (int)tiles);
+    else hipLaunchKernelGGL(gemm_nt_pipe2_group_kernel, dim3((unsigned)grid), dim3(256), 4 * (64 + 64) * BK * 2, (hipStream_t)stream, ga, n, (int)tiles);
     return dhaug_launch_status();
 }
 

@@ -252,6 +252,30 @@ def test_gemm_nt_big_tiles_epilogues(ops, M):
     assert (cb.float() - cb_old.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,n", [(1536, 4), (512, 4), (1536 + 72, 2), (200, 3)])
+def test_gemm_nt_group_128_tiles_equal_single_launches(ops, M, n):
+    """dhaug_gemm_bf16_group on 128 x 128 tiles (a motion critic's branch layers at one depth as ONE launch: DenseDim 1000, K = 1008
+    with a short last stage, ragged row and column tiles) is BIT-identical to one launch per member on the 64 x 64-tile kernel: the
+    k-steps are summed in that kernel's order.  Forward form (bias + bf16 residual + ReLU, zero-padded output) and the masked
+    input-gradient form; members differ in operands."""
+    gen = torch.Generator().manual_seed(11)
+    N, K, Kp = 1000, 1000, 1008
+    mk = lambda rows, cols, sc: _bf(torch.cat([torch.randn(rows, cols, generator=gen) * sc, torch.zeros(rows, Kp - cols)], 1)).cuda()
+    As, Ws, Rs, Ys = ([mk(M, K, 0.5) for _ in range(n)], [mk(N, K, K ** -0.5) for _ in range(n)], [mk(M, N, 1.0) for _ in range(n)],
+                      [mk(M, N, 1.0) for _ in range(n)])
+    bias = [torch.randn(N, generator=gen).cuda() for _ in range(n)]
+    outs = ops.gemm_nt_group([dict(A=As[i], B=Ws[i], N=N, K=Kp, bias=bias[i], res_bf16=Rs[i], act=1, n_pad=Kp) for i in range(n)])
+    for i in range(n):
+        one, _ = ops.gemm_nt(As[i], Ws[i], N, Kp, bias=bias[i], res_bf16=Rs[i], act=1, out_bf16=True, n_pad=Kp)
+        assert outs[i].shape == (M, Kp) and torch.equal(outs[i], one), i
+    ref = torch.relu(As[0].float().cpu().double() @ Ws[0].float().cpu().double().t() + bias[0].cpu().double() + Rs[0].float().cpu().double()[:, :N])
+    assert maxabs(outs[0][:, :N].float(), ref) <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
+    gs = ops.gemm_nt_group([dict(A=As[i], B=Ws[i], N=N, K=Kp, res_bf16=Rs[i], dmask=Ys[i], dmask_act=1, n_pad=Kp) for i in range(n)])
+    for i in range(n):
+        one = ops.gemm_nt_dmask(As[i], Ws[i], N, Kp, Ys[i], 1, 0.0, res_bf16=Rs[i])
+        assert torch.equal(gs[i][:, :N], one[:, :N]), i
+
+
 @pytest.mark.parametrize("M,K,act,slope,use_bias,use_res", [(4096, 256, 1, 0.0, True, True), (65536, 256, 2, 0.01, True, False),
                                                             (192, 128, 0, 0.0, False, True), (64, 256, 1, 0.0, False, False),
                                                             (33280, 128, 1, 0.0, True, True)])
