@@ -101,6 +101,18 @@ class _Math:
     def empty(self, M, n, dev):
         return torch.empty((M, self.width(n)), dtype=BF16 if self.bf16 else torch.float32, device=dev)
 
+    def empty_blocks(self, M, nb, Dw, dev):
+        """(M, nb * Dw) buffer whose Dw-wide column blocks become A operands of GEMMs with K = ceil16(Dw) (the cotangent of a
+        concatenation, handed to the branches block by block).  Where Dw is not a multiple of 16 (DenseDim 1000) a block's rows are
+        read 16 - Dw % 16 columns beyond the block -- against zero columns of the weights' operand copy, so the values only have to be
+        FINITE: inside the buffer they are the next block's / the next row's cotangents, but the last row of the last block would be
+        read beyond the allocation (found in round 5 with torch.empty poisoned: NaN x 0).  Such a buffer gets one more row, its head zeroed."""
+        if not self.bf16 or Dw % 16 == 0:
+            return None                              # (no over-read: the product allocates its output as usual)
+        buf = torch.empty((M + 1, self.width(nb * Dw)), dtype=BF16, device=dev)
+        buf[M, :16].zero_()
+        return buf[:M]
+
     def _a(self, a, k):
         """activation-side operand of a (fp32 (M,k) network input / bf16 hidden / fp32 hidden)"""
         if self.bf16:
@@ -642,7 +654,7 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
     gz_m1, gz_m0 = Mb.bwd(m, gz_m2, mh, m0)
     if Dw == 256 and all(getattr(y[bi][-1], "_dhaug_bits", None) is not None for bi in range(nb)):
         cat._dhaug_bits_cols = [y[bi][-1]._dhaug_bits for bi in range(nb)]      # (the mask of column block bi: its branch's sign bits)
-    gcat = Lm.bwd(m, gz_m0, cat, RELU, 0.0)                  # (3B, nb*D): cotangents at every branch's last fc2
+    gcat = Lm.bwd(m, gz_m0, cat, RELU, 0.0, out=m.empty_blocks(M3, nb, Dw, dev))   # (3B, nb*D): cotangents at every branch's last fc2
     g1, g2, gin = [], [], []
     if _layer_major(m, branches):
         g1, g2 = _bwd_layer_major(m, branches, gcat, h, y, Dw)

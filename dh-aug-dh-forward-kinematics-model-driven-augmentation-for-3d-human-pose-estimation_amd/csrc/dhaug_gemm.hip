@@ -518,9 +518,9 @@ __device__ __forceinline__ void nt_pipe2_body(const GemmArgs& p, long long tile)
             f.w[ks] = *reinterpret_cast<const bf16x8*>(bufB + rowb * (BK * 2) + ((chunk ^ ((rowb >> 1) & 7)) << 4));
         }
     };
-    f32x16 acc, acc2;
+    f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc2[r] = 0.0f; }
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
     for (int s = 0; s < NSTG; ++s)
         if (s < nkt) copy_stage(s);
@@ -551,10 +551,13 @@ __device__ __forceinline__ void nt_pipe2_body(const GemmArgs& p, long long tile)
         if (kbeg + BK > p.K && p.K >= BK) ks0 = (int)((kbeg - (p.K - BK)) >> 4);
         const int ks1 = p.K >= BK ? 4 : (int)(p.K >> 4);
         if (ks0 == 0 && ks1 == 4) {
+            // (k ascending into ONE accumulator -- back-to-back matrix instructions on the same accumulator need no wait states on
+            // this part; round 4 alternated two sets for 3 %.  One set is what lets the grouped launch's 128 x 128 tiles give a wave
+            // 64 x 64 outputs within its registers and stay bit-identical to this kernel: gemm_nt_g128_group_kernel)
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.w[0], cur.x[0], acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.w[1], cur.x[1], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.w[1], cur.x[1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.w[2], cur.x[2], acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.w[3], cur.x[3], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.w[3], cur.x[3], acc, 0, 0, 0);
         } else {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
@@ -565,8 +568,6 @@ __device__ __forceinline__ void nt_pipe2_body(const GemmArgs& p, long long tile)
         step(kt, f0, f1);
         if (kt + 1 < nkt) step(kt + 1, f1, f0);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
     p_lds_barrier();                                            // the staging buffers become the C tile
     {
         const int m = wm * 32 + (lane & 31);
@@ -623,12 +624,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_pipe2_group_kernel(GemmGroupAr
 // three critics' streams wait (measured in round 4: 35 us alone against 4 x 12.7, but the video iteration SLOWER, 17.2 against
 // 15.4 ms) -- and stage 393 MB.  A 128 x 128 tile stages half the bytes per output and the four layers are 384 workgroups: ONE
 // round at two workgroups per CU (four 16 KB stages of 32 k: 64 KB), a quarter of the card's slot-time, and the stream's chain is one
-// launch per depth instead of four.  Eight waves of 64 x 32 (three fragment reads feed two matrix instructions; four per SIMD, 128
-// registers each); the stage mechanics of the kernels above (global -> LDS without registers, exact vmcnt waits, LDS-only barriers;
-// 64-byte stage rows with chunk c of row r at c ^ ((r >> 2) & 3) as in the 256 x 256-tile kernel); the epilogue through the fp32
-// C image in two passes of 64 rows.  The k-steps are summed in `gemm_nt_pipe2_kernel`'s order (k-steps of its whole 64-wide stages
-// alternate between two accumulators, those of its short last stage go to the first, the two are added at the end): the result is
-// bit-identical to one launch per layer on that kernel, whatever the tiling (tests/test_gpu_loops.py, grouped against not).
+// launch per depth instead of four.  Eight waves of 64 x 32 (four per SIMD, 128 registers; other forms: see the body); the stage mechanics of gemm_nt_pipe2_kernel (global -> LDS without registers, exact vmcnt waits, LDS-only
+// barriers, the next stage's fragments under this stage's matrix instructions) with 64-byte stage rows, chunk c of row r at
+// c ^ ((r >> 2) & 3) as in the 256 x 256-tile kernel; the epilogue through the fp32 C image in two passes of 64 rows.  The k-steps are
+// summed in gemm_nt_pipe2_kernel's order (k ascending, one accumulator): the result is bit-identical to one launch per layer on that
+// kernel, whatever the tiling (tests/test_gpu_loops.py, grouped against not; tests/test_gpu_kernels.py).
 constexpr int Q_BM = 128, Q_BN = 128, Q_BK = 32, Q_NSTG = 4;
 constexpr int Q_STG = (Q_BM + Q_BN) * Q_BK * 2;                              // 16 384 bytes per stage
 constexpr int Q_LDS = Q_NSTG * Q_STG;                                        // 65 536: two workgroups per CU
@@ -666,20 +666,22 @@ __device__ __forceinline__ void nt_g128_body(const GemmArgs& p, long long tile) 
 #pragma unroll
         for (int i = 0; i < NCP; ++i) p_copy16(pg[i] + k0, base + rowoff[i]);
     };
-    // two accumulator sets of 2 x 16 registers (the 64 x 64-tile kernel's even / odd k-steps): eight waves of 64 x 32.  (Four waves
-    // of 64 x 64 need 256 accumulator registers for the two sets -- all a wave has at two workgroups per CU; the two sets as two WAVES
-    // of a pair, each 64 x 64 on one k-step parity and four fragment reads for four matrix instructions, met in the C image: measured
-    // SLOWER, 36.4 against 28.9 us for four 1 536-row layers -- a stage's time is its barrier and the LDS fill, not its fragment reads.)
-    f32x16 acc[2], acc2[2];
+    // ONE accumulator per matrix tile, k ascending, like gemm_nt_pipe2_kernel.  Forms of this kernel *(measured, four 1 536 x 1000 x
+    // 1000 members / four 512-row ones)*: eight waves of 64 x 32, fragments read behind the stage's barrier 28.9 / 16.5 us; the same
+    // with the next stage's fragments under this stage's matrix instructions (this form) 28.2 / 16.8; five stages instead of four
+    // 29.3 / 16.7; four waves of 64 x 64 (four fragment reads per four matrix instructions instead of three per two) 30.1 / 19.2; the
+    // two accumulator sets of round 4's 64 x 64-tile kernel as the two waves of a pair 36.4 / 21.2.  All land within 10 % of each
+    // other: what a stage costs is its 16 KB through the LDS-DMA path (~32 B/clk per CU: 512 of the ~620 clocks a stage takes), not
+    // its fragment reads, its barrier or the depth of the prefetch -- fewer staged bytes per output is what would shorten it.
+    f32x16 acc[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[a][r] = 0.0f; acc2[a][r] = 0.0f; }
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
 #pragma unroll
-    for (int s2 = 0; s2 < Q_NSTG - 1; ++s2)
+    for (int s2 = 0; s2 < Q_NSTG; ++s2)
         if (s2 < nkt) copy_stage(s2);
     const int r31 = lane & 31, h = lane >> 5;
-    const int nfull = (int)(p.K / 64) * 4;                      // k-steps inside the 64 x 64-tile kernel's whole stages: they alternate accumulators
     int fxo[2], fwo;                                            // the lane's fragment rows: byte offset, swizzle in bits 4..5
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -690,51 +692,57 @@ __device__ __forceinline__ void nt_g128_body(const GemmArgs& p, long long tile) 
         const int rw = 32 * wn + r31;
         fwo = Q_BM * Q_BK * 2 + rw * (Q_BK * 2) + (((rw >> 2) & 3) << 4);
     }
-    // one stage: wait for it, publish it, refill the buffer released by the barrier, two k-steps.  `tail` (a constant at both call
-    // sites): the stages behind the 64 x 64-tile kernel's last whole stage, whose k-steps all go to the first accumulator set
-    auto stage = [&](int kt, const bool tail) {
-        // stage kt must have landed; younger: stages kt + 1, kt + 2 (2 copies each) where they exist
-        const int younger = nkt - 1 - kt;
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        p_lds_barrier();                                        // stage kt is in LDS for everybody, stage kt - 1 is released
-        if (kt + Q_NSTG - 1 < nkt) copy_stage(kt + Q_NSTG - 1);
+    // As in gemm_nt_pipe2_kernel, the fragments of stage kt + 1 are requested right behind the barrier that publishes them and travel
+    // under stage kt's matrix instructions (two fragment sets); a stage's buffer is free once its fragments are in registers, so the
+    // copy issued behind the barrier is stage kt + 4's: four stages buffered or in flight.
+    struct Frags { bf16x8 x[2][2], w[2]; };                     // [k-step][row tile], [k-step]
+    auto read_frags = [&](int kt, Frags& f) {
         const unsigned char* buf = smem_raw + (kt % Q_NSTG) * Q_STG;
-        bf16x8 fx[2][2], fw[2];                                 // [k-step][row tile], [k-step]
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int cs = (2 * ks + h) << 4;                   // (chunk ^ swizzle) << 4 == (chunk << 4) ^ (swizzle << 4)
 #pragma unroll
-            for (int a = 0; a < 2; ++a) fx[ks][a] = *reinterpret_cast<const bf16x8*>(buf + ((fxo[a] & ~63) | ((fxo[a] & 48) ^ cs)));
-            fw[ks] = *reinterpret_cast<const bf16x8*>(buf + ((fwo & ~63) | ((fwo & 48) ^ cs)));
-        }
-        if (!tail) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[0], fx[0][a], acc[a], 0, 0, 0);
-                acc2[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[1], fx[1][a], acc2[a], 0, 0, 0);
-            }
-        } else {
-            const long long kbeg = (long long)kt * Q_BK;
-            int ks0 = 0;
-            if (kbeg + Q_BK > p.K && p.K >= Q_BK) ks0 = (int)((kbeg - (p.K - Q_BK)) >> 4);   // (the short last stage was copied as the last full window)
-            const int ks1 = p.K >= Q_BK ? 2 : (int)(p.K >> 4);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                if (ks >= ks0 && ks < ks1) {
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks], fx[ks][a], acc[a], 0, 0, 0);
-                }
+            for (int a = 0; a < 2; ++a) f.x[ks][a] = *reinterpret_cast<const bf16x8*>(buf + ((fxo[a] & ~63) | ((fxo[a] & 48) ^ cs)));
+            f.w[ks] = *reinterpret_cast<const bf16x8*>(buf + ((fwo & ~63) | ((fwo & 48) ^ cs)));
         }
     };
-    const int nmain = nfull / 2 < nkt ? nfull / 2 : nkt;         // stages whose two k-steps alternate between the accumulator sets
-    for (int kt = 0; kt < nmain; ++kt) stage(kt, false);
-    for (int kt = nmain; kt < nkt; ++kt) stage(kt, true);
+    {
+        const int younger = nkt - 1 < 3 ? nkt - 1 : 3;          // stages 1 .. 3 may still fly (2 copies each)
+        if (younger == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p_lds_barrier();
+    }
+    Frags f0, f1;
+    read_frags(0, f0);
+    auto step = [&](int kt, const Frags& cur, Frags& nxt) {
+        if (kt + 1 < nkt) {
+            // stage kt + 1 must have landed; issued so far: stages up to min(kt + 3, nkt - 1)
+            const int younger = nkt - 2 - kt < 2 ? nkt - 2 - kt : 2;
+            if (younger == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            p_lds_barrier();                                    // stage kt + 1 is in LDS for everybody; everybody holds stage kt's fragments
+            if (kt + Q_NSTG < nkt) copy_stage(kt + Q_NSTG);     // (into stage kt's buffer)
+            read_frags(kt + 1, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const long long kbeg = (long long)kt * Q_BK;
+        int ks0 = 0;
+        if (kbeg + Q_BK > p.K && p.K >= Q_BK) ks0 = (int)((kbeg - (p.K - Q_BK)) >> 4);       // (the short last stage was copied as the last full window)
+        const int ks1 = p.K >= Q_BK ? 2 : (int)(p.K >> 4);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int ks = 0; ks < 2; ++ks)
+            if (ks >= ks0 && ks < ks1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][r] += acc2[a][r];
+                for (int a = 0; a < 2; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.w[ks], cur.x[ks][a], acc[a], 0, 0, 0);
+            }
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        step(kt, f0, f1);
+        if (kt + 1 < nkt) step(kt + 1, f1, f0);
+    }
     p_lds_barrier();                                            // the staging buffers become the C image
 #pragma unroll
     for (int r = 0; r < 2; ++r) {                               // rows [64 r, +64) of the tile: the waves with wm == r hold them

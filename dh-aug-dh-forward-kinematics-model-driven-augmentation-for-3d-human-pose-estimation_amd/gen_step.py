@@ -61,7 +61,7 @@ class _BranchNet:
         cat = s["cat"]
         if Dw == 256 and all(getattr(s["y"][bi][-1], "_dhaug_bits", None) is not None for bi in range(len(self.br))):
             cat._dhaug_bits_cols = [s["y"][bi][-1]._dhaug_bits for bi in range(len(self.br))]
-        gcat = self.Lm.bwd(m, gz_m0, cat, RELU, 0.0)
+        gcat = self.Lm.bwd(m, gz_m0, cat, RELU, 0.0, out=m.empty_blocks(cat.shape[0], len(self.br), Dw, cat.device))
         gin = []
         for bi, br in enumerate(self.br):
             _, a2 = CS.stack_bwd(m, br.blocks, gcat[:, bi * Dw:(bi + 1) * Dw], s["h"][bi], s["y"][bi])

@@ -328,12 +328,13 @@ def test_motion_critic_step_vs_reference_at_dense_dim_1000(M, golden, tag):
     gp = O.gradient_penalty(net, g["real"].reshape(rows, -1), g["fake"].reshape(rows, -1), g["alpha"])
     lr_, lf_ = net(g["real"]).mean(), net(g["fake"]).mean()
     (lf_ - lr_ + gp).backward()
+    print("bf16 %s step: W %.6g / oracle %.6g, D_cost %.6g / oracle %.6g (gp %.6g)" % (tag, Wb, (lr_ - lf_).item(), Cb, (lf_ - lr_ + gp).item(), gp.item()))
     assert abs(Wb - (lr_ - lf_).item()) <= 3e-3 * max(1.0, abs(Wb)) and abs(Cb - (lf_ - lr_ + gp).item()) <= 2e-2 * max(1.0, abs(Cb))
     # Element-wise bound of the DenseDim-256 step (2e-2 of a weight gradient's scale, 4e-2 for biases) for all but a handful of
     # elements: with 2 B = 32 real / fake rows and B = 16 interpolated ones a unit whose pre-activation sits within bf16 rounding of
     # zero has its mask on one side in the kernels and on the other in the emulation, and ONE flipped (row, unit) moves that unit's
-    # gradient row by up to 1 / 16 of its size (measured: 6.5e-2 on diff_pos_3d_block1.fc2.weight, 8.6e-2 on a bias) -- so at most
-    # 1e-3 of a tensor's elements may exceed the bound, and none 2e-1.
+    # gradient row by up to 1 / 16 of its size (measured: 6.5e-2 on diff_pos_3d_block1.fc2.weight, 8.6e-2 on a bias) -- so three units'
+    # worth of a tensor's elements (3 / rows, at least 1e-3) may exceed the bound, and none 2e-1.
     worst = {1: 0.0, 2: 0.0}
     for k, r in net.grads().items():
         scale = r.abs().max().item()
@@ -344,7 +345,9 @@ def test_motion_critic_step_vs_reference_at_dense_dim_1000(M, golden, tag):
         e = err.max().item()
         worst[r.dim()] = max(worst[r.dim()], e)
         bound = 2e-2 if r.dim() == 2 else 4e-2
-        assert (err > bound).double().mean().item() <= (1e-3 if r.dim() == 2 else 2e-2) and e <= 2e-1, (k, e, scale)
+        # (a flipped unit moves ONE row of its layer's weight gradient and one bias element: three units' worth may be over the bound)
+        allowed = max(1e-3, 3.0 / r.shape[0])
+        assert (err > bound).double().mean().item() <= allowed and e <= 2e-1, (k, e, scale, (err > bound).double().mean().item())
     print("bf16 %s step at DenseDim 1000 vs bf16-emulated oracle: worst element error %.2e (weights) / %.2e (biases) of scale"
           % (tag, worst[2], worst[1]))
 
@@ -378,6 +381,55 @@ def test_motion_critic_step_branch_layers_grouped_equals_layer_by_layer(M, tag, 
     a, b = res
     assert a[0] == b[0] and a[1] == b[1] and torch.isfinite(a[2]).all()
     assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+
+
+@pytest.mark.parametrize("tag", ["m3", "m2"])
+@pytest.mark.parametrize("grouped", [True, False])
+def test_motion_critic_step_reads_no_unwritten_memory(M, tag, grouped, monkeypatch):
+    """DenseDim 1000 is not a multiple of 16: the cotangent of a motion critic's concatenation is handed to the branches as 1000-wide
+    column blocks that the backward GEMMs read 1008 wide (against zero columns of the weights' operand copy) -- the last row of the
+    last block used to be read 16 bytes beyond the allocation, and NaN x 0 = NaN (found in round 5; critic_step._Math.empty_blocks).
+    With every torch.empty buffer pre-filled with NaN / a huge value the step gives the same bits as without, in both launch forms."""
+    from dhaug_amd.models_Fk_GAN import Fk_discriminator as dis
+    from dhaug_amd import critic_step as CS
+    B, R, D = 16, 9, 1000
+    monkeypatch.setattr(CS, "NT_GROUP", grouped)
+    args = _args(batch_size=B, single_or_multi_train_mode="multi", architecture="3,3", video_Dis_DenseDim_3D=D, video_Dis_DenseDim_2D=D)
+    cls = dis.Video_motion_Fk_3D_Discriminator if tag == "m3" else dis.Video_motion_Fk_2D_Discriminator
+    sd = GU.seeded_state_dict(LU.motion_shapes(D, R)[0 if tag == "m3" else 1], 77)
+    gen = torch.Generator().manual_seed(9)
+    w = 48 if tag == "m3" else 32
+    real = (torch.randn(B, R, w, generator=gen) * 0.3).cuda()
+    fake = (real.cpu() + 0.05 * torch.randn(B, R, w, generator=gen)).cuda()
+    alpha = torch.rand(B if tag == "m3" else B * R, 1, generator=gen).cuda()
+
+    def run():
+        net = cls("cuda", args, R)
+        net.load_state_dict(sd)
+        net.precision = "bf16"
+        net = net.cuda()
+        opt = M.train.FusedAdam(net.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        W, C = M.train.train_Fk_discriminator(net, real, fake, Summary(), None, "motion_" + tag, opt, args,
+                                              dis_mode="motion" if tag == "m3" else "single", alpha=alpha)
+        return W.item(), C.item(), opt.flat_grad.clone(), opt.flat_param.clone()
+    ref = run()
+    assert torch.isfinite(ref[2]).all()
+    real_empty, real_empty_like = torch.empty, torch.empty_like
+    for poison in (float("nan"), 3.0e38):
+        def fill(t):
+            if t.is_cuda and t.numel():
+                if t.dtype.is_floating_point:
+                    t.fill_(poison)
+                else:
+                    t.view(torch.uint8).fill_(255)
+            return t
+        monkeypatch.setattr(torch, "empty", lambda *a, **k: fill(real_empty(*a, **k)))
+        monkeypatch.setattr(torch, "empty_like", lambda *a, **k: fill(real_empty_like(*a, **k)))
+        got = run()
+        monkeypatch.setattr(torch, "empty", real_empty)
+        monkeypatch.setattr(torch, "empty_like", real_empty_like)
+        assert got[0] == ref[0] and got[1] == ref[1], (tag, poison, got[:2], ref[:2])
+        assert torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3]), (tag, poison)
 
 
 # ------------------------------------------------------------------------------- BASELINE configs[4] widths (DenseDim 1000)
