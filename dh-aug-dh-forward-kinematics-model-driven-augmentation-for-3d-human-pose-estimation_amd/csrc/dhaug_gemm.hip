@@ -2090,8 +2090,14 @@ struct Block2Args {
 constexpr int B2_BM = 32, B2_IMG = B2_BM * F_PITCH, B2_NX = 4;
 constexpr int B2_LDS = (B2_NX + 4) * B2_IMG + B2_NX * 2048 + 1024;
 
+#ifdef DHAUG_PIPE_TIMING
+#define B2_STAMP(i) if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && (i) < 128) g_pipe_stamps[(threadIdx.x >> 8) * 128 + (i)] = (long long)__builtin_readcyclecounter();
+#else
+#define B2_STAMP(i)
+#endif
 __global__ __launch_bounds__(512, 1) void gemm_block2_kernel(Block2Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    B2_STAMP(0)
     unsigned char* sX = smem;                                                // [4][IMG]
     unsigned char* sG = smem + B2_NX * B2_IMG;                               // [2][IMG]  Y1
     unsigned char* sO = sG + 2 * B2_IMG;                                     // [2][IMG]  Y2
@@ -2138,32 +2144,48 @@ __global__ __launch_bounds__(512, 1) void gemm_block2_kernel(Block2Args p) {
         const uint32_t* bsrc = ((wave & 1) ? bits2 : bits1) + tile * 256 + ln * 4;
         tn_copy16(bsrc, wave < 2 ? sB + buf * 2048 + wave * 1024 : sScratch);
     };
+    // this stage's weights: feature slices cw and cw + 4, resident for the whole block.  *(r5)* They come THROUGH LDS: the eight
+    // waves copy the 256 x 256 matrix as whole rows (LDS-DMA, two rows per instruction, the images' chunk swizzle) into the 128 KB
+    // the tile images will use, the stage's waves read their fragments from there like activation fragments; W1 first, then W2.
+    // Loaded straight from global memory a fragment is 16 bytes per lane of 32 different rows -- four separate accesses per quad for
+    // the address coalescer: phase stamps (tools/stamp_block2.py) showed 9 600 (stage A) / 19 500 (stage B) clocks until the 32
+    // loads per lane were ISSUED, 10 us of the 25 a block costs whatever its batch.  The store drain of the previous block of a
+    // stack (its rows are this block's operand) waits behind the first copy instead of in front of it.
+    bf16x8 wf[2][16];
+#pragma unroll 1
+    for (int ws = 0; ws < 2; ++ws) {                                         // ws = 0: W1 (stage A's waves read), 1: W2 (stage B's)
+        const uint16_t* W = ws ? P->W2 : P->W1;
+        const long long ldw = ws ? P->ldw2 : P->ldw1;
+        {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row0 = (wave * 16 + q) * 2, row = row0 + (ln >> 5), c = (ln & 31) ^ (row & 15);
+                tn_copy16(W + (long long)row * ldw + c * 8, smem + row0 * F_PITCH);
+            }
+        }
+        if (ws == 0 && blk > 0) asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_inv sc1" ::: "memory");   // (+ the previous block's row stores)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        f_lds_barrier();
+        if ((ws == 1) == stageB) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) wf[t][k] = *reinterpret_cast<const bf16x8*>(smem + 32 * (cw + 4 * t) * F_PITCH + (lfx ^ (k << 5)));
+        }
+        f_lds_barrier();                                                     // (fragments in registers: the area is free again)
+    }
     if (0 < nt) copy_tile(0);
     if (1 < nt) copy_tile(1);
-
-    // this stage's weights: feature slices cw and cw + 4, resident for the whole launch
-    bf16x8 wf[2][16];
-    {
-        const uint16_t* W = stageB ? P->W2 : P->W1;
-        const long long ldw = stageB ? P->ldw2 : P->ldw1;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const uint16_t* wrow = W + (long long)(32 * (cw + 4 * t) + r31) * ldw + 8 * h;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) wf[t][k] = *reinterpret_cast<const bf16x8*>(wrow + 16 * k);
-        }
-    }
-    // the weights (compiler-tracked loads) land HERE: the empty asm statements use them, so hipcc's waitcnt pass puts its
-    // waits in front of them -- left to their first use it repeats a countdown to vmcnt(0) inside the tile loop, which
-    // would drain the LDS-DMA copies it does not know about at every tile
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(wf[t][k]));
+    B2_STAMP(1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    B2_STAMP(2)
     f_lds_barrier();                                                         // tiles 0 and 1 are in LDS
+    B2_STAMP(3)
 
     for (int i = 0; i <= nt + 1; ++i) {
+        B2_STAMP(8 + 8 * i)
         // ---- tile i+2's rows and bits into the image tile i-2 left (stage B was done with it at the last barrier).  (A fifth
         // image / two tiles in flight was measured: 80.4 against 77.6 us at 3B rows -- the reads are not what waits.)
         if (i + 2 < nt) copy_tile(i + 2);
@@ -2198,7 +2220,9 @@ __global__ __launch_bounds__(512, 1) void gemm_block2_kernel(Block2Args p) {
                 }
             }
         };
+        B2_STAMP(9 + 8 * i)
         if (stageB) stream_out();
+        B2_STAMP(10 + 8 * i)
         // ---- compute: stage A tile i, stage B tile i-1
         const int j = stageB ? i - 1 : i;
         if (j >= 0 && j < nt) {                                              // (wave-uniform)
@@ -2255,19 +2279,45 @@ __global__ __launch_bounds__(512, 1) void gemm_block2_kernel(Block2Args p) {
                     *reinterpret_cast<uint2*>(D + (lep ^ ((16 * t + gq) << 4))) = o;
                 }
         }
+        B2_STAMP(11 + 8 * i)
         if (!stageB) stream_out();
+        B2_STAMP(12 + 8 * i)
         if (i > nt) break;
         // ---- tile i+1 must be in LDS when the barrier opens.  vmcnt retires in issue order; per wave and iteration the
         // order is [3 copies] ... [4 row stores]: younger than tile i+1's copies (issued at the top of iteration i-1) are that
         // iteration's 4 stores, this one's 3 copies and 4 stores.  The first iterations and the last ones (where some of those
         // do not exist) drain instead.
-        if (i >= 3 && i + 2 < nt) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // *(r5)* ... are counted too instead of drained: a drain waits for the acknowledgement of the row stores issued a moment
+        // ago, a full memory round trip per iteration -- six of the ten iterations of a B-row tangent block (eight tiles per
+        // workgroup), and most of the 25 us a block costs at ONE tile per workgroup (tools/time_block2_sweep.py).  Younger than tile
+        // i+1's copies: the row stores of iteration i-1 (stage A: tile i-2's image, stage B: tile i-3's), this iteration's copies
+        // (tile i+2) and row stores (stage A: tile i-1, stage B: tile i-2), each where the tile exists.  No tile i+1 (or i = 0: tiles
+        // 0 and 1 were waited for in front of the loop): nothing to wait for -- the images are LDS traffic, ordered by the barrier.
+        int young = -1;
+        if (i >= 1 && i + 1 < nt) {
+            const int sp = stageB ? i - 3 : i - 2, sc = stageB ? i - 2 : i - 1;
+            young = ((sp >= 0 && sp < nt) ? 4 : 0) + ((i + 2 < nt) ? 3 : 0) + ((sc >= 0 && sc < nt) ? 4 : 0);
+        }
+        switch (young) {                                                     // (wave-uniform)
+            case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            default: break;
+        }
+        B2_STAMP(13 + 8 * i)
         f_lds_barrier();
+        B2_STAMP(14 + 8 * i)
     }
+    B2_STAMP(4)
     // every row this workgroup stored is in L2 (its next block reads them back: through a clean L1), every image is free
-    asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_inv sc1" ::: "memory");
-    f_lds_barrier();
+    // (the rows this workgroup stored are the next block's operand: their drain -- and the L1 invalidate -- waits behind the next
+    // block's first weight copy; the last block's stores are completed by the end of the kernel)
+    B2_STAMP(5)
+    f_lds_barrier();                                                         // every image is free
+    B2_STAMP(6)
     }
 }
 
