@@ -107,6 +107,15 @@ class Block2(ctypes.Structure):
                 ("Y2", _vp), ("ldy2", _i64)]
 
 
+class TopDesc(ctypes.Structure):
+    """struct dhaug_top_desc (include/dhaug.h)"""
+    _fields_ = [("seed", _vp), ("ld_seed", _i64), ("wout", _vp), ("ld_wout", _i64), ("x", _vp), ("ldx", _i64), ("m1", _vp), ("mh", _vp),
+                ("m0", _vp), ("ld_m", _i64), ("w2", _vp), ("ldw2", _i64), ("w1", _vp), ("ldw1", _i64), ("wm", _vp), ("ldwm", _i64),
+                ("bits0", _vp), ("bits1", _vp), ("g2", _vp), ("g1", _vp), ("g0", _vp), ("ld_g", _i64), ("gcat", _vp), ("ld_gcat", _i64),
+                ("M", _i64), ("n0", _i64), ("nc", _i64), ("mask_act", _i32), ("mask_slope", _f32)]
+
+
+SIGNATURES["dhaug_critic_top_backward_bf16"] = [ctypes.POINTER(TopDesc), _vp]
 BLOCK2_MAX = 3
 SIGNATURES["dhaug_gemm_block2_stack_bf16"] = [_vp, _i64, ctypes.POINTER(Block2), _i32, _i32, _f32, _i64, _vp]
 TN_GROUP_MAX = 42

@@ -614,6 +614,14 @@ def _tan_layer_major(m, branches, u_first, hs, ys):
     return u, uh
 
 
+def _top_fusable(m, Lm, Mb, Lo, nb, Dw, M, masks, cat):
+    """the top of the critic (merge layer -> merge block -> logit layer) as one launch per sweep: ops.critic_top_backward"""
+    n0 = Lm.N
+    return (m.bf16 and nb == 2 and Dw == 256 and Lm.K == 512 and Lo.N == 1 and Lo.K == n0 and Mb.fc1.N == n0 and Mb.fc1.K == n0
+            and Mb.fc2.N == n0 and Mb.fc2.K == n0 and Lm.act == RELU and Mb.fc1.act == RELU and Mb.fc2.act == RELU
+            and ops.top_backward_ok(M, n0, 512, masks, getattr(cat, "_dhaug_bits_cols", None)))
+
+
 def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, input_grad, tangents, pen_view=None, fwd=None):
     """The four sweeps for a critic of the form  cat_b(branch_b(feat_b(x))) -> Linear(100)+ReLU -> myResNet(100) -> Linear(1).
     X (3*rows, W) fp32 = [real; fake; x_hat] (ops.gp_assemble); feats(X) -> one fp32 input per branch (3*rows each);
@@ -650,11 +658,17 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
         logits = Lo.fwd(m, m1, out_f32=True)
     # ---- 2. backward chain
     gzo = seeds(B, m, dev)
-    gz_m2 = Lo.bwd(m, gzo, m1, RELU, 0.0)
-    gz_m1, gz_m0 = Mb.bwd(m, gz_m2, mh, m0)
     if Dw == 256 and all(getattr(y[bi][-1], "_dhaug_bits", None) is not None for bi in range(nb)):
         cat._dhaug_bits_cols = [y[bi][-1]._dhaug_bits for bi in range(nb)]      # (the mask of column block bi: its branch's sign bits)
-    gcat = Lm.bwd(m, gz_m0, cat, RELU, 0.0, out=m.empty_blocks(M3, nb, Dw, dev))   # (3B, nb*D): cotangents at every branch's last fc2
+    if _top_fusable(m, Lm, Mb, Lo, nb, Dw, M3, (m1, mh, m0), cat):
+        # merge layer, merge block and logit layer in ONE launch: the 100-wide cotangents stay in LDS between the layers
+        gz_m2, gz_m1, gz_m0, gcat = ops.critic_top_backward(
+            gzo, A._w_nn(Lo.W, m.prec)[:, 0], m1, mh, m0, A._w_nn(Mb.fc2.W, m.prec), A._w_nn(Mb.fc1.W, m.prec), A._w_nn(Lm.W, m.prec),
+            cat._dhaug_bits_cols, Lm.N, RELU, 0.0)
+    else:
+        gz_m2 = Lo.bwd(m, gzo, m1, RELU, 0.0)
+        gz_m1, gz_m0 = Mb.bwd(m, gz_m2, mh, m0)
+        gcat = Lm.bwd(m, gz_m0, cat, RELU, 0.0, out=m.empty_blocks(M3, nb, Dw, dev))   # (3B, nb*D): cotangents at every branch's last fc2
     g1, g2, gin = [], [], []
     if _layer_major(m, branches):
         g1, g2 = _bwd_layer_major(m, branches, gcat, h, y, Dw)

@@ -330,6 +330,9 @@ def gemm_nt_dmask(A, B, N, K, dmask, dmask_act, dmask_slope=0.0, res_bf16=None, 
 
 
 NT_GROUP_MAX = 8
+# the top of a branch critic (merge layer, merge block, logit layer) as one launch per sweep (dhaug_critic_top_*): DHAUG_NO_TOP_FUSED=1
+# runs the separate launches
+TOP_FUSED = os.environ.get("DHAUG_NO_TOP_FUSED") is None
 
 
 def gemm_nt_group(members):
@@ -662,6 +665,40 @@ def rank1_mask(seed, w_col, mask, n, act, slope=0.0, out=None):
     _lib.call("dhaug_rank1_mask_bf16", _p(seed), seed.stride(0), _p(w_col), w_col.stride(0), _p(mask), mask.stride(0), _p(out),
               out.stride(0), M, n, pad, act, float(slope), _stream())
     return out
+
+
+def top_backward_ok(M, n0, nc, masks, bits_cols):
+    """dhaug_critic_top_backward_bf16 covers: whole 64-row tiles, a merge block of at most 112 features behind a concatenation of two
+    256-wide branches whose masks are sign-bit arrays, bf16 activations with 16-byte aligned rows"""
+    return (TOP_FUSED and M >= 64 and M % 64 == 0 and 1 <= n0 <= 112 and nc == 512 and bits_cols is not None and len(bits_cols) == 2
+            and all(b is not None for b in bits_cols)
+            and all(t.dtype == BF16 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.shape[1] >= 112
+                    and t.data_ptr() % 16 == 0 for t in masks))
+
+
+def critic_top_backward(seed, w_out_col, m1, mh, m0, W2nn, W1nn, Wmnn, bits_cols, n0, act, slope=0.0, gcat=None):
+    """sweep 2 through the top of a branch critic in ONE launch (dhaug_critic_top_backward_bf16): returns (gz_m2, gz_m1, gz_m0, gcat) --
+    bf16 (M, 112) cotangents at the logit layer's input / the merge block's fc1 pre-activation / the merge layer's pre-activation, and
+    (M, 512) at the branches' outputs.  seed (M, >= 1) bf16; w_out_col: the logit layer's weights along dim 0; m1, mh, m0: saved
+    activations; W2nn, W1nn (n0, >= 112), Wmnn (512, >= 112): operand copies whose rows are the products' outputs."""
+    M = m1.shape[0]
+    dev = m1.device
+    g2, g1, g0 = (torch.empty((M, 112), dtype=BF16, device=dev) for _ in range(3))
+    if gcat is None:
+        gcat = torch.empty((M, 512), dtype=BF16, device=dev)
+    assert gcat.dtype == BF16 and gcat.stride(1) == 1 and gcat.shape[0] == M and gcat.shape[1] >= 512
+    assert all(b.device == dev for b in bits_cols), "sign bits must live on the operands' device"
+    d = _lib.TopDesc()
+    d.seed, d.ld_seed, d.wout, d.ld_wout = _p(seed), seed.stride(0), _p(w_out_col), w_out_col.stride(0)
+    d.x, d.ldx = None, 0
+    d.m1, d.mh, d.m0, d.ld_m = _p(m1), _p(mh), _p(m0), m1.stride(0)
+    assert mh.stride(0) == m1.stride(0) and m0.stride(0) == m1.stride(0)
+    d.w2, d.ldw2, d.w1, d.ldw1, d.wm, d.ldwm = _p(W2nn), W2nn.stride(0), _p(W1nn), W1nn.stride(0), _p(Wmnn), Wmnn.stride(0)
+    d.bits0, d.bits1 = _p(bits_cols[0]), _p(bits_cols[1])
+    d.g2, d.g1, d.g0, d.ld_g, d.gcat, d.ld_gcat = _p(g2), _p(g1), _p(g0), 112, _p(gcat), gcat.stride(0)
+    d.M, d.n0, d.nc, d.mask_act, d.mask_slope = M, n0, 512, act, float(slope)
+    _lib.call("dhaug_critic_top_backward_bf16", ctypes.byref(d), _stream())
+    return g2, g1, g0, gcat
 
 
 def add_f32(a, b):

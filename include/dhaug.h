@@ -564,6 +564,33 @@ int dhaug_critic_scalars(const float* logits, int64_t ld, const float* pen, int6
                          float* scratch /* DHAUG_CRITIC_SCALARS_SCRATCH floats, any content */, void* stream);
 #define DHAUG_CRITIC_SCALARS_SCRATCH 192
 
+/* The TOP of a branch critic -- merge layer (concatenation of two 256-wide branches -> n0 <= 112 features), one n0-wide myResNet
+ * block, the 1-wide logit layer (R/models_Fk_GAN/Fk_discriminator.py:149-201: merge_previous, merge_block1, output) -- in the
+ * explicit training step, ONE launch per sweep; the n0-wide tensors stay in LDS between the layers, results bit-identical to the
+ * launches replaced (dhaug_rank1_mask_bf16 + three dhaug_gemm_bf16_dmask_pad / dhaug_gemm_bf16_dbits_wide calls).
+ *   dhaug_critic_top_backward_bf16 (sweep 2):
+ *     g2 = bf16(seed w_out) * act'(m1);  g1 = (g2 W2^T) * act'(mh);  g0 = (g1 W1^T + g2) * act'(m0);  gcat = (g0 Wm^T) * act'(cat)
+ *     with W2 / W1 (n0, >= 112) and Wm (512, >= 112) the operand copies whose ROWS are the product's outputs (the "nn" copies of
+ *     merge_block1.fc2 / fc1 and merge_previous), the masks of the concatenation as the two sign-bit arrays of its 256-column blocks
+ *     (struct dhaug_mlp_unit.bits).  m1, mh, m0: the saved activations (M, ld_m) bf16; g2, g1, g0 (M, ld_g) bf16 with zero columns
+ *     [n0, 112); gcat (M, ld_gcat >= 512).  M a multiple of 64 (DHAUG_EUNSUPPORTED otherwise: the caller uses the separate launches).
+ * All matrices bf16 with 16-byte aligned rows. */
+typedef struct dhaug_top_desc {
+    const uint16_t* seed; int64_t ld_seed;              /* (M, >= 1): column 0 = the logit cotangent of the row */
+    const uint16_t* wout; int64_t ld_wout;              /* the logit layer's n0 weights, element stride ld_wout */
+    const uint16_t* x; int64_t ldx;                     /* tangent sweep: the tangent of the concatenation (M, 512) */
+    const uint16_t* m1; const uint16_t* mh; const uint16_t* m0; int64_t ld_m;
+    const uint16_t* w2; int64_t ldw2;
+    const uint16_t* w1; int64_t ldw1;
+    const uint16_t* wm; int64_t ldwm;
+    const uint32_t* bits0; const uint32_t* bits1;
+    uint16_t* g2; uint16_t* g1; uint16_t* g0; int64_t ld_g;
+    uint16_t* gcat; int64_t ld_gcat;
+    int64_t M; int64_t n0; int64_t nc;                  /* nc = 512 */
+    int32_t mask_act; float mask_slope;
+} dhaug_top_desc;
+int dhaug_critic_top_backward_bf16(const dhaug_top_desc* d, void* stream);
+
 /* First step of a critic's backward chain, through its 1-wide logit layer: out[r][c] = bf16(seed[r] * w[c]) * act'(mask[r][c])
  * for c < N, zero in [N, pad_cols) -- (gz W_out) * act'(y) of R/models_Fk_GAN/Fk_discriminator.py:201,266's backward, which as
  * a GEMM has K = 1.  seed: bf16, one value per row (stride ld_seed); w: the layer's N weights as bf16 (stride ld_w); mask, out:

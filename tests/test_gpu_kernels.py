@@ -252,6 +252,37 @@ def test_gemm_nt_big_tiles_epilogues(ops, M):
     assert (cb.float() - cb_old.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M", [64, 8192, 64 * 515])
+def test_critic_top_backward_equals_the_four_launches(ops, M):
+    """dhaug_critic_top_backward_bf16 (merge layer, 100-wide merge block and logit layer of the 3D critic's backward chain in one
+    launch) against the launches it replaces -- dhaug_rank1_mask_bf16, two dhaug_gemm_bf16_dmask_pad (the second with the skip), one
+    dhaug_gemm_bf16_dbits_wide: bit-identical cotangents, zero pad columns included; one tile, one tile per workgroup, ragged tile counts."""
+    gen = torch.Generator().manual_seed(21)
+    n0 = 100
+    act = lambda: _bf(torch.cat([torch.relu(torch.randn(M, n0, generator=gen)), torch.zeros(M, 12)], 1)).cuda()   # saved activations (M, 112)
+    m1, mh, m0 = act(), act(), act()
+    seed = _bf(torch.cat([torch.randn(M, 1, generator=gen) * 0.01, torch.zeros(M, 15)], 1)).cuda()
+    mk = lambda rows, cols, pad: _bf(torch.cat([torch.randn(rows, cols, generator=gen) / cols ** 0.5, torch.zeros(rows, pad - cols)], 1)).cuda()
+    W2nn, W1nn, Wmnn = mk(n0, n0, 112), mk(n0, n0, 112), mk(512, n0, 112)
+    wout = mk(n0, 1, 16)                                          # the logit layer's "nn" copy: (100, 16), column 0
+    nb = (M + 127) // 128 * 4 * 256
+    bits = [torch.randint(-2**31, 2**31 - 1, (nb,), dtype=torch.int32, generator=gen).cuda() for _ in range(2)]
+    cat = torch.zeros(M, 512, dtype=torch.bfloat16, device="cuda")
+    cat._dhaug_bits_cols = bits
+    assert ops.top_backward_ok(M, n0, 512, (m1, mh, m0), bits)
+    g2, g1, g0, gcat = ops.critic_top_backward(seed, wout[:, 0], m1, mh, m0, W2nn, W1nn, Wmnn, bits, n0, 1, 0.0)
+    r2 = ops.rank1_mask(seed, wout[:, 0], m1, n0, 1, 0.0)
+    r1 = ops.gemm_nt_dmask(r2, W2nn, n0, 112, mh, 1, 0.0)
+    r0 = ops.gemm_nt_dmask(r1, W1nn, n0, 112, m0, 1, 0.0, res_bf16=r2)
+    rcat = ops.gemm_nt_dmask(r0, Wmnn, 512, 112, cat, 1, 0.0)
+    for name, a, b in (("g2", g2, r2), ("g1", g1, r1), ("g0", g0, r0), ("gcat", gcat, rcat)):
+        assert a.shape == b.shape and torch.equal(a, b), (name, (a.float() - b.float()).abs().max().item())
+    # and against plain fp64 arithmetic on the same operands (the rounding points named in the kernel)
+    f = lambda t: t.float().cpu().double()
+    e2 = (f(seed)[:, :1] * f(wout)[:, 0][None, :]) * (f(m1)[:, :n0] > 0)
+    assert (f(g2)[:, :n0] - e2).abs().max().item() <= 2.0 ** -8 * max(1e-6, e2.abs().max().item())
+
+
 @pytest.mark.parametrize("M,n", [(1536, 4), (512, 4), (1536 + 72, 2), (200, 3)])
 def test_gemm_nt_group_128_tiles_equal_single_launches(ops, M, n):
     """dhaug_gemm_bf16_group on 128 x 128 tiles (a motion critic's branch layers at one depth as ONE launch: DenseDim 1000, K = 1008
