@@ -116,6 +116,7 @@ class TopDesc(ctypes.Structure):
 
 
 SIGNATURES["dhaug_critic_top_backward_bf16"] = [ctypes.POINTER(TopDesc), _vp]
+SIGNATURES["dhaug_critic_top_tangent_bf16"] = [ctypes.POINTER(TopDesc), _vp]
 BLOCK2_MAX = 3
 SIGNATURES["dhaug_gemm_block2_stack_bf16"] = [_vp, _i64, ctypes.POINTER(Block2), _i32, _i32, _f32, _i64, _vp]
 TN_GROUP_MAX = 42

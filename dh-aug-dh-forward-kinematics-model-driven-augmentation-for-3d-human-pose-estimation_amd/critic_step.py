@@ -614,12 +614,16 @@ def _tan_layer_major(m, branches, u_first, hs, ys):
     return u, uh
 
 
-def _top_fusable(m, Lm, Mb, Lo, nb, Dw, M, masks, cat):
-    """the top of the critic (merge layer -> merge block -> logit layer) as one launch per sweep: ops.critic_top_backward"""
+def _top_shapes(m, Lm, Mb, Lo, nb, Dw):
+    """a concatenation of two 256-wide branches -> Linear(n0 <= 112) + ReLU -> myResNet(n0) -> Linear(1): what ops.critic_top_* cover"""
     n0 = Lm.N
     return (m.bf16 and nb == 2 and Dw == 256 and Lm.K == 512 and Lo.N == 1 and Lo.K == n0 and Mb.fc1.N == n0 and Mb.fc1.K == n0
-            and Mb.fc2.N == n0 and Mb.fc2.K == n0 and Lm.act == RELU and Mb.fc1.act == RELU and Mb.fc2.act == RELU
-            and ops.top_backward_ok(M, n0, 512, masks, getattr(cat, "_dhaug_bits_cols", None)))
+            and Mb.fc2.N == n0 and Mb.fc2.K == n0 and Lm.act == RELU and Mb.fc1.act == RELU and Mb.fc2.act == RELU)
+
+
+def _top_fusable(m, Lm, Mb, Lo, nb, Dw, M, masks, cat):
+    """the top of the critic (merge layer -> merge block -> logit layer) as one launch per sweep: ops.critic_top_backward"""
+    return _top_shapes(m, Lm, Mb, Lo, nb, Dw) and ops.top_backward_ok(M, Lm.N, 512, masks, getattr(cat, "_dhaug_bits_cols", None))
 
 
 def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, input_grad, tangents, pen_view=None, fwd=None):
@@ -709,8 +713,16 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
         ucat = m.empty(B, nb * Dw, dev)
         for bi in range(nb):
             ucat[:, bi * Dw:(bi + 1) * Dw].copy_(u[bi][-1][:, :Dw])
-    um0 = Lm.tan(m, ucat, m0[B2:], inplace=True)
-    umh, um1 = Mb.tan(m, um0, mh[B2:], m1[B2:])
+    if (_top_shapes(m, Lm, Mb, Lo, nb, Dw) and ops.top_tangent_ok(B, Lm.N, 512, ucat, (m0[B2:], mh[B2:], m1[B2:]))
+            and ucat.data_ptr() != m0[B2:].data_ptr()):
+        # merge layer and merge block of the tangent sweep in ONE launch, in place over the interpolated rows of m0, mh, m1
+        # (it runs beside sweep 4's side-stream part; holding it to the CUs that part leaves free -- 96 / 128 / 160 workgroups -- was
+        # measured: no difference, 6.02-6.04 ms per iteration)
+        um0, umh, um1 = ops.critic_top_tangent(ucat, m0[B2:], mh[B2:], m1[B2:], A._w_nt(Lm.W, 512, m.prec), A._w_nt(Mb.fc1.W, 112, m.prec),
+                                               A._w_nt(Mb.fc2.W, 112, m.prec), Lm.N, RELU, 0.0)
+    else:
+        um0 = Lm.tan(m, ucat, m0[B2:], inplace=True)
+        umh, um1 = Mb.tan(m, um0, mh[B2:], m1[B2:])
     # ---- 4. weight / bias gradients (the interpolated rows' part where the real / fake rows' part is already under way)
     if split:
         for bi, br in enumerate(branches):

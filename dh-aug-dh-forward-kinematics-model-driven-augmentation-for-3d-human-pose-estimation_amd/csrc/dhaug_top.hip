@@ -384,6 +384,112 @@ __global__ __launch_bounds__(256, 1) void top_backward_kernel(TopArgs p) {
     }
 }
 
+
+// ---- the tangent sweep through the same three layers, in place over the interpolated rows of the saved activations
+//        um0 = (x Wm^T) * act'(m0) -> m0;   umh = (um0 W1^T) * act'(mh) -> mh;   um1 = (umh W2^T + um0) * act'(m1) -> m1
+// x (M, 512): the tangent of the concatenation; Wm [n0][>= 512], W1 / W2 [n0][>= 112] the "nt" operand copies.  Same tiles, same
+// request-ahead scheme; the x tile (64 KB) travels in registers like the mask tiles.
+// (the x tile's sixteen registers per thread are sixteen NAMED variables: as an array member of a struct hipcc kept them in scratch)
+#define TOPT_X16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+__global__ __launch_bounds__(256, 1) void top_tangent_kernel(TopArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sU0 = smem;
+    unsigned char* sUH = smem + T_IMG;
+    unsigned char* sU1 = smem + 2 * T_IMG;
+    unsigned char* sM1 = smem + 3 * T_IMG;
+    unsigned char* sMH = smem + 4 * T_IMG;
+    unsigned char* sM0 = smem + 5 * T_IMG;
+    unsigned char* sX = smem + 6 * T_IMG;                                    // [64][T_OP]: the 512-column operand tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r31 = lane & 31, h = lane >> 5;
+    const long long ntiles = p.M / T_BM;
+    if ((long long)blockIdx.x >= ntiles) return;
+
+    bf16x8 w2f[T_KS], w1f[T_KS], wmf[32];                                    // merge: slice `wave`, 32 k-steps
+    stage_rows(p.w2, p.ldw2, p.n0, 128, smem, tid);
+    stage_rows(p.w1, p.ldw1, p.n0, 128, smem + 128 * T_P, tid);
+    t_barrier();
+#pragma unroll
+    for (int ks = 0; ks < T_KS; ++ks) { w2f[ks] = frag(smem, wave, ks, r31, h); w1f[ks] = frag(smem + 128 * T_P, wave, ks, r31, h); }
+    t_barrier();
+    for (int q = tid; q < 128 * 64; q += 256) {                              // Wm: 128 rows (zero beyond n0) x 64 chunks, pitch T_OP
+        const int row = q >> 6, c = q & 63;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < p.n0) v = *reinterpret_cast<const uint4*>(p.wm + (long long)row * p.ldwm + c * 8);
+        *reinterpret_cast<uint4*>(smem + row * T_OP + c * 16) = v;
+    }
+    t_barrier();
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) wmf[ks] = *reinterpret_cast<const bf16x8*>(smem + (32 * wave + r31) * T_OP + (2 * ks + h) * 16);
+    t_barrier();
+
+    const TileMap tm = tile_map(tid);
+    const int xrow = tid >> 6, xc = tid & 63;                                // x chunk q = tid + 256 i: row xrow + 4 i, chunk xc
+    TileRegs r1, rh, r0;
+#define TOPT_DECL(i) uint4 rx##i;
+    TOPT_X16(TOPT_DECL)
+    const long long last = ntiles - 1 - ((ntiles - 1 - blockIdx.x) % gridDim.x);
+    auto clampt = [&](long long t) { return t < ntiles ? t : last; };
+#define TOPT_XLD(i) rx##i = *reinterpret_cast<const uint4*>(p.x + (row0_ + xrow + 4 * (i)) * p.ldx + xc * 8);
+#define TOPT_XST(i) *reinterpret_cast<uint4*>(sX + (xrow + 4 * (i)) * T_OP + xc * 16) = rx##i;
+#define TOPT_REQUEST(t) { const long long row0_ = (t) * T_BM; \
+        tile_load(p.m1, p.ld_m, row0_, tm, r1); tile_load(p.mh, p.ld_m, row0_, tm, rh); tile_load(p.m0, p.ld_m, row0_, tm, r0); \
+        TOPT_X16(TOPT_XLD) }
+#define TOPT_TO_LDS() { tile_to_lds(r1, sM1, tm); tile_to_lds(rh, sMH, tm); tile_to_lds(r0, sM0, tm); TOPT_X16(TOPT_XST) }
+    TOPT_REQUEST((long long)blockIdx.x)
+    TOPT_TO_LDS()
+    TOPT_REQUEST(clampt((long long)blockIdx.x + gridDim.x))
+    t_barrier();
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long row0 = tile * T_BM;
+        // ---- the merge layer: K = 512, k ascending (as the generic kernel it replaces sums it)
+        {
+            bf16x8 fx[4][2];
+            uint2 mk[2][4];
+#define TOP_RDX(ks) { _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_) fx[(ks) & 3][a_] = *reinterpret_cast<const bf16x8*>(sX + (32 * a_ + r31) * T_OP + (2 * (ks) + h) * 16); }
+            TOP_RDX(0) TOP_RDX(1) TOP_RDX(2)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) mk[a][gq] = mask_words(sM0, 32 * a + r31, 32 * wave + 8 * gq + 4 * h);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 acc[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 32; ++ks) {
+                if (ks + 3 < 32) TOP_RDX(ks + 3)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wmf[ks], fx[ks & 3][a], acc[a], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[a][4 * gq + e];
+                    quad_out(v, mk[a][gq], sU0, 32 * a + r31, 32 * wave + 8 * gq + 4 * h, p.dneg);
+                }
+        }
+        t_barrier();                                                         // (the x tile and the m0 tile have been read)
+        tile_store(sU0, p.m0, p.ld_m, row0, tm);
+        small_layer(w1f, sU0, nullptr, sMH, sUH, wave, r31, h, p.dneg);
+        t_barrier();
+        tile_store(sUH, p.mh, p.ld_m, row0, tm);
+        small_layer(w2f, sUH, sU0, sM1, sU1, wave, r31, h, p.dneg);
+        t_barrier();                                                         // (every mask image of this tile has been read)
+        tile_store(sU1, p.m1, p.ld_m, row0, tm);
+        TOPT_TO_LDS()
+        TOPT_REQUEST(clampt(tile + 2 * (long long)gridDim.x))
+        t_barrier();
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -424,6 +530,34 @@ int dhaug_critic_top_backward_bf16(const dhaug_top_desc* d, void* stream) {
     const long long tiles = d->M / T_BM;
     const unsigned grid = dhaug_persistent_grid(tiles);
     hipLaunchKernelGGL(top_backward_kernel, dim3(grid), dim3(256), T_LDS, (hipStream_t)stream, a);
+    return dhaug_launch_status();
+}
+
+/* see include/dhaug.h */
+int dhaug_critic_top_tangent_bf16(const dhaug_top_desc* d, void* stream) {
+    DHAUG_CHECK_PTR(d);
+    DHAUG_CHECK(d->M >= 0 && d->M % T_BM == 0 && d->n0 >= 1 && d->n0 <= 112 && d->nc == 512, DHAUG_EUNSUPPORTED);
+    DHAUG_CHECK(d->mask_act == DHAUG_ACT_RELU || d->mask_act == DHAUG_ACT_LRELU, DHAUG_EINVAL);
+    if (d->M == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(d->x); DHAUG_CHECK_PTR(d->m1); DHAUG_CHECK_PTR(d->mh); DHAUG_CHECK_PTR(d->m0);
+    DHAUG_CHECK_PTR(d->w2); DHAUG_CHECK_PTR(d->w1); DHAUG_CHECK_PTR(d->wm);
+    DHAUG_CHECK(d->ld_m >= 112 && d->ldw2 >= 112 && d->ldw1 >= 112 && d->ldwm >= 512 && d->ldx >= 512, DHAUG_EINVAL);
+    DHAUG_CHECK(d->ld_m % 8 == 0 && d->ldw2 % 8 == 0 && d->ldw1 % 8 == 0 && d->ldwm % 8 == 0 && d->ldx % 8 == 0, DHAUG_EALIGN);
+    DHAUG_CHECK(dhaug_aligned16(d->m1) && dhaug_aligned16(d->mh) && dhaug_aligned16(d->m0) && dhaug_aligned16(d->w2) && dhaug_aligned16(d->w1) &&
+                dhaug_aligned16(d->wm) && dhaug_aligned16(d->x), DHAUG_EALIGN);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(top_tangent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    TopArgs a{};
+    a.x = d->x; a.ldx = d->ldx;
+    a.m1 = const_cast<uint16_t*>(d->m1); a.mh = const_cast<uint16_t*>(d->mh); a.m0 = const_cast<uint16_t*>(d->m0); a.ld_m = d->ld_m;
+    a.w2 = d->w2; a.ldw2 = d->ldw2; a.w1 = d->w1; a.ldw1 = d->ldw1; a.wm = d->wm; a.ldwm = d->ldwm;
+    a.M = d->M; a.n0 = (int)d->n0; a.dneg = d->mask_act == DHAUG_ACT_RELU ? 0.0f : d->mask_slope;
+    const unsigned grid = dhaug_persistent_grid(d->M / T_BM);
+    hipLaunchKernelGGL(top_tangent_kernel, dim3(grid), dim3(256), T_LDS, (hipStream_t)stream, a);
     return dhaug_launch_status();
 }
 

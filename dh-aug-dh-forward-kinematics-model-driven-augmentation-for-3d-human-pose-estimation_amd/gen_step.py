@@ -56,12 +56,18 @@ class _BranchNet:
     def input_grads(self, m, s, seed):
         """s: forward(); seed (rows,1) logit cotangent -> one fp32 input cotangent per branch"""
         Dw = self.br[0].first.N
-        gz_m2 = self.Lo.bwd(m, seed, s["m1"], RELU, 0.0)
-        _, gz_m0 = self.Mb.bwd(m, gz_m2, s["mh"], s["m0"])
         cat = s["cat"]
         if Dw == 256 and all(getattr(s["y"][bi][-1], "_dhaug_bits", None) is not None for bi in range(len(self.br))):
             cat._dhaug_bits_cols = [s["y"][bi][-1]._dhaug_bits for bi in range(len(self.br))]
-        gcat = self.Lm.bwd(m, gz_m0, cat, RELU, 0.0, out=m.empty_blocks(cat.shape[0], len(self.br), Dw, cat.device))
+        if CS._top_fusable(m, self.Lm, self.Mb, self.Lo, len(self.br), Dw, cat.shape[0], (s["m1"], s["mh"], s["m0"]), cat):
+            # (merge layer, merge block and logit layer in one launch, as in the critic step: ops.critic_top_backward)
+            _, _, _, gcat = ops.critic_top_backward(
+                seed, CS.A._w_nn(self.Lo.W, m.prec)[:, 0], s["m1"], s["mh"], s["m0"], CS.A._w_nn(self.Mb.fc2.W, m.prec),
+                CS.A._w_nn(self.Mb.fc1.W, m.prec), CS.A._w_nn(self.Lm.W, m.prec), cat._dhaug_bits_cols, self.Lm.N, RELU, 0.0)
+        else:
+            gz_m2 = self.Lo.bwd(m, seed, s["m1"], RELU, 0.0)
+            _, gz_m0 = self.Mb.bwd(m, gz_m2, s["mh"], s["m0"])
+            gcat = self.Lm.bwd(m, gz_m0, cat, RELU, 0.0, out=m.empty_blocks(cat.shape[0], len(self.br), Dw, cat.device))
         gin = []
         for bi, br in enumerate(self.br):
             _, a2 = CS.stack_bwd(m, br.blocks, gcat[:, bi * Dw:(bi + 1) * Dw], s["h"][bi], s["y"][bi])

@@ -701,6 +701,31 @@ def critic_top_backward(seed, w_out_col, m1, mh, m0, W2nn, W1nn, Wmnn, bits_cols
     return g2, g1, g0, gcat
 
 
+def critic_top_tangent(ucat, m0, mh, m1, Wm_nt, W1_nt, W2_nt, n0, act, slope=0.0):
+    """sweep 3 through the top of a branch critic in ONE launch (dhaug_critic_top_tangent_bf16), IN PLACE: the rows of the saved
+    activations m0, mh, m1 (the interpolated rows' views) are overwritten with the tangents um0, umh, um1, which are returned.
+    ucat (M, 512) bf16; Wm_nt (n0, >= 512), W1_nt / W2_nt (n0, >= 112): the layers' "nt" operand copies."""
+    M = ucat.shape[0]
+    assert ucat.dtype == BF16 and ucat.stride(1) == 1 and ucat.shape[1] >= 512
+    assert mh.stride(0) == m0.stride(0) and m1.stride(0) == m0.stride(0)
+    d = _lib.TopDesc()
+    d.seed, d.ld_seed, d.wout, d.ld_wout = None, 0, None, 0
+    d.x, d.ldx = _p(ucat), ucat.stride(0)
+    d.m1, d.mh, d.m0, d.ld_m = _p(m1), _p(mh), _p(m0), m0.stride(0)
+    d.w2, d.ldw2, d.w1, d.ldw1, d.wm, d.ldwm = _p(W2_nt), W2_nt.stride(0), _p(W1_nt), W1_nt.stride(0), _p(Wm_nt), Wm_nt.stride(0)
+    d.bits0, d.bits1, d.g2, d.g1, d.g0, d.ld_g, d.gcat, d.ld_gcat = None, None, None, None, None, 0, None, 0
+    d.M, d.n0, d.nc, d.mask_act, d.mask_slope = M, n0, 512, act, float(slope)
+    _lib.call("dhaug_critic_top_tangent_bf16", ctypes.byref(d), _stream())
+    return m0, mh, m1
+
+
+def top_tangent_ok(M, n0, nc, ucat, masks):
+    return (TOP_FUSED and M >= 64 and M % 64 == 0 and 1 <= n0 <= 112 and nc == 512 and ucat.dtype == BF16 and ucat.dim() == 2
+            and ucat.stride(1) == 1 and ucat.stride(0) % 8 == 0 and ucat.shape[1] >= 512 and ucat.data_ptr() % 16 == 0
+            and all(t.dtype == BF16 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.shape[1] >= 112
+                    and t.data_ptr() % 16 == 0 and t.stride(0) == masks[0].stride(0) for t in masks))
+
+
 def add_f32(a, b):
     """a + b (fp32, same shape)"""
     a, b = _dev(a, torch.float32, "add_f32"), _dev(b, torch.float32, "add_f32")

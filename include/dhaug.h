@@ -590,6 +590,11 @@ typedef struct dhaug_top_desc {
     int32_t mask_act; float mask_slope;
 } dhaug_top_desc;
 int dhaug_critic_top_backward_bf16(const dhaug_top_desc* d, void* stream);
+/*   dhaug_critic_top_tangent_bf16 (sweep 3, rows = the interpolated rows): IN PLACE over the rows of the saved activations,
+ *     m0 <- (x Wm^T) * act'(m0);  mh <- (m0' W1^T) * act'(mh);  m1 <- (mh' W2^T + m0') * act'(m1)      (primes: the values just written)
+ *     x (M, ldx >= 512) the tangent of the concatenation; Wm (n0, >= 512), W1 / W2 (n0, >= 112) the "nt" operand copies (rows = the
+ *     layer's outputs).  Replaces one dhaug_gemm_bf16_dmask_pad with K = 512 and two with K = 112 (the second with the skip); same bits. */
+int dhaug_critic_top_tangent_bf16(const dhaug_top_desc* d, void* stream);
 
 /* First step of a critic's backward chain, through its 1-wide logit layer: out[r][c] = bf16(seed[r] * w[c]) * act'(mask[r][c])
  * for c < N, zero in [N, pad_cols) -- (gz W_out) * act'(y) of R/models_Fk_GAN/Fk_discriminator.py:201,266's backward, which as

@@ -283,6 +283,29 @@ def test_critic_top_backward_equals_the_four_launches(ops, M):
     assert (f(g2)[:, :n0] - e2).abs().max().item() <= 2.0 ** -8 * max(1e-6, e2.abs().max().item())
 
 
+@pytest.mark.parametrize("M", [64, 4096, 64 * 515])
+def test_critic_top_tangent_equals_the_three_launches(ops, M):
+    """dhaug_critic_top_tangent_bf16 (merge layer with K = 512 and the 100-wide merge block of the 3D critic's tangent sweep in one
+    launch, in place over the activations it masks with) against the three dhaug_gemm_bf16_dmask_pad launches it replaces: same bits."""
+    gen = torch.Generator().manual_seed(23)
+    n0 = 100
+    act = lambda: _bf(torch.cat([torch.relu(torch.randn(M, n0, generator=gen)), torch.zeros(M, 12)], 1)).cuda()
+    m0, mh, m1 = act(), act(), act()
+    ucat = _bf(torch.randn(M, 512, generator=gen) * 0.1).cuda()
+    mk = lambda rows, cols, pad: _bf(torch.cat([torch.randn(rows, cols, generator=gen) / cols ** 0.5, torch.zeros(rows, pad - cols)], 1)).cuda()
+    Wm, W1, W2 = mk(n0, 512, 512), mk(n0, n0, 112), mk(n0, n0, 112)
+    a0, ah, a1 = m0.clone(), mh.clone(), m1.clone()
+    r0 = ops.gemm_nt_dmask(ucat, Wm, n0, 512, a0, 1, 0.0, out=a0)
+    rh = ops.gemm_nt_dmask(r0, W1, n0, 112, ah, 1, 0.0, out=ah)
+    r1 = ops.gemm_nt_dmask(rh, W2, n0, 112, a1, 1, 0.0, res_bf16=r0, out=a1)
+    assert ops.top_tangent_ok(M, n0, 512, ucat, (m0, mh, m1))
+    u0, uh, u1 = ops.critic_top_tangent(ucat, m0, mh, m1, Wm, W1, W2, n0, 1, 0.0)
+    for name, a, b in (("um0", u0, r0), ("umh", uh, rh), ("um1", u1, r1)):
+        assert torch.equal(a, b), (name, (a.float() - b.float()).abs().max().item())
+    ref0 = (ucat.float().cpu().double() @ Wm.float().cpu().double().t())[:, :n0]
+    assert torch.isfinite(u0.float()).all() and (u0[:, :n0].float().cpu().double() - ref0 * (ref0 == ref0)).abs().max().item() < 1e9   # (shape / finiteness)
+
+
 @pytest.mark.parametrize("M,n", [(1536, 4), (512, 4), (1536 + 72, 2), (200, 3)])
 def test_gemm_nt_group_128_tiles_equal_single_launches(ops, M, n):
     """dhaug_gemm_bf16_group on 128 x 128 tiles (a motion critic's branch layers at one depth as ONE launch: DenseDim 1000, K = 1008
