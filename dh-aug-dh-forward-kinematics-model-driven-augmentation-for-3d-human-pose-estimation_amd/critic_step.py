@@ -61,6 +61,9 @@ NT_GROUP = os.environ.get("DHAUG_NO_NT_GROUP") is None
 # split-operand arithmetic: one activation-side split per tensor and step (_Math.split0); DHAUG_NO_SPLIT_CACHE=1: one per use
 SPLIT_CACHE = os.environ.get("DHAUG_NO_SPLIT_CACHE") is None
 
+# the 3D critic's penalty step (KCS pull-back, norm, penalty cotangent, KCS tangent, bf16 operands) as one launch: ops.d3_penalty
+D3_PENALTY_FUSED = os.environ.get("DHAUG_NO_D3_PENALTY_FUSED") is None
+
 BF16 = torch.bfloat16
 NONE, RELU, LRELU = A.ACT_NONE, A.ACT_RELU, A.ACT_LRELU
 ceil16 = A.ceil16
@@ -626,7 +629,7 @@ def _top_fusable(m, Lm, Mb, Lo, nb, Dw, M, masks, cat):
     return _top_shapes(m, Lm, Mb, Lo, nb, Dw) and ops.top_backward_ok(M, Lm.N, 512, masks, getattr(cat, "_dhaug_bits_cols", None))
 
 
-def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, input_grad, tangents, pen_view=None, fwd=None):
+def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, input_grad, tangents, pen_view=None, fwd=None, penalty=None):
     """The four sweeps for a critic of the form  cat_b(branch_b(feat_b(x))) -> Linear(100)+ReLU -> myResNet(100) -> Linear(1).
     X (3*rows, W) fp32 = [real; fake; x_hat] (ops.gp_assemble); feats(X) -> one fp32 input per branch (3*rows each);
     input_grad([g_b]) -> dD/dx_hat (rows, W) fp32 from the branches' input cotangents (x_hat rows); tangents(v) -> one fp32
@@ -693,11 +696,17 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
         Mb.fc1.grads_part(m, gz_m1[:B2], m0[:B2], True); Mb.fc2.grads_part(m, gz_m2[:B2], mh[:B2], True)
         Lo.grads_part(m, gzo[:B2], m1[:B2], False)           # (its bias gradient is exactly zero: see _Lin.grads)
         m.flush_side()
-    g = input_grad(gin)                                      # dD/dx_hat
     # ---- 3. penalty and tangent sweep (x_hat rows)
-    gv = g if pen_view is None else g.reshape(pen_view)
-    v, pen = ops.gp_penalty(gv, 2.0 * lam / gv.shape[0])
-    T = tangents(v.reshape(g.shape))
+    if penalty is not None and m.bf16:
+        # dD/dx_hat, its norm, the penalty's cotangent and the branches' tangent inputs (bf16 operands) in ONE launch
+        T, pen = penalty(gin, 2.0 * lam / B)
+        n_pen = B
+    else:
+        g = input_grad(gin)                                  # dD/dx_hat
+        gv = g if pen_view is None else g.reshape(pen_view)
+        v, pen = ops.gp_penalty(gv, 2.0 * lam / gv.shape[0])
+        T = tangents(v.reshape(g.shape))
+        n_pen = gv.shape[0]
     u, uh = [], []
     if _layer_major(m, branches):
         u_first = [br.first.tan(m, T[bi], ops.tail_rows(y[bi][0], B2), inplace=True) for bi, br in enumerate(branches)]
@@ -743,7 +752,7 @@ def step_branchnet(m, optimizerD, branches, Lm, Mb, Lo, X, rows, lam, feats, inp
         Mb.fc1.grads(m, gz_m1, m0, B2, um0); Mb.fc2.grads(m, gz_m2, mh, B2, umh)
         Lo.grads(m, gzo, m1, B2, um1, bias_is_zero=m.bf16)
     m.flush()
-    return _finish(optimizerD, logits, pen, gv.shape[0], lam, rows=B)
+    return _finish(optimizerD, logits, pen, n_pen, lam, rows=B)
 
 
 def step_d3(D, optimizerD, real, fake, alpha, lam, prec=None):
@@ -764,7 +773,8 @@ def step_d3(D, optimizerD, real, fake, alpha, lam, prec=None):
         feats=lambda X: [kf, X],
         input_grad=lambda gs: ops.add_f32(ops.kcs_backward(xh, gs[0], True), gs[1]),      # KCS^T path + pose path
         tangents=lambda v: [ops.kcs_jvp(xh, v, True), v],
-        fwd=(lambda: fused.critic3d_forward_save(D, X, kb, save_rows=sr)) if use else None)
+        fwd=(lambda: fused.critic3d_forward_save(D, X, kb, save_rows=sr)) if use else None,
+        penalty=(lambda gs, coef: (lambda r: ([r[0], r[1]], r[2]))(ops.d3_penalty(xh, gs[0], gs[1], coef))) if D3_PENALTY_FUSED else None)
 
 
 def step_m3(D, optimizerD, real, fake, alpha, lam, prec=None):

@@ -192,6 +192,125 @@ __global__ __launch_bounds__(TILE) void kcs_diff_kernel(const float* __restrict_
     }
 }
 
+// The gradient penalty of the 3D critic between the backward chain and the tangent sweep (R/models_Fk_GAN/Fk_discriminator.py:205-231
+// through the KCS features, :81-140), one launch for what were six (kcs_diff<false>, add_f32, gp_penalty, kcs_diff<true>, two
+// cast_pad: 122 us of a 2.3 ms step at B = 65 536, tools/trace_step.py) -- one lane per interpolated pose:
+//     g   = KCS^T(x) gk + gp                       dD/dx_hat: the KCS branch's input cotangent pulled back + the pose branch's
+//     n   = ||g||_2,  pen = (n - 1)^2,  v = coef (n - 1) / n g      (0 where n = 0: torch's norm subgradient)
+//     tk  = dKCS(x)[v]                             the KCS branch's tangent input; the pose branch's is v
+// and the two tangent inputs leave as the bf16 operands the tangent sweep and sweep 4 read ((N, 32) and (N, 48), zero pads).
+// Same operations in the same order as the kernels replaced -- the row's sum of squares in gp_penalty_kernel's butterfly order --
+// (fp32 results equal to the last bit or two: hipcc contracts a few multiply-adds differently per kernel).
+__global__ __launch_bounds__(TILE) void d3_penalty_kernel(const float* __restrict__ pose, const float* __restrict__ gk,
+                                                          const float* __restrict__ gp, float coef, uint16_t* __restrict__ tk_bf16,
+                                                          uint16_t* __restrict__ v_bf16, float* __restrict__ pen, long long N) {
+    __shared__ float lp[TILE * PS];
+    __shared__ float la[TILE * PS];
+    const int lane = threadIdx.x;
+    const long long ntiles = (N + TILE - 1) / TILE;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long base = tile * TILE;
+        const int rows = (int)((N - base) < TILE ? (N - base) : TILE);
+        rows_in<48, PS>(pose + base * 48, lp, rows, lane);
+        rows_in<30, 31>(gk + base * 30, la, rows, lane);
+        __syncthreads();
+        const int row = lane < rows ? lane : 0;
+        V3 p[16], b[15];
+        float len[15];
+        load_joints(lp, row, p);
+        bones(p, b, len);
+        // ---- VJP (kcs_diff_kernel<false>, with lengths)
+        V3 gb[15];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+            const float gl = la[row * 31 + 15 + i];
+            gb[i] = (gl / len[i]) * b[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 15; ++k) {
+            const int i = kKcsI[k], j = kKcsJ[k];
+            const float g = la[row * 31 + k];
+            const float inv = 1.0f / (len[i] * len[j]);
+            const float c = dot(b[i], b[j]) * inv;
+            gb[i] = gb[i] + g * (inv * b[j] - (c / (len[i] * len[i])) * b[i]);
+            gb[j] = gb[j] + g * (inv * b[i] - (c / (len[j] * len[j])) * b[j]);
+        }
+        V3 gj[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) gj[j] = mk(0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 15; ++i) { gj[kBoneC[i]] = gj[kBoneC[i]] + gb[i]; gj[kBoneP[i]] = gj[kBoneP[i]] - gb[i]; }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(gj[j].x), "+v"(gj[j].y), "+v"(gj[j].z));
+        __syncthreads();                                                      // (every lane has read its gk row)
+        rows_in<48, PS>(gp + base * 48, la, rows, lane);
+        __syncthreads();
+        // ---- + the pose branch's cotangent (add_f32_kernel: a + b with a the pulled-back one), the penalty (gp_penalty_kernel)
+        // (the values that the separate launches hand over through memory are made opaque here: with -ffp-contract=fast hipcc would
+        // otherwise contract across the seams -- g * g + ..., k g_c - k g_p -- and the bits would differ)
+        float g[48];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            g[3 * j] = gj[j].x + la[row * PS + 3 * j]; g[3 * j + 1] = gj[j].y + la[row * PS + 3 * j + 1]; g[3 * j + 2] = gj[j].z + la[row * PS + 3 * j + 2];
+        }
+#pragma unroll
+        for (int c = 0; c < 48; ++c) asm volatile("" : "+v"(g[c]));
+        float t[64];                                                          // the wave-wide butterfly of gp_penalty_kernel, in one lane
+#pragma unroll
+        for (int c = 0; c < 64; ++c) {
+            t[c] = c < 48 ? g[c] * g[c] : 0.0f;
+            asm volatile("" : "+v"(t[c]));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+            for (int c = 0; c < o; ++c) t[c] = t[c] + t[c + o];
+        const float n = sqrtf(t[0]), d = n - 1.0f;
+        const float kk = n > 0.0f ? coef * d / n : 0.0f;
+        V3 tp[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            tp[j] = mk(kk * g[3 * j], kk * g[3 * j + 1], kk * g[3 * j + 2]);
+            asm volatile("" : "+v"(tp[j].x), "+v"(tp[j].y), "+v"(tp[j].z));
+        }
+        // ---- JVP (kcs_diff_kernel<true>, with lengths) of v
+        V3 tb[15];
+        float dl[15], out[30];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) { tb[i] = tp[kBoneC[i]] - tp[kBoneP[i]]; dl[i] = dot(b[i], tb[i]) / len[i]; }
+#pragma unroll
+        for (int k = 0; k < 15; ++k) {
+            const int i = kKcsI[k], j = kKcsJ[k];
+            const float inv = 1.0f / (len[i] * len[j]);
+            const float c = dot(b[i], b[j]) * inv;
+            out[k] = (dot(tb[i], b[j]) + dot(b[i], tb[j])) * inv - c * (dl[i] / len[i] + dl[j] / len[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 15; ++i) out[15 + i] = dl[i];
+        __syncthreads();                                                      // (every lane has read its gp row)
+        if (lane < rows) pen[base + lane] = d * d;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { lp[lane * PS + 3 * j] = tp[j].x; lp[lane * PS + 3 * j + 1] = tp[j].y; lp[lane * PS + 3 * j + 2] = tp[j].z; }
+#pragma unroll
+        for (int c = 0; c < 30; ++c) la[lane * 31 + c] = out[c];
+        __syncthreads();
+        {   // v: rows of 48 bf16, tk: rows of 32 bf16 (30 + 2 zeros): one packed pair per lane and step
+            uint32_t* dv = reinterpret_cast<uint32_t*>(v_bf16 + base * 48);
+            for (int e = lane; e < rows * 24; e += TILE) {
+                const int r = e / 24, c = 2 * (e - r * 24);
+                dv[e] = (uint32_t)dhaug_f32_to_bf16(lp[r * PS + c]) | ((uint32_t)dhaug_f32_to_bf16(lp[r * PS + c + 1]) << 16);
+            }
+            uint32_t* dk = reinterpret_cast<uint32_t*>(tk_bf16 + base * 32);
+            for (int e = lane; e < rows * 16; e += TILE) {
+                const int r = e >> 4, c = 2 * (e & 15);
+                const float a = c < 30 ? la[r * 31 + c] : 0.0f, bb = (c + 1) < 30 ? la[r * 31 + c + 1] : 0.0f;
+                dk[e] = (uint32_t)dhaug_f32_to_bf16(a) | ((uint32_t)dhaug_f32_to_bf16(bb) << 16);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // camera: one lane per joint
 // ---------------------------------------------------------------------------------------------------
@@ -426,6 +545,19 @@ int dhaug_kcs_jvp(const float* pose16, const float* tangent, float* tan_feat, in
     DHAUG_CHECK_PTR(pose16); DHAUG_CHECK_PTR(tangent); DHAUG_CHECK_PTR(tan_feat);
     hipLaunchKernelGGL(kcs_diff_kernel<true>, dim3(grid1d((N + TILE - 1) / TILE, 1)), dim3(TILE), 0, (hipStream_t)stream,
                        pose16, tangent, tan_feat, with_lengths, (long long)N);
+    return dhaug_launch_status();
+}
+
+/* see include/dhaug.h */
+int dhaug_d3_penalty(const float* pose16, const float* grad_kcs, const float* grad_pose, float coef, uint16_t* tan_kcs_bf16,
+                     uint16_t* tan_pose_bf16, float* pen, int64_t N, void* stream) {
+    DHAUG_CHECK(N >= 0, DHAUG_EINVAL);
+    if (N == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(pose16); DHAUG_CHECK_PTR(grad_kcs); DHAUG_CHECK_PTR(grad_pose); DHAUG_CHECK_PTR(tan_kcs_bf16); DHAUG_CHECK_PTR(tan_pose_bf16);
+    DHAUG_CHECK_PTR(pen);
+    DHAUG_CHECK((reinterpret_cast<uintptr_t>(tan_kcs_bf16) & 3) == 0 && (reinterpret_cast<uintptr_t>(tan_pose_bf16) & 3) == 0, DHAUG_EALIGN);
+    hipLaunchKernelGGL(d3_penalty_kernel, dim3(grid1d((N + TILE - 1) / TILE, 1)), dim3(TILE), 0, (hipStream_t)stream, pose16, grad_kcs,
+                       grad_pose, coef, tan_kcs_bf16, tan_pose_bf16, pen, (long long)N);
     return dhaug_launch_status();
 }
 

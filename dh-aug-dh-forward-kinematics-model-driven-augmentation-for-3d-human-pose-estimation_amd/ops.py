@@ -636,6 +636,21 @@ def gp_penalty(grad, coef):
     return v, pen
 
 
+def d3_penalty(pose16, grad_kcs, grad_pose, coef):
+    """The 3D critic's penalty step in one launch (dhaug_d3_penalty): from the x_hat poses (N, 48) fp32 and the two branches' input
+    cotangents (N, 30) / (N, 48) fp32 -> (tangent input of the KCS branch (N, 32) bf16, of the pose branch (N, 48) bf16, pen (N) fp32)
+    = kcs_backward + add_f32 + gp_penalty + kcs_jvp + the two bf16 casts (same operations, same order)."""
+    x = _dev(pose16, torch.float32, "d3_penalty").reshape(-1, 48)
+    N = x.shape[0]
+    gk = _dev(grad_kcs, torch.float32, "d3_penalty").reshape(N, 30)
+    gp = _dev(grad_pose, torch.float32, "d3_penalty").reshape(N, 48)
+    tk = torch.empty((N, 32), dtype=BF16, device=x.device)
+    tv = torch.empty((N, 48), dtype=BF16, device=x.device)
+    pen = torch.empty((N,), dtype=torch.float32, device=x.device)
+    _lib.call("dhaug_d3_penalty", _p(x), _p(gk), _p(gp), float(coef), _p(tk), _p(tv), _p(pen), N, _stream())
+    return tk, tv, pen
+
+
 CRITIC_SCALARS_SCRATCH = 192      # floats: DHAUG_CRITIC_SCALARS_SCRATCH of include/dhaug.h (tests/test_cpu_boundary.py compares)
 
 

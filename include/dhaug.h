@@ -596,6 +596,15 @@ int dhaug_critic_top_backward_bf16(const dhaug_top_desc* d, void* stream);
  *     layer's outputs).  Replaces one dhaug_gemm_bf16_dmask_pad with K = 512 and two with K = 112 (the second with the skip); same bits. */
 int dhaug_critic_top_tangent_bf16(const dhaug_top_desc* d, void* stream);
 
+/* The 3D critic's gradient penalty between its backward chain and its tangent sweep in ONE launch (R/models_Fk_GAN/Fk_discriminator.py:
+ * 205-231 with the KCS transform of :81-140): g = KCS^T(pose) grad_kcs + grad_pose = dD/dx_hat (N, 48); pen[b] = (||g_b|| - 1)^2;
+ * v_b = coef (||g_b|| - 1) / ||g_b|| g_b (0 where the norm is 0); tan_kcs = dKCS(pose)[v].  grad_kcs (N, 30): cosines then lengths;
+ * outputs: tan_kcs_bf16 (N, 32) and tan_pose_bf16 = v (N, 48) as the bf16 operands of the tangent sweep's first layers, pen (N) fp32.
+ * The operations of dhaug_kcs_backward + dhaug_add_f32 + dhaug_gp_penalty + dhaug_kcs_jvp + two dhaug_cast_pad_bf16 calls in their order (fp32
+ * results equal to the last bit or two: the compiler contracts multiply-adds per kernel). */
+int dhaug_d3_penalty(const float* pose16, const float* grad_kcs, const float* grad_pose, float coef, uint16_t* tan_kcs_bf16,
+                     uint16_t* tan_pose_bf16, float* pen, int64_t N, void* stream);
+
 /* First step of a critic's backward chain, through its 1-wide logit layer: out[r][c] = bf16(seed[r] * w[c]) * act'(mask[r][c])
  * for c < N, zero in [N, pad_cols) -- (gz W_out) * act'(y) of R/models_Fk_GAN/Fk_discriminator.py:201,266's backward, which as
  * a GEMM has K = 1.  seed: bf16, one value per row (stride ld_seed); w: the layer's N weights as bf16 (stride ld_w); mask, out:

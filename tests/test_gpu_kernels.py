@@ -252,6 +252,36 @@ def test_gemm_nt_big_tiles_epilogues(ops, M):
     assert (cb.float() - cb_old.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("N", [1, 64, 1000, 65536])
+def test_d3_penalty_equals_the_six_launches(ops, N):
+    """dhaug_d3_penalty (KCS pull-back of the KCS branch's input cotangent + the pose branch's, the row norm, the penalty and its
+    cotangent, the KCS tangent, both tangent inputs as bf16 operands: one launch) against kcs_backward, add_f32, gp_penalty, kcs_jvp and
+    the two casts it replaces, a dead row (zero cotangent) included."""
+    gen = torch.Generator().manual_seed(31)
+    x = GU.synth_pose16(N, seed=5).reshape(N, 48).cuda()
+    x = x - x[:, :3].repeat(1, 16)
+    gk = (torch.randn(N, 30, generator=gen) * 0.01).cuda()
+    gp = (torch.randn(N, 48, generator=gen) * 0.01).cuda()
+    if N > 3:
+        gk[3] = 0.0; gp[3] = 0.0                                  # every unit of the critic dead on this row: norm 0
+    coef = 2.0 * 10.0 / N
+    g = ops.add_f32(ops.kcs_backward(x, gk, True), gp)
+    v, pen = ops.gp_penalty(g, coef)
+    tk = ops.kcs_jvp(x, v, True)
+    r_tk, r_v = ops.cast_pad_bf16(tk, 32), ops.cast_pad_bf16(v, 48)
+    f_tk, f_v, f_pen = ops.d3_penalty(x, gk, gp, coef)
+    # the same operations in the same order; hipcc contracts a few multiply-adds differently in the two kernels, so the fp32 values
+    # may differ in the last bit (and, through it, a bf16 value by one ulp on a rounding boundary)
+    assert (f_pen - pen).abs().max().item() <= 4e-7 * max(1.0, pen.abs().max().item())
+    for a, b in ((f_v, r_v), (f_tk, r_tk)):
+        a, b = a.float(), b.float()
+        assert (a - b).abs().max().item() <= 2.0 ** -7 * b.abs().max().item() + 1e-30
+        assert (a == b).float().mean().item() >= 0.99
+    assert torch.isfinite(f_pen).all() and torch.isfinite(f_v.float()).all() and torch.isfinite(f_tk.float()).all()
+    if N > 3:
+        assert f_pen[3].item() == 1.0 and f_v[3].abs().max().item() == 0.0
+
+
 @pytest.mark.parametrize("M", [64, 8192, 64 * 515])
 def test_critic_top_backward_equals_the_four_launches(ops, M):
     """dhaug_critic_top_backward_bf16 (merge layer, 100-wide merge block and logit layer of the 3D critic's backward chain in one
