@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT || exit 1
 R=${1:-r03}
 O=gpurun_out/profiles
 mkdir -p $O
-B="python bench.py --no-cpu-baseline --no-extra --no-roofline --prewarm 0"
+B="python bench.py --no-cpu-baseline --no-extra --no-roofline --prewarm 0 --reps 1"
 stats() {  # name, args...
   local name=$1; shift
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$name -o r -- "$@" > gpurun_out/prof_$name.log 2>&1 || return 1

@@ -2,7 +2,7 @@
 # development: rocprofv3 kernel stats of a few eager GAN iterations -> gpurun_out/prof_step_stats.csv (top 40 lines printed)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT || exit 1
 rm -rf gpurun_out/prof_step
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_step -o r -- python bench.py --no-cpu-baseline --no-extra --no-roofline --prewarm 0 --workload gan_step --steps 10 --warmup 5 --graph off > gpurun_out/prof_step.log 2>&1 || { tail -5 gpurun_out/prof_step.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_step -o r -- python bench.py --no-cpu-baseline --no-extra --no-roofline --prewarm 0 --workload gan_step --steps 10 --warmup 5 --reps 1 --graph off > gpurun_out/prof_step.log 2>&1 || { tail -5 gpurun_out/prof_step.log; exit 1; }
 cp $(find gpurun_out/prof_step -name "*kernel_stats.csv" | head -1) gpurun_out/prof_step_stats.csv
 rm -rf gpurun_out/prof_step
 python - <<'PY'
