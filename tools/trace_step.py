@@ -34,7 +34,17 @@ def run():
     for _ in range(6):
         d3(); d2()
     torch.cuda.synchronize()
-    for fn in (d3, d3, d2, d2):
+    if os.environ.get("GSTEP"):                  # whole iterations: without / with the generator step
+        cp = torch.zeros(B, 16, device="cuda"); cp[:, 9:13] = torch.tensor(quat, device="cuda"); cp[:, 13:16] = torch.tensor(trans, device="cuda")
+        it = lambda g: T.gan_iteration(args, m, rc, cp, r2, ["S1"], None, None, do_g_step=g, camera=(quat, trans, cam9))
+        for _ in range(6):
+            it(False)
+        it(True); it(False)
+        torch.cuda.synchronize()
+        seq = (lambda: it(False), lambda: it(True), lambda: it(False), lambda: it(True))
+    else:
+        seq = (d3, d3, d2, d2)
+    for fn in seq:
         time.sleep(0.03)
         t0 = time.perf_counter()
         fn()
