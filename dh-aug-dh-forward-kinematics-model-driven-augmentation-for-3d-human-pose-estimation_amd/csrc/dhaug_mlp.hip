@@ -47,7 +47,7 @@ enum { U_LOAD_F32 = 0, U_LOAD_BF16 = 1, U_STORE_BF16 = 2, U_GEMM = 3 };
 // max(v, v * 0) in fp32 like the LeakyReLU layers' mul + max (NaN * 0 = NaN, max(NaN, NaN) = NaN), so a diverged network is
 // REPORTED by D_cost as the reference's ATen ops report it.  The inference unit keeps the integer max on the packed bf16
 // pair (v_pk_max_i16: +NaN passes, -NaN -- what the matrix pipe produces -- becomes 0).
-#if defined(DHAUG_MLP_SAVE_TU) || defined(DHAUG_MLP_NAN_SAFE)
+#if (defined(DHAUG_MLP_SAVE_TU) || defined(DHAUG_MLP_NAN_SAFE)) && !defined(SAVE_ABL_NONANSAFE)
 constexpr bool NAN_SAFE_TU = true;
 #else
 constexpr bool NAN_SAFE_TU = false;
@@ -483,7 +483,12 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 // (tried, r5: v_maximum3_f32 v, 0, 0 -- gfx950's NaN-propagating maximum -- as the forward-with-save unit's ReLU in place of
 // max(v, v * neg): ONE instruction per element instead of two, and the 3D critic's forward-with-save launch went from 510 to
 // 717 us; the instruction is far from full rate on this part.  Removed.)
-template <bool LEAKY, int RESMODE, int KS = MLP_MAX_KSTEPS, bool SAVE = false, bool BITS = SAVE>
+#ifdef SAVE_ABL_NOBITS                      /* timing only: no sign bits are computed or stored */
+#define SAVE_BITS_DEFAULT false
+#else
+#define SAVE_BITS_DEFAULT SAVE
+#endif
+template <bool LEAKY, int RESMODE, int KS = MLP_MAX_KSTEPS, bool SAVE = false, bool BITS = SAVE_BITS_DEFAULT>
 __device__ __forceinline__ void stack_layer(const StackDesc& d, const StackDesc& nd, unsigned char* smem, int wave, int lane,
                                             const WHalf& wlo, WHalf& nlo, WHalf& whi, f32x16 (&seed)[MLP_NS],
                                             const bf16x8 (&idf)[2], int dbg, __amdgpu_buffer_rsrc_t sv, int sv_ld,
