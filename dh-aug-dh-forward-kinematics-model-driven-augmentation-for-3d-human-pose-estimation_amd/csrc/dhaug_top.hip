@@ -24,6 +24,8 @@ namespace {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // a 16-byte chunk in registers (HIP's uint4 is a struct: copies of it
+                                                                   // through references became memcpys into scratch objects)
 
 constexpr int T_BM = 64;                    // rows per tile
 constexpr int T_KS = 7;                     // k-steps of a 100-wide operand (112 columns)
@@ -56,13 +58,27 @@ __device__ long long g_top_stamps[64];
 __device__ __forceinline__ void t_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float bf2f(uint32_t lo16) { return __builtin_bit_cast(float, lo16 << 16); }
 
-// rows [0, rows) x 14 chunks of a row-major bf16 matrix -> an LDS image of pitch T_P (rows beyond `rows` up to `pad_rows`: zero)
-__device__ __forceinline__ void stage_rows(const uint16_t* W, long long ldw, int rows, int pad_rows, unsigned char* img, int tid) {
-    for (int q = tid; q < pad_rows * T_NC; q += 256) {
-        const int row = q / T_NC, c = q - row * T_NC;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < rows) v = *reinterpret_cast<const uint4*>(W + (long long)row * ldw + c * 8);
-        *reinterpret_cast<uint4*>(img + row * T_P + c * 16) = v;
+// rows [0, rows) x 14 chunks of a row-major bf16 matrix -> an LDS image of pitch T_P (rows beyond `rows` up to PAD_ROWS: zero).
+// Up to 14 chunks per thread are requested before the first is written: as a plain loop (load, wait, write, 28 times for the merge
+// operand, every workgroup after the same lines) the staging was 17 us of a launch -- as long as two of its twelve tiles.
+template <int PAD_ROWS>
+__device__ __forceinline__ void stage_rows(const uint16_t* W, long long ldw, int rows, unsigned char* img, int tid) {
+    constexpr int N = PAD_ROWS * T_NC / 256, G = N < 14 ? N : 14;
+    static_assert(PAD_ROWS * T_NC % 256 == 0 && N % G == 0, "whole passes");
+#pragma unroll
+    for (int j0 = 0; j0 < N; j0 += G) {
+        u32x4 v[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int q = tid + 256 * (j0 + j), row = q / T_NC, c = q - row * T_NC;
+            v[j] = u32x4{0, 0, 0, 0};
+            if (row < rows) v[j] = *reinterpret_cast<const u32x4*>(W + (long long)row * ldw + c * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int q = tid + 256 * (j0 + j), row = q / T_NC, c = q - row * T_NC;
+            *reinterpret_cast<u32x4*>(img + row * T_P + c * 16) = v[j];
+        }
     }
 }
 // fragment (slice of 32 rows, k-step ks) of a staged matrix: lane (r31, h) = row 32 slice + r31, columns 16 ks + 8 h ..
@@ -74,53 +90,54 @@ __device__ __forceinline__ bf16x8 frag(const unsigned char* img, int slice, int 
 // LDS image -> global rows.  The thread's chunks (row, c) = (q / 14, q % 14), q = tid + 256 i, are computed ONCE (TileMap: the LDS
 // offset and the row / column of each of its four chunks) -- as opaque per-use values they were 36 divisions by 14 per tile on a lone
 // wave per SIMD, hoisted by hipcc they became ~40 loop-carried pointers and the kernel spilled.
-struct TileRegs { uint4 v[4]; };
+struct TileRegs { u32x4 v0, v1, v2, v3; };
 struct TileMap { int lds[4]; int row[4]; int col[4]; bool ok3; };
 __device__ __forceinline__ TileMap tile_map(int tid) {
     TileMap m;
+    m.ok3 = tid + 768 < T_BM * T_NC;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int q = tid + 256 * i, row = q / T_NC, c = q - row * T_NC;
+        // (the fourth chunk exists for half the threads; the other half repeats chunk q - 128 on the way IN -- the same bytes to the same
+        // LDS address, no branch, no conditional load for hipcc's wait counts to be pessimistic about -- and skips it on the way out)
+        const int q = tid + 256 * i - (i == 3 && !m.ok3 ? 128 : 0), row = q / T_NC, c = q - row * T_NC;
         m.lds[i] = row * T_P + c * 16; m.row[i] = row; m.col[i] = c * 8;
     }
-    m.ok3 = tid + 768 < T_BM * T_NC;
     return m;
 }
 __device__ __forceinline__ void tile_load(const uint16_t* m, long long ld, long long row0, const TileMap& tm, TileRegs& r) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        r.v[i] = make_uint4(0, 0, 0, 0);
-        if (i < 3 || tm.ok3) r.v[i] = *reinterpret_cast<const uint4*>(m + (row0 + tm.row[i]) * ld + tm.col[i]);
-    }
+    r.v0 = *reinterpret_cast<const u32x4*>(m + (row0 + tm.row[0]) * ld + tm.col[0]);
+    r.v1 = *reinterpret_cast<const u32x4*>(m + (row0 + tm.row[1]) * ld + tm.col[1]);
+    r.v2 = *reinterpret_cast<const u32x4*>(m + (row0 + tm.row[2]) * ld + tm.col[2]);
+    r.v3 = *reinterpret_cast<const u32x4*>(m + (row0 + tm.row[3]) * ld + tm.col[3]);
 }
 __device__ __forceinline__ void tile_to_lds(const TileRegs& r, unsigned char* img, const TileMap& tm) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (i < 3 || tm.ok3) *reinterpret_cast<uint4*>(img + tm.lds[i]) = r.v[i];
+    *reinterpret_cast<u32x4*>(img + tm.lds[0]) = r.v0;
+    *reinterpret_cast<u32x4*>(img + tm.lds[1]) = r.v1;
+    *reinterpret_cast<u32x4*>(img + tm.lds[2]) = r.v2;
+    *reinterpret_cast<u32x4*>(img + tm.lds[3]) = r.v3;
 }
 // (One wave per SIMD has nobody to hide an LDS round trip behind, and hipcc sinks every LDS read to its use: the reads of a phase are
 // issued together and fenced off from their uses.)
 __device__ __forceinline__ void tile_store(const unsigned char* img, uint16_t* g, long long ld, long long row0, const TileMap& tm) {
-    uint4 v[4];
+    u32x4 v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        v[i] = make_uint4(0, 0, 0, 0);
-        if (i < 3 || tm.ok3) v[i] = *reinterpret_cast<const uint4*>(img + tm.lds[i]);
-    }
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const u32x4*>(img + tm.lds[i]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        if (i < 3 || tm.ok3) *reinterpret_cast<uint4*>(g + (row0 + tm.row[i]) * ld + tm.col[i]) = v[i];
+        if (i < 3 || tm.ok3) *reinterpret_cast<u32x4*>(g + (row0 + tm.row[i]) * ld + tm.col[i]) = v[i];
 }
 
 // the lane's 4 consecutive values of register quad gq (features f0 .. f0 + 3 of its row): mask with the activation words `mk`
-// (read from the mask image up front), round, store into the result image.  Quads beyond the 112 columns of the images are skipped
-// (slice 3 covers features 96 .. 127).
+// (read from the mask image up front), round, store into the result image.  Slice 3 covers features 96 .. 127 and the images have 112
+// columns + 16 pad bytes per row: the quads of features 112 .. 119 fall into the pad bytes as they are, those of 120 .. 127 are sent
+// there too (qoff) -- no branch around a quad (a wave-uniform branch per quad was a third of the epilogues' time); what lands in the
+// pad bytes is never read as data (fragments and row stores take the 14 chunks of a row).
+__device__ __forceinline__ int qoff(int f0) { return (f0 >= 120 ? f0 - 8 : f0) * 2; }
 __device__ __forceinline__ uint2 mask_words(const unsigned char* mimg, int row, int f0) {
-    return f0 < 112 ? *reinterpret_cast<const uint2*>(mimg + row * T_P + f0 * 2) : make_uint2(0, 0);
+    return *reinterpret_cast<const uint2*>(mimg + row * T_P + qoff(f0));
 }
 __device__ __forceinline__ void quad_out(float (&v)[4], uint2 mk, unsigned char* dimg, int row, int f0, float dneg) {
-    if (f0 >= 112) return;
     const short y0 = (short)(mk.x & 0xffffu), y1 = (short)(mk.x >> 16), y2 = (short)(mk.y & 0xffffu), y3 = (short)(mk.y >> 16);
     v[0] = y0 > 0 ? v[0] : v[0] * dneg;                     // a positive bf16 is a positive int16
     v[1] = y1 > 0 ? v[1] : v[1] * dneg;
@@ -129,7 +146,7 @@ __device__ __forceinline__ void quad_out(float (&v)[4], uint2 mk, unsigned char*
     uint2 o;
     o.x = (uint32_t)dhaug_f32_to_bf16(v[0]) | ((uint32_t)dhaug_f32_to_bf16(v[1]) << 16);
     o.y = (uint32_t)dhaug_f32_to_bf16(v[2]) | ((uint32_t)dhaug_f32_to_bf16(v[3]) << 16);
-    *reinterpret_cast<uint2*>(dimg + row * T_P + f0 * 2) = o;
+    *reinterpret_cast<uint2*>(dimg + row * T_P + qoff(f0)) = o;
 }
 
 // a 100 -> 100 layer on the tile: wave w = feature slice w, both 32-row tiles; src / res / mask / dst are LDS images
@@ -191,15 +208,47 @@ __global__ __launch_bounds__(256, 1) void top_backward_kernel(TopArgs p) {
     const long long ntiles = p.M / T_BM;
     if ((long long)blockIdx.x >= ntiles) return;
 
+    // Everything a tile reads from global memory -- its three mask tiles, its rows' seeds, its sign-bit words -- is requested TWO TILES
+    // AHEAD, into registers, and moves to the LDS images one tile ahead: the memory counter retires in order, so a wait for a load
+    // also waits for every store issued before it, and a load waited for a whole tile after its issue has nothing in front of it any
+    // more.  (First form: the seeds and the sign bits loaded where they are used -- each of those waits drained the previous phase's row
+    // stores, a memory round trip: 16 us per tile, 192 us for 3B = 196 608 rows against 184 for the four launches.)
+    // WHERE in the tile they are requested matters as much: all 18 loads of a thread in one place -- 72 instructions, 576 cache lines
+    // a CU, several round trips' worth of outstanding misses -- took 4 100 .. 4 900 clocks to ISSUE wherever they stood (phase stamps,
+    // DHAUG_TOP_TIMING); one mask tile per layer boundary (4 loads a thread, right behind the move of its predecessor into the image
+    // the layer just finished reading) issues in ~200.  131 -> 116 us at 196 608 rows with that and the staging below; a tile is then
+    // 8.6 us for 154 KB, 4.6 TB/s over 256 CUs -- the card's copy rate is 5.3.
+    const TileMap tm = tile_map(tid);
+    TileRegs r1, rh, r0;
+    uint32_t sd[2], bw[2][2];                                                // this tile: seed of the lane's row in row tile a; bits [block][a]
+    // (a macro, not a lambda: tiles passed to a lambda by reference across the weight staging stayed in scratch)
+    // (the small loads FIRST: the wait for the mask tiles at the end of the tile then covers them -- requested behind the masks, their
+    // first use in the next iteration was a wait of its own, and that one drained the tile's row stores)
+#define TOPB_SMALL(t, S2, B2) { const long long row0_ = (t) * T_BM; \
+        _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_) { \
+            S2[a_] = p.seed[(row0_ + 32 * a_ + r31) * p.ld_seed]; \
+            const long long R_ = (row0_ >> 5) + a_; \
+            B2[0][a_] = p.bits0[(R_ * 4 + wave) * 64 + lane]; \
+            B2[1][a_] = p.bits1[(R_ * 4 + wave) * 64 + lane]; \
+        } }
+#define TOPB_REQUEST(t, Q1, QH, Q0, S2, B2) { TOPB_SMALL(t, S2, B2) tile_load(p.m1, p.ld_m, (t) * T_BM, tm, Q1); \
+        tile_load(p.mh, p.ld_m, (t) * T_BM, tm, QH); tile_load(p.m0, p.ld_m, (t) * T_BM, tm, Q0); }
+    uint32_t sd1[2], bw1[2][2];                                              // the next tile's seeds / bits (its masks: in r1, rh, r0)
+    const long long last = ntiles - 1 - ((ntiles - 1 - blockIdx.x) % gridDim.x);   // this workgroup's last tile
+    auto clampt = [&](long long t) { return t < ntiles ? t : last; };
+    // The first two tiles are requested HERE, in front of the weight staging (whose round trips they share).
+    TileRegs q1, qh, q0;
+    TOPB_REQUEST((long long)blockIdx.x, r1, rh, r0, sd, bw)
+    TOPB_REQUEST(clampt((long long)blockIdx.x + gridDim.x), q1, qh, q0, sd1, bw1)
     // ---- weights -> registers, through LDS (whole rows in, fragments out)
     bf16x8 w2f[T_KS], w1f[T_KS], wmf[2][2][T_KS];                           // merge: [block b][t]: slice 8 b + wave + 4 t of the 16
-    stage_rows(p.w2, p.ldw2, p.n0, 128, smem, tid);
-    stage_rows(p.w1, p.ldw1, p.n0, 128, smem + 128 * T_P, tid);
+    stage_rows<128>(p.w2, p.ldw2, p.n0, smem, tid);
+    stage_rows<128>(p.w1, p.ldw1, p.n0, smem + 128 * T_P, tid);
     t_barrier();
 #pragma unroll
     for (int ks = 0; ks < T_KS; ++ks) { w2f[ks] = frag(smem, wave, ks, r31, h); w1f[ks] = frag(smem + 128 * T_P, wave, ks, r31, h); }
     t_barrier();
-    stage_rows(p.wm, p.ldwm, 512, 512, smem, tid);                           // 512 x 240 = 122 880 bytes
+    stage_rows<512>(p.wm, p.ldwm, 512, smem, tid);                           // 512 x 240 = 122 880 bytes
     t_barrier();
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -224,38 +273,8 @@ __global__ __launch_bounds__(256, 1) void top_backward_kernel(TopArgs p) {
     }
     t_barrier();                                                             // (the staging area becomes the images)
 
-    // Everything a tile reads from global memory -- its three mask tiles, its rows' seeds, its sign-bit words -- is requested ONE TILE
-    // AHEAD, at the top of the previous tile and in front of that tile's stores: the memory counter retires in order, so a wait for a
-    // load also waits for every store issued before it.  (First form: the seeds and the sign bits loaded where they are used -- each of
-    // those waits drained the previous phase's row stores, a memory round trip: 16 us per tile, 192 us for 3B = 196 608 rows against
-    // 184 for the four launches.)  The loop body is straight-line code (the last tile re-requests its own data) so that hipcc counts
-    // the outstanding operations exactly.
-    const TileMap tm = tile_map(tid);
-    TileRegs r1, rh, r0;
-    uint32_t sd[2], bw[2][2];                                                // this tile: seed of the lane's row in row tile a; bits [block][a]
-    auto request = [&](long long t, TileRegs& q1, TileRegs& qh, TileRegs& q0, uint32_t (&s2)[2], uint32_t (&b2)[2][2]) {
-        const long long row0 = t * T_BM;
-        // (the small loads FIRST: the wait for the mask tiles at the end of the tile then covers them -- requested behind the masks,
-        // their first use in the next iteration was a wait of its own, and that one drained the tile's row stores)
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            s2[a] = p.seed[(row0 + 32 * a + r31) * p.ld_seed];
-            const long long R = (row0 >> 5) + a;
-            b2[0][a] = p.bits0[(R * 4 + wave) * 64 + lane];
-            b2[1][a] = p.bits1[(R * 4 + wave) * 64 + lane];
-        }
-        tile_load(p.m1, p.ld_m, row0, tm, q1); tile_load(p.mh, p.ld_m, row0, tm, qh); tile_load(p.m0, p.ld_m, row0, tm, q0);
-    };
-    // ... and TWO tiles ahead for the order of issue: tile i + 1's mask tiles go from the registers to LDS in the MIDDLE of tile i (behind
-    // fc1, the last reader of tile i's masks), and tile i + 2 is requested right there -- in front of the merge layer, whose 16 row
-    // stores per thread are what fills the memory queue (requested behind them at the top of the next tile, the 18 loads took 4 100
-    // clocks to issue: phase stamps, DHAUG_TOP_TIMING).
-    uint32_t sd1[2], bw1[2][2];                                              // the next tile's seeds / bits (its masks: in r1, rh, r0)
-    const long long last = ntiles - 1 - ((ntiles - 1 - blockIdx.x) % gridDim.x);   // this workgroup's last tile
-    auto clampt = [&](long long t) { return t < ntiles ? t : last; };
-    request(blockIdx.x, r1, rh, r0, sd, bw);
     tile_to_lds(r1, sM1, tm); tile_to_lds(rh, sMH, tm); tile_to_lds(r0, sM0, tm);
-    request(clampt((long long)blockIdx.x + gridDim.x), r1, rh, r0, sd1, bw1);
+    r1 = q1; rh = qh; r0 = q0;
     t_barrier();
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long row0 = tile * T_BM;
@@ -287,19 +306,29 @@ __global__ __launch_bounds__(256, 1) void top_backward_kernel(TopArgs p) {
         t_barrier();
         TOP_STAMP(3)
         tile_store(sG2, p.g2, p.ld_g, row0, tm);
+        // (the m1 image has had its one reader: the next tile's goes in, the tile after that is requested)
+        const long long t2 = clampt(tile + 2 * (long long)gridDim.x);
+        tile_to_lds(r1, sM1, tm);
+        TOPB_SMALL(t2, sd2, bw2)
+        tile_load(p.m1, p.ld_m, t2 * T_BM, tm, r1);
         TOP_STAMP(4)
         // ---- merge_block1.fc2, fc1 (the skip joins before the mask)
         small_layer(w2f, sG2, nullptr, sMH, sG1, wave, r31, h, p.dneg);
         TOP_STAMP(5)
         t_barrier();
         tile_store(sG1, p.g1, p.ld_g, row0, tm);
+        tile_to_lds(rh, sMH, tm);
+        tile_load(p.mh, p.ld_m, t2 * T_BM, tm, rh);
         TOP_STAMP(6)
         small_layer(w1f, sG1, sG2, sM0, sG0, wave, r31, h, p.dneg);
         TOP_STAMP(7)
         t_barrier();                                                         // (every mask image of this tile has been read)
+        TOP_STAMP(13)
         tile_store(sG0, p.g0, p.ld_g, row0, tm);
-        tile_to_lds(r1, sM1, tm); tile_to_lds(rh, sMH, tm); tile_to_lds(r0, sM0, tm);
-        request(clampt(tile + 2 * (long long)gridDim.x), r1, rh, r0, sd2, bw2);
+        TOP_STAMP(14)
+        tile_to_lds(r0, sM0, tm);
+        TOP_STAMP(15)
+        tile_load(p.m0, p.ld_m, t2 * T_BM, tm, r0);
         TOP_STAMP(8)
         // ---- the merge layer: 512 outputs, masks = the sign bits of the branches' last layers (dhaug_mlp_unit.bits layout: the word of
         // lane (r31, h) of forward wave w and 32-row tile R holds the lane's elements of slices w (t = 0) and w + 4 (t = 1)); one
@@ -390,7 +419,9 @@ __global__ __launch_bounds__(256, 1) void top_backward_kernel(TopArgs p) {
 // x (M, 512): the tangent of the concatenation; Wm [n0][>= 512], W1 / W2 [n0][>= 112] the "nt" operand copies.  Same tiles, same
 // request-ahead scheme; the x tile (64 KB) travels in registers like the mask tiles.
 // (the x tile's sixteen registers per thread are sixteen NAMED variables: as an array member of a struct hipcc kept them in scratch)
-#define TOPT_X16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+#define TOPT_X8A(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#define TOPT_X8B(M) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+#define TOPT_X16(M) TOPT_X8A(M) TOPT_X8B(M)
 __global__ __launch_bounds__(256, 1) void top_tangent_kernel(TopArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sU0 = smem;
@@ -407,17 +438,23 @@ __global__ __launch_bounds__(256, 1) void top_tangent_kernel(TopArgs p) {
     if ((long long)blockIdx.x >= ntiles) return;
 
     bf16x8 w2f[T_KS], w1f[T_KS], wmf[32];                                    // merge: slice `wave`, 32 k-steps
-    stage_rows(p.w2, p.ldw2, p.n0, 128, smem, tid);
-    stage_rows(p.w1, p.ldw1, p.n0, 128, smem + 128 * T_P, tid);
+    stage_rows<128>(p.w2, p.ldw2, p.n0, smem, tid);
+    stage_rows<128>(p.w1, p.ldw1, p.n0, smem + 128 * T_P, tid);
     t_barrier();
 #pragma unroll
     for (int ks = 0; ks < T_KS; ++ks) { w2f[ks] = frag(smem, wave, ks, r31, h); w1f[ks] = frag(smem + 128 * T_P, wave, ks, r31, h); }
     t_barrier();
-    for (int q = tid; q < 128 * 64; q += 256) {                              // Wm: 128 rows (zero beyond n0) x 64 chunks, pitch T_OP
-        const int row = q >> 6, c = q & 63;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < p.n0) v = *reinterpret_cast<const uint4*>(p.wm + (long long)row * p.ldwm + c * 8);
-        *reinterpret_cast<uint4*>(smem + row * T_OP + c * 16) = v;
+#pragma unroll
+    for (int j0 = 0; j0 < 32; j0 += 16) {                                    // Wm: 128 rows (zero beyond n0) x 64 chunks, pitch T_OP;
+        u32x4 v[16];                                                         // sixteen requests, then their writes (see stage_rows)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int row = (tid >> 6) + 4 * (j0 + j), c = tid & 63;
+            v[j] = u32x4{0, 0, 0, 0};
+            if (row < p.n0) v[j] = *reinterpret_cast<const u32x4*>(p.wm + (long long)row * p.ldwm + c * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) *reinterpret_cast<u32x4*>(smem + ((tid >> 6) + 4 * (j0 + j)) * T_OP + (tid & 63) * 16) = v[j];
     }
     t_barrier();
 #pragma unroll
@@ -433,9 +470,10 @@ __global__ __launch_bounds__(256, 1) void top_tangent_kernel(TopArgs p) {
     auto clampt = [&](long long t) { return t < ntiles ? t : last; };
 #define TOPT_XLD(i) rx##i = *reinterpret_cast<const uint4*>(p.x + (row0_ + xrow + 4 * (i)) * p.ldx + xc * 8);
 #define TOPT_XST(i) *reinterpret_cast<uint4*>(sX + (xrow + 4 * (i)) * T_OP + xc * 16) = rx##i;
+    // requests in the order the loop issues them (a mask tile or half the x tile per layer boundary, see top_backward_kernel)
 #define TOPT_REQUEST(t) { const long long row0_ = (t) * T_BM; \
-        tile_load(p.m1, p.ld_m, row0_, tm, r1); tile_load(p.mh, p.ld_m, row0_, tm, rh); tile_load(p.m0, p.ld_m, row0_, tm, r0); \
-        TOPT_X16(TOPT_XLD) }
+        TOPT_X8A(TOPT_XLD) tile_load(p.m0, p.ld_m, row0_, tm, r0); TOPT_X8B(TOPT_XLD) tile_load(p.mh, p.ld_m, row0_, tm, rh); \
+        tile_load(p.m1, p.ld_m, row0_, tm, r1); }
 #define TOPT_TO_LDS() { tile_to_lds(r1, sM1, tm); tile_to_lds(rh, sMH, tm); tile_to_lds(r0, sM0, tm); TOPT_X16(TOPT_XST) }
     TOPT_REQUEST((long long)blockIdx.x)
     TOPT_TO_LDS()
@@ -478,14 +516,19 @@ __global__ __launch_bounds__(256, 1) void top_tangent_kernel(TopArgs p) {
         }
         t_barrier();                                                         // (the x tile and the m0 tile have been read)
         tile_store(sU0, p.m0, p.ld_m, row0, tm);
+        const long long row0_ = clampt(tile + 2 * (long long)gridDim.x) * T_BM;   // the tile requested during this one
+        tile_to_lds(r0, sM0, tm); TOPT_X16(TOPT_XST)                         // the next tile's x and m0 go in, ...
+        TOPT_X8A(TOPT_XLD) tile_load(p.m0, p.ld_m, row0_, tm, r0);           // ... the tile after that is requested: x rows 0 .. 31, m0
         small_layer(w1f, sU0, nullptr, sMH, sUH, wave, r31, h, p.dneg);
         t_barrier();
         tile_store(sUH, p.mh, p.ld_m, row0, tm);
+        tile_to_lds(rh, sMH, tm);
+        TOPT_X8B(TOPT_XLD) tile_load(p.mh, p.ld_m, row0_, tm, rh);
         small_layer(w2f, sUH, sU0, sM1, sU1, wave, r31, h, p.dneg);
         t_barrier();                                                         // (every mask image of this tile has been read)
         tile_store(sU1, p.m1, p.ld_m, row0, tm);
-        TOPT_TO_LDS()
-        TOPT_REQUEST(clampt(tile + 2 * (long long)gridDim.x))
+        tile_to_lds(r1, sM1, tm);
+        tile_load(p.m1, p.ld_m, row0_, tm, r1);
         t_barrier();
     }
 }

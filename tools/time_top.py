@@ -1,5 +1,6 @@
 """Development aid: the fused top-of-the-critic backward launch (dhaug_critic_top_backward_bf16) against the four launches it replaces,
-at 3B = 196 608 rows; fifty calls replayed as one hipGraph."""
+and the tangent launch, at M = 3B = 196 608 rows (env M); twenty calls replayed as one hipGraph.  STAMPS=1 with a -DDHAUG_TOP_TIMING
+build (DHAUG_LIB, DHAUG_ABLATION_BUILD=1): the phases of one tile of the backward launch in clocks."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -26,7 +27,11 @@ def four():
 
 
 one = lambda: ops.critic_top_backward(seed, wout[:, 0], m1, mh, m0, W2, W1, Wm, bits, n0, 1, 0.0, gcat=gc)
-for name, fn in (("four launches", four), ("one launch", one)):
+# the tangent sweep (M rows here; the step runs it over the B interpolated rows), in place over copies of the activations
+ucat = bf(torch.randn(M, 512, device="cuda"))
+WmT, t0, th, t1 = mk(n0, 512, 512), m0.clone(), mh.clone(), m1.clone()
+tan = lambda: ops.critic_top_tangent(ucat, t0, th, t1, WmT, W1, W2, n0, 1, 0.0)
+for name, fn in (("four launches", four), ("one launch", one), ("tangent launch", tan)):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph(); st = torch.cuda.Stream()
@@ -52,3 +57,4 @@ if os.environ.get("STAMPS"):
     for i, n in enumerate(names):
         print("  %-20s %6d clocks" % (n, st[i + 1] - st[i]))
     print("  tile total %d" % (st[12] - st[0]))
+    print("  inside phase 7: barrier %d, store g0 %d, masks -> LDS %d, requests %d" % (st[13] - st[7], st[14] - st[13], st[15] - st[14], st[8] - st[15]))
