@@ -13,7 +13,7 @@
 // symbol and computes garbage (tests/test_cpu_boundary.py::test_ablation_switches_need_an_ablation_build).
 #if !defined(DHAUG_ABLATION_BUILD)
 #if defined(T4_ABL_NOSTORE) || defined(T4_ABL_NOCOMPUTE) || defined(ABL_NOWRITE) || defined(ABL_NOREAD) || defined(ABL_NOWLOAD) || \
-    defined(SAVE_ABL_NOSTORE) || defined(SAVE_ABL_BRANCH) || defined(SAVE_ABL_NOBITS) || defined(SAVE_ABL_NONANSAFE) || defined(SAVE_ABL_NULLSTORES) || defined(MOVE_BATCH_OVERRIDE) || \
+    defined(SAVE_ABL_NOSTORE) || defined(SAVE_ABL_BRANCH) || defined(SAVE_ABL_NOBITS) || defined(SAVE_ABL_NONANSAFE) || defined(SAVE_ABL_NULLSTORES) || defined(MOVE_BATCH_OVERRIDE) || defined(LOAD_ABL_NOROWS32) || \
     defined(DHAUG_MLP_TIMING) || defined(DHAUG_MLP_TIMING_UNITS) || defined(DHAUG_STAMP_TID) || defined(DHAUG_PIPE_TIMING) || defined(DHAUG_TOP_TIMING) || \
     defined(W_NO_XCD_MAP) || defined(X3_NWAVES) || defined(X3_SPREAD) || defined(X3_RING) || defined(X3_TIMING) || \
     defined(X3_STAMP_TID) || defined(X3_REG_STASH) || defined(X3_WS_NT) || defined(X3_EPI_FENCE) || defined(X3_WRITE128) || \

@@ -78,7 +78,7 @@ struct Unit {
 // plan of a GEMM unit.  Stack: bits 0-3 lead k-steps, 4-9 run.  Single layer: bits 16-23 shape (chunks * 16 + chunks of
 // source 1), 24-27 feature slices
 enum { PLAN_STACK = 1 << 13, PLAN_LEAKY = 1 << 10, PLAN_ALT = 1 << 11, PLAN_TAIL = 1 << 12, PLAN_TAIL_BF16 = 1 << 14, PLAN_OUT = 1 << 28,
-       PLAN_DOT = 1 << 29 };
+       PLAN_DOT = 1 << 29, PLAN_PAIR = 1 << 30 };                            // PAIR: this unit and the next run as one (gemm_pair)
 
 struct Program {
     int nunits;
@@ -178,25 +178,16 @@ __device__ __forceinline__ void load_chunk(const uint16_t* w1, const uint16_t* w
 //               -- sched_barrier --   8 MFMAs (2 slices x 4 row tiles) on the fragments read during step k-2
 // NS = feature slices this wave really owns in this layer (2: slices wave and wave+4; 1: only slice wave -- layers
 // narrower than 160 features); waves with no slice skip the layer.
+// everything a layer requests from global memory up front: the first two chunks of its weight fragments, its bias (the
+// accumulators' start value), and -- DOT_OUT, see the epilogue -- the lane's 16 weights of the folded logit layer and its bias
 template <int NCH, int NCH1, int NS>
-__device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int wave, int lane, int dbg) {
-    DHAUG_LSTAMP(dbg)
-    // opaque: everything derived from the lane id below is recomputed per call (a few VALU) instead of being hoisted out
-    // of the unit loop and parked on registers the stacks need
-    asm volatile("" : "+v"(lane));
-    bf16x8 ring[3][NS][MLP_CH];
-    const int r31 = lane & 31, h = lane >> 5;
+__device__ __forceinline__ void layer_requests(UnitPtr u, int wave, int lane, bf16x8 (&ring)[3][NS][MLP_CH], f32x16 (&seed)[NS],
+                                               f32x4 (&dv)[4], float& dbias, bool& dot_out) {
+    const int h = lane >> 5;
     const uint16_t* w1 = u->w;
     const uint16_t* w2 = NCH1 < NCH ? u->w2 : u->w;
     load_chunk<0, NCH, NCH1, NS>(w1, w2, wave, lane, ring[0]);
     if constexpr (NCH > 1) load_chunk<1, NCH, NCH1, NS>(w1, w2, wave, lane, ring[1]);
-    f32x16 acc[NS][MLP_MT];
-    const unsigned char* src1 = buf_base(smem, u->src);
-    const int pbs1 = buf_pitch_bytes(u->src);
-    const unsigned char* src2 = NCH1 < NCH ? buf_base(smem, u->src2) : src1;
-    const int pbs2 = NCH1 < NCH ? buf_pitch_bytes(u->src2) : pbs1;
-    // the bias is the accumulators' start value (requested here, first used by the first MFMA)
-    f32x16 seed[NS];
 #pragma unroll
     for (int t = 0; t < NS; ++t)
 #pragma unroll
@@ -205,17 +196,68 @@ __device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int w
 #pragma unroll
             for (int e = 0; e < 4; ++e) seed[t][4 * g + e] = b4[e];
         }
-    // DOT_OUT (see the epilogue): the lane's 16 weights of the folded logit layer and its bias, requested up front
     constexpr bool CAN_DOT = NS == 1 && NCH <= 2 && NCH1 == NCH;             // (shapes checked on the host)
-    const bool dot_out = CAN_DOT && (u->flags & F_DOT_OUT);
-    f32x4 dv[4];
-    float dbias = 0.f;
+    dot_out = CAN_DOT && (u->flags & F_DOT_OUT);
+    dbias = 0.f;
     if (dot_out) {
         const float* v = reinterpret_cast<const float*>(u->w2);
 #pragma unroll
         for (int g = 0; g < 4; ++g) dv[g] = *reinterpret_cast<const f32x4*>(v + 32 * wave + 8 * g + 4 * h);
         dbias = (wave == 0 && h == 0) ? v[256] : 0.f;
     }
+}
+
+template <int NCH, int NCH1, int NS>
+__device__ __forceinline__ void layer_body(UnitPtr u, unsigned char* smem, int wave, int lane, int dbg, bf16x8 (&ring)[3][NS][MLP_CH],
+                                           f32x16 (&seed)[NS], f32x4 (&dv)[4], float dbias, bool dot_out);
+
+template <int NCH, int NCH1, int NS>
+__device__ __forceinline__ void gemm_layer(UnitPtr u, unsigned char* smem, int wave, int lane, int dbg) {
+    DHAUG_LSTAMP(dbg)
+    // opaque: everything derived from the lane id below is recomputed per call (a few VALU) instead of being hoisted out
+    // of the unit loop and parked on registers the stacks need
+    asm volatile("" : "+v"(lane));
+    bf16x8 ring[3][NS][MLP_CH];
+    f32x16 seed[NS];
+    f32x4 dv[4];
+    float dbias;
+    bool dot_out;
+    layer_requests<NCH, NCH1, NS>(u, wave, lane, ring, seed, dv, dbias, dot_out);
+    layer_body<NCH, NCH1, NS>(u, smem, wave, lane, dbg, ring, seed, dv, dbias, dot_out);
+}
+
+// Two consecutive narrow layers (two chunks of k, one feature slice per wave: the 100-wide top of the critics) as ONE unit: both
+// layers' weights, biases and logit vector are requested before the first k loop, so the second layer starts on registers that
+// are already there, and the pair costs one dispatch (3 900 + 5 700 + 2 x ~800 clocks of dispatch as two units of the 3D critic's
+// 112 000-clock tile; phase stamps).  Same arithmetic as the two units.
+__device__ __forceinline__ void lds_barrier();
+__device__ __forceinline__ void gemm_pair(UnitPtr ua, UnitPtr ub, unsigned char* smem, int wave, int lane, int dbg) {
+    DHAUG_LSTAMP(dbg)
+    asm volatile("" : "+v"(lane));
+    bf16x8 ra[3][1][MLP_CH], rb[3][1][MLP_CH];
+    f32x16 sa[1], sb[1];
+    f32x4 dva[4], dvb[4];
+    float da, db;
+    bool dota, dotb;
+    layer_requests<2, 2, 1>(ua, wave, lane, ra, sa, dva, da, dota);
+    layer_requests<2, 2, 1>(ub, wave, lane, rb, sb, dvb, db, dotb);
+    layer_body<2, 2, 1>(ua, smem, wave, lane, dbg, ra, sa, dva, da, false);
+    lds_barrier();
+    DHAUG_LSTAMP(dbg + 2)
+    layer_body<2, 2, 1>(ub, smem, wave, lane, dbg + 4, rb, sb, dvb, db, dotb);
+}
+
+template <int NCH, int NCH1, int NS>
+__device__ __forceinline__ void layer_body(UnitPtr u, unsigned char* smem, int wave, int lane, int dbg, bf16x8 (&ring)[3][NS][MLP_CH],
+                                           f32x16 (&seed)[NS], f32x4 (&dv)[4], float dbias, bool dot_out) {
+    const int r31 = lane & 31, h = lane >> 5;
+    const uint16_t* w1 = u->w;
+    const uint16_t* w2 = NCH1 < NCH ? u->w2 : u->w;
+    f32x16 acc[NS][MLP_MT];
+    const unsigned char* src1 = buf_base(smem, u->src);
+    const int pbs1 = buf_pitch_bytes(u->src);
+    const unsigned char* src2 = NCH1 < NCH ? buf_base(smem, u->src2) : src1;
+    const int pbs2 = NCH1 < NCH ? buf_pitch_bytes(u->src2) : pbs1;
     constexpr int KT = NCH * MLP_CH;                            // k-steps in total
     bf16x8 fx[3][MLP_MT];                                       // activation fragments: read two k-steps ahead (one wave per
                                                                 // SIMD: nobody else hides the LDS latency)
@@ -999,40 +1041,50 @@ constexpr int MOVE_BATCH = 16;
 template <int NB>
 __device__ __forceinline__ void load_f32_pass(const float* g, long long ld, int cols, unsigned char* dst, int pb, long long m0,
                                               long long M, Sweep& sw) {
+    // Every access is issued, at a clamped address (the tile's last row, the row's last group), and what lies outside becomes
+    // zero afterwards: as `if (inside) v[i] = load` hipcc gave each access a branch of its own -- in the linear form below with a
+    // wait right behind the access and ~50 register moves per slot (the whole array copied between two homes): 3 600 clocks for
+    // six LDS reads per thread, and for global reads one memory round trip after the other.
     f32x4 v[NB];
     int off[NB];
+    bool in[NB];
+    const long long lastrow = M - 1;
+    const int lastc = (cols >> 2) - 1;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const long long gm = m0 + sw.row;
-        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         off[i] = sw.row < MLP_BM ? chunk_off(sw.row, sw.c >> 1, pb) + ((sw.c & 1) << 3) : -1;
-        if (sw.row < MLP_BM && gm < M && sw.c * 4 < cols) v[i] = *reinterpret_cast<const f32x4*>(g + gm * ld + sw.c * 4);
+        in[i] = sw.row < MLP_BM && gm < M && sw.c * 4 < cols;
+        v[i] = *reinterpret_cast<const f32x4*>(g + (gm < M ? gm : lastrow) * ld + (sw.c < lastc ? sw.c : lastc) * 4);
         sw.next();
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         uint2 o;
-        o.x = pack_bf16x2(v[i][0], v[i][1]);
-        o.y = pack_bf16x2(v[i][2], v[i][3]);
+        o.x = in[i] ? pack_bf16x2(v[i][0], v[i][1]) : 0u;
+        o.y = in[i] ? pack_bf16x2(v[i][2], v[i][3]) : 0u;
         if (off[i] >= 0) *reinterpret_cast<uint2*>(dst + off[i]) = o;
     }
 }
 template <int NB>
 __device__ __forceinline__ void load_bf16_pass(const uint16_t* g, long long ld, int cols, unsigned char* img, int pb, long long m0,
                                                long long M, Sweep& sw) {
-    uint4 v[NB];
+    u32x4_t v[NB];                                                           // (clamped addresses, zeros afterwards: see load_f32_pass)
     int off[NB];
+    const long long lastrow = M - 1;
+    const int lastc = (cols >> 3) - 1;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const long long gm = m0 + sw.row;
-        v[i] = make_uint4(0, 0, 0, 0);
         off[i] = sw.row < MLP_BM ? chunk_off(sw.row, sw.c, pb) : -1;
-        if (sw.row < MLP_BM && gm < M && sw.c * 8 < cols) v[i] = *reinterpret_cast<const uint4*>(g + gm * ld + sw.c * 8);
+        const bool in = sw.row < MLP_BM && gm < M && sw.c * 8 < cols;
+        v[i] = *reinterpret_cast<const u32x4_t*>(g + (gm < M ? gm : lastrow) * ld + (sw.c < lastc ? sw.c : lastc) * 8);
+        if (!in) v[i] = u32x4_t{0u, 0u, 0u, 0u};
         sw.next();
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-        if (off[i] >= 0) *reinterpret_cast<uint4*>(img + off[i]) = v[i];
+        if (off[i] >= 0) *reinterpret_cast<u32x4_t*>(img + off[i]) = v[i];
 }
 
 // fp32 LOAD when the row's 16-byte groups (Q4 = 16 or 32, zero fill included) divide the workgroup: a thread keeps its
@@ -1044,13 +1096,22 @@ __device__ __forceinline__ void load_f32_fast(const float* g, long long ld, int 
     constexpr int RS = MLP_THREADS / Q4, NB = MLP_BM / RS;            // rows per step, steps
     const int r0 = tid / Q4, c = tid % Q4;
     const bool col_live = c * 4 < cols;
-    const float* p = g + (m0 + r0) * ld + c * 4;
+    const float* p = g + (m0 + r0) * ld + (col_live ? c * 4 : 0);
     const long long stride = (long long)RS * ld;
     f32x4 v[NB];
+    if (m0 + MLP_BM <= M) {                                                  // (workgroup-uniform) a whole tile: no access has a branch of its own
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (col_live && m0 + r0 + i * RS < M) v[i] = *reinterpret_cast<const f32x4*>(p + i * stride);
+        for (int i = 0; i < NB; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + i * stride);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m0 + r0 + i * RS < M) v[i] = *reinterpret_cast<const f32x4*>(p + i * stride);
+        }
+    }
+    if (!col_live) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // LDS: row * pitch + (((c >> 1) ^ (row & 15)) << 4) + (c & 1) * 8; row & 15 is r0 & 15 (RS = 16) or alternates with ^ 8 (RS = 8)
     const int half = (c & 1) << 3, cc = c >> 1;
@@ -1074,19 +1135,19 @@ __device__ __forceinline__ void load_f32_linear(const float* g, int cols, unsign
     const long long live = (M - m0 < MLP_BM ? M - m0 : (long long)MLP_BM) * gpr;
     const float* p = g + m0 * cols;
     const float rc = __builtin_amdgcn_rcpf((float)gpr);                      // idx < 4096: floor((idx + 0.5) / gpr) is exact in fp32
-    f32x4 v[NB];
+    f32x4 v[NB];                                                             // (clamped addresses, zeros afterwards: see load_f32_pass)
+    const int lastg = (int)live - 1;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int idx = tid + MLP_THREADS * i;
-        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (idx < live) v[i] = *reinterpret_cast<const f32x4*>(p + 4 * idx);
+        v[i] = *reinterpret_cast<const f32x4*>(p + 4 * (idx < lastg ? idx : lastg));
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int idx = tid + MLP_THREADS * i, row = (int)(((float)idx + 0.5f) * rc), c = idx - row * gpr;
         uint2 o;
-        o.x = pack_bf16x2(v[i][0], v[i][1]);
-        o.y = pack_bf16x2(v[i][2], v[i][3]);
+        o.x = idx < live ? pack_bf16x2(v[i][0], v[i][1]) : 0u;
+        o.y = idx < live ? pack_bf16x2(v[i][2], v[i][3]) : 0u;
         if (idx < total) *reinterpret_cast<uint2*>(dst + chunk_off(row, c >> 1, pb) + ((c & 1) << 3)) = o;
     }
     const int c0 = cols >> 2, np = (((cols + 63) & ~63) >> 2) - c0;          // zero fill, 8-byte groups
@@ -1094,6 +1155,62 @@ __device__ __forceinline__ void load_f32_linear(const float* g, int cols, unsign
     for (int j = tid; j < MLP_BM * np; j += MLP_THREADS) {
         const int row = (int)(((float)j + 0.5f) * rn), c = c0 + j - row * np;
         *reinterpret_cast<uint2*>(dst + chunk_off(row, c >> 1, pb) + ((c & 1) << 3)) = make_uint2(0u, 0u);
+    }
+}
+
+// LOADs of tiles whose rows are contiguous in memory with a row length known at compile time -- the critics' inputs: 48-column
+// poses, 32-column projections (fp32, G groups of four per row), the 32-column KCS operand (bf16, Q chunks of eight per row).
+// One wave per SIMD issues a vector instruction every four clocks at best and has nobody to hide behind: the generic passes' ~90
+// instructions per slot (sweep, 64-bit addresses, float reciprocal, swizzle) were 2 000 - 3 000 clocks of a LOAD beside one
+// memory round trip.  Here: clamped 32-bit offsets, division by a constant, all requests first, zeros by select.
+template <int G>
+__device__ __forceinline__ void load_f32_rows(const float* g, unsigned char* dst, int pb, long long m0, long long M, int tid) {
+    constexpr int N = MLP_BM * G / MLP_THREADS, Z = (16 - G % 16) % 16;      // groups per thread; zero groups per row (to 64 columns)
+    const long long left = M - m0;
+    const int live = (left < MLP_BM ? (int)left : MLP_BM) * G, lastg = live - 1;
+    const f32x4* p = reinterpret_cast<const f32x4*>(g + m0 * (4 * G));
+    f32x4 v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int idx = tid + MLP_THREADS * i;
+        v[i] = p[idx < lastg ? idx : lastg];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int idx = tid + MLP_THREADS * i, row = idx / G, c = idx - row * G;
+        uint2 o;
+        o.x = idx < live ? pack_bf16x2(v[i][0], v[i][1]) : 0u;
+        o.y = idx < live ? pack_bf16x2(v[i][2], v[i][3]) : 0u;
+        *reinterpret_cast<uint2*>(dst + chunk_off(row, c >> 1, pb) + ((c & 1) << 3)) = o;
+    }
+#pragma unroll
+    for (int i = 0; i < MLP_BM * Z / MLP_THREADS; ++i) {
+        const int k = tid + MLP_THREADS * i, row = k / (Z > 0 ? Z : 1), c = G + k - row * Z;
+        *reinterpret_cast<uint2*>(dst + chunk_off(row, c >> 1, pb) + ((c & 1) << 3)) = make_uint2(0u, 0u);
+    }
+}
+template <int Q>
+__device__ __forceinline__ void load_bf16_rows(const uint16_t* g, unsigned char* img, int pb, long long m0, long long M, int tid) {
+    constexpr int N = MLP_BM * Q / MLP_THREADS, Z = 8 - Q;                   // chunks per thread; zero chunks per row (64 columns)
+    const long long left = M - m0;
+    const int live = (left < MLP_BM ? (int)left : MLP_BM) * Q, lastc = live - 1;
+    const u32x4_t* p = reinterpret_cast<const u32x4_t*>(g + m0 * (8 * Q));
+    u32x4_t v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int idx = tid + MLP_THREADS * i;
+        v[i] = p[idx < lastc ? idx : lastc];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int idx = tid + MLP_THREADS * i, row = idx / Q, c = idx - row * Q;
+        if (idx >= live) v[i] = u32x4_t{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4_t*>(img + chunk_off(row, c, pb)) = v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < MLP_BM * Z / MLP_THREADS; ++i) {
+        const int k = tid + MLP_THREADS * i, row = k / (Z > 0 ? Z : 1), c = Q + k - row * Z;
+        *reinterpret_cast<u32x4_t*>(img + chunk_off(row, c, pb)) = u32x4_t{0u, 0u, 0u, 0u};
     }
 }
 
@@ -1107,11 +1224,15 @@ __device__ __forceinline__ void move_unit(UnitPtr u, unsigned char* smem, long l
         const float* g = static_cast<const float*>(u->g);
         unsigned char* dst = buf_base(smem, u->dst);
         const int pb = buf_pitch_bytes(u->dst), q4 = ((cols + 63) & ~63) >> 2;
-        // (measured: 128-column noise 6.8k -> 5.6k clocks; the 16-group form for 48 / 32 columns is SLOWER than the generic
-        // pass, 9.5k vs 4.7k -- eight back-to-back requests per thread to rows 3 KB apart -- and is not used)
+        // contiguous rows of a known length: the lean passes (3D critic: pose LOAD 4 700 -> 2 400 clocks, KCS operand 3 300 -> 1 200;
+        // 112.1 -> 109.0 us at 65 536 poses with the branch-free generic passes).  The generator's 128-column noise tile is 64 KB per
+        // workgroup, all workgroups at once -- 5 500 - 7 500 clocks whatever the pass: that one is the card's bandwidth.
+#ifndef LOAD_ABL_NOROWS32
+        if (ld == cols && cols == 128) { load_f32_rows<32>(g, dst, pb, m0, M, tid); return; }
+#endif
         if (q4 == 32) { load_f32_fast<32>(g, ld, cols, dst, pb, m0, M, tid); return; }
-        // (measured: 32 columns 4.7k -> 3.6k clocks.  Every 8-accesses-per-thread form tried for the 48-column pose -- this
-        // one, the strided one, an 8-slot generic pass -- took ~9k against the 16-slot generic pass's 4.8k; not understood)
+        if (ld == cols && cols == 48) { load_f32_rows<12>(g, dst, pb, m0, M, tid); return; }
+        if (ld == cols && cols == 32) { load_f32_rows<8>(g, dst, pb, m0, M, tid); return; }
         if (ld == cols && cols <= 32) { load_f32_linear<4>(g, cols, dst, pb, m0, M, tid); return; }
         Sweep sw(tid, q4);
         while (sw.row < MLP_BM) load_f32_pass<MOVE_BATCH>(g, ld, cols, dst, pb, m0, M, sw);
@@ -1122,6 +1243,7 @@ __device__ __forceinline__ void move_unit(UnitPtr u, unsigned char* smem, long l
     unsigned char* img = buf_base(smem, id);
     const int pb = buf_pitch_bytes(id);
     const int q8 = (kind == U_LOAD_BF16 ? ((cols + 63) & ~63) : cols) >> 3;
+    if (kind == U_LOAD_BF16 && ld == cols && cols == 32) { load_bf16_rows<4>(g, img, pb, m0, M, tid); return; }
     Sweep sw(tid, q8);
     if (kind == U_LOAD_BF16) {
         while (sw.row < MLP_BM) {
@@ -1176,6 +1298,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void fused_mlp_kernel(Program prog,
             // where the program continues, and that unit's header: requested now, used after this unit
             int ni = i + 1;
             if (kind == U_GEMM && (plan & PLAN_STACK)) ni = i + ((plan & 15) != 0) + ((plan >> 4) & 63) + ((plan & (PLAN_TAIL | PLAN_TAIL_BF16)) ? 1 : 0);
+            if (kind == U_GEMM && (plan & PLAN_PAIR)) ni = i + 2;
             {
                 UnitPtr nu = units + (ni < nunits ? ni : 0);
                 hk = nu->kind;
@@ -1220,6 +1343,16 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void fused_mlp_kernel(Program prog,
                     continue;                                                // (stamps of the run's inner layers stay 0)
                 }
                 const int nslices = (plan >> 24) & 15, dbg = MLP_MAX_UNITS + 64 + 4 * ui;
+                if (plan & PLAN_PAIR) {                                      // (both layers: <= 4 slices, one per wave)
+                    gemm_pair(u, u + 1, smem, wave, lane, dbg);
+                    if ((u + 1)->flags & F_DOT_OUT) {
+                        lds_barrier();
+                        dot_output(u + 1, smem, m0, M, tid);
+                    }
+                    lds_barrier();
+                    DHAUG_LSTAMP(dbg + 7)
+                    continue;
+                }
 #define DHAUG_SHAPES(NS)                                                                   \
     switch ((plan >> 16) & 255) {                              /* validated on the host */ \
         case 1 * 16 + 1: gemm_single<1, 1, NS>(u, smem, wave, lane, dbg); break;                 \
@@ -1334,8 +1467,17 @@ int plan_unit(const Program& p, int i) {
     }
     if (run < p.min_run || run > 63) {
         const int c1 = (u.ksteps + 3) / 4, c2 = (u.ksteps2 + 3) / 4;
+        // two narrow layers in a row (two chunks of k, at most 128 features, every wave owning a slice of both, nothing saved, the
+        // first one an ordinary layer; the unit before must not have claimed this one as ITS second half) run as one unit
+        auto narrow = [&](const Unit& v) {
+            return v.kind == U_GEMM && v.ksteps2 == 0 && v.ksteps > 4 && v.ksteps <= 8 && v.N > 96 && v.N <= 128 && !(v.flags & F_OUT_F32) &&
+                   v.save == nullptr;
+        };
+        const bool second = i > 0 && (U[i - 1].plan & PLAN_PAIR) && U[i - 1].kind == U_GEMM && !(U[i - 1].plan & PLAN_STACK);
+        const bool pair = !second && i + 1 < p.nunits && narrow(u) && !(u.flags & F_DOT_OUT) && narrow(U[i + 1]) &&
+                          !getenv("DHAUG_MLP_NOPAIR");
         return (((c1 + c2) * 16 + c1) << 16) | (((u.N + 31) >> 5) << 24) | ((u.flags & F_OUT_F32) ? PLAN_OUT : 0) |
-               ((u.flags & F_DOT_OUT) ? PLAN_DOT : 0);
+               ((u.flags & F_DOT_OUT) ? PLAN_DOT : 0) | (pair ? PLAN_PAIR : 0);
     }
     const Unit* tu = U + i0 + run;
     const bool tail = i0 + run < p.nunits && tu->kind == U_GEMM && (tu->flags & F_OUT_F32) && tu->ksteps == 16 &&
