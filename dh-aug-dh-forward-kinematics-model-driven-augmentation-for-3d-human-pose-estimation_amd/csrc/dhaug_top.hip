@@ -71,8 +71,10 @@ __device__ __forceinline__ void stage_rows(const uint16_t* W, long long ldw, int
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             const int q = tid + 256 * (j0 + j), row = q / T_NC, c = q - row * T_NC;
-            v[j] = u32x4{0, 0, 0, 0};
-            if (row < rows) v[j] = *reinterpret_cast<const u32x4*>(W + (long long)row * ldw + c * 8);
+            // (every request issued, at a clamped row, zeros by select: with `if (row < rows) v[j] = load` hipcc gives each request a
+            // branch of its own and a full wait behind it -- 42 round trips one after the other)
+            v[j] = *reinterpret_cast<const u32x4*>(W + (long long)(row < rows ? row : rows - 1) * ldw + c * 8);
+            if (row >= rows) v[j] = u32x4{0, 0, 0, 0};
         }
 #pragma unroll
         for (int j = 0; j < G; ++j) {
@@ -445,16 +447,16 @@ __global__ __launch_bounds__(256, 1) void top_tangent_kernel(TopArgs p) {
     for (int ks = 0; ks < T_KS; ++ks) { w2f[ks] = frag(smem, wave, ks, r31, h); w1f[ks] = frag(smem + 128 * T_P, wave, ks, r31, h); }
     t_barrier();
 #pragma unroll
-    for (int j0 = 0; j0 < 32; j0 += 16) {                                    // Wm: 128 rows (zero beyond n0) x 64 chunks, pitch T_OP;
-        u32x4 v[16];                                                         // sixteen requests, then their writes (see stage_rows)
+    for (int j0 = 0; j0 < 32; j0 += 8) {                                   // Wm: 128 rows (zero beyond n0) x 64 chunks, pitch T_OP;
+        u32x4 v[8];                                                        // eight requests, then their writes (see stage_rows)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < 8; ++j) {
             const int row = (tid >> 6) + 4 * (j0 + j), c = tid & 63;
-            v[j] = u32x4{0, 0, 0, 0};
-            if (row < p.n0) v[j] = *reinterpret_cast<const u32x4*>(p.wm + (long long)row * p.ldwm + c * 8);
+            v[j] = *reinterpret_cast<const u32x4*>(p.wm + (long long)(row < p.n0 ? row : p.n0 - 1) * p.ldwm + c * 8);
+            if (row >= p.n0) v[j] = u32x4{0, 0, 0, 0};
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) *reinterpret_cast<u32x4*>(smem + ((tid >> 6) + 4 * (j0 + j)) * T_OP + (tid & 63) * 16) = v[j];
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(smem + ((tid >> 6) + 4 * (j0 + j)) * T_OP + (tid & 63) * 16) = v[j];
     }
     t_barrier();
 #pragma unroll
