@@ -878,10 +878,12 @@ __device__ __forceinline__ void load_unit(UnitPtr u, unsigned char* smem, long l
     for (int i0 = tid; i0 < total; i0 += X3_THREADS * NB) {
         f32x2 v[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int i = i0 + j * X3_THREADS, row = i >> sh, c2 = i & (pairs - 1);
-            v[j] = f32x2{0.f, 0.f};
-            if (i < total && m0 + row < M && 2 * c2 < cols) v[j] = *reinterpret_cast<const f32x2*>(g + (m0 + row) * ld + 2 * c2);
+        for (int j = 0; j < NB; ++j) {                                        // (every access issued, at a clamped address, zeros by
+            const int i = i0 + j * X3_THREADS, row = i >> sh, c2 = i & (pairs - 1);   // select: no branch per access -- csrc/dhaug_mlp.hip)
+            const long long gm = m0 + row < M ? m0 + row : M - 1;
+            const int cc = 2 * c2 < cols ? 2 * c2 : cols - 2;
+            v[j] = *reinterpret_cast<const f32x2*>(g + gm * ld + cc);
+            if (!(i < total && m0 + row < M && 2 * c2 < cols)) v[j] = f32x2{0.f, 0.f};
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
