@@ -681,7 +681,7 @@ __device__ __forceinline__ void nt_g128_body(const GemmArgs& p, long long tile) 
     // ONE accumulator per matrix tile, k ascending, like gemm_nt_pipe2_kernel.  Forms of this kernel *(measured, four 1 536 x 1000 x
     // 1000 members / four 512-row ones)*: eight waves of 64 x 32, fragments read behind the stage's barrier 28.9 / 16.5 us; the same
     // with the next stage's fragments under this stage's matrix instructions (this form) 28.2 / 16.8; five stages instead of four
-    // 29.3 / 16.7; four waves of 64 x 64 (four fragment reads per four matrix instructions instead of three per two) 30.1 / 19.2; the
+    // 29.3 / 16.7 (six or eight, one workgroup per CU: 37.4 - 37.9 / 19.4); four waves of 64 x 64 (four fragment reads per four matrix instructions instead of three per two) 30.1 / 19.2; the
     // two accumulator sets of round 4's 64 x 64-tile kernel as the two waves of a pair 36.4 / 21.2.  All land within 10 % of each
     // other: what a stage costs is its 16 KB through the LDS-DMA path (~32 B/clk per CU: 512 of the ~620 clocks a stage takes), not
     // its fragment reads, its barrier or the depth of the prefetch -- fewer staged bytes per output is what would shorten it.
