@@ -386,6 +386,54 @@ def test_fused_forward_matches_layerwise(M, D, B):
         assert maxabs(fused.critic2d(D2, x2), l2_l + 1.0) <= 2e-2 * l2_l.abs().max().item() + 1e-6
 
 
+@pytest.mark.parametrize("B", [1, 127, 129, 1000, 4096 + 37])
+def test_fused_load_passes_and_paired_units_bit_for_bit(M, B, monkeypatch):
+    """the LOAD units' passes for contiguous rows of a known length (48 / 32 / 128 fp32 columns, the 32-column bf16 KCS operand) against
+    the generic passes -- the same tensors handed over as column views of wider ones, so that ld != cols --, and the critics' two narrow
+    top layers as ONE unit against two units (DHAUG_MLP_NOPAIR): same logits / head, bit for bit, whole and ragged tiles"""
+    from dhaug_amd import fused, ops
+    args = make_args(batch_size=B, Gen_DenseDim=256, Dis_DenseDim_3D=256, Dis_DenseDim_2D=256)
+    fk = M.fkm.Forward_Kinematics_DH_Model(args, ["S1"], None)
+    torch.manual_seed(15)
+    G = M.gen.Fk_Generator(fk, args, "cuda").cuda()
+    D3 = M.dis.Fk_3D_Discriminator("cuda", args).cuda()
+    D2 = M.dis.Fk_2D_Discriminator(args, 16).cuda()
+    g = torch.Generator().manual_seed(16)
+    z = torch.randn(B, 128, generator=g).cuda()
+    x3 = GU.synth_pose16(B, seed=18); x3 = (x3 - x3[:, :1]).reshape(B, 48).cuda().contiguous()
+    x2 = ((torch.rand(B, 32, generator=g) - 0.5) * 1.6).cuda()
+    kcs = ops.kcs_forward(x3, True, f32=False, bf16_ld=32)[1]
+
+    def wide(t, extra):                                          # the same values as a column view of a wider tensor: ld != cols
+        w = torch.full((t.shape[0], t.shape[1] + extra), 7.0, dtype=t.dtype, device=t.device)
+        w[:, :t.shape[1]] = t
+        v = w[:, :t.shape[1]]
+        assert v.stride(0) != t.shape[1] and torch.equal(v, t)
+        return v
+
+    def run(views):
+        zz, a3, a2, kk = (wide(z, 8), wide(x3, 16), wide(x2, 8), wide(kcs, 32)) if views else (z, x3, x2, kcs)
+        with torch.no_grad():
+            u3, (o3,) = fused.D3["program"](D3, fused._net(D3, fused.D3, "bf16")._fresh(), dict(x=a3, kcs=kk), B)
+            fused.launch(u3, B, "bf16")
+            u2, o2 = fused.D2["program"](D2, fused._net(D2, fused.D2, "bf16")._fresh(), dict(x=a2), B)
+            fused.launch(u2, B, "bf16")
+            ug, og = fused.GEN["program"](G, fused._net(G, fused.GEN, "bf16")._fresh(), dict(z=zz), B)
+            fused.launch(ug, B, "bf16")
+        o2 = o2[0] if isinstance(o2, (tuple, list)) else o2
+        return o3.clone(), o2.clone(), og.clone()
+
+    lean = run(False)
+    generic = run(True)
+    for a, b in zip(lean, generic):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    monkeypatch.setenv("DHAUG_MLP_NOPAIR", "1")
+    two_units = run(False)
+    monkeypatch.delenv("DHAUG_MLP_NOPAIR")
+    for a, b in zip(lean, two_units):
+        assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------- epoch loops
 class _Summary:
     def __init__(self, epoch=0):
