@@ -56,6 +56,8 @@ SIGNATURES = {
     "dhaug_adam_repack_step": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _f32, _vp, _i32, _i64, _vp, _i32, _vp],
     "dhaug_gp_assemble": [_vp, _vp, _vp, _vp, _i64, _i64, _vp],
     "dhaug_gp_penalty": [_vp, _vp, _vp, _i64, _i64, _f32, _vp],
+    "dhaug_gp_assemble_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],
+    "dhaug_gp_penalty_bf16": [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _f32, _vp],
     "dhaug_d3_penalty": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _vp],
     "dhaug_critic_scalars": [_vp, _i64, _vp, _i64, _i64, _f32, _vp, _vp, _vp],
     "dhaug_rank1_mask_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _f32, _vp],

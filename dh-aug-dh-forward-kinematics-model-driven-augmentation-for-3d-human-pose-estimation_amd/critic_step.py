@@ -61,6 +61,10 @@ NT_GROUP = os.environ.get("DHAUG_NO_NT_GROUP") is None
 # split-operand arithmetic: one activation-side split per tensor and step (_Math.split0); DHAUG_NO_SPLIT_CACHE=1: one per use
 SPLIT_CACHE = os.environ.get("DHAUG_NO_SPLIT_CACHE") is None
 
+# bf16 operands that a kernel of the step writes beside its fp32 result anyway (the assembled real / fake rows, the penalty's cotangent,
+# the KCS operand) are registered as the casts of those tensors instead of being cast again (DHAUG_NO_SEED_CASTS=1: cast launches)
+SEED_CASTS = os.environ.get("DHAUG_NO_SEED_CASTS") is None
+
 # the 3D critic's penalty step (KCS pull-back, norm, penalty cotangent, KCS tangent, bf16 operands) as one launch: ops.d3_penalty
 D3_PENALTY_FUSED = os.environ.get("DHAUG_NO_D3_PENALTY_FUSED") is None
 
@@ -131,6 +135,12 @@ class _Math:
             hit = (ops.cast_pad_bf16(a, width), a)       # (the source stays referenced: no address is reused inside the step)
             self._casts[key] = hit
         return hit[0]
+
+    def seed_cast(self, a, width, b):
+        """b IS the bf16 copy cast(a, width) would make -- its producer wrote it beside a (ops.gp_assemble / gp_penalty, the KCS
+        operand of ops.kcs_forward): registered, no launch (the casts were 8 launches and ~90 us of a single-frame iteration)"""
+        if self.bf16 and b is not None and b.dtype == BF16 and tuple(b.shape) == (a.shape[0], width):
+            self._casts[(a.data_ptr(), tuple(a.shape), tuple(a.stride()), width)] = (b, a)
 
     def split0(self, a, k, mode=0):
         """the activation-side split of fp32 a (rows, k) -- made ONCE per tensor and step: a layer's input, cotangent and tangent
@@ -509,9 +519,10 @@ def step_d2(D, optimizerD, real, fake, alpha, lam, prec=None):
          _Lin(D.pose_layer_4, NONE), _Lin(D.layer_last, LRELU, D.slope), _Lin(D.layer_pred, NONE)]
     s = D.slope
     optimizerD.zero_grad()
-    X = ops.gp_assemble(real, fake, alpha)
+    X = ops.gp_assemble(real, fake, alpha, bf16_rows=m.bf16 and SEED_CASTS)
     B = X.shape[0] // 3
     B2 = 2 * B
+    m.seed_cast(X[:B2], ceil16(X.shape[1]), getattr(X, "_dhaug_bf16_rows", None))
     from . import fused
     if m.bf16 and FUSED_STEP_FORWARD and fused.step_forward_supported(D):
         r = fused.critic2d_forward_save(D, X, save_rows=B2 if (SKIP_XHAT_SAVES and fused.partial_save_ok(B)) else 0)
@@ -538,7 +549,8 @@ def step_d2(D, optimizerD, real, fake, alpha, lam, prec=None):
             lay.grads_part(m, gz[:B2], x[:B2], lay is not L[5])
         m.flush_side()
     g = L[0].bwd(m, gz1[B2:], None, NONE, 0.0, out_f32=True)                 # (B,32) fp32: dD/dx_hat
-    v, pen = ops.gp_penalty(g, 2.0 * lam / B)
+    v, pen = ops.gp_penalty(g, 2.0 * lam / B, bf16=m.bf16 and SEED_CASTS)
+    m.seed_cast(v, ceil16(v.shape[1]), getattr(v, "_dhaug_bf16", None))
     tail = ops.tail_rows                                      # (x_hat rows of a saved activation, its sign bits attached)
     u1 = L[0].tan(m, v, tail(d1, B2), inplace=True)
     t2, t3 = tail(d2, B2), tail(d3, B2)
@@ -761,12 +773,16 @@ def step_d3(D, optimizerD, real, fake, alpha, lam, prec=None):
     br = [_Branch(D.special_KCS_previous[0], (D.special_KCS_block1, D.special_KCS_block2, D.special_KCS_block3)),
           _Branch(D.previous[0], (D.block1, D.block2, D.block3))]
     optimizerD.zero_grad()
-    X = ops.gp_assemble(real, fake, alpha)                                   # (3B,48)
+    X = ops.gp_assemble(real, fake, alpha, bf16_rows=m.bf16 and SEED_CASTS)  # (3B,48)
     B = X.shape[0] // 3
     xh = X[2 * B:]
     from . import fused
     use = m.bf16 and FUSED_STEP_FORWARD and fused.step_forward_supported(D)
     kf, kb = ops.kcs_forward(X, True, f32=True, bf16_ld=32 if use else 0)    # fp32 features (first layer's weight gradient) [+ bf16 operand]
+    if SEED_CASTS:                                                           # sweep 4's bf16 operands of the two input layers exist already
+        m.seed_cast(X[:2 * B], ceil16(X.shape[1]), getattr(X, "_dhaug_bf16_rows", None))
+        if use and kb is not None:
+            m.seed_cast(kf[:2 * B], 32, kb[:2 * B])
     sr = 2 * B if (use and SKIP_XHAT_SAVES and fused.partial_save_ok(B)) else 0
     return step_branchnet(
         m, optimizerD, br, _Lin(D.merge_previous[0], RELU), _Block(D.merge_block1), _Lin(D.output, NONE), X, B, lam,

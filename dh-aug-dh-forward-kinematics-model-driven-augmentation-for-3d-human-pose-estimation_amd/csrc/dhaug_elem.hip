@@ -376,9 +376,11 @@ __global__ __launch_bounds__(256) void nn_from_nt_kernel(const dhaug_repack_desc
 
 // rows [0,B) = real, [B,2B) = fake, [2B,3B) = alpha*real + (1-alpha)*fake: the batch one critic step scores
 // (R/models_Fk_GAN/model_fk_gan_train.py:186-198, R/models_Fk_GAN/Fk_discriminator.py:210-216)
+// outb (optional): the real / fake rows once more as bf16 (2B, ldb) -- the operand sweep 4 contracts the input layer's cotangent with;
+// as a cast launch of its own it re-read what this kernel has in registers
 __global__ __launch_bounds__(256) void gp_assemble_kernel(const float* __restrict__ real, const float* __restrict__ fake,
                                                           const float* __restrict__ alpha, float* __restrict__ out,
-                                                          long long B, long long W) {
+                                                          long long B, long long W, uint16_t* __restrict__ outb, long long ldb) {
     const long long total = B * W;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long b = i / W;
@@ -386,12 +388,18 @@ __global__ __launch_bounds__(256) void gp_assemble_kernel(const float* __restric
         out[i] = r;
         out[total + i] = f;
         out[2 * total + i] = a * r + ((1.0f - a) * f);
+        if (outb != nullptr) {
+            const long long c = i - b * W;
+            outb[b * ldb + c] = dhaug_f32_to_bf16(r);
+            outb[(B + b) * ldb + c] = dhaug_f32_to_bf16(f);
+        }
     }
 }
 
 // one wave per row: n = ||g_b||_2, pen[b] = (n - 1)^2, v_b = coef * (n - 1) / n * g_b  (= d/dg of coef/2 * (n-1)^2)
 __global__ __launch_bounds__(256) void gp_penalty_kernel(const float* __restrict__ g, float* __restrict__ v,
-                                                         float* __restrict__ pen, long long B, int W, float coef) {
+                                                         float* __restrict__ pen, long long B, int W, float coef,
+                                                         uint16_t* __restrict__ vb, long long ldvb) {
     const int lane = threadIdx.x & 63;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
     for (long long b = wave; b < B; b += nw) {
@@ -405,7 +413,11 @@ __global__ __launch_bounds__(256) void gp_penalty_kernel(const float* __restrict
         // n == 0 (every unit of the critic dead on this row): torch's norm has subgradient 0 there (the reference's
         // gradients.norm(2, dim=1) back-propagates 0, not -inf * 0 = NaN)
         const float k = n > 0.0f ? coef * d / n : 0.0f;
-        for (int c = lane; c < W; c += 64) v[b * W + c] = k * row[c];
+        for (int c = lane; c < W; c += 64) {
+            const float vv = k * row[c];
+            v[b * W + c] = vv;
+            if (vb != nullptr) vb[b * ldvb + c] = dhaug_f32_to_bf16(vv);   // (the tangent sweep's first operand: see gp_assemble_kernel)
+        }
     }
 }
 
@@ -740,7 +752,17 @@ int dhaug_gp_assemble(const float* real, const float* fake, const float* alpha, 
     if (B == 0) return DHAUG_OK;
     DHAUG_CHECK_PTR(real); DHAUG_CHECK_PTR(fake); DHAUG_CHECK_PTR(alpha); DHAUG_CHECK_PTR(out);
     hipLaunchKernelGGL(gp_assemble_kernel, dim3(grid1d(B * W, 256)), dim3(256), 0, (hipStream_t)stream, real, fake, alpha, out,
-                       (long long)B, (long long)W);
+                       (long long)B, (long long)W, static_cast<uint16_t*>(nullptr), 0LL);
+    return dhaug_launch_status();
+}
+
+int dhaug_gp_assemble_bf16(const float* real, const float* fake, const float* alpha, float* out, uint16_t* rows_bf16, int64_t ld_bf16,
+                           int64_t B, int64_t W, void* stream) {
+    DHAUG_CHECK(B >= 0 && W >= 1 && ld_bf16 >= W, DHAUG_EINVAL);
+    if (B == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(real); DHAUG_CHECK_PTR(fake); DHAUG_CHECK_PTR(alpha); DHAUG_CHECK_PTR(out); DHAUG_CHECK_PTR(rows_bf16);
+    hipLaunchKernelGGL(gp_assemble_kernel, dim3(grid1d(B * W, 256)), dim3(256), 0, (hipStream_t)stream, real, fake, alpha, out,
+                       (long long)B, (long long)W, rows_bf16, (long long)ld_bf16);
     return dhaug_launch_status();
 }
 
@@ -749,7 +771,17 @@ int dhaug_gp_penalty(const float* grad, float* v, float* pen, int64_t B, int64_t
     if (B == 0) return DHAUG_OK;
     DHAUG_CHECK_PTR(grad); DHAUG_CHECK_PTR(v); DHAUG_CHECK_PTR(pen);
     hipLaunchKernelGGL(gp_penalty_kernel, dim3(grid1d((B + 3) / 4, 1)), dim3(256), 0, (hipStream_t)stream, grad, v, pen,
-                       (long long)B, (int)W, coef);
+                       (long long)B, (int)W, coef, static_cast<uint16_t*>(nullptr), 0LL);
+    return dhaug_launch_status();
+}
+
+int dhaug_gp_penalty_bf16(const float* grad, float* v, uint16_t* v_bf16, int64_t ld_bf16, float* pen, int64_t B, int64_t W, float coef,
+                          void* stream) {
+    DHAUG_CHECK(B >= 0 && W >= 1 && W <= (1 << 20) && ld_bf16 >= W, DHAUG_EINVAL);
+    if (B == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(grad); DHAUG_CHECK_PTR(v); DHAUG_CHECK_PTR(v_bf16); DHAUG_CHECK_PTR(pen);
+    hipLaunchKernelGGL(gp_penalty_kernel, dim3(grid1d((B + 3) / 4, 1)), dim3(256), 0, (hipStream_t)stream, grad, v, pen,
+                       (long long)B, (int)W, coef, v_bf16, (long long)ld_bf16);
     return dhaug_launch_status();
 }
 

@@ -612,8 +612,9 @@ def adam_step_dev(param, grad, exp_avg, exp_avg_sq, step_dev, lr=1e-4, betas=(0.
 
 
 # --------------------------------------------------------------------------------------- WGAN-GP arithmetic
-def gp_assemble(real, fake, alpha, out=None):
-    """(3B, W) fp32 = [real; fake; alpha * real + (1 - alpha) * fake]"""
+def gp_assemble(real, fake, alpha, out=None, bf16_rows=False):
+    """(3B, W) fp32 = [real; fake; alpha * real + (1 - alpha) * fake].  bf16_rows (W a multiple of 16): the real / fake rows also as
+    bf16 (2B, W), attached as out._dhaug_bf16_rows -- what cast_pad_bf16(out[:2B], W) would make, from the same launch"""
     r = _dev(real, torch.float32, "gp_assemble")
     r = r.reshape(r.shape[0], -1)
     f = _dev(fake, torch.float32, "gp_assemble").reshape(r.shape)
@@ -622,16 +623,27 @@ def gp_assemble(real, fake, alpha, out=None):
     assert a.shape[0] == B
     if out is None:
         out = torch.empty((3 * B, W), dtype=torch.float32, device=r.device)
+    if bf16_rows and W % 16 == 0:
+        xb = torch.empty((2 * B, W), dtype=BF16, device=r.device)
+        _lib.call("dhaug_gp_assemble_bf16", _p(r), _p(f), _p(a), _p(out), _p(xb), W, B, W, _stream())
+        out._dhaug_bf16_rows = xb
+        return out
     _lib.call("dhaug_gp_assemble", _p(r), _p(f), _p(a), _p(out), B, W, _stream())
     return out
 
 
-def gp_penalty(grad, coef):
-    """per-row (||g|| - 1)^2 and the penalty's cotangent coef * (n - 1) / n * g"""
+def gp_penalty(grad, coef, bf16=False):
+    """per-row (||g|| - 1)^2 and the penalty's cotangent coef * (n - 1) / n * g.  bf16 (W a multiple of 16): v also as bf16,
+    attached as v._dhaug_bf16 (= cast_pad_bf16(v, W), from the same launch)"""
     g = _dev(grad, torch.float32, "gp_penalty")
     B, W = g.shape
     v = torch.empty_like(g)
     pen = torch.empty((B,), dtype=torch.float32, device=g.device)
+    if bf16 and W % 16 == 0:
+        vb = torch.empty((B, W), dtype=BF16, device=g.device)
+        _lib.call("dhaug_gp_penalty_bf16", _p(g), _p(v), _p(vb), W, _p(pen), B, W, float(coef), _stream())
+        v._dhaug_bf16 = vb
+        return v, pen
     _lib.call("dhaug_gp_penalty", _p(g), _p(v), _p(pen), B, W, float(coef), _stream())
     return v, pen
 

@@ -537,10 +537,17 @@ int dhaug_adam_repack_step(float* param, const float* grad, float* exp_avg, floa
 /* out (3B, W) fp32: rows [0,B) = real, [B,2B) = fake, [2B,3B) = alpha_b * real + (1 - alpha_b) * fake -- the batch one
  * critic step scores (the two critic passes and the penalty's interpolates as one batch). */
 int dhaug_gp_assemble(const float* real, const float* fake, const float* alpha, float* out, int64_t B, int64_t W, void* stream);
+/* ... and rows [0, 2B) (real, fake) once more as bf16 (2B, ld_bf16 >= W; columns beyond W are not written): the operand the step's
+ * weight-gradient sweep contracts the input layer's cotangent with, without a cast launch of its own (same rounding: nearest even) */
+int dhaug_gp_assemble_bf16(const float* real, const float* fake, const float* alpha, float* out, uint16_t* rows_bf16, int64_t ld_bf16,
+                           int64_t B, int64_t W, void* stream);
 
 /* Per row b of grad (B, W) = dD/dx_hat:  n = ||grad_b||_2;  pen[b] = (n - 1)^2;  v_b = coef * (n - 1) / n * grad_b, the
  * cotangent of the penalty on grad (coef = 2 * LAMBDA / B gives d/dgrad of LAMBDA * mean((n - 1)^2)). */
 int dhaug_gp_penalty(const float* grad, float* v, float* pen, int64_t B, int64_t W, float coef, void* stream);
+/* ... with v also as bf16 (B, ld_bf16 >= W): the tangent sweep's first operand */
+int dhaug_gp_penalty_bf16(const float* grad, float* v, uint16_t* v_bf16, int64_t ld_bf16, float* pen, int64_t B, int64_t W, float coef,
+                          void* stream);
 
 /* Frame differences of clips (the motion critics' diff branches, R/models_Fk_GAN/Fk_discriminator.py:458-460,489-492,570-573):
  * x (rows, R*in_w) -> out (rows, (R-1)*w), out[r][f][c] = x[r][f+1][c] - x[r][f][c] over the first w columns of every frame;

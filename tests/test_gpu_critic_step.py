@@ -322,6 +322,49 @@ def test_sweep4_in_two_parts_equals_one_part(M, tag):
         assert (g1[k] - g0[k]).abs().max().item() <= 1e-4 * scale + 1e-12, (k, (g1[k] - g0[k]).abs().max().item(), scale)
 
 
+def test_bf16_operands_written_beside_fp32_results_equal_the_cast_launches(M):
+    """dhaug_gp_assemble_bf16 / dhaug_gp_penalty_bf16 / the KCS operand of dhaug_kcs_forward: the bf16 tensors these launches write
+    beside their fp32 results are, bit for bit, what dhaug_cast_pad_bf16 makes of those results (critic_step registers them as the
+    casts of those tensors: _Math.seed_cast)"""
+    from dhaug_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for B, W in ((1000, 32), (2048 + 64, 48), (7, 48)):
+        r, f, a = torch.randn(B, W, generator=g).cuda(), torch.randn(B, W, generator=g).cuda() * 3, torch.rand(B, 1, generator=g).cuda()
+        X0 = ops.gp_assemble(r, f, a)
+        X1 = ops.gp_assemble(r, f, a, bf16_rows=True)
+        assert torch.equal(X0, X1) and torch.equal(X1._dhaug_bf16_rows, ops.cast_pad_bf16(X1[:2 * B], W))
+        gr = torch.randn(B, W, generator=g).cuda()
+        gr[B // 2] = 0.0                                         # (a dead row: the penalty's cotangent is 0 there)
+        v0, p0 = ops.gp_penalty(gr, 0.37)
+        v1, p1 = ops.gp_penalty(gr, 0.37, bf16=True)
+        assert torch.equal(v0, v1) and torch.equal(p0, p1) and torch.equal(v1._dhaug_bf16, ops.cast_pad_bf16(v1, W))
+    x = (GU.synth_pose16(3000, seed=4)).reshape(3000, 48).cuda()
+    kf, kb = ops.kcs_forward(x, True, f32=True, bf16_ld=32)
+    assert torch.equal(kb, ops.cast_pad_bf16(kf, 32))
+
+
+@pytest.mark.parametrize("tag", ["d3", "d2"])
+def test_step_with_registered_casts_equals_step_with_cast_launches(M, tag):
+    """critic_step.SEED_CASTS: the same step, bit for bit (the operands are the same bits; only the launches that made them differ)"""
+    B, D = 2048, 256
+    args = _args(B, D)
+    shapes = GU.shapes_d3(D) if tag == "d3" else GU.shapes_d2(D)
+    sd = GU.seeded_state_dict(shapes, 41)
+    data = _data(tag, B, 12)
+    assert M.cs.SEED_CASTS
+    W1, C1, g1, p1 = _run(M, tag, args, sd, "bf16", data, True)
+    M.cs.SEED_CASTS = False
+    try:
+        W0, C0, g0, p0 = _run(M, tag, args, sd, "bf16", data, True)
+    finally:
+        M.cs.SEED_CASTS = True
+    assert W1 == W0 and C1 == C0
+    for k in g0:
+        if g0[k].numel() > 1:                                    # (the logit layer's bias slot: see test_step_is_bit_reproducible_under_load)
+            assert torch.equal(g1[k], g0[k]), k
+            assert torch.equal(p1[k], p0[k]), k
+
+
 @pytest.mark.parametrize("tag", ["d3", "d2"])
 def test_step_is_bit_reproducible_under_load(M, tag):
     """every kernel of the explicit step sums in a fixed order (the one exception, the logit layer's bias slot, is excluded): the
