@@ -5,6 +5,8 @@
 # gpurun_out/profiles/* there afterwards; <round>_STAMP.txt holds the collection time bench.py quotes as traffic_source).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT || exit 1
 R=${1:-r03}
+ONLY=${2:-all}                      # optional: the workloads to (re)collect, e.g. "step video" (tags: fwd fwd_parity step video d3 d3_parity fk)
+want() { [ "$ONLY" = all ] || [[ " $ONLY " == *" $1 "* ]]; }
 O=gpurun_out/profiles
 mkdir -p $O
 B="python bench.py --no-cpu-baseline --no-extra --no-roofline --prewarm 0 --reps 1"
@@ -14,28 +16,28 @@ stats() {  # name, args...
   cp $(find gpurun_out/prof_$name -name "*kernel_stats.csv" | head -1) $O/${R}_${name}_kernel_stats.csv
   rm -rf gpurun_out/prof_$name
 }
-stats fwd $B --steps 200 --warmup 50 || exit 1
-stats fwd_parity $B --steps 100 --warmup 20 --precision parity || exit 1
-stats step $B --workload gan_step --steps 10 --warmup 5 --graph off || exit 1
-stats video $B --workload video --steps 5 --warmup 3 --graph off || exit 1
-stats d3 python tools/prof_fused_d3.py bf16 || exit 1
-stats d3_parity python tools/prof_fused_d3.py f16x3 || exit 1
-stats fk python tools/prof_fk.py || exit 1
+want fwd && { stats fwd $B --steps 200 --warmup 50 || exit 1; }
+want fwd_parity && { stats fwd_parity $B --steps 100 --warmup 20 --precision parity || exit 1; }
+want step && { stats step $B --workload gan_step --steps 10 --warmup 5 --graph off || exit 1; }
+want video && { stats video $B --workload video --steps 5 --warmup 3 --graph off || exit 1; }
+want d3 && { stats d3 python tools/prof_fused_d3.py bf16 || exit 1; }
+want d3_parity && { stats d3_parity python tools/prof_fused_d3.py f16x3 || exit 1; }
+want fk && { stats fk python tools/prof_fk.py || exit 1; }
 pmc() {  # tag, counter, args...
   local tag=$1 c=$2; shift 2
   timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -o r -- "$@" > gpurun_out/pmc_${tag}_$c.log 2>&1 || return 1
 }
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
-  pmc fwd $c $B --steps 20 --warmup 5 || exit 1
-  pmc d3 $c python tools/prof_fused_d3.py bf16 || exit 1
-  pmc d3p $c python tools/prof_fused_d3.py f16x3 || exit 1
+  want fwd && { pmc fwd $c $B --steps 20 --warmup 5 || exit 1; }
+  want d3 && { pmc d3 $c python tools/prof_fused_d3.py bf16 || exit 1; }
+  want d3_parity && { pmc d3p $c python tools/prof_fused_d3.py f16x3 || exit 1; }
 done
-for c in FETCH_SIZE WRITE_SIZE; do pmc fk $c python tools/prof_fk.py || exit 1; done
+for c in FETCH_SIZE WRITE_SIZE; do want fk && { pmc fk $c python tools/prof_fk.py || exit 1; }; done
 # training workloads (configs[2] and configs[4]): 5 eager iterations each (3 timed + 2 warm-up: exactly one of them runs the
 # G step, the steady-state mix), every dispatch counted
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
-  pmc step $c $B --workload gan_step --steps 3 --warmup 2 --graph off || exit 1
-  pmc video $c $B --workload video --steps 3 --warmup 2 --graph off || exit 1
+  want step && { pmc step $c $B --workload gan_step --steps 3 --warmup 2 --graph off || exit 1; }
+  want video && { pmc video $c $B --workload video --steps 3 --warmup 2 --graph off || exit 1; }
 done
 python - <<PY
 import csv, collections, glob
