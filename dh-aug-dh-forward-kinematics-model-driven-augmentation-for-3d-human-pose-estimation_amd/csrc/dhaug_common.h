@@ -18,7 +18,9 @@
     defined(W_NO_XCD_MAP) || defined(X3_NWAVES) || defined(X3_SPREAD) || defined(X3_RING) || defined(X3_TIMING) || \
     defined(X3_STAMP_TID) || defined(X3_REG_STASH) || defined(X3_WS_NT) || defined(X3_EPI_FENCE) || defined(X3_WRITE128) || \
     defined(X3_ABL_NOSPLIT) || defined(X3_ABL_NOWRITE) || defined(X3_ABL_NOWS) || defined(X3_ABL_NOREAD) || \
-    defined(X3_ABL_NOWLOAD) || defined(X3_ABL_NOEPI) || defined(X3_AB_SPLIT) || defined(X3_PRIO_SEL)
+    defined(X3_ABL_NOWLOAD) || defined(X3_ABL_NOEPI) || defined(X3_AB_SPLIT) || defined(X3_PRIO_SEL) || \
+    defined(P8_ABL_NOMMA) || defined(P8_ABL_NOREAD) || defined(P8_ABL_NOCOPY) || defined(P8_ABL_NOEPI) || defined(P8_ABL_NOSTAGGER) || \
+    defined(P8_ABL_NOPRIO) || defined(P8_TIMING)
 #error "a development / ablation switch is defined without -DDHAUG_ABLATION_BUILD: this would build a library with wrong results"
 #endif
 #endif

@@ -17,6 +17,7 @@
 // hardware transpose read, because the contraction index m is the slow axis in memory.
 #include <cstdlib>
 #include "dhaug_common.h"
+#include "dhaug_gemm_args.h"
 #include <stdlib.h>
 
 namespace {
@@ -26,40 +27,7 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct GemmArgs {
-    const uint16_t* A; long long lda;
-    const uint16_t* B; long long ldb;
-    const float* bias;
-    const uint16_t* res; long long ld_res;
-    const float* resf; long long ld_resf;
-    uint16_t* cb; long long ldcb; long long npad;
-    float* cf; long long ldcf;
-    long long M, N, K, W;          // W = output width covered by tiles (N, or the zero-padded width)
-    int act; float slope;
-    const uint16_t* dmask; long long ld_dmask; float dneg;   // optional: result *= (dmask > 0 ? 1 : dneg)  (nt256 kernel only)
-    const uint32_t* dbits;                                   // the same mask as a sign-bit array (dhaug_mlp_unit.bits layout)
-    const uint32_t* dbits2;                                  // ... of output columns 256..511 (gemm_nt_ws_kernel: a layer whose output is two 256-wide blocks)
-    int abl;                                                 // development (big-tile kernel): 1 no epilogue, 2 no reads / MFMAs, 4 no copies
-    const float* dmaskf; long long ld_dmaskf;                // the same mask from an fp32 activation (split-operand arithmetic): kernels
-                                                             // whose epilogue is nt_store_tile
-};
-
-// A GemmArgs copied word by word out of the kernarg segment (the grouped kernels below) holds pointers hipcc knows nothing about: every
-// access through them was a FLAT instruction -- which counts in the LDS counter as well, so each wait for an LDS read in the epilogue also
-// waited for the row stores before it.  Passing the pointers through the global address space restores global_load / global_store
-// (measured: the grouped launches take what they took, 28.9 / 17.3 us for four 1 536- / 512-row members -- the epilogue is not what waits).
-template <class T> __device__ __forceinline__ T* as_global(T* q) { return (T*)(__attribute__((address_space(1))) T*)reinterpret_cast<uintptr_t>(q); }
-__device__ __forceinline__ void globalize(GemmArgs& p) {
-    p.A = as_global(p.A); p.B = as_global(p.B); p.bias = as_global(p.bias); p.res = as_global(p.res); p.resf = as_global(p.resf);
-    p.cb = as_global(p.cb); p.cf = as_global(p.cf); p.dmask = as_global(p.dmask); p.dbits = as_global(p.dbits); p.dbits2 = as_global(p.dbits2);
-    p.dmaskf = as_global(p.dmaskf);
-}
-
-// branch-free activation: v > 0 ? v : v * neg, neg = 0 (ReLU) / slope (LeakyReLU) / 1 (identity)
-__device__ __forceinline__ float apply_act(float v, int act, float slope) {
-    const float neg = act == DHAUG_ACT_RELU ? 0.0f : (act == DHAUG_ACT_LRELU ? slope : 1.0f);
-    return v > 0.0f ? v : v * neg;
-}
+using namespace dhaug_gemm;        // GemmArgs, GemmGroupArgs, apply_act, ... (dhaug_gemm_args.h)
 
 constexpr int BK = 64;
 
@@ -598,8 +566,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_pipe2_kernel(GemmArgs p) { nt_
 // at the same depth (dhaug_gemm_bf16_group).  A 1 536 x 1000 x 1000 layer is 384 of these tiles -- one and a half waves of the card's
 // 512 workgroup slots, behind a launch of its own; four of them are three full waves behind ONE launch.  The member's arguments are
 // read from the kernarg segment with scalar loads (a by-value array indexed dynamically would be copied to scratch).
-constexpr int NT_GROUP_MAX = 8;
-struct GemmGroupArgs { GemmArgs g[NT_GROUP_MAX]; };
 // Which member a workgroup takes: workgroups go to the eight XCDs round-robin and every XCD has its own 4 MB L2, so with 2, 4 or 8
 // members each member gets XCDs of its own (member = XCD * n / 8): an XCD's L2 then holds ONE member's weights (2 MB at DenseDim
 // 1000) beside the activation rows in flight.  *(measured, four 1 536 x 1000 x 1000 members)* dealt member by member the launch takes
@@ -619,15 +585,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_pipe2_group_kernel(GemmGroupAr
     }
     if (tile >= tiles || member >= n) return;
     GemmArgs p;
-    {
-        static_assert(sizeof(GemmArgs) % 8 == 0, "copied as 8-byte words");
-        const unsigned long long __attribute__((address_space(4)))* src = (const unsigned long long __attribute__((address_space(4)))*)(
-            (const unsigned char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + member * sizeof(GemmArgs));
-        unsigned long long* dst = reinterpret_cast<unsigned long long*>(&p);
-#pragma unroll
-        for (int i = 0; i < (int)(sizeof(GemmArgs) / 8); ++i) dst[i] = src[i];
-    }
-    globalize(p);
+    load_group_member(p, member);
     nt_pipe2_body(p, tile);
 }
 
@@ -789,14 +747,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_g128_group_kernel(GemmGroupArg
     }
     if (tile >= tiles || member >= n) return;
     GemmArgs p;
-    {
-        const unsigned long long __attribute__((address_space(4)))* src = (const unsigned long long __attribute__((address_space(4)))*)(
-            (const unsigned char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + member * sizeof(GemmArgs));
-        unsigned long long* dst = reinterpret_cast<unsigned long long*>(&p);
-#pragma unroll
-        for (int i = 0; i < (int)(sizeof(GemmArgs) / 8); ++i) dst[i] = src[i];
-    }
-    globalize(p);
+    load_group_member(p, member);
     nt_g128_body(p, tile);
 }
 
@@ -2508,6 +2459,8 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
         getenv("DHAUG_GEMM_NOWIDE") == nullptr && getenv("DHAUG_GEMM_NOBIG") == nullptr && getenv("DHAUG_GEMM_NOPIPE") == nullptr) {
         // long batch, tiles enough for most of the card: 256 x 256 tiles, eight waves (the DenseDim-1000 layers of the frame
         // critics; the 256-wide layers of the split-operand parity arithmetic, K' = 3 K or 6 K)
+        // (since round 6: the ping-pong kernel of dhaug_gemm_p8.hip; DHAUG_GEMM_NOP8=1 keeps the five-stage kernel below)
+        if (getenv("DHAUG_GEMM_NOP8") == nullptr && dhaug_p8_supported(p)) return dhaug_p8_launch(s, p);
         p.abl = DHAUG_ABL_ENV("DHAUG_BIG_ABL");   // (development: timing only)
         return launch_wide(s, p);
     }
@@ -2597,6 +2550,14 @@ int dhaug_gemm_bf16_group(const dhaug_gemm_desc* d, int n, void* stream) {
     const GemmArgs& p = ga.g[0];
     // 128 x 128 tiles (half the staged bytes, a quarter of the workgroups) unless the group is too small to fill the card with them
     // or DHAUG_NT_GROUP_TILE=64 asks for the 64 x 64 form
+    // long members of wide layers: 256 x 256 ping-pong tiles (dhaug_gemm_p8.hip) -- fewer workgroups at a higher rate each, which leaves
+    // CUs to the other critics' streams (DHAUG_NT_GROUP_P8_ROWS: the shortest member that takes them; 0 = never)
+    const long long p8_rows = getenv("DHAUG_NT_GROUP_P8_ROWS") ? atoll(getenv("DHAUG_NT_GROUP_P8_ROWS")) : 1024;
+    if (p8_rows > 0 && p.M >= p8_rows && p.W >= 512) {
+        bool ok = true;
+        for (int i = 0; i < n; ++i) ok = ok && dhaug_p8_supported(ga.g[i]);
+        if (ok) return dhaug_p8_launch_group((hipStream_t)stream, ga, n);
+    }
     static const int tile_env = getenv("DHAUG_NT_GROUP_TILE") ? atoi(getenv("DHAUG_NT_GROUP_TILE")) : 0;
     const bool big = tile_env != 64 && p.K >= 32 && p.M >= 128;
     const int T = big ? 128 : 64;

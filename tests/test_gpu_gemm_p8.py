@@ -1,0 +1,155 @@
+"""The 256 x 256 x 64 ping-pong NT kernel (csrc/dhaug_gemm_p8.hip): the DenseDim-1000 layers of long batches and of the grouped branch
+layers, through the C-ABI (dhaug_gemm_bf16, dhaug_gemm_bf16_dmask_pad, dhaug_gemm_bf16_dmask_f32, dhaug_gemm_bf16_group), against fp64
+products of the bf16 operands and against the kernels it replaces (DHAUG_GEMM_NOP8 / DHAUG_NT_GROUP_P8_ROWS=0)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def maxabs(a, b):
+    return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import dhaug_amd
+    from dhaug_amd import ops as o
+    dhaug_amd._lib.lib()            # fail loudly if the HIP extension is missing
+    return o
+
+
+def _operands(M, N, K, Kp, seed):
+    gen = torch.Generator().manual_seed(seed)
+    A = torch.zeros(M, Kp); A[:, :K] = torch.randn(M, K, generator=gen) * 0.5
+    W = torch.zeros(N, Kp); W[:, :K] = torch.randn(N, K, generator=gen) / K ** 0.5
+    return _bf(A).cuda(), _bf(W).cuda(), gen
+
+
+# (M, N, K, Kp): Kp is the operands' padded width = the K the kernel is given.  K tails of 48 / 16 / 32 / none; ragged row blocks; ragged
+# column tiles; 256-wide layers of the split-operand arithmetic (K' = 6 K); the shortest K the kernel takes (two K-tiles).
+SHAPES = [(13824, 1000, 1000, 1008), (40960 + 8, 1000, 1000, 1008), (41000, 512, 976, 976), (40970, 256, 1536, 1536), (20500, 1000, 160, 160),
+          (41216, 264, 128, 128), (10241, 1000, 1024, 1024)]
+
+
+@pytest.mark.parametrize("M,N,K,Kp", SHAPES)
+def test_p8_plain_fp32_out(ops, M, N, K, Kp):
+    A, W, _ = _operands(M, N, K, Kp, M + N + K)
+    ref = A.float().cpu().double() @ W.float().cpu().double().t()
+    _, cf = ops.gemm_nt(A, W, N, Kp, out_f32=True)
+    assert maxabs(cf, ref) <= 2e-5 * max(1.0, ref.abs().max().item())
+    os.environ["DHAUG_GEMM_NOP8"] = "1"
+    try:
+        _, cf_old = ops.gemm_nt(A, W, N, Kp, out_f32=True)
+    finally:
+        del os.environ["DHAUG_GEMM_NOP8"]
+    # both sum in fp32; only the order of the k-steps differs
+    assert maxabs(cf, cf_old) <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("act,slope", [(0, 0.0), (1, 0.0), (2, 0.01)])
+def test_p8_epilogues(ops, act, slope):
+    """bias + bf16 residual + activation with a zero-padded bf16 output AND an fp32 output in one launch; the fp32-residual form; the
+    masked input-gradient forms (bf16 mask; fp32 mask with fp32 result: the split-operand arithmetic's dhaug_gemm_bf16_dmask_f32)"""
+    M, N, K, Kp = 40960 + 77, 1000, 1000, 1008
+    A, W, gen = _operands(M, N, K, Kp, 7 + act)
+    R = torch.zeros(M, Kp); R[:, :N] = torch.randn(M, N, generator=gen)
+    Y = torch.zeros(M, Kp); Y[:, :N] = torch.randn(M, N, generator=gen)
+    R, Y = _bf(R).cuda(), _bf(Y).cuda()
+    bias = torch.randn(N, generator=gen).cuda()
+    pre = A.float().cpu().double() @ W.float().cpu().double().t()
+    z = pre + bias.cpu().double() + R[:, :N].float().cpu().double()
+    ref = z if act == 0 else (torch.relu(z) if act == 1 else torch.nn.functional.leaky_relu(z, slope))
+    scale = max(1.0, ref.abs().max().item())
+    cb, cf = ops.gemm_nt(A, W, N, Kp, bias=bias, res_bf16=R, act=act, slope=slope, out_bf16=True, n_pad=Kp, out_f32=True)
+    assert maxabs(cf, ref) <= 3e-5 * scale
+    assert cb.shape == (M, Kp) and cb[:, N:].abs().max().item() == 0.0
+    assert maxabs(cb[:, :N].float(), cf.to(torch.bfloat16).float()) == 0.0
+    resf = torch.randn(M, N, generator=gen).cuda()
+    _, cf2 = ops.gemm_nt(A, W, N, Kp, bias=bias, res_f32=resf, act=0, out_f32=True)
+    assert maxabs(cf2, pre + bias.cpu().double() + resf.cpu().double()) <= 3e-5 * scale
+    if act != 0:
+        dneg = 0.0 if act == 1 else slope
+        g = ops.gemm_nt_dmask(A, W, N, Kp, Y, act, slope, res_bf16=R)
+        m = (Y[:, :N].float().cpu() > 0).double()
+        refg = (pre + R[:, :N].float().cpu().double()) * (m + (1 - m) * dneg)
+        assert g.shape[1] == Kp and g[:, N:].abs().max().item() == 0.0
+        assert maxabs(g[:, :N].float(), refg) <= 2.0 ** -8 * max(1.0, refg.abs().max().item())
+        yf = torch.randn(M, N, generator=gen).cuda()
+        gf = ops.gemm_nt_dmask_f32(A, W, N, Kp, yf, act, slope, res_f32=resf)
+        mf = (yf.cpu() > 0).double()
+        reff = (pre + resf.cpu().double()) * (mf + (1 - mf) * dneg)
+        assert maxabs(gf, reff) <= 3e-5 * max(1.0, reff.abs().max().item())
+
+
+def test_p8_column_block_views(ops):
+    """operands and outputs as column blocks of wider buffers (the cotangent of a concatenation, the branches' column blocks of the
+    merge layer's input): row strides larger than the widths, nothing outside the view's own columns is written"""
+    M, N, K, Kp = 40960, 1000, 1000, 1008
+    A, W, gen = _operands(M, N, K, Kp, 3)
+    wide_in = torch.zeros(M, 2 * Kp, dtype=torch.bfloat16, device="cuda"); wide_in[:, Kp:] = A
+    wide_out = torch.full((M, 2 * Kp), 7.0, dtype=torch.bfloat16, device="cuda")
+    ref = torch.relu(A.float().cpu().double() @ W.float().cpu().double().t())
+    ops.gemm_nt(wide_in[:, Kp:], W, N, Kp, act=1, c_bf16=wide_out[:, :Kp], n_pad=Kp)
+    assert maxabs(wide_out[:, :N].float(), ref) <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
+    assert wide_out[:, N:Kp].abs().max().item() == 0.0 and (wide_out[:, Kp:] == 7.0).all()
+
+
+@pytest.mark.parametrize("M,n", [(1536, 4), (1536, 2), (1100, 3), (2048 + 5, 1)])
+def test_p8_group_equals_single_launches(ops, M, n):
+    """dhaug_gemm_bf16_group on the ping-pong tiles (members of >= 1024 rows): bit-identical to one dhaug_gemm_bf16 launch per member
+    on the same kernel where that launch takes it, and equal within bf16 rounding to the 128 x 128-tile group kernel it replaces"""
+    N, K, Kp = 1000, 1000, 1008
+    gen = torch.Generator().manual_seed(M + n)
+    mem, refs = [], []
+    for i in range(n):
+        A, W, _ = _operands(M, N, K, Kp, 100 * i + M)
+        R = torch.zeros(M, Kp); R[:, :N] = torch.randn(M, N, generator=gen)
+        Y = torch.zeros(M, Kp); Y[:, :N] = torch.randn(M, N, generator=gen)
+        R, Y = _bf(R).cuda(), _bf(Y).cuda()
+        bias = torch.randn(N, generator=gen).cuda()
+        if i % 2 == 0:
+            mem.append(dict(A=A, B=W, N=N, K=Kp, bias=bias, res_bf16=R, act=1, n_pad=Kp))
+            refs.append(torch.relu(A.float().cpu().double() @ W.float().cpu().double().t() + bias.cpu().double() + R[:, :N].float().cpu().double()))
+        else:
+            mem.append(dict(A=A, B=W, N=N, K=Kp, res_bf16=R, dmask=Y, dmask_act=1, n_pad=Kp))
+            refs.append((A.float().cpu().double() @ W.float().cpu().double().t() + R[:, :N].float().cpu().double()) * (Y[:, :N].float().cpu() > 0).double())
+    outs = ops.gemm_nt_group(mem)
+    for o, r in zip(outs, refs):
+        assert o.shape == (M, Kp) and o[:, N:].abs().max().item() == 0.0
+        assert maxabs(o[:, :N].float(), r) <= 2.0 ** -8 * max(1.0, r.abs().max().item())
+    os.environ["DHAUG_NT_GROUP_P8_ROWS"] = "0"
+    try:
+        old = ops.gemm_nt_group(mem)
+    finally:
+        del os.environ["DHAUG_NT_GROUP_P8_ROWS"]
+    for o, q, r in zip(outs, old, refs):
+        assert (o.float() - q.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, r.abs().max().item())
+    again = ops.gemm_nt_group(mem)                               # deterministic: no atomics, one summation order
+    for o, q in zip(outs, again):
+        assert torch.equal(o, q)
+
+
+def test_p8_reads_nothing_beyond_k(ops):
+    """the operand rows are K = 1008 wide and the last K-tile covers k = 960 .. 1023: what lies behind a row's K columns (the next row,
+    or for the LAST row the end of the allocation) must not reach the result -- NaN-filled neighbours, operands at the end of their
+    allocations"""
+    M, N, K, Kp = 40960, 1000, 1000, 1008
+    A, W, _ = _operands(M, N, K, Kp, 11)
+    ref = A.float().cpu().double() @ W.float().cpu().double().t()
+    bufA = torch.full((M * Kp + 4096,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    bufW = torch.full((N * Kp + 4096,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    # the operands end exactly where their buffers' valid part ends; everything behind is NaN
+    a = bufA[:M * Kp].view(M, Kp); a.copy_(A)
+    w = bufW[:N * Kp].view(N, Kp); w.copy_(W)
+    _, cf = ops.gemm_nt(a, w, N, Kp, out_f32=True)
+    assert torch.isfinite(cf).all()
+    assert maxabs(cf, ref) <= 2e-5 * max(1.0, ref.abs().max().item())
