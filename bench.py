@@ -111,19 +111,19 @@ def profile_stats(name, kernel_substr):
 
 def with_profile(block, name, kernel_substr, work):
     """adds the tracked profile's durations to a roofline block (work = flops or bytes per launch; block["peak"] in T or G
-    units per second): `frac` / `achieved` become the figures that follow from the profile's MEAN launch duration (what a
-    reader recomputes from profiles/), the live HIP-event measurement of THIS run is kept as frac_events / achieved_events"""
+    units per second).  `frac` / `achieved` / `avg_us` stay what THIS run measured with HIP events (a regression of the kernel
+    moves them); the figures that follow from the TRACKED profile's launch durations -- what a reader recomputes from
+    profiles/, collected under rocprofv3 with the build stamped in <tag>_STAMP.txt -- stand beside them as frac_profile_mean /
+    frac_profile_min / achieved_profile_mean.  The two must agree up to the profiler's lower clocks (a few per cent)."""
     ps = profile_stats(name, kernel_substr)
-    block["frac_events"], block["achieved_events"], block["frac_source"] = block["frac"], block["achieved"], "HIP events of this run"
+    block["frac_source"] = "HIP events of this run (avg_us)"
     if ps:
         unit = 1e12 if block["unit"] == "TFLOP/s" else 1e9
         block.update(ps)
         block["frac_profile_mean"] = work / (ps["profile_mean_us"] * 1e-6) / unit / block["peak"]
         block["frac_profile_min"] = work / (ps["profile_min_us"] * 1e-6) / unit / block["peak"]
-        # the headline fraction is the one the TRACKED profile reproduces (its mean launch duration, clocks as under the
-        # profiler); the live HIP-event figure of this run stays beside it as frac_events / achieved_events / avg_us
-        block["frac"], block["achieved"] = block["frac_profile_mean"], work / (ps["profile_mean_us"] * 1e-6) / unit
-        block["frac_source"] = "mean launch duration in " + ps["profile_file"]
+        block["achieved_profile_mean"] = work / (ps["profile_mean_us"] * 1e-6) / unit
+        block["profile_agrees"] = bool(abs(block["frac_profile_mean"] / block["frac"] - 1.0) <= 0.15)
     return block
 
 
@@ -662,11 +662,16 @@ def main():
             out["roofline_video_step"] = {"kernel": "one video GAN iteration (B = 512 x R = 9, DenseDim 1000): 2 + 2 frame-critic and 4 + 4 motion-critic steps, sampling, G step every 5th",
                                           "bound": "hbm", "achieved": by_v / tvb / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": by_v / tvb / 1e9 / HBM_PEAK_GBS, "traffic": trv, "traffic_source": pmc_stamp(),
+                                          "traffic_note": "traffic = PMC total of the TRACKED profile (not this run); achieved / frac = this run's time",
                                           "algorithmic_bytes_per_iteration": by_v, "traffic_over_algorithmic": (trv / by_v) if trv else None,
                                           "ms_per_iteration": tvb * 1e3}
             del gv, mv
-        except Exception as ex:                      # never lose the headline line to an optional measurement
+        except Exception as ex:                      # never lose the headline line to an optional measurement ...
             extra["video_error"] = repr(ex)[:300]
+    # ... but never hide its failure either: every optional measurement that raised is named at the top level of the line
+    failed = sorted(k for k in extra if k.endswith("_error"))
+    if failed:
+        out["extra_errors"] = {k: extra[k] for k in failed}
     out["extra"] = extra
 
     gen_mac, d3_mac, d2_mac = mac_per_pose(D, R)
@@ -818,7 +823,7 @@ def main():
         dist.destroy_process_group()
 
 
-PROFILE_TAG = next((t for t in ("r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", t + "_STAMP.txt"))), "r03")
+PROFILE_TAG = next((t for t in ("r06", "r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", t + "_STAMP.txt"))), "r03")
 
 
 def pmc_stamp():

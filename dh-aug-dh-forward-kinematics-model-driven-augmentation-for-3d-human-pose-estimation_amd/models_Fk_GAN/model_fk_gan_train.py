@@ -378,8 +378,18 @@ def generator_step(args, G, oG, critics, weights, camera, flip, noise=None, scal
     return (-gen_loss).detach()
 
 
-def gan_iteration(args, poseFk_dict, inputs_3d, cam_param, target_d2d, train_subjects, summary=None, writer=None,
-                  do_g_step=False, camera=None, rng=np.random, draws=None):
+def gan_iteration(*a, **k):
+    """_gan_iteration with the fused inference programs it launches (the sampling pass, the G step's value-only evaluations) in
+    their NaN-propagating form: a diverged generator or critic shows as NaN in the iteration's costs, as in the reference's ATen
+    arithmetic, instead of being clipped to finite values by the integer-max ReLU of the inference kernels (+5 % on launches that
+    are ~2 % of an iteration).  The flag is read when a kernel is LAUNCHED, so an iteration captured into a hipGraph keeps it on
+    replay: set here, inside the captured region's function, eager and graphed iterations behave alike."""
+    with ops.nan_propagation(True):
+        return _gan_iteration(*a, **k)
+
+
+def _gan_iteration(args, poseFk_dict, inputs_3d, cam_param, target_d2d, train_subjects, summary=None, writer=None,
+                   do_g_step=False, camera=None, rng=np.random, draws=None):
     """One pass of R/models_Fk_GAN/model_fk_gan_train.py:281-489 on one real batch.
     inputs_3d (B,16,3) camera-space real poses, cam_param (B,>=16) with quaternion at [9:13] and translation at
     [13:16], target_d2d (B,16,2).  draws: a Draws object replaying recorded noise / jitter / GP coefficients.

@@ -21,8 +21,14 @@ def _rev(x, R, width):
     return torch.flip(x.reshape(-1, R, width), dims=[1]).contiguous()
 
 
-def video_gan_iteration(args, poseFk_dict, inputs_3d, cam_param, inputs_2d, train_subjects, summary, writer=None,
-                        do_g_step=False, camera=None, rng=np.random, draws=None):
+def video_gan_iteration(*a, **k):
+    """_video_gan_iteration with the fused inference programs in their NaN-propagating form (see gan_iteration)"""
+    with ops.nan_propagation(True):
+        return _video_gan_iteration(*a, **k)
+
+
+def _video_gan_iteration(args, poseFk_dict, inputs_3d, cam_param, inputs_2d, train_subjects, summary, writer=None,
+                         do_g_step=False, camera=None, rng=np.random, draws=None):
     """inputs_3d (B,R,16,3) camera-space real clips, cam_param (B,>=16), inputs_2d (B,R,16,2).
 
     Critic-step conventions of the reference, reproduced: the 3D motion critic steps run with dis_mode='motion' (gradient

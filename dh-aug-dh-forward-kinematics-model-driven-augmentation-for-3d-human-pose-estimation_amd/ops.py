@@ -474,7 +474,9 @@ class workgroup_cap:
 class nan_propagation:
     """with nan_propagation(True): the fused INFERENCE programs launched inside apply ReLU as max(v, v * 0) -- a NaN / inf input
     row reaches its logit, NaN weights reach every logit, as in the reference (dhaug_set_nan_propagation; process-wide default:
-    DHAUG_NAN_PROPAGATION=1 in the environment)"""
+    DHAUG_NAN_PROPAGATION=1 in the environment).  The training iterations (gan_iteration, video_gan_iteration) always run inside it.
+    The flag is a process-wide value read when a kernel is LAUNCHED: a hipGraph keeps the setting it was CAPTURED with, so wrapping
+    the replay of an already captured graph changes nothing -- wrap the capture (or the function that is captured)."""
 
     def __init__(self, on=True):
         self.on = int(bool(on))

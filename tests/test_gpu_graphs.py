@@ -165,3 +165,35 @@ def test_graphed_video_iterations_equal_eager(M):
         assert int(dg[ok].step_dev.item()) == int(de[ok].step_dev.item()) > 0, ok
         a, b = dg[ok].flat_param, de[ok].flat_param
         assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-12, (ok, (a - b).abs().max().item())
+
+
+def test_a_diverged_generator_shows_in_the_iteration_eager_and_graphed(M):
+    """gan_iteration runs the fused inference programs (the sampling pass G(z), the G step's value-only evaluations) in their
+    NaN-propagating form (ops.nan_propagation: read when a kernel is launched, so a captured iteration keeps it on replay): NaN
+    weights in the generator reach the critic steps' costs -- D_cost, Wasserstein_D -- as they would through the reference's ATen
+    arithmetic (R/models_Fk_GAN/model_fk_gan_train.py:305-341), in the eager iteration and in its hipGraph replay alike."""
+    from test_gpu_models import make_args
+    from dhaug_amd import autograd_ops as A
+    B, D = 256, 256
+    args = make_args(batch_size=B, Gen_DenseDim=D, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D)
+    x3 = GU.synth_pose16(B, seed=3).cuda() + torch.tensor([0.0, 0.0, 4.5], device="cuda")
+    x2 = ((torch.rand(B, 16, 2, generator=torch.Generator().manual_seed(5)) - 0.5) * 1.2).cuda()
+    cp = torch.zeros(B, 16, device="cuda")
+    cp[:, 9:13] = torch.tensor(M.cam[0], device="cuda")
+    cp[:, 13:16] = torch.tensor(M.cam[1], device="cuda")
+    for graphed in (False, True):
+        d = _build(M, args, D)
+        run = (M.graphs.GraphedGanIteration(M.train.gan_iteration, args, d, ["S1"], argparse.Namespace(epoch=10, train_iter_num=0))
+               if graphed else None)
+        call = (lambda: run(x3, cp, x2, False, M.cam)) if graphed else (
+            lambda: M.train.gan_iteration(args, d, x3, cp, x2, ["S1"], None, None, do_g_step=False, camera=M.cam))
+        if not graphed:
+            r = call()
+            assert torch.isfinite(r["D_cost_3D"]).item() and torch.isfinite(r["D_cost_2D"]).item()
+        with torch.no_grad():
+            d["model_G"].block2.fc1.weight[3, 7] = float("nan")          # a diverged generator: one NaN weight in its trunk
+        A.bump_weight_epoch()
+        for _ in range(2):                                               # (graphed: the capturing call, then a pure replay)
+            r = call()
+            assert torch.isnan(r["D_cost_3D"]).item() and torch.isnan(r["D_cost_2D"]).item(), ("graphed" if graphed else "eager")
+            assert torch.isnan(r["pos_3d_cam"]).any().item()

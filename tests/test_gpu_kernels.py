@@ -311,6 +311,15 @@ def test_critic_top_backward_equals_the_four_launches(ops, M):
     f = lambda t: t.float().cpu().double()
     e2 = (f(seed)[:, :1] * f(wout)[:, 0][None, :]) * (f(m1)[:, :n0] > 0)
     assert (f(g2)[:, :n0] - e2).abs().max().item() <= 2.0 ** -8 * max(1e-6, e2.abs().max().item())
+    # ... layer by layer from each layer's own (bf16) input: g1 = (g2 W2) relu'(mh), g0 = (g1 W1 + g2) relu'(m0), gcat = (g0 Wm) relu'(cat)
+    near = lambda got, want: (got - want).abs().max().item() <= 2.0 ** -8 * max(1e-6, want.abs().max().item())
+    e1 = (f(g2)[:, :n0] @ f(W2nn)[:, :n0].t()) * (f(mh)[:, :n0] > 0)
+    e0 = (f(g1)[:, :n0] @ f(W1nn)[:, :n0].t() + f(g2)[:, :n0]) * (f(m0)[:, :n0] > 0)
+    assert near(f(g1)[:, :n0], e1) and near(f(g0)[:, :n0], e0)
+    ecat = f(g0)[:, :n0] @ f(Wmnn)[:, :n0].t()                       # (M, 512) before the branches' sign-bit masks
+    gc = f(gcat)
+    kept = gc != 0                                                   # where the mask kept the value it must be the product's
+    assert kept.float().mean().item() > 0.2 and (gc - ecat)[kept].abs().max().item() <= 2.0 ** -8 * max(1e-6, ecat.abs().max().item())
 
 
 @pytest.mark.parametrize("M", [64, 4096, 64 * 515])
@@ -332,8 +341,15 @@ def test_critic_top_tangent_equals_the_three_launches(ops, M):
     u0, uh, u1 = ops.critic_top_tangent(ucat, m0, mh, m1, Wm, W1, W2, n0, 1, 0.0)
     for name, a, b in (("um0", u0, r0), ("umh", uh, rh), ("um1", u1, r1)):
         assert torch.equal(a, b), (name, (a.float() - b.float()).abs().max().item())
-    ref0 = (ucat.float().cpu().double() @ Wm.float().cpu().double().t())[:, :n0]
-    assert torch.isfinite(u0.float()).all() and (u0[:, :n0].float().cpu().double() - ref0 * (ref0 == ref0)).abs().max().item() < 1e9   # (shape / finiteness)
+    # and against plain fp64 arithmetic on the same operands, layer by layer from the launch's own (bf16) inputs of each layer: a layout
+    # error shared with the three launches it replaces would pass the comparison above
+    f = lambda t: t.float().cpu().double()
+    near = lambda got, want: (f(got)[:, :n0] - want).abs().max().item() <= 2.0 ** -8 * max(1e-6, want.abs().max().item())
+    e0 = (f(ucat) @ f(Wm).t())[:, :n0] * (f(m0)[:, :n0] > 0)
+    eh = (f(u0)[:, :n0] @ f(W1)[:, :n0].t()) * (f(mh)[:, :n0] > 0)
+    e1 = (f(uh)[:, :n0] @ f(W2)[:, :n0].t() + f(u0)[:, :n0]) * (f(m1)[:, :n0] > 0)
+    assert near(u0, e0) and near(uh, eh) and near(u1, e1)
+    assert u0[:, n0:].abs().max().item() == 0.0 and uh[:, n0:].abs().max().item() == 0.0 and u1[:, n0:].abs().max().item() == 0.0
 
 
 @pytest.mark.parametrize("M,n", [(1536, 4), (512, 4), (1536 + 72, 2), (200, 3)])
