@@ -2455,7 +2455,9 @@ static int gemm_bf16_impl(const uint16_t* A, int64_t lda, const uint16_t* B, int
             default: break;
         }
     }
-    if (width >= 256 && ((M + W_BM - 1) / W_BM) * ((width + W_BN - 1) / W_BN) >= 160 && K >= 64 && lda >= 64 && ldb >= 64 &&
+    // (DHAUG_GEMM_WIDE_MIN_TILES: a test switch -- the golden-vector tests reach these kernels with a few hundred rows)
+    const long long wide_min_tiles = getenv("DHAUG_GEMM_WIDE_MIN_TILES") ? atoll(getenv("DHAUG_GEMM_WIDE_MIN_TILES")) : 160;
+    if (width >= 256 && ((M + W_BM - 1) / W_BM) * ((width + W_BN - 1) / W_BN) >= wide_min_tiles && K >= 64 && lda >= 64 && ldb >= 64 &&
         getenv("DHAUG_GEMM_NOWIDE") == nullptr && getenv("DHAUG_GEMM_NOBIG") == nullptr && getenv("DHAUG_GEMM_NOPIPE") == nullptr) {
         // long batch, tiles enough for most of the card: 256 x 256 tiles, eight waves (the DenseDim-1000 layers of the frame
         // critics; the 256-wide layers of the split-operand parity arithmetic, K' = 3 K or 6 K)

@@ -176,7 +176,7 @@ int dhaug_center_flip_backward(const float* grad_out, float* grad_in, int64_t N,
  * Dense layers: bf16 MFMA GEMM with fused epilogue
  * ---------------------------------------------------------------------------------------------------- */
 
-/* C[M,N] = act( A[M,K] * B[N,K]^T + bias[N] + residual[M,N] )      (v_mfma_f32_32x32x16_bf16, fp32 acc)
+/* C[M,N] = act( A[M,K] * B[N,K]^T + bias[N] + residual[M,N] )      (v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16, fp32 acc)
  * A, B bf16 row-major, contraction dimension contiguous in both (nn.Linear weight layout [out,in]).
  * Replaces nn.Linear + ReLU/LeakyReLU + residual add of myResNet (R/models_Fk_GAN/special_operate.py:490-510)
  * and the Linear stacks of R/models_Fk_GAN/Fk_generator.py:95-103, Fk_discriminator.py:156-178,243-249.
@@ -187,7 +187,17 @@ int dhaug_center_flip_backward(const float* grad_out, float* grad_in, int64_t N,
  *   c_bf16   : optional bf16 output (M, ldc_bf16); columns [N, n_pad_zero) are written as 0 so the result
  *              can feed the next GEMM as a zero-padded operand.
  *   c_f32    : optional fp32 output (M, ldc_f32).
- * At least one output must be given. */
+ * At least one output must be given.
+ * READ EXTENT (every dhaug_gemm_bf16* entry point, dhaug_gemm_bf16_group members included): each of the M rows of A and of the N
+ * rows of B is read over EXACTLY K columns -- elements [r * ld, r * ld + K) of row r, nothing beyond them (no kernel reads past
+ * column K; the K tail of a tile is clamped or zero-sourced) -- and the rows of residual / dmask over N columns.  A caller that
+ * passes a K wider than the data of a row (a 1000-column block of a wider buffer contracted with K = 1008 against zero weight
+ * columns) must therefore own all K columns of the LAST row too, and they must hold finite values: 0 * NaN = NaN.  The Python
+ * host layer gives such buffers a guard row (critic_step._Math.empty_blocks, gen_step); tests/test_gpu_graphs.py::
+ * test_whole_iterations_read_no_unwritten_memory and tests/test_gpu_gemm_p8.py::test_p8_reads_nothing_beyond_k hold both sides.
+ * Kernels: 256-wide layers of whole 32-row tiles -> gemm_nt256s; K <= 256 -> the weight-stationary kernel; wide layers with tiles
+ * enough for the card (and grouped members of >= 1024 rows) -> the 256 x 256 x 64 ping-pong kernel (csrc/dhaug_gemm_p8.hip);
+ * otherwise 64 x 64 / 128 x 128 pipelined tiles.  All sum k ascending into one fp32 accumulator per output. */
 int dhaug_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
                     const float* bias, const uint16_t* residual, int64_t ld_res,
                     const float* residual_f32, int64_t ld_res_f32,

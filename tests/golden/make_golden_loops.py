@@ -9,8 +9,11 @@
                            flip on (R/models_Fk_GAN/video_GAN_fun.py:79-601) incl. the (-1, R, 32) view of quirk q6
   motion_step_m{3,2}_D32   one train_Fk_discriminator call on each motion critic in the mode the video loop uses for it
                            (M3: dis_mode='motion', GP over B clips; M2: default mode, GP over B*R frames -- :219-232,:341-346)
-  motion_step_m{3,2}_D1000 the same at DenseDim 1000 (the reference's default width, README video command), B = 16 clips:
+  motion_step_m{3,2}_D1000 the same at DenseDim 1000 (the reference's default width, README video command), B = 128 clips:
                            gradients and weight changes as compact records (`python make_golden_loops.py motion_step_D1000`)
+  gan_loop_D1000.npz       the single-frame loop at DenseDim 1000 (R/function_aug/config.py:101-109: the default of every
+                           *DenseDim*), B = 128: the frame critics' twenty steps and the G step at the video path's width
+                           (`python make_golden_loops.py gan_loop_D1000`); compact records
 
 Build-container only (imports /root/reference through _ref_import.py).  The reference draws its random numbers from the
 global torch / numpy generators inside the loop; the draws are RECORDED here (torch.randn / rand / randint and the FK
@@ -129,7 +132,7 @@ def scalars(writer):
     return out
 
 
-def single_frame_loop(M, D=32):
+def single_frame_loop(M, D=32, B=64):
     """D = 32: every tensor whole (gan_loop_D32).  D = 256 -- the width of the reference's README command and of the benchmark
     (gan_loop_D256): the networks have 0.44 / 0.88 / 0.27 M parameters, so weights and gradients are kept as compact records of
     their CHANGE from the seeded initial weights (golden_util.compact: strided samples + seeded +-1 projections; biases and
@@ -137,7 +140,7 @@ def single_frame_loop(M, D=32):
     train, gen, dis, fkm, h36m = M["train"], M["gen"], M["dis"], M["fkm"], M["h36m"]
     import utils.utils as ru
     import golden_util as GU
-    B, ITERS = 64, 5
+    ITERS = 5
     small = D == 32
     args = RI.make_args(batch_size=B, Gen_DenseDim=D, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D, flip_GAN_model_input=True)
     train.torch = cpu_torch_proxy()
@@ -145,7 +148,7 @@ def single_frame_loop(M, D=32):
     G = gen.Fk_Generator(fk, args, "cpu")
     D3 = dis.Fk_3D_Discriminator("cpu", args)
     D2 = dis.Fk_2D_Discriminator(args, 16)
-    seeds = dict(G=1100, D3=1200, D2=1300) if small else dict(G=1150, D3=1250, D2=1350)
+    seeds = dict(G=1100, D3=1200, D2=1300) if small else (dict(G=1150, D3=1250, D2=1350) if D == 256 else dict(G=1170, D3=1270, D2=1370))
     init = {}
     for tag, net, s in (("G", G, seeds["G"]), ("d3", D3, seeds["D3"]), ("d2", D2, seeds["D2"])):
         net.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=s))
@@ -340,7 +343,7 @@ def video_D1000(M):
 
 def motion_steps_D1000(M):
     """One train_Fk_discriminator call on each MOTION critic at the width of the reference's README video command (DenseDim 1000:
-    R/function_aug/config.py:101-109, 25.5 M / 12.5 M parameters), R = 9, B = 16 clips, in the mode the video loop uses for it
+    R/function_aug/config.py:101-109, 25.5 M / 12.5 M parameters), R = 9, B = 128 clips (round 6; 16 before: too few rows for an element-wise bf16 comparison), in the mode the video loop uses for it
     (M3: dis_mode='motion', penalty over B clips; M2: default mode, penalty over B*R frames): the training kernels of the video
     path (1000-wide NT layers, wide grouped contractions, adam_nt) are pinned to the reference above DenseDim 32.  Gradients and
     the weights' CHANGE are kept as compact records (golden_util.compact)."""
@@ -348,7 +351,7 @@ def motion_steps_D1000(M):
     train, dis = M["train"], M["dis"]
     import utils.utils as ru
     train.torch = cpu_torch_proxy()
-    B, R, D = 16, 9, 1000
+    B, R, D = 128, 9, 1000
     args = RI.make_args(batch_size=B, video_Dis_DenseDim_3D=D, video_Dis_DenseDim_2D=D, single_or_multi_train_mode="multi",
                         architecture="3,3", random_seed=7)
     summary = ru.Summary("/tmp/dhaug_ref_summary")
@@ -391,6 +394,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "gan_loop_D256":
         torch.set_num_threads(8)
         single_frame_loop(M, 256)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "gan_loop_D1000":
+        torch.set_num_threads(8)
+        single_frame_loop(M, 1000, B=128)
         return
     single_frame_loop(M)
     video_loop(M)

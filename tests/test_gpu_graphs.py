@@ -197,3 +197,68 @@ def test_a_diverged_generator_shows_in_the_iteration_eager_and_graphed(M):
             r = call()
             assert torch.isnan(r["D_cost_3D"]).item() and torch.isnan(r["D_cost_2D"]).item(), ("graphed" if graphed else "eager")
             assert torch.isnan(r["pos_3d_cam"]).any().item()
+
+
+@pytest.mark.parametrize("D,B,graphed", [(256, 2048, False), (256, 2048, True), (1000, 160, False)])
+def test_whole_iterations_read_no_unwritten_memory(M, D, B, graphed, monkeypatch):
+    """Five whole single-frame iterations -- sampling pass, four critic steps each, the explicit G step on the fifth (gen_step.py: trunk
+    with saved activations, FK tail, camera, both critics' chains, the flipped value-only evaluations through the fused inference
+    programs, the grouped weight gradients) -- with EVERY torch.empty / empty_like buffer pre-filled with NaN, then with 3e38: the same
+    critics (bit for bit after the first iteration; the later ones and the G step within what its atomically summed short contractions
+    allow) as with fresh memory, eager and as hipGraphs, at DenseDim 256 (fused programs) and at DenseDim 1000 (layer GEMMs incl. the
+    ping-pong kernel, whose 1000-wide column blocks are read 1008 wide: the guard rows of critic_step / gen_step).  An operand row,
+    pad column or guard row that nobody wrote would show as NaN / as a huge value.  (tests/test_gpu_critic_step.py holds single critic
+    steps to the same probe; tools/poison.py is the development form.)"""
+    from test_gpu_models import make_args
+    if D == 1000:
+        monkeypatch.setenv("DHAUG_GEMM_WIDE_MIN_TILES", "1")
+    args = make_args(batch_size=B, Gen_DenseDim=D, Dis_DenseDim_3D=D, Dis_DenseDim_2D=D)
+    x3 = GU.synth_pose16(B, seed=3).cuda() + torch.tensor([0.0, 0.0, 4.5], device="cuda")
+    x2 = ((torch.rand(B, 16, 2, generator=torch.Generator().manual_seed(5)) - 0.5) * 1.2).cuda()
+    cp = torch.zeros(B, 16, device="cuda")
+    cp[:, 9:13] = torch.tensor(M.cam[0], device="cuda")
+    cp[:, 13:16] = torch.tensor(M.cam[1], device="cuda")
+    mk = lambda: M.train.ConstDraws(noise=[torch.randn(B, 128, generator=torch.Generator().manual_seed(1)).cuda()],
+                                    scaler=[(torch.randint(-200, 200, (B, 8), generator=torch.Generator().manual_seed(2)) / 1000.0).cuda()],
+                                    alpha=[torch.rand(B, 1, generator=torch.Generator().manual_seed(3)).cuda()])
+
+    def run():
+        d, dr = _build(M, args, D), mk()
+        it = (M.graphs.GraphedGanIteration(M.train.gan_iteration, args, d, ["S1"], None) if graphed else None)
+        first, res = None, None
+        for i in range(5):
+            if graphed:
+                res = it(x3, cp, x2, i == 4, M.cam, draws=dr)
+            else:
+                res = M.train.gan_iteration(args, d, x3, cp, x2, ["S1"], None, None, do_g_step=(i == 4), camera=M.cam, draws=dr)
+            if i == 0:
+                first = {ok: d[ok].flat_param.clone() for ok in ("optimizer_d3d", "optimizer_d2d")}
+        torch.cuda.synchronize()
+        return first, {ok: d[ok].flat_param.clone() for ok in ("optimizer_d3d", "optimizer_d2d", "optimizer_G")}, \
+            {k: (v.item() if torch.is_tensor(v) and v.numel() == 1 else None) for k, v in res.items()}
+    ref_first, ref_last, ref_s = run()
+    real_empty, real_empty_like = torch.empty, torch.empty_like
+    for poison in (float("nan"), 3.0e38):
+        def fill(t):
+            if t.is_cuda and t.numel():
+                if t.dtype.is_floating_point:
+                    t.fill_(poison)
+                else:
+                    t.view(torch.uint8).fill_(255)
+            return t
+        monkeypatch.setattr(torch, "empty", lambda *a, **k: fill(real_empty(*a, **k)))
+        monkeypatch.setattr(torch, "empty_like", lambda *a, **k: fill(real_empty_like(*a, **k)))
+        try:
+            first, last, s = run()
+        finally:
+            monkeypatch.setattr(torch, "empty", real_empty)
+            monkeypatch.setattr(torch, "empty_like", real_empty_like)
+        for ok in ref_first:                                     # two steps of each critic: deterministic kernels, the same bits
+            assert torch.equal(first[ok], ref_first[ok]), (ok, poison, (first[ok] - ref_first[ok]).abs().max().item())
+        for ok, steps in (("optimizer_d3d", 10), ("optimizer_d2d", 10), ("optimizer_G", 1)):
+            assert torch.isfinite(last[ok]).all(), (ok, poison)
+            # (later iterations: one last-bit difference of an atomically summed gradient becomes a +-lr step of that weight)
+            assert (last[ok] - ref_last[ok]).abs().max().item() <= 2.05e-4 * steps, (ok, poison, (last[ok] - ref_last[ok]).abs().max().item())
+        for k, v in ref_s.items():
+            if v is not None:
+                assert s[k] is not None and abs(s[k] - v) <= 1e-3 * max(1.0, abs(v)), (k, poison, s[k], v)

@@ -141,16 +141,22 @@ def _run_single_loop(M, g, D, precision):
 
 
 @pytest.mark.parametrize("precision", ["bf16x6", "bf16"])
-def test_single_frame_loop_vs_reference_at_dense_dim_256(M, golden, precision):
-    """The reference's own five-iteration loop at the width of its README command and of the benchmark (gan_loop_D256).  At
+@pytest.mark.parametrize("D", [256, 1000])
+def test_single_frame_loop_vs_reference_at_dense_dim_256(M, golden, precision, D, monkeypatch):
+    """(D = 1000: the same loop at the reference's DEFAULT width, R/function_aug/config.py:101-109 -- gan_loop_D1000, B = 128: the frame
+    critics' twenty steps and the G step through the video path's DenseDim-1000 training kernels: the 256 x 256-tile ping-pong NT
+    kernel (DHAUG_GEMM_WIDE_MIN_TILES=1 lets the test's 384 rows reach it), the wide grouped weight-gradient contractions, adam_nt,
+    the explicit G step at that width.)
+    The reference's own five-iteration loop at the width of its README command and of the benchmark (gan_loop_D256).  At
     DenseDim 256 the iteration runs the kernels the timed training step runs -- the fused forward-with-save programs, the
     two-layer block kernel, the sign-bit masks, the grouped weight gradients, the explicit G step -- which the DenseDim-32
     loop never enters.
       bf16x6 (fp32-grade, layer by layer): pairs, scalars, G-step gradients and all weights at the DenseDim-32 tolerances;
       bf16 (the TIMED arithmetic): the pairs of the first iterations are the bf16 generator's (no golden tolerance), the
       scalars of all twenty critic steps within 5e-2, the G-step gradients and the weight changes by direction and size."""
-    g = golden("gan_loop_D256")
-    D = 256
+    g = golden("gan_loop_D%d" % D)
+    if D == 1000:
+        monkeypatch.setenv("DHAUG_GEMM_WIDE_MIN_TILES", "1")
     d, w, p3, p2, r = _run_single_loop(M, g, D, precision)
     ref = LU.scalar_series(g)
     assert set(ref) == set(w.s)
@@ -159,7 +165,7 @@ def test_single_frame_loop_vs_reference_at_dense_dim_256(M, golden, precision):
         # pairs: the generator's 256-wide trunk in six bf16 terms per product is ~1e-6 in the head; the root is 10 tanh(head) and
         # the projection divides by the camera depth, so the pairs are held to 1e-4 m / 3e-4 (measured: see the print)
         e3, e2 = maxabs(torch.cat(p3), g["buf_p3"]), maxabs(torch.cat(p2), g["buf_p2"])
-        print("bf16x6 loop at D = 256: pairs differ by %.2e m (3D) / %.2e (2D)" % (e3, e2))
+        print("bf16x6 loop at D = %d: pairs differ by %.2e m (3D) / %.2e (2D)" % (D, e3, e2))
         assert e3 <= 1e-4 and e2 <= 3e-4, (e3, e2)
         scalars_close(w, g, 2e-4)
         worst = 0.0
@@ -170,7 +176,7 @@ def test_single_frame_loop_vs_reference_at_dense_dim_256(M, golden, precision):
             worst = max(worst, (got[kk].double() - rec[kk].double()).abs().max().item() / rec[kk].abs().max().item())
         # (the critics the G step differentiates through have taken 9 - 10 Adam steps of lr * g / (|g| + eps): the elements whose
         # gradient is within rounding of zero have stepped +-lr either way, and the G-step gradient sees those critics)
-        print("bf16x6 loop at D = 256: worst G-step gradient element error %.2e of its tensor's scale" % worst)
+        print("bf16x6 loop at D = %d: worst G-step gradient element error %.2e of its tensor's scale" % (D, worst))
         for i, (k, p) in enumerate(d["model_G"].named_parameters()):
             GU.compact_close(p.grad.detach().float().cpu(), LU.compact_record(g, "gstep_grad__", k), 100 + i, 1e-7, 1.5e-2, k)
         for key, prefix, steps in (("model_d3d", "final_d3__", 10), ("model_d2d", "final_d2__", 10), ("model_G", "final_G__", 1)):
@@ -215,7 +221,7 @@ def test_single_frame_loop_vs_reference_at_dense_dim_256(M, golden, precision):
             agree += int((torch.sign(got[big]) == torch.sign(rec[kk].double()[big])).sum())
             total += int(big.sum())
         assert total > 1000 and agree >= 0.97 * total, (key, agree, total)
-    print("bf16 loop at D = 256: worst G-step gradient cosine %.4f" % worst)
+    print("bf16 loop at D = %d: worst G-step gradient cosine %.4f" % (D, worst))
 
 
 def test_video_loop_vs_reference(M, golden):
@@ -284,15 +290,16 @@ def test_motion_critic_step_vs_reference(M, golden, tag):
 @pytest.mark.parametrize("tag", ["m3", "m2"])
 def test_motion_critic_step_vs_reference_at_dense_dim_1000(M, golden, tag):
     """The video path's TRAINING kernels at the width of the reference's README video command (DenseDim 1000: the 1000-wide NT
-    layers, the wide grouped weight-gradient contractions, adam_nt) against the reference's own train_Fk_discriminator on B = 16
+    layers, the wide grouped weight-gradient contractions, adam_nt) against the reference's own train_Fk_discriminator on B = 128
     clips (tests/golden/make_golden_loops.py motion_step_D1000; compact records): (1) in the fp32-grade arithmetic at the golden
     tolerances of the DenseDim-32 / 256 step tests; (2) in the TIMED bf16 arithmetic element-wise against the oracle's bf16
-    emulation (<= 2e-2 of every weight gradient's scale, biases 4e-2, but for <= 1e-3 of a tensor's elements: mask flips at B = 16), whose fp32 form test_oracle_loops.py holds to the same
+    emulation (<= 2e-2 of EVERY element of a weight gradient's scale, biases 4e-2), whose fp32 form test_oracle_loops.py holds to the same
     fixture on CPU."""
     from dhaug_amd.models_Fk_GAN import Fk_discriminator as dis
     from oracle import dhaug_oracle as O
     g = golden("motion_step_%s_D1000" % tag)
-    B, R, D = 16, 9, 1000
+    B, R, D = 128, 9, 1000
+    assert g["real"].shape[0] == B * R
     args = _args(batch_size=B, single_or_multi_train_mode="multi", architecture="3,3", video_Dis_DenseDim_3D=D, video_Dis_DenseDim_2D=D)
     cls = dis.Video_motion_Fk_3D_Discriminator if tag == "m3" else dis.Video_motion_Fk_2D_Discriminator
     sd = GU.seeded_state_dict(LU.motion_shapes(D, R)[0 if tag == "m3" else 1], int(g["weight_seed"]))
@@ -330,11 +337,10 @@ def test_motion_critic_step_vs_reference_at_dense_dim_1000(M, golden, tag):
     (lf_ - lr_ + gp).backward()
     print("bf16 %s step: W %.6g / oracle %.6g, D_cost %.6g / oracle %.6g (gp %.6g)" % (tag, Wb, (lr_ - lf_).item(), Cb, (lf_ - lr_ + gp).item(), gp.item()))
     assert abs(Wb - (lr_ - lf_).item()) <= 3e-3 * max(1.0, abs(Wb)) and abs(Cb - (lf_ - lr_ + gp).item()) <= 2e-2 * max(1.0, abs(Cb))
-    # Element-wise bound of the DenseDim-256 step (2e-2 of a weight gradient's scale, 4e-2 for biases) for all but a handful of
-    # elements: with 2 B = 32 real / fake rows and B = 16 interpolated ones a unit whose pre-activation sits within bf16 rounding of
-    # zero has its mask on one side in the kernels and on the other in the emulation, and ONE flipped (row, unit) moves that unit's
-    # gradient row by up to 1 / 16 of its size (measured: 6.5e-2 on diff_pos_3d_block1.fc2.weight, 8.6e-2 on a bias) -- so three units'
-    # worth of a tensor's elements (3 / rows, at least 1e-3) may exceed the bound, and none 2e-1.
+    # Element-wise bound of the DenseDim-256 step: 2e-2 of a weight gradient's scale, 4e-2 for biases -- for EVERY element.  (Round 5's
+    # fixture had B = 16 clips: one unit whose pre-activation sat within bf16 rounding of zero, masked on one side in the kernels and
+    # on the other in the emulation, moved its gradient row by up to 1 / 16, and the test allowed three such units per tensor up to
+    # 2e-1.  At B = 128 a flipped (row, unit) weighs 1 / 128: the allowance is gone.)
     worst = {1: 0.0, 2: 0.0}
     for k, r in net.grads().items():
         scale = r.abs().max().item()
@@ -344,10 +350,7 @@ def test_motion_critic_step_vs_reference_at_dense_dim_1000(M, golden, tag):
         err = (gb[k].double() - r.double()).abs() / scale
         e = err.max().item()
         worst[r.dim()] = max(worst[r.dim()], e)
-        bound = 2e-2 if r.dim() == 2 else 4e-2
-        # (a flipped unit moves ONE row of its layer's weight gradient and one bias element: three units' worth may be over the bound)
-        allowed = max(1e-3, 3.0 / r.shape[0])
-        assert (err > bound).double().mean().item() <= allowed and e <= 2e-1, (k, e, scale, (err > bound).double().mean().item())
+        assert e <= (2e-2 if r.dim() == 2 else 4e-2), (k, e, scale, (err > 2e-2).double().mean().item())
     print("bf16 %s step at DenseDim 1000 vs bf16-emulated oracle: worst element error %.2e (weights) / %.2e (biases) of scale"
           % (tag, worst[2], worst[1]))
 

@@ -34,11 +34,12 @@ def test_single_frame_loop_golden(golden):
             assert maxabs(net.state()[k], g[tag + k]) <= 5e-6, (tag, k)
 
 
-def test_single_frame_loop_golden_at_dense_dim_256(golden):
+@pytest.mark.parametrize("D", [256, 1000])
+def test_single_frame_loop_golden_at_dense_dim_256(golden, D):
     """the same loop at the width of the reference's README command and of the benchmark (gan_loop_D256: weights and gradients
-    as compact records -- strided samples + seeded +-1 projections -- of their change from the seeded initial weights)"""
-    g = golden("gan_loop_D256")
-    D = 256
+    as compact records -- strided samples + seeded +-1 projections -- of their change from the seeded initial weights), and at the
+    reference's DEFAULT width (gan_loop_D1000, B = 128: R/function_aug/config.py:101-109)"""
+    g = golden("gan_loop_D%d" % D)
     r = LU.replay_single_oracle(g, D)
     assert maxabs(r["buf_p3"], g["buf_p3"]) <= 5e-6 and maxabs(r["buf_p2"], g["buf_p2"]) <= 5e-6
     for name, ref in LU.scalar_series(g).items():
@@ -49,7 +50,10 @@ def test_single_frame_loop_golden_at_dense_dim_256(golden):
     names = {t: list(init[t]) for t in init}
     for i, k in enumerate(names["G"]):
         ref = LU.compact_record(g, "gstep_grad__", k)
-        GU.compact_close(r["g_grads"][k], ref, 100 + i, 1e-7, 5e-4, "gstep_grad " + k)
+        # (D = 1000: measured 1.2e-3 of the tensor's scale at worst -- the critics the G step differentiates through have taken ten
+        # sign-like Adam steps, and with 12 M parameters more elements sit within rounding of a zero gradient; pairs, scalars and
+        # the critics' weights agree as at D = 256)
+        GU.compact_close(r["g_grads"][k], ref, 100 + i, 1e-7, 5e-4 if D == 256 else 2.5e-3, "gstep_grad " + k)
     # weights: the CHANGE over the loop (10 Adam steps of 1e-4 for the critics, 1 for the generator); an element whose gradient
     # is within rounding of zero may step the other way (lr * g / (|g| + eps)), hence the hard bound of (steps x lr)
     for tag, net, prefix, steps in (("G", r["G"], "final_G__", 1), ("d3", r["D3"], "final_d3__", 10), ("d2", r["D2"], "final_d2__", 10)):
@@ -105,10 +109,10 @@ def test_motion_critic_step_golden(golden, tag):
 
 @pytest.mark.parametrize("tag", ["m3", "m2"])
 def test_motion_critic_step_golden_at_dense_dim_1000(golden, tag):
-    """the same at the reference's DEFAULT width (DenseDim 1000, README video command; 25.5 M / 12.5 M parameters, B = 16 clips):
+    """the same at the reference's DEFAULT width (DenseDim 1000, README video command; 25.5 M / 12.5 M parameters, B = 128 clips):
     scalars, every gradient (compact records: strided samples + seeded +-1 projections) and the Adam update"""
     g = golden("motion_step_%s_D1000" % tag)
-    B, R, D = 16, 9, 1000
+    B, R, D = 128, 9, 1000
     shapes = LU.motion_shapes(D, R)[0 if tag == "m3" else 1]
     sd = GU.seeded_state_dict(shapes, int(g["weight_seed"]))
     fwd = (lambda x, p: O.motion_d3_forward(x, p, R)) if tag == "m3" else (lambda x, p: O.motion_d2_forward(x, p, R))
