@@ -67,6 +67,12 @@ __device__ __forceinline__ uint16_t dhaug_f32_to_bf16(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(uint16_t, b);
 }
+// clamp to [-1, 1] as torch.clamp does it (R/common/camera.py:62-94 project_to_2d): a NaN stays a NaN -- fminf / fmaxf return the
+// other operand.  The test reads the bit pattern, so it also holds in the translation units built with -ffinite-math-only.
+__host__ __device__ __forceinline__ float dhaug_clamp_pm1(float x) {
+    const float c = fminf(fmaxf(x, -1.0f), 1.0f);
+    return (__builtin_bit_cast(uint32_t, x) & 0x7fffffffu) > 0x7f800000u ? x : c;
+}
 __device__ __forceinline__ float dhaug_bf16_to_f32(uint16_t h) {
     return __builtin_bit_cast(float, (uint32_t)h << 16);
 }

@@ -398,7 +398,7 @@ __device__ __forceinline__ float pack2(float a, float b) {                      
 // divisions taken through one corrected reciprocal
 __device__ __forceinline__ void project_nr(V3 xc, const float* __restrict__ c, float& ox, float& oy) {
     const float rz = rcp_nr(xc.z);
-    const float u = fminf(fmaxf(div_nr(xc.x, rz, xc.z), -1.0f), 1.0f), v = fminf(fmaxf(div_nr(xc.y, rz, xc.z), -1.0f), 1.0f);
+    const float u = dhaug_clamp_pm1(div_nr(xc.x, rz, xc.z)), v = dhaug_clamp_pm1(div_nr(xc.y, rz, xc.z));
     const float r2 = u * u + v * v;
     const float radial = 1.0f + (c[4] * r2 + c[5] * (r2 * r2) + c[6] * (r2 * r2 * r2));
     const float tan = c[7] * u + c[8] * v;

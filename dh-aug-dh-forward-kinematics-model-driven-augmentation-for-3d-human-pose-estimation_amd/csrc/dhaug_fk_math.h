@@ -171,7 +171,7 @@ DHAUG_HD void w2c_project(V3 xw, const float* __restrict__ q, const float* __res
     const V3 uv = cross(qv, x);
     const V3 uuv = cross(qv, uv);
     const V3 xc = x + 2.0f * (q[0] * uv + uuv);
-    const float u = fminf(fmaxf(xc.x / xc.z, -1.0f), 1.0f), v = fminf(fmaxf(xc.y / xc.z, -1.0f), 1.0f);
+    const float u = dhaug_clamp_pm1(xc.x / xc.z), v = dhaug_clamp_pm1(xc.y / xc.z);
     const float r2 = u * u + v * v;
     const float radial = 1.0f + (c[4] * r2 + c[5] * (r2 * r2) + c[6] * (r2 * r2 * r2));
     const float tan = c[7] * u + c[8] * v;

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void w2c_project_kernel(const float* __restric
         V3 xc = qrot(cam.q[0], mk(-cam.q[1], -cam.q[2], -cam.q[3]), x);      // qinverse: conjugate
         if (cam3d) { cam3d[3 * i] = xc.x; cam3d[3 * i + 1] = xc.y; cam3d[3 * i + 2] = xc.z; }
         if (proj2d) {                                                        // R/common/camera.py:82-94
-            float u = fminf(fmaxf(xc.x / xc.z, -1.0f), 1.0f), v = fminf(fmaxf(xc.y / xc.z, -1.0f), 1.0f);
+            float u = dhaug_clamp_pm1(xc.x / xc.z), v = dhaug_clamp_pm1(xc.y / xc.z);
             float r2 = u * u + v * v;
             float radial = 1.0f + (cam.c[4] * r2 + cam.c[5] * (r2 * r2) + cam.c[6] * (r2 * r2 * r2));
             float tan = cam.c[7] * u + cam.c[8] * v;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void w2c_project_bwd_kernel(const float* __res
         if (g2) {
             const float gx = g2[2 * i] * cam.c[0], gy = g2[2 * i + 1] * cam.c[1];
             const float ur = xc.x / xc.z, vr = xc.y / xc.z;
-            const float u = fminf(fmaxf(ur, -1.0f), 1.0f), v = fminf(fmaxf(vr, -1.0f), 1.0f);
+            const float u = dhaug_clamp_pm1(ur), v = dhaug_clamp_pm1(vr);
             const float r2 = u * u + v * v;
             const float k1 = cam.c[4], k2 = cam.c[5], k3 = cam.c[6], p1 = cam.c[7], p2 = cam.c[8];
             const float s = 1.0f + (k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2) + (p1 * u + p2 * v);
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void project_batch_kernel(const float* __restr
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < njoints; i += (long long)gridDim.x * 256) {
         const float* c = cam9 + (i >> 4) * 9;
         const float x = cam3d[3 * i], y = cam3d[3 * i + 1], z = cam3d[3 * i + 2];
-        const float u = fminf(fmaxf(x / z, -1.0f), 1.0f), v = fminf(fmaxf(y / z, -1.0f), 1.0f);
+        const float u = dhaug_clamp_pm1(x / z), v = dhaug_clamp_pm1(y / z);
         const float r2 = u * u + v * v;
         const float radial = 1.0f + (c[4] * r2 + c[5] * (r2 * r2) + c[6] * (r2 * r2 * r2));
         const float tan = c[7] * u + c[8] * v;

@@ -92,3 +92,24 @@ def compact_close(t, ref, seed, atol, rtol, name=""):
     assert (got["sample"].double() - ref["sample"].double()).abs().max().item() <= atol + rtol * scale, name
     n = t.numel()
     assert (got["proj"] - ref["proj"].double()).abs().max().item() <= 4.0 * (atol + rtol * scale) * n ** 0.5, name
+
+
+def compact_close_but_flips(t, ref, seed, atol, rtol, name="", max_flips=4, flip_rtol=0.15):
+    """compact_close for gradients of LONG batches at fp32-grade arithmetic: every recorded element within atol + rtol * max|ref|, EXCEPT
+    at most max_flips elements, which may be off by up to flip_rtol * max|ref| -- the units whose pre-activation lies within fp32
+    rounding of zero somewhere in the batch: their ReLU mask falls on the other side than in the reference's run, and ONE flipped
+    (row, unit) moves that unit's bias-gradient element by the row's whole cotangent (measured at B = 128 clips, DenseDim 1000: three
+    such elements in the 3D motion critic, 6e-5 on gradients of scale 1e-3; with ~1e7 pre-activations per step a handful of them within
+    1e-7 of zero is what a normal distribution gives).  The projections keep compact_close's bound (a few flipped elements vanish in a
+    sum over the whole tensor)."""
+    got = compact(t, seed)
+    key = "full" if "full" in ref else "sample"
+    scale = ref[key].abs().max().item()
+    err = (got[key].double() - ref[key].double()).abs()
+    over = err > atol + rtol * scale
+    assert int(over.sum()) <= max_flips, (name, int(over.sum()), err.max().item(), scale)
+    assert err.max().item() <= atol + flip_rtol * scale, (name, err.max().item(), scale)
+    if "proj" in ref:
+        n = t.numel()
+        assert (got["proj"] - ref["proj"].double()).abs().max().item() <= 4.0 * (atol + rtol * scale) * n ** 0.5 + max_flips * flip_rtol * scale, name
+    return int(over.sum())
