@@ -2555,7 +2555,8 @@ int dhaug_gemm_bf16_group(const dhaug_gemm_desc* d, int n, void* stream) {
     // long members of wide layers: 256 x 256 ping-pong tiles (dhaug_gemm_p8.hip) -- fewer workgroups at a higher rate each, which leaves
     // CUs to the other critics' streams (DHAUG_NT_GROUP_P8_ROWS: the shortest member that takes them; 0 = never)
     const long long p8_rows = getenv("DHAUG_NT_GROUP_P8_ROWS") ? atoll(getenv("DHAUG_NT_GROUP_P8_ROWS")) : 1024;
-    if (p8_rows > 0 && p.M >= p8_rows && p.W >= 512) {
+    const long long p8_tiles = getenv("DHAUG_NT_GROUP_P8_TILES") ? atoll(getenv("DHAUG_NT_GROUP_P8_TILES")) : 96;
+    if (p8_rows > 0 && p.M >= p8_rows && p.W >= 512 && n * ((p.M + 255) / 256) * ((p.W + 255) / 256) >= p8_tiles) {
         bool ok = true;
         for (int i = 0; i < n; ++i) ok = ok && dhaug_p8_supported(ga.g[i]);
         if (ok) return dhaug_p8_launch_group((hipStream_t)stream, ga, n);

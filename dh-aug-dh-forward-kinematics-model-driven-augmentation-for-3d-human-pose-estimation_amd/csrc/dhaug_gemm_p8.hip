@@ -412,24 +412,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(GemmArgs p) {
     p8_body(p, mb, nb);
 }
 
-// the grouped form (members of one shape; with 2, 4 or 8 members each member gets XCDs of its own: see gemm_nt_pipe2_group_kernel)
+// The grouped form (members of one shape).  With 2, 4 or 8 members each member gets 8 / n XCDs of its own (an XCD's L2 then holds ONE
+// member's weights: see gemm_nt_pipe2_group_kernel), and inside a member the column tiles of one row block stay on ONE of those XCDs:
+// XCD j of the member takes row blocks j, j + per, ... with their column tiles one after the other.  (Dealt tile by tile over the
+// member's XCDs, as the first version did, the four column tiles of a row block sat on four XCDs and each fetched the block's activation
+// rows from beyond L2 for itself: 98 MB counted per launch of the video iteration's groups against 20 - 60 MB of operands.)
 __global__ __launch_bounds__(512, 2) void gemm_nt_p8_group_kernel(GemmGroupArgs grp, int n, int tiles) {
     (void)grp;
-    int member;
-    long long tile;
+    GemmArgs p;
     if (n == 2 || n == 4 || n == 8) {
         const int per = 8 / n, xcd = blockIdx.x & 7;
-        member = xcd / per;
-        tile = (long long)(blockIdx.x >> 3) * per + (xcd % per);
+        const int member = xcd / per;
+        load_group_member(p, member);
+        const long long ntn = (p.W + P_BN - 1) / P_BN, q = blockIdx.x >> 3;
+        const long long mb = (q / ntn) * per + (xcd % per), nb = q % ntn;
+        if (mb * P_BM >= p.M) return;
+        p8_body(p, mb, nb);
     } else {
-        member = blockIdx.x / tiles;
-        tile = blockIdx.x - (long long)member * tiles;
+        const int member = blockIdx.x / tiles;
+        const long long tile = blockIdx.x - (long long)member * tiles;
+        if (member >= n) return;
+        load_group_member(p, member);
+        const long long ntn = (p.W + P_BN - 1) / P_BN;
+        p8_body(p, tile / ntn, tile % ntn);
     }
-    if (tile >= tiles || member >= n) return;
-    GemmArgs p;
-    load_group_member(p, member);
-    const long long ntn = (p.W + P_BN - 1) / P_BN;
-    p8_body(p, tile / ntn, tile % ntn);
 }
 
 template <typename Kern>
@@ -485,7 +491,10 @@ int dhaug_p8_launch_group(hipStream_t s, const dhaug_gemm::GemmGroupArgs& g, int
     const dhaug_gemm::GemmArgs& p = g.g[0];
     const long long tiles = ((p.M + P_BM - 1) / P_BM) * ((p.W + P_BN - 1) / P_BN);
     long long grid = tiles * n;
-    if (n == 2 || n == 4 || n == 8) grid = (tiles + 8 / n - 1) / (8 / n) * 8;
+    if (n == 2 || n == 4 || n == 8) {
+        const long long per = 8 / n, mblocks = (p.M + P_BM - 1) / P_BM, ntn = (p.W + P_BN - 1) / P_BN;
+        grid = ((mblocks + per - 1) / per) * ntn * 8;                 // (row blocks of a member dealt over its XCDs: see the kernel)
+    }
     DHAUG_CHECK(grid <= 0x7fffffffLL && tiles <= 0x7fffffffLL, DHAUG_EUNSUPPORTED);
     hipLaunchKernelGGL(gemm_nt_p8_group_kernel, dim3((unsigned)grid), dim3(512), P_LDS, s, g, n, (int)tiles);
     return dhaug_launch_status();
