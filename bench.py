@@ -617,15 +617,18 @@ def main():
                 extra["fwd_D1000_note"] = ("G trunk + D3 + D2, DenseDim 1000, bf16, layer GEMMs (256 x 256 x 64 ping-pong kernel, "
                                            "csrc/dhaug_gemm_p8.hip: a 1000-wide layer has 500 flop per activation byte -- matrix-bound "
                                            "layer by layer, no cross-layer fusion needed), eager")
-                # the same pass in the arithmetic that meets the 1e-4 logit tolerance at this width (bf16x6: six bf16 product terms per
-                # product, fp32 activations, layer by layer -- tests/test_gpu_models.py video_D1000)
-                for m_ in (g1k, d31k, d21k):
-                    m_.precision = "bf16x6"
-                t1p, _ = timed(fwd1k, 3, 1)
-                extra["fwd_D1000_parity_ms_per_step"] = t1p / 3 * 1e3
-                extra["fwd_D1000_parity_poses_per_s"] = B * 3 / t1p
-                extra["fwd_D1000_parity_frac_of_mfma_peak_algorithmic"] = 2.0 * (mg + m3_ + m2_) * B * 3 / t1p / 2.5e15
-                extra["fwd_D1000_parity_note"] = "bf16x6 (K' = 6 K split operands, fp32 activations): logits <= 1e-4 rel at DenseDim 1000"
+                # the same pass in the arithmetics that meet the 1e-4 logit tolerance at this width (tests/test_gpu_loops.py video_D1000):
+                # "f16x3" = IEEE-half pairs, three product terms, as layer GEMMs on the ping-pong tiles (dhaug_gemm_f16x3; the fused parity
+                # programs' arithmetic, which stop at DenseDim 256), and "bf16x6" (six bf16 product terms; the training paths' parity mode)
+                for prec_, key_ in (("f16x3", "fwd_D1000_parity"), ("bf16x6", "fwd_D1000_bf16x6")):
+                    for m_ in (g1k, d31k, d21k):
+                        m_.precision = prec_
+                    t1p, _ = timed(fwd1k, 3, 1)
+                    extra[key_ + "_ms_per_step"] = t1p / 3 * 1e3
+                    extra[key_ + "_poses_per_s"] = B * 3 / t1p
+                    extra[key_ + "_frac_of_mfma_peak_algorithmic"] = 2.0 * (mg + m3_ + m2_) * B * 3 / t1p / 2.5e15
+                extra["fwd_D1000_parity_note"] = ("f16x3 layer GEMMs (fp16 hi + lo operands, K' = 3 K, fp32 activations; narrow layers in bf16x6): "
+                                                  "logits <= 1e-4 rel at DenseDim 1000; algorithmic flops -- the kernels execute 3x")
                 del m1k, g1k, d31k, d21k
             except Exception as ex:
                 extra["fwd_D1000_error"] = repr(ex)[:200]

@@ -27,6 +27,7 @@ from . import ops
 BF16 = torch.bfloat16
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 TERMS = {"bf16x3": 3, "bf16x6": 6}
+F16X3_LAYER = "f16x3l"     # forward-only layer arithmetic: IEEE-half pairs on dhaug_gemm_f16x3 (see _raw_linear)
 # (activation-side segment, weight-side segment) holding (hi, mid|lo ...) for the TN products
 _SEG = {3: dict(hi=0, lo=2), 6: dict(hi=0, mid=2, lo=5)}
 _PAIRS = {3: (("hi", "hi"), ("hi", "lo"), ("lo", "hi")),
@@ -105,7 +106,10 @@ def _w_nt(W, Kp, prec):
     key = (Kp, prec)
     if key not in d:
         Wd = W.detach()
-        d[key] = ops.cast_pad_bf16(Wd, Kp) if prec == "bf16" else ops.split_bf16(Wd, 1, TERMS[prec], Kp)
+        if prec == F16X3_LAYER:
+            d[key] = ops.split_f16(Wd, 1, Kp)
+        else:
+            d[key] = ops.cast_pad_bf16(Wd, Kp) if prec == "bf16" else ops.split_bf16(Wd, 1, TERMS[prec], Kp)
     return d[key]
 
 
@@ -149,6 +153,15 @@ def _raw_linear(x, W, bias, res, act, slope, prec, out_f32):
         cb, cf = ops.gemm_nt(xb, _w_nt(W, Kp, prec), N, Kp, bias=bias, res_bf16=rb, res_f32=rf, act=act, slope=slope,
                              out_bf16=not out_f32, n_pad=ceil16(N), out_f32=out_f32)
         return cf if out_f32 else cb
+    if prec == F16X3_LAYER:
+        # the fused parity programs' arithmetic (IEEE-half pairs, three product terms) as a layer GEMM on the ping-pong tiles: forward
+        # passes without a graph at widths the fused programs do not cover (DenseDim 1000); a layer whose shape the kernel does not take
+        # (the 100-wide merge block, the 1-wide logit layer, K < 48) runs in "bf16x6" -- fp32-grade either way
+        xf = x.float() if x.dtype == BF16 else x
+        rf = res if (res is None or (res.dtype == torch.float32 and res.stride(-1) == 1)) else res.float().contiguous()
+        if ops.gemm_f16x3_ok(N, 3 * Kp, bias, rf) and xf.dim() == 2 and xf.stride(1) == 1:
+            return ops.gemm_nt_f16x3(ops.split_f16(xf, 0, Kp), _w_nt(W, Kp, prec), N, 3 * Kp, bias=bias, res_f32=rf, act=act, slope=slope)
+        prec = "bf16x6"
     T = TERMS[prec]
     x3 = ops.split_bf16(x.float() if x.dtype == BF16 else x, 0, T, Kp)
     _, cf = ops.gemm_nt(x3, _w_nt(W, Kp, prec), N, T * Kp, bias=bias, res_f32=res, act=act, slope=slope, out_f32=True)

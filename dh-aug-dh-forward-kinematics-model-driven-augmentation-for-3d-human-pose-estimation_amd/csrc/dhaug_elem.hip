@@ -55,6 +55,9 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
 // relative.  Each segment is pad_cols wide, zero padded.
 // (eight columns per thread: one or two 16-byte loads, `terms` 16-byte stores -- the first version stored 2 bytes per lane and
 // segment and ran at the store instruction rate, 66 us for a 196 608 x 256 operand; pad_cols is a multiple of 8)
+// F16: the pieces are IEEE half values (x = hi + lo: 22 significant bits; terms = 3) for dhaug_gemm_f16x3 -- the fused parity
+// programs' arithmetic (csrc/dhaug_mlp_x3.hip) as a layer GEMM.  |x| must stay below 65 504.
+template <bool F16>
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ src, long long ld_src,
                                                     uint16_t* __restrict__ dst, long long rows, long long cols,
                                                     long long pad_cols, int mode, int terms) {
@@ -73,10 +76,17 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ sr
         uint32_t hi[4], mid[4], lo[4];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const uint16_t h = dhaug_f32_to_bf16(x[e]);
-            const float r1 = x[e] - dhaug_bf16_to_f32(h);
-            const uint16_t m = dhaug_f32_to_bf16(r1);
-            const uint16_t l = dhaug_f32_to_bf16(r1 - dhaug_bf16_to_f32(m));
+            uint16_t h, m, l;
+            if (F16) {
+                const _Float16 hh = (_Float16)x[e];
+                const _Float16 mm = (_Float16)(x[e] - (float)hh);
+                h = __builtin_bit_cast(uint16_t, hh); m = __builtin_bit_cast(uint16_t, mm); l = 0;
+            } else {
+                h = dhaug_f32_to_bf16(x[e]);
+                const float r1 = x[e] - dhaug_bf16_to_f32(h);
+                m = dhaug_f32_to_bf16(r1);
+                l = dhaug_f32_to_bf16(r1 - dhaug_bf16_to_f32(m));
+            }
             if (e & 1) { hi[e >> 1] |= (uint32_t)h << 16; mid[e >> 1] |= (uint32_t)m << 16; lo[e >> 1] |= (uint32_t)l << 16; }
             else { hi[e >> 1] = h; mid[e >> 1] = m; lo[e >> 1] = l; }
         }
@@ -625,8 +635,20 @@ int dhaug_split_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ro
     if (rows == 0) return DHAUG_OK;
     DHAUG_CHECK_PTR(src); DHAUG_CHECK_PTR(dst);
     DHAUG_CHECK(pad_cols % 8 == 0 && dhaug_aligned16(dst), DHAUG_EALIGN);
-    hipLaunchKernelGGL(split_kernel, dim3(grid1d(rows * (pad_cols / 8), 256)), dim3(256), 0, (hipStream_t)stream, src,
+    hipLaunchKernelGGL(split_kernel<false>, dim3(grid1d(rows * (pad_cols / 8), 256)), dim3(256), 0, (hipStream_t)stream, src,
                        (long long)ld_src, dst, (long long)rows, (long long)cols, (long long)pad_cols, mode, terms);
+    return dhaug_launch_status();
+}
+
+/* see include/dhaug.h */
+int dhaug_split_f16(const float* src, int64_t ld_src, uint16_t* dst, int64_t rows, int64_t cols, int64_t pad_cols, int mode,
+                    void* stream) {
+    DHAUG_CHECK(rows >= 0 && cols >= 1 && pad_cols >= cols && ld_src >= cols && (mode == 0 || mode == 1), DHAUG_EINVAL);
+    if (rows == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(src); DHAUG_CHECK_PTR(dst);
+    DHAUG_CHECK(pad_cols % 8 == 0 && dhaug_aligned16(dst), DHAUG_EALIGN);
+    hipLaunchKernelGGL(split_kernel<true>, dim3(grid1d(rows * (pad_cols / 8), 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (long long)ld_src, dst, (long long)rows, (long long)cols, (long long)pad_cols, mode, 3);
     return dhaug_launch_status();
 }
 

@@ -2518,6 +2518,23 @@ int dhaug_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t l
                           ldc_f32, M, N, K, act, slope, nullptr, 0, 1.0f, &done, stream);
 }
 
+/* see include/dhaug.h */
+int dhaug_gemm_f16x3(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias, const float* residual_f32,
+                     int64_t ld_res_f32, float* c_f32, int64_t ldc_f32, int64_t M, int64_t N, int64_t K, int act, float slope, void* stream) {
+    DHAUG_CHECK(M >= 0 && N >= 1 && K >= 16, DHAUG_EINVAL);
+    DHAUG_CHECK(act >= DHAUG_ACT_NONE && act <= DHAUG_ACT_LRELU, DHAUG_EINVAL);
+    if (M == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(A); DHAUG_CHECK_PTR(B); DHAUG_CHECK_PTR(c_f32);
+    DHAUG_CHECK(K % 16 == 0, DHAUG_EUNSUPPORTED);
+    DHAUG_CHECK(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && dhaug_aligned16(A) && dhaug_aligned16(B), DHAUG_EALIGN);
+    if (residual_f32) DHAUG_CHECK(ld_res_f32 >= N, DHAUG_EINVAL);
+    DHAUG_CHECK(ldc_f32 >= N, DHAUG_EINVAL);
+    GemmArgs p{A, lda, B, ldb, bias, nullptr, 0, residual_f32, ld_res_f32, nullptr, 0, 0, c_f32, ldc_f32, M, N, K, N, act, slope,
+               nullptr, 0, 1.0f, nullptr, nullptr, 0};
+    DHAUG_CHECK(dhaug_p8_supported(p), DHAUG_EUNSUPPORTED);
+    return dhaug_p8_launch_f16((hipStream_t)stream, p);
+}
+
 int dhaug_gemm_bf16_dmask_pad(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const uint16_t* residual,
                               int64_t ld_res, const uint16_t* dmask, int64_t ld_dmask, int dmask_act, float dmask_slope,
                               uint16_t* c_bf16, int64_t ldc_bf16, int64_t n_pad_zero, int64_t M, int64_t N, int64_t K, void* stream) {

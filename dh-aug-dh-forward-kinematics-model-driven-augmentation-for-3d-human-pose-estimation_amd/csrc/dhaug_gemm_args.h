@@ -62,4 +62,5 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 // alignment); the launchers enqueue on `s` and return a DHAUG_* / hipError_t code.
 bool dhaug_p8_supported(const dhaug_gemm::GemmArgs& p);
 int dhaug_p8_launch(hipStream_t s, const dhaug_gemm::GemmArgs& p);
+int dhaug_p8_launch_f16(hipStream_t s, const dhaug_gemm::GemmArgs& p);     // the same tiles on IEEE-half operands (dhaug_gemm_f16x3)
 int dhaug_p8_launch_group(hipStream_t s, const dhaug_gemm::GemmGroupArgs& g, int n);

@@ -41,6 +41,7 @@ namespace {
 using namespace dhaug_gemm;
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned char __attribute__((address_space(3))) * lds_addr;
 
@@ -77,6 +78,8 @@ __device__ __forceinline__ void p8_copy16_v(const void* g, lds_addr lds_wave_bas
 }
 __device__ __forceinline__ void p8_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
+// F16: the operands are IEEE half values (dhaug_gemm_f16x3); same tiles, same schedule, v_mfma_f32_16x16x32_f16
+template <bool F16>
 struct P8 {
     // per-lane byte offsets of the copies' sources, relative to the tile's first row of A / B: [region][i]
     unsigned voff[4][2];
@@ -153,7 +156,11 @@ struct P8 {
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
-                    acc[MT0 + mt][NT0 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][ks], xf[mt][ks], acc[MT0 + mt][NT0 + nt], 0, 0, 0);
+                    if (F16)
+                        acc[MT0 + mt][NT0 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[nt][ks]), __builtin_bit_cast(f16x8, xf[mt][ks]),
+                                                                                         acc[MT0 + mt][NT0 + nt], 0, 0, 0);
+                    else
+                        acc[MT0 + mt][NT0 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt][ks], xf[mt][ks], acc[MT0 + mt][NT0 + nt], 0, 0, 0);
     }
 
     // phase Q of K-tile t (buffer B = t & 1)
@@ -330,6 +337,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmArgs& p, const f32x4 (&acc
     }
 }
 
+template <bool F16>
 __device__ __forceinline__ void p8_body(const GemmArgs& p, long long mb, long long nb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char p8sm[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -337,7 +345,7 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, long long mb, long lo
     const int wm = wave >> 2, wn = wave & 3;
     const long long m0 = mb * P_BM, n0 = nb * P_BN;
 
-    P8 s;
+    P8<F16> s;
     s.wave = wave;
     s.K = p.K;
     s.nkt = (int)((p.K + P_BK - 1) / P_BK);
@@ -375,7 +383,7 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, long long mb, long lo
 
     P8_STAMP(0)
     // prologue: K-tile 0 and the first two regions of K-tile 1 (nkt >= 2)
-    s.stage<R_XL>(0); s.stage<R_WL>(0); s.stage<R_WH>(0); s.stage<R_XH>(0); s.stage<R_XL>(1); s.stage<R_WL>(1);
+    s.template stage<R_XL>(0); s.template stage<R_WL>(0); s.template stage<R_WH>(0); s.template stage<R_XH>(0); s.template stage<R_XL>(1); s.template stage<R_WL>(1);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                // XL, WL, WH(0); XH(0) is waited for in phase 1
     p8_barrier();
 #ifndef P8_ABL_NOSTAGGER
@@ -383,8 +391,8 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, long long mb, long lo
 #endif
     P8_STAMP(1)
     for (int t = 0; t < s.nkt; t += 2) {
-        s.ktile<0>(t);
-        if (t + 1 < s.nkt) s.ktile<1>(t + 1);
+        s.template ktile<0>(t);
+        if (t + 1 < s.nkt) s.template ktile<1>(t + 1);
     }
 #ifndef P8_ABL_NOSTAGGER
     if (wm == 0) p8_barrier();                                       // (every wave has passed the same number of barriers)
@@ -404,12 +412,13 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, long long mb, long lo
 // Workgroups go to the eight XCDs round-robin, and every XCD has its own L2: the column tiles of ONE row block are given to workgroups
 // b, b + 8, b + 16 ... (same XCD, started together), so the row block's activation rows come from beyond L2 once, not once per column
 // tile.  (Row blocks are padded to a multiple of eight: a workgroup beyond the batch leaves at once.)
+template <bool F16>
 __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(GemmArgs p) {
     const long long ntn = (p.W + P_BN - 1) / P_BN;
     const long long j = blockIdx.x >> 3;
     const long long mb = (j / ntn) * 8 + (blockIdx.x & 7), nb = j % ntn;
     if (mb * P_BM >= p.M) return;
-    p8_body(p, mb, nb);
+    p8_body<F16>(p, mb, nb);
 }
 
 // The grouped form (members of one shape).  With 2, 4 or 8 members each member gets 8 / n XCDs of its own (an XCD's L2 then holds ONE
@@ -427,14 +436,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_group_kernel(GemmGroupArgs 
         const long long ntn = (p.W + P_BN - 1) / P_BN, q = blockIdx.x >> 3;
         const long long mb = (q / ntn) * per + (xcd % per), nb = q % ntn;
         if (mb * P_BM >= p.M) return;
-        p8_body(p, mb, nb);
+        p8_body<false>(p, mb, nb);
     } else {
         const int member = blockIdx.x / tiles;
         const long long tile = blockIdx.x - (long long)member * tiles;
         if (member >= n) return;
         load_group_member(p, member);
         const long long ntn = (p.W + P_BN - 1) / P_BN;
-        p8_body(p, tile / ntn, tile % ntn);
+        p8_body<false>(p, tile / ntn, tile % ntn);
     }
 }
 
@@ -468,18 +477,21 @@ extern "C" int dhaug_debug_p8_stamps(long long* out, int n) {
 }
 #endif
 
-int dhaug_p8_launch(hipStream_t s, const dhaug_gemm::GemmArgs& p) {
+template <bool F16>
+static int p8_launch_single(hipStream_t s, const dhaug_gemm::GemmArgs& p) {
     static bool configured = false;
     if (!configured) {
-        const int e = p8_configure(gemm_nt_p8_kernel);
+        const int e = p8_configure(gemm_nt_p8_kernel<F16>);
         if (e != 0) return e;
         configured = true;
     }
     const long long grid = (((p.M + P_BM - 1) / P_BM + 7) / 8 * 8) * ((p.W + P_BN - 1) / P_BN);
     DHAUG_CHECK(grid <= 0x7fffffffLL, DHAUG_EUNSUPPORTED);
-    hipLaunchKernelGGL(gemm_nt_p8_kernel, dim3((unsigned)grid), dim3(512), P_LDS, s, p);
+    hipLaunchKernelGGL(gemm_nt_p8_kernel<F16>, dim3((unsigned)grid), dim3(512), P_LDS, s, p);
     return dhaug_launch_status();
 }
+int dhaug_p8_launch(hipStream_t s, const dhaug_gemm::GemmArgs& p) { return p8_launch_single<false>(s, p); }
+int dhaug_p8_launch_f16(hipStream_t s, const dhaug_gemm::GemmArgs& p) { return p8_launch_single<true>(s, p); }
 
 int dhaug_p8_launch_group(hipStream_t s, const dhaug_gemm::GemmGroupArgs& g, int n) {
     static bool configured = false;

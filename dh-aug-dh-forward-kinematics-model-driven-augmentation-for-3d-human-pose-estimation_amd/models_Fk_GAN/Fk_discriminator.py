@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from .. import autograd_ops as A
 from .. import fused
-from .Fk_generator import default_precision, graph_precision
+from .Fk_generator import default_precision, forward_precision, graph_precision
 from .special_operate import myResNet
 
 
@@ -76,7 +76,7 @@ class Fk_3D_Discriminator(nn.Module):
         x = input.reshape(-1, 48)
         if p in fused.MODES and x.is_cuda and _no_graph(self, x) and fused.supported(self.args.Dis_DenseDim_3D):
             return fused.critic3d(self, x.float(), center, kcs, p)  # one launch, activations stay in LDS
-        p = graph_precision(p)
+        p = forward_precision(p)
         if center:
             x = A.center_flip(x.reshape(-1, 16, 3), True, False).reshape(-1, 48)
         k = _branch(A.KcsFn.apply(x, True), self.special_KCS_previous[0],
@@ -125,7 +125,7 @@ class Fk_2D_Discriminator(nn.Module):
         x = x.reshape(-1, 32)
         if p in fused.MODES and x.is_cuda and _no_graph(self, x) and fused.supported(self.args.Dis_DenseDim_2D):
             return fused.critic2d(self, x.float(), p)
-        p = graph_precision(p)
+        p = forward_precision(p)
         d1 = A.linear(x, self.pose_layer_1.weight, self.pose_layer_1.bias, None, L, s, p)
         d2 = A.linear(d1, self.pose_layer_2.weight, self.pose_layer_2.bias, None, L, s, p)
         d3 = A.linear(d2, self.pose_layer_3.weight, self.pose_layer_3.bias, d1, L, s, p)
@@ -154,10 +154,10 @@ class Video_motion_Fk_3D_Discriminator(nn.Module):
 
     def _b(self, x, name):
         return _branch(x.contiguous(), getattr(self, name + "_previous")[0],
-                       [getattr(self, "%s_block%d" % (name, i)) for i in (1, 2, 3)], graph_precision(self.precision))
+                       [getattr(self, "%s_block%d" % (name, i)) for i in (1, 2, 3)], forward_precision(self.precision))
 
     def forward(self, input):
-        R, p = self.video_frame_num, graph_precision(self.precision)
+        R, p = self.video_frame_num, forward_precision(self.precision)
         x = input.reshape(-1, 48)
         kc = A.KcsFn.apply(x, False).reshape(-1, R * 15)
         outs = [self._b(kc, "special_KCS"), self._b(_frame_diff(kc, R, 15), "diff_special_KCS")]
@@ -187,10 +187,10 @@ class Video_motion_Fk_2D_Discriminator(nn.Module):
 
     def _b(self, x, name):
         return _branch(x.contiguous(), getattr(self, name + "_previous")[0],
-                       [getattr(self, "%s_block%d" % (name, i)) for i in (1, 2, 3)], graph_precision(self.precision))
+                       [getattr(self, "%s_block%d" % (name, i)) for i in (1, 2, 3)], forward_precision(self.precision))
 
     def forward(self, input):
-        R, p = self.video_frame_num, graph_precision(self.precision)
+        R, p = self.video_frame_num, forward_precision(self.precision)
         x = input.reshape(-1, 32)
         a = self._b(x.reshape(-1, R * 32), "pos_2d")
         b = self._b(_frame_diff(x.reshape(-1, 16, 2)[:, 0, :], R, 2), "root_diff_2d")

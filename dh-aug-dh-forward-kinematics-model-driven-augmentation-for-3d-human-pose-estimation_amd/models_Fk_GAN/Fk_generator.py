@@ -33,6 +33,14 @@ def graph_precision(p):
     return "bf16x6" if p == "f16x3" else p
 
 
+def forward_precision(p):
+    """arithmetic of a layer-by-layer FORWARD pass for a module precision: 'f16x3' without a graph -> the same arithmetic as layer GEMMs
+    (autograd_ops.F16X3_LAYER, dhaug_gemm_f16x3: any width, the reference's default DenseDim 1000 included); with a graph -> 'bf16x6'"""
+    if p == "f16x3" and not torch.is_grad_enabled():
+        return A.F16X3_LAYER
+    return graph_precision(p)
+
+
 class _GeneratorBase(nn.Module):
     def __init__(self, frames, FK_DH_Class, args, device, INPUT_VEC_DIM):
         super().__init__()
@@ -72,7 +80,7 @@ class _GeneratorBase(nn.Module):
         if self._use_fused(z):
             from .. import fused
             return fused.generator_head(self, z.float(), self.precision)
-        p = graph_precision(self.precision)
+        p = forward_precision(self.precision)
         lin = self.preprocess[0]
         x = A.linear(z, lin.weight, lin.bias, None, A.ACT_RELU, 0.0, p)
         x = self.block3(self.block2(self.block1(x, p), p), p)

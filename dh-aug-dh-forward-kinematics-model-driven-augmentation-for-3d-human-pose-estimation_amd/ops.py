@@ -262,6 +262,40 @@ def split_bf16(src, mode, terms, pad_cols=None):
     return dst
 
 
+def split_f16(src, mode, pad_cols=None):
+    """fp32 (rows, cols) -> (rows, 3 * pad_cols) IEEE-half pieces of x = hi + lo: mode 0 [hi|hi|lo] (activation side), mode 1 [hi|lo|hi]
+    (weight side) -- the operands of gemm_nt_f16x3.  |x| < 65 504."""
+    s = _dev(src, torch.float32, "split_f16") if src.is_contiguous() or not (src.dim() == 2 and src.stride(1) == 1) else src
+    assert s.dtype == torch.float32 and s.is_cuda and s.dim() == 2 and s.stride(1) == 1
+    rows, cols = s.shape
+    pad_cols = ceil_to(cols, 16) if pad_cols is None else pad_cols
+    dst = torch.empty((rows, 3 * pad_cols), dtype=torch.float16, device=s.device)
+    _lib.call("dhaug_split_f16", _p(s), s.stride(0), _p(dst), rows, cols, pad_cols, mode, _stream())
+    return dst
+
+
+def gemm_f16x3_ok(N, K3, bias=None, res_f32=None):
+    """shapes dhaug_gemm_f16x3 takes (the ping-pong tiles: csrc/dhaug_gemm_p8.hip)"""
+    al = lambda t: t is None or (t.data_ptr() % 16 == 0)
+    return (N % 8 == 0 and K3 >= 128 and K3 % 16 == 0 and al(bias) and al(res_f32)
+            and (res_f32 is None or (res_f32.stride(1) == 1 and res_f32.stride(0) % 4 == 0)))
+
+
+def gemm_nt_f16x3(A, B, N, K3, bias=None, res_f32=None, act=0, slope=0.0, out=None):
+    """fp32 (M, N) = act(A B^T + bias + res_f32) on IEEE-half operands: A = split_f16(x, 0), B = split_f16(W, 1), K3 = 3 * padded width
+    (dhaug_gemm_f16x3: the "f16x3" arithmetic as a layer GEMM)."""
+    assert A.dtype == torch.float16 and B.dtype == torch.float16 and A.is_cuda and B.is_cuda
+    M = A.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    assert out.dtype == torch.float32 and out.stride(1) == 1 and out.shape[0] == M
+    if bias is not None:
+        bias = _dev(bias, torch.float32, "gemm_nt_f16x3")
+    _lib.call("dhaug_gemm_f16x3", _p(A), A.stride(0), _p(B), B.stride(0), _p(bias), _p(res_f32), 0 if res_f32 is None else res_f32.stride(0),
+              _p(out), out.stride(0), M, N, K3, act, float(slope), _stream())
+    return out
+
+
 def gemm_nt(A, B, N, K, bias=None, res_bf16=None, res_f32=None, act=0, slope=0.0, out_bf16=False, n_pad=0,
             out_f32=False, lda=None, ldb=None, c_bf16=None, c_f32=None):
     """C[M,N] = act(A[M,K] B[N,K]^T + bias + residual).  A, B bf16 (row strides lda/ldb default to their widths).

@@ -376,6 +376,22 @@ int dhaug_cast_transpose_bf16(const float* src, int64_t ld_src, uint16_t* dst, i
 int dhaug_split_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t rows, int64_t cols,
                      int64_t pad_cols, int mode, int terms, void* stream);
 
+/* The same split with IEEE-half pieces, x = hi + lo (22 significant bits; three product terms: mode 0 row = [hi|hi|lo], mode 1
+ * [hi|lo|hi]): the operands of dhaug_gemm_f16x3.  |x| < 65 504. */
+int dhaug_split_f16(const float* src, int64_t ld_src, uint16_t* dst, int64_t rows, int64_t cols, int64_t pad_cols, int mode,
+                    void* stream);
+
+/* c_f32[M,N] = act( A[M,K] * B[N,K]^T + bias + residual_f32 ) on IEEE-half operands (v_mfma_f32_16x16x32_f16, fp32 accumulate):
+ * with A = dhaug_split_f16(x, mode 0) and B = dhaug_split_f16(W, mode 1), K = 3 * padded width, this is the layer
+ * x W^T in the "f16x3" arithmetic of the fused parity programs (Whi Xhi + Whi Xlo + Wlo Xhi: logits <= 1e-4 rel of the fp32
+ * reference, R/models_Fk_GAN/Fk_discriminator.py:180-201, 253-266, 381-587) at ANY width -- the parity-grade forward at the
+ * reference's default DenseDim 1000 (R/function_aug/config.py:101-109), where the fused programs do not apply.  Runs on the
+ * 256 x 256 x 64 ping-pong tiles (csrc/dhaug_gemm_p8.hip); takes K >= 128, N % 8 == 0, ldc_f32 % 4 == 0 and 16-byte aligned bias /
+ * residual / output, DHAUG_EUNSUPPORTED otherwise (the caller then runs that layer in "bf16x6").  Read extent as dhaug_gemm_bf16. */
+int dhaug_gemm_f16x3(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias, const float* residual_f32,
+                     int64_t ld_res_f32, float* c_f32, int64_t ldc_f32, int64_t M, int64_t N, int64_t K, int act, float slope,
+                     void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Fused multi-layer forward (one launch per network; activations stay in LDS)
  * ---------------------------------------------------------------------------------------------------- */

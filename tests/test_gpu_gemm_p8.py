@@ -153,3 +153,35 @@ def test_p8_reads_nothing_beyond_k(ops):
     _, cf = ops.gemm_nt(a, w, N, Kp, out_f32=True)
     assert torch.isfinite(cf).all()
     assert maxabs(cf, ref) <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K", [(4, 1000, 1000), (300, 1000, 432), (40960 + 3, 1000, 1000), (8200, 256, 48)])
+def test_f16x3_layer_gemm(ops, M, N, K):
+    """dhaug_split_f16 + dhaug_gemm_f16x3: x W^T + bias + residual, activation, in the fused parity programs' arithmetic (IEEE-half
+    pairs x = hi + lo, Whi Xhi + Whi Xlo + Wlo Xhi on v_mfma_f32_16x16x32_f16) as a layer GEMM at any width: against fp64 on the fp32
+    operands at 3e-6 of the result's scale (one bf16 pass: 4e-3; "bf16x3": 2e-4), the split itself exactly"""
+    gen = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=gen) * 0.7).cuda()
+    W = (torch.randn(N, K, generator=gen) / K ** 0.5).cuda()
+    bias = torch.randn(N, generator=gen).cuda()
+    res = torch.randn(M, N, generator=gen).cuda()
+    Kp = (K + 15) // 16 * 16
+    x3, w3 = ops.split_f16(x, 0, Kp), ops.split_f16(W, 1, Kp)
+    assert x3.shape == (M, 3 * Kp) and w3.shape == (N, 3 * Kp) and x3.dtype == torch.float16
+    hi = x.half()
+    lo = (x - hi.float()).half()
+    assert torch.equal(x3[:, :K], hi) and torch.equal(x3[:, Kp:Kp + K], hi) and torch.equal(x3[:, 2 * Kp:2 * Kp + K], lo)
+    assert torch.equal(w3[:, Kp:Kp + K], (W - W.half().float()).half()) and torch.equal(w3[:, 2 * Kp:2 * Kp + K], W.half())
+    if Kp > K:
+        assert x3[:, K:Kp].abs().max().item() == 0 and x3[:, 2 * Kp + K:].abs().max().item() == 0
+    assert ops.gemm_f16x3_ok(N, 3 * Kp, bias, res)
+    z = x.cpu().double() @ W.cpu().double().t() + bias.cpu().double() + res.cpu().double()
+    for act, slope, ref in ((0, 0.0, z), (1, 0.0, torch.relu(z)), (2, 0.01, torch.nn.functional.leaky_relu(z, 0.01))):
+        y = ops.gemm_nt_f16x3(x3, w3, N, 3 * Kp, bias=bias, res_f32=res, act=act, slope=slope)
+        assert maxabs(y, ref) <= 3e-6 * max(1.0, ref.abs().max().item()), (act, maxabs(y, ref))
+    y0 = ops.gemm_nt_f16x3(x3, w3, N, 3 * Kp)
+    assert maxabs(y0, x.cpu().double() @ W.cpu().double().t()) <= 3e-6 * max(1.0, z.abs().max().item())
+    # a shape the kernel does not take is refused, not computed wrongly
+    assert not ops.gemm_f16x3_ok(100, 3 * Kp) and not ops.gemm_f16x3_ok(N, 96)
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt_f16x3(x3, w3[:100], 100, 3 * Kp)

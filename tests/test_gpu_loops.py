@@ -484,6 +484,19 @@ def test_video_D1000_forward_vs_reference(M, golden):
                     m3=d["model_motion_d3d"](g["x3"].cuda()), m2=d["model_motion_d2d"](g["x2"].cuda()))
         for k, v in outs.items():
             assert rel(v, g["logit_" + k]) <= 1e-4, (k, rel(v, g["logit_" + k]))
+        # module precision "f16x3" at this width: no fused program applies, the layers run the SAME arithmetic (IEEE-half pairs, three
+        # product terms) as GEMMs on the ping-pong tiles (dhaug_gemm_f16x3; the narrow layers in "bf16x6") -- the tolerance again
+        for k, m in d.items():
+            if k.startswith("model"):
+                m.precision = "f16x3"
+        fake3 = G(g["z"].cuda(), bone_len_scaler=g["scaler"])
+        assert maxabs(fake3, g["fake"]) <= 3e-5
+        outs3 = dict(d3=d["model_d3d"](g["x3"].cuda()), d2=d["model_d2d"](g["x2"].cuda()),
+                     m3=d["model_motion_d3d"](g["x3"].cuda()), m2=d["model_motion_d2d"](g["x2"].cuda()))
+        for k, v in outs3.items():
+            print("f16x3 layer path at DenseDim 1000: %s logits %.2e rel (bf16x6: %.2e)" % (k, rel(v, g["logit_" + k]), rel(outs[k], g["logit_" + k])))
+            assert rel(v, g["logit_" + k]) <= 1e-4, (k, rel(v, g["logit_" + k]))
+            assert not torch.equal(v, outs[k]), k                               # (it IS another arithmetic than bf16x6)
         for k, m in d.items():
             if k.startswith("model"):
                 m.precision = "bf16"
