@@ -351,10 +351,13 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, long long mb, long lo
     s.nkt = (int)((p.K + P_BK - 1) / P_BK);
     s.tail = (p.K % P_BK) != 0;
     s.sm = (lds_addr)p8sm;
+    // (a column tile that lies wholly in the zero-pad columns [N, n_pad) has no weight row of its own: it reads the last one and
+    // stores zeros)
+    const long long n0r = n0 < p.N ? n0 : p.N - 1;
     s.baseA = p.A + m0 * p.lda;
-    s.baseB = p.B + n0 * p.ldb;
+    s.baseB = p.B + n0r * p.ldb;
     {
-        const long long rows_a = p.M - m0, rows_b = p.N - n0;   // valid rows from the tile's first (>= 1); rows beyond read the last valid one
+        const long long rows_a = p.M - m0, rows_b = p.N - n0r;  // valid rows from the tile's first (>= 1); rows beyond read the last valid one
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int rho = 16 * wave + 8 * i + (lane >> 3);                    // LDS row of the region

@@ -185,3 +185,17 @@ def test_f16x3_layer_gemm(ops, M, N, K):
     assert not ops.gemm_f16x3_ok(100, 3 * Kp) and not ops.gemm_f16x3_ok(N, 96)
     with pytest.raises(RuntimeError):
         ops.gemm_nt_f16x3(x3, w3[:100], 100, 3 * Kp)
+
+
+def test_p8_column_tile_wholly_in_the_pad(ops):
+    """N = 256 with n_pad = 272: the second 256-column tile holds nothing but zero-pad columns -- it must write its zeros without
+    reading a weight row that does not exist"""
+    M, N, K = 40960, 256, 512                                   # (K > 256: the wide-layer path)
+    A, W, gen = _operands(M, N, K, K, 5)
+    bufW = torch.full((N * K + 8,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    w = bufW[:N * K].view(N, K); w.copy_(W)
+    ref = torch.relu(A.float().cpu().double() @ W.float().cpu().double().t())
+    out = torch.full((M, 272), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(A, w, N, K, act=1, c_bf16=out, n_pad=272)
+    assert maxabs(out[:, :N].float(), ref) <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
+    assert out[:, N:].abs().max().item() == 0.0
