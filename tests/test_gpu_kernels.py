@@ -334,6 +334,7 @@ def test_critic_top_tangent_equals_the_three_launches(ops, M):
     mk = lambda rows, cols, pad: _bf(torch.cat([torch.randn(rows, cols, generator=gen) / cols ** 0.5, torch.zeros(rows, pad - cols)], 1)).cuda()
     Wm, W1, W2 = mk(n0, 512, 512), mk(n0, n0, 112), mk(n0, n0, 112)
     a0, ah, a1 = m0.clone(), mh.clone(), m1.clone()
+    k0, kh, k1 = [(t.float().cpu()[:, :n0] > 0).double() for t in (m0, mh, m1)]      # (both forms overwrite the activations they mask with)
     r0 = ops.gemm_nt_dmask(ucat, Wm, n0, 512, a0, 1, 0.0, out=a0)
     rh = ops.gemm_nt_dmask(r0, W1, n0, 112, ah, 1, 0.0, out=ah)
     r1 = ops.gemm_nt_dmask(rh, W2, n0, 112, a1, 1, 0.0, res_bf16=r0, out=a1)
@@ -345,9 +346,9 @@ def test_critic_top_tangent_equals_the_three_launches(ops, M):
     # error shared with the three launches it replaces would pass the comparison above
     f = lambda t: t.float().cpu().double()
     near = lambda got, want: (f(got)[:, :n0] - want).abs().max().item() <= 2.0 ** -8 * max(1e-6, want.abs().max().item())
-    e0 = (f(ucat) @ f(Wm).t())[:, :n0] * (f(m0)[:, :n0] > 0)
-    eh = (f(u0)[:, :n0] @ f(W1)[:, :n0].t()) * (f(mh)[:, :n0] > 0)
-    e1 = (f(uh)[:, :n0] @ f(W2)[:, :n0].t() + f(u0)[:, :n0]) * (f(m1)[:, :n0] > 0)
+    e0 = (f(ucat) @ f(Wm).t())[:, :n0] * k0
+    eh = (f(u0)[:, :n0] @ f(W1)[:, :n0].t()) * kh
+    e1 = (f(uh)[:, :n0] @ f(W2)[:, :n0].t() + f(u0)[:, :n0]) * k1
     assert near(u0, e0) and near(uh, eh) and near(u1, e1)
     assert u0[:, n0:].abs().max().item() == 0.0 and uh[:, n0:].abs().max().item() == 0.0 and u1[:, n0:].abs().max().item() == 0.0
 
