@@ -20,6 +20,17 @@
 //     the ring = three in flight per CU, exact vmcnt waits, LDS-only barriers; columns beyond a layer's width are copied from
 //     16 zero bytes (every lane of every copy stays active: the vmcnt arithmetic is the same in every wave);
 //   * fragments leave the row-major stage through the hardware transpose read (ds_read_b64_tr_b16).
+// Where the operands are SHORT and the layers wide (a video step: 12 - 24 layers of 1000 x 1000 over 1 536 - 9 216 rows, every 256 x 256
+// block one workgroup over all rows) the launch is bound by the stage body, not by memory.  Measured per 32-row stage on 12 such layers
+// of 4 608 rows (tools/abl_tn_wide.sh, round 6): MFMAs alone 0.60 us (16 per wave, 20 where the column sums ride along, at the ~2 GHz
+// the card holds under them: the matrix pipe's own time), fragment reads alone 0.25 us, copies alone 0.22 us; together 0.97 us -- the
+// three mostly one after the other, 0.24 - 0.29 of the MFMA peak per launch.  Tried and not kept: all 24 fragment reads of a stage
+// ahead of its first MFMA and the column-sum stages as a loop of their own (no branch between MFMAs): no change; the two waves of
+// every SIMD a half stage apart (one reads while the other multiplies, two barriers per stage, the copies issued between the MFMAs):
+// hides the reads (compute without copies 153 us against 157) but each copy then stalls the issuing wave's MFMA stream for ~150
+// clocks -- 194 - 212 us against 180 for the launch, and 5.0 - 5.25 TB/s against 5.5 on the single-frame step's long operands.
+// What did pay there: adding into the gradient slots with all of a tile's old values requested at once (see the epilogue), 245 -> 150 us
+// for 24 layers of 1 536 rows; consecutive work items on one XCD (see the kernel's first lines), a further 5 %.
 #include <cstdlib>
 #include <algorithm>
 #include "dhaug_common.h"
@@ -102,14 +113,20 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(TnGroup grp_by_va
     const int abl = *(const int __attribute__((address_space(4)))*)(ka + __builtin_offsetof(TnGroup, abl));
     float* ws = *(float* const __attribute__((address_space(4)))*)(ka + __builtin_offsetof(TnGroup, ws));
     LayerPtr layers = (LayerPtr)(ka + __builtin_offsetof(TnGroup, L));
+    // Workgroup -> work.  A launch with layers wider than 256 (abl bit 16, grid a multiple of 8) deals CONSECUTIVE work items to ONE
+    // XCD (workgroup b runs on XCD b % 8): the 4 x 4 blocks of a DenseDim-1000 layer share their operand slabs four ways, and only
+    // blocks behind the same L2 read a slab from memory once.  Dealt round-robin, every block fetched its own copy: the video
+    // step's launches moved 5 - 7 TB/s through the fabric whatever their shape, 3 000 clocks per 32-row stage with 211 workgroups
+    // resident against 1 400 with 128.
+    const int bx = (abl & 16) ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     int li = 0;
     for (int i = 1; i < nlayers; ++i)
-        if ((int)blockIdx.x >= layers[i].wg0) li = i;
+        if (bx >= layers[i].wg0) li = i;
     LayerPtr L = layers + li;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w1 = wave >> 1, w2 = wave & 1;
-    const int jw = (int)blockIdx.x - L->wg0;
+    const int jw = bx - L->wg0;
     if (jw >= L->nwg) return;
     // the workgroup's 256 x 256 block of the layer, and its slice of the batch
     const int split = L->split, blk = jw / split, j = jw - blk * split;
@@ -189,25 +206,42 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(TnGroup grp_by_va
         const long long ldc = L->ldc;
         const int accm = L->accumulate;
         float* csum = (L->colsum != nullptr && bj == 0) ? L->colsum + 256 * bi : nullptr;
+        // Adding into the slot: ALL of a 32-row tile's old values are requested before the first is used (written element by
+        // element, `*d = *d + acc`, every one of a wave's 128 read-modify-writes waited for its own load -- vmcnt(0), i.e. for the
+        // stores before it as well: 128 memory round trips in a row, ~100 us per workgroup; that, not the contraction, was
+        // what the video step's launches took: 1 536-row layers 245 us for 48 stages)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int th = 0; th < 4; ++th) {                          // a 32-row tile in two halves of 8 register rows (register budget)
+            const int t = th >> 1, rb = (th & 1) * 8;
             if (64 * w1 + 32 * t >= n1) continue;
+            float old[8][4], olds[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int r1 = 64 * w1 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            for (int q = 0; q < 8; ++q) {
+                const int r = rb + q, r1 = 64 * w1 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c1 = 128 * w2 + 32 * u + (lane & 31);
+                    old[q][u] = (accm && r1 < n1 && c1 < n2) ? C[r1 * ldc + c1] : 0.0f;
+                }
+                olds[q] = (accm && csum != nullptr && w2 == 0 && (lane & 31) == 0 && r1 < n1) ? csum[r1] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {                         // (the loads stay up there: values pinned before the first store)
+                asm volatile("" : "+v"(olds[q]));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(old[q][u]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = rb + q, r1 = 64 * w1 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (r1 >= n1) continue;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int c1 = 128 * w2 + 32 * u + (lane & 31);
-                    if (c1 < n2) {
-                        float* d = C + r1 * ldc + c1;
-                        *d = accm ? *d + acc[t][u][r] : acc[t][u][r];
-                    }
+                    if (c1 < n2) C[r1 * ldc + c1] = old[q][u] + acc[t][u][r];
                 }
-                if (csum != nullptr && w2 == 0 && (lane & 31) == 0) {
-                    const float sv = cs_rows > 0 ? accs[t][r] : 0.0f;
-                    csum[r1] = accm ? csum[r1] + sv : sv;
-                }
+                if (csum != nullptr && w2 == 0 && (lane & 31) == 0) csum[r1] = olds[q] + (cs_rows > 0 ? accs[t][r] : 0.0f);
             }
         }
         return;
@@ -289,6 +323,13 @@ int dhaug_gemm_tn_group_bf16_phase(const dhaug_tn_layer* layers, int n, float* w
     if (n == 0) return DHAUG_OK;
     DHAUG_CHECK_PTR(layers); DHAUG_CHECK_PTR(workspace);
     DHAUG_CHECK(dhaug_aligned16(workspace), DHAUG_EALIGN);
+    // the layers with the most blocks first (the order within a launch means nothing: distinct outputs): consecutive work items share
+    // an XCD (kernel, abl bit 16), and a 16-block layer that starts at a multiple of 16 stays behind one L2
+    dhaug_tn_layer ordered[T2_MAX_LAYERS];
+    std::copy(layers, layers + n, ordered);
+    auto blocks_of = [](const dhaug_tn_layer& s) { return ((s.N1 + 255) / 256) * ((s.N2 + 255) / 256); };
+    std::stable_sort(ordered, ordered + n, [&](const dhaug_tn_layer& a, const dhaug_tn_layer& b) { return blocks_of(a) > blocks_of(b); });
+    layers = ordered;
     TnGroup g;
     g.nlayers = n;
     g.abl = DHAUG_ABL_ENV("DHAUG_TN256_ABL");
@@ -373,7 +414,9 @@ int dhaug_gemm_tn_group_bf16_phase(const dhaug_tn_layer* layers, int n, float* w
     }
     if (phase != 0) g.abl |= 8;
     DHAUG_CHECK(slot <= T2_MAX_WG, DHAUG_EUNSUPPORTED);
-    (void)wide; (void)blocks;
+    (void)blocks;
+    static const bool xcd_deal = getenv("DHAUG_TN_NO_XCD_DEAL") == nullptr;
+    if (wide && xcd_deal) { g.abl |= 16; wg = (wg + 7) & ~7; }     // (workgroups beyond the last layer's range return at once)
     hipStream_t s = (hipStream_t)stream;
     static bool configured = false;
     if (!configured) {
@@ -389,6 +432,10 @@ int dhaug_gemm_tn_group_bf16_phase(const dhaug_tn_layer* layers, int n, float* w
         int rc = dhaug_launch_status();
         if (rc != DHAUG_OK || phase == 1) return rc;
     }
+    // (nothing to sum where every block had one workgroup that added its result into the slot itself: a video step's wide layers)
+    bool sums = phase != 0;
+    for (int i = 0; i < n; ++i) sums = sums || g.L[i].split > 1;
+    if (!sums) return DHAUG_OK;
     hipLaunchKernelGGL(tn_group_reduce_kernel, dim3(256, (unsigned)n), dim3(256), 0, s, g);
     return dhaug_launch_status();
 }
