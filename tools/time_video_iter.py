@@ -49,7 +49,7 @@ for i in range(20):
 torch.cuda.synchronize()
 print("20 iterations back to back: %.2f ms each" % ((time.perf_counter() - t0) * 1e3 / 20))
 # the items of the no-G-step replay, one by one
-key = [k for k in gv.graphs if not k[1]] if all(isinstance(k, tuple) for k in gv.graphs) else list(gv.graphs)
+key = [k for k in gv.graphs if not k[0]] if all(isinstance(k, tuple) for k in gv.graphs) else list(gv.graphs)   # (key[0]: with the G step)
 fc = gv.graphs[key[0]]
 cur = torch.cuda.current_stream()
 for kind, obj in getattr(fc, "items", []):
@@ -66,3 +66,18 @@ for kind, obj in getattr(fc, "items", []):
             cur.wait_stream(st)
     torch.cuda.synchronize()
     print("  item %-5s %s: %.3f ms" % (kind, "" if kind == "graph" else "(%d chains)" % len(obj), (time.perf_counter() - t0) * 1e3))
+
+# the forked chains of that replay, each alone on an idle card (what the fork overlaps)
+for kind, obj in getattr(fc, "items", []):
+    if kind == "graph":
+        continue
+    for i, (st, g) in enumerate(obj):
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(st):
+                g.replay()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        print("  chain %d alone: %.3f ms" % (i, min(ts)))
