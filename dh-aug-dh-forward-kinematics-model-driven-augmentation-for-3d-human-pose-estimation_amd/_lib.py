@@ -43,6 +43,7 @@ SIGNATURES = {
     "dhaug_cast_transpose_bf16": [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp],
     "dhaug_split_bf16": [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp],
     "dhaug_split_f16": [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp],
+    "dhaug_gemm_bf16x6_planes": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _f32, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _f32, _vp],
     "dhaug_gemm_f16x3": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _f32, _vp],
     "dhaug_colsum_f32": [_vp, _i64, _vp, _i64, _i64, _i32, _vp],
     "dhaug_colsum_bf16": [_vp, _i64, _vp, _i64, _i64, _i32, _vp],
@@ -103,7 +104,8 @@ class AdamDesc(ctypes.Structure):
 class TnLayer(ctypes.Structure):
     """struct dhaug_tn_layer (include/dhaug.h)"""
     _fields_ = [("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("C", _vp), ("ldc", _i64), ("colsum_a", _vp),
-                ("colsum_rows", _i64), ("M", _i64), ("N1", _i32), ("N2", _i32), ("accumulate", _i32), ("max_workgroups", _i32)]
+                ("colsum_rows", _i64), ("M", _i64), ("N1", _i32), ("N2", _i32), ("accumulate", _i32), ("max_workgroups", _i32),
+                ("planes_a", _i32), ("planes_b", _i32)]
 
 
 class Block2(ctypes.Structure):

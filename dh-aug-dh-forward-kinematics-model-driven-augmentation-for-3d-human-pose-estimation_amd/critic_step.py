@@ -60,6 +60,11 @@ TN_MAIN_WGS = int(os.environ.get("DHAUG_TN_MAIN_WGS", "0"))  # workgroups of the
 NT_GROUP = os.environ.get("DHAUG_NO_NT_GROUP") is None
 # split-operand arithmetic: one activation-side split per tensor and step (_Math.split0); DHAUG_NO_SPLIT_CACHE=1: one per use
 SPLIT_CACHE = os.environ.get("DHAUG_NO_SPLIT_CACHE") is None
+# split-operand arithmetic ("bf16x6"): an operand whose padded width is 64 * 2^j is split into its three distinct pieces ONCE, as planes
+# [hi | mid | lo] (6 bytes per value instead of 12, and one split where the forward / backward chains and sweep 4 wanted two layouts);
+# the layer products (ops.gemm_nt_planes) and the grouped weight-gradient launch read the pieces in the order of the six-segment operand --
+# bit-identical results.  DHAUG_X6_PLANES=0: six-segment operands everywhere.
+PLANES = os.environ.get("DHAUG_X6_PLANES", "1") != "0"
 
 # bf16 operands that a kernel of the step writes beside its fp32 result anyway (the assembled real / fake rows, the penalty's cotangent,
 # the KCS operand) are registered as the casts of those tensors instead of being cast again (DHAUG_NO_SEED_CASTS=1: cast launches)
@@ -149,24 +154,50 @@ class _Math:
         (no address is reused inside a step); nothing in the schedule writes a tensor after it was an operand."""
         if not a.is_contiguous():                    # (a column block: split where it lies, one per use)
             return ops.split_bf16(a if (a.dim() == 2 and a.stride(1) == 1) else a.contiguous(), mode, self.T, ceil16(k))
+        hit = self.cached_split(a, k, mode)
+        if hit is not None:
+            return hit
         p, rows, cols = a.data_ptr(), a.shape[0], a.shape[1]
-        if SPLIT_CACHE and cols == k:
-            for bp, brows, bcols, bmode, sp in self._splits:
-                if bmode == mode and bcols == cols and p >= bp and (p - bp) % (4 * cols) == 0:
-                    r0 = (p - bp) // (4 * cols)
-                    if r0 + rows <= brows:
-                        return sp if (r0 == 0 and rows == brows) else sp[r0:r0 + rows]
         sp = ops.split_bf16(a, mode, self.T, ceil16(k))
         if SPLIT_CACHE and cols == k:
             self._splits.append((p, rows, cols, mode, sp))
             self._split_src.append(a)                # (referenced until flush: no address is reused inside a step)
         return sp
 
+    def planes_ok(self, k):
+        """an fp32 operand k wide may travel as three planes (see PLANES)"""
+        kp = ceil16(k)
+        return PLANES and not self.bf16 and self.T == 6 and kp >= 64 and (kp & (kp - 1)) == 0
+
+    def cached_split(self, a, k, mode):
+        """the split of (a row range of) this tensor made earlier in the step, or None"""
+        if not (SPLIT_CACHE and a.is_contiguous() and a.shape[1] == k):
+            return None
+        p, rows, cols = a.data_ptr(), a.shape[0], a.shape[1]
+        for bp, brows, bcols, bmode, sp in self._splits:
+            if bmode == mode and bcols == cols and p >= bp and (p - bp) % (4 * cols) == 0:
+                r0 = (p - bp) // (4 * cols)
+                if r0 + rows <= brows:
+                    return sp if (r0 == 0 and rows == brows) else sp[r0:r0 + rows]
+        return None
+
     def mm(self, a, W, orient, bias=None, res=None, act=NONE, slope=0.0, mask=None, mask_act=NONE, out=None, out_f32=False):
         """(a @ W^T if orient == 'nt' else a @ W) + bias + res, then act(.) or, with `mask`, * mask_act'(mask)."""
         N, K = W.shape
         n, k = (N, K) if orient == "nt" else (K, N)
         kp = ceil16(k)
+        if (self.planes_ok(k) and a.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1
+                and self.cached_split(a, k, 1 if (orient == "nn" and SPLIT_CACHE) else 0) is None):   # (a six-segment split made for a product the ping-pong kernel does not take serves this one too)
+            masked = mask is not None and mask_act != NONE
+            resc = res if (res is None or res.is_contiguous()) else res.contiguous()
+            if ((resc is None or resc.dtype == torch.float32) and (not masked or (mask.dtype == torch.float32 and mask.stride(1) == 1))
+                    and (out is None or (out.dtype == torch.float32 and out.stride(1) == 1))
+                    and ops.gemm_planes_ok(n, kp, bias, resc, mask if masked else None, out)):
+                swap = orient == "nn" and SPLIT_CACHE        # (the weights' operand copies as below)
+                Bop = A._w_nt(W, kp, self.prec) if orient == "nt" else A._w_nn(W, self.prec, 0 if swap else 1)
+                return ops.gemm_nt_planes(self.split0(a, k, 2), Bop, n, kp, bias=bias, res_f32=resc, act=act, slope=slope,
+                                          dmask_f32=mask if masked else None, dmask_act=mask_act if masked else NONE, dmask_slope=slope,
+                                          out=out, x_order=1 if swap else 0)
         # split-operand arithmetic, backward chain (orient "nn"): the cotangent is split ONCE, in the weight-side layout -- the
         # layout sweep 4 contracts it in (autograd_ops._raw_outer) -- and meets the weights in the activation-side layout
         swap = (not self.bf16) and orient == "nn" and SPLIT_CACHE
@@ -320,13 +351,17 @@ class _Math:
             return
         rowm = lambda t: t if (t.dim() == 2 and t.stride(1) == 1) else t.contiguous()      # (row-major, any row pitch)
         gc, xc = rowm(g), rowm(x)
-        g1, x3 = self.split0(gc, N, 1), self.split0(xc, K)
         TM, Np, Kp = self.T * gc.shape[0], ceil16(N), ceil16(K)
-        if TN_GROUP and ops.tn_group_ok(TM, min(N, 256), min(K, 256), 0) and (wslot.data_ptr(), 2) not in self._tn_slots:
+        grouped = TN_GROUP and ops.tn_group_ok(TM, min(N, 256), min(K, 256), 0) and (wslot.data_ptr(), 2) not in self._tn_slots
+        # (planes: the grouped launch only, layers of one 256 x 256 block; it reads piece (0 1 0 1 2 0)[t] of g and (0 0 1 1 0 2)[t] of x)
+        pa = 2 if (grouped and N <= 256 and K <= 256 and self.planes_ok(N) and self.cached_split(gc, N, 1) is None) else 0
+        pb = 1 if (grouped and N <= 256 and K <= 256 and self.planes_ok(K) and self.cached_split(xc, K, 0) is None) else 0
+        g1, x3 = self.split0(gc, N, 2 if pa else 1), self.split0(xc, K, 2 if pb else 0)
+        if grouped:
             # the split-operand contraction (ONE contraction over T * M rows: autograd_ops._raw_outer) joins the step's grouped launch
             # like a bf16 one.  A second contribution to the same gradient (the interpolated rows' part) waits for a second launch:
             # the items of one launch are summed into their slots concurrently.
-            item = (g1.view(TM, Np), x3.view(TM, Kp), N, K, wslot, None, 0, True, TM, None, None)
+            item = (g1.view(-1, Np), x3.view(-1, Kp), N, K, wslot, None, 0, True, TM, None, None, pa, pb)
             key = wslot.data_ptr()
             if key in self._tn_slots:
                 self.tn2.append(item)

@@ -21,6 +21,10 @@ struct GemmArgs {
     int abl;                                                 // development (big-tile kernels): 1 no epilogue, 2 no reads / MFMAs, 4 no copies
     const float* dmaskf; long long ld_dmaskf;                // the same mask from an fp32 activation (split-operand arithmetic): kernels
                                                              // whose epilogue is nt_store_tile / the ping-pong kernel's
+    // The ping-pong kernel only (dhaug_gemm_bf16x6_planes): A holds the THREE distinct bf16 pieces of a split fp32 operand as planes
+    // [hi | mid | lo] of xp_kp columns each (lda >= 3 xp_kp) and K = 6 xp_kp: K-segment s of the contraction reads plane
+    // (xp_map >> 2 s) & 3.  xp_lg = 1 + log2(xp_kp / 64); 0: A is an ordinary K-wide operand.
+    int xp_lg; unsigned xp_map; long long xp_kp;
 };
 
 // Up to eight independent GEMMs of ONE shape as one launch (dhaug_gemm_bf16_group)

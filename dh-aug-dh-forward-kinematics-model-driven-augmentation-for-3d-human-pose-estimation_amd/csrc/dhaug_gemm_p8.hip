@@ -92,13 +92,19 @@ struct P8 {
     int wave, nkt;
     long long K;
     bool tail;
+    int xp_lg; unsigned xp_map; long long xp_kp;        // A as three planes of a split operand (GemmArgs): K-tile -> column offset in A
     f32x4 acc[8][4];
     bf16x8 xf[4][2], wlo[2][2], whi[2][2];
 
     template <int R>
     __device__ __forceinline__ void stage(int kt) {
         const lds_addr dst = sm + (kt & 1) * P_BUF + R * P_HALF + wave * 2048;
-        const uint16_t* base = (R < 2 ? baseA : baseB) + (long long)kt * P_BK;
+        long long koff = (long long)kt * P_BK;
+        if (R < 2 && xp_lg != 0) {                      // (wave-uniform: scalar arithmetic)
+            const int seg = kt >> (xp_lg - 1), within = kt & ((1 << (xp_lg - 1)) - 1);
+            koff = (long long)((xp_map >> (2 * seg)) & 3u) * xp_kp + (long long)within * P_BK;
+        }
+        const uint16_t* base = (R < 2 ? baseA : baseB) + koff;
 #ifdef P8_ABL_NOCOPY
         return;
 #endif
@@ -350,6 +356,7 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, long long mb, long lo
     s.K = p.K;
     s.nkt = (int)((p.K + P_BK - 1) / P_BK);
     s.tail = (p.K % P_BK) != 0;
+    s.xp_lg = p.xp_lg; s.xp_map = p.xp_map; s.xp_kp = p.xp_kp;
     s.sm = (lds_addr)p8sm;
     // (a column tile that lies wholly in the zero-pad columns [N, n_pad) has no weight row of its own: it reads the last one and
     // stores zeros)
@@ -460,7 +467,10 @@ int p8_configure(Kern kern) {
 bool dhaug_p8_supported(const dhaug_gemm::GemmArgs& p) {
     const long long ldmax = p.lda > p.ldb ? p.lda : p.ldb;
     const auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
-    if (!(p.M > 0 && p.K >= 2 * P_BK && p.K % 8 == 0 && p.N % 8 == 0 && p.npad % 8 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.lda >= p.K &&
+    const bool planes = p.xp_lg != 0;
+    if (planes && !(p.xp_lg >= 1 && p.xp_lg <= 8 && p.xp_kp == ((long long)P_BK << (p.xp_lg - 1)) && p.K == 6 * p.xp_kp && p.lda >= 3 * p.xp_kp))
+        return false;
+    if (!(p.M > 0 && p.K >= 2 * P_BK && p.K % 8 == 0 && p.N % 8 == 0 && p.npad % 8 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && (planes || p.lda >= p.K) &&
           p.ldb >= p.K && ldmax * 2 * P_BM < (1ll << 31) && p.dbits == nullptr && p.dbits2 == nullptr && al(p.A, 16) && al(p.B, 16)))
         return false;
     // the epilogue's vector accesses: eight columns per lane

@@ -58,7 +58,7 @@ struct TnLayer {
     int nst;                        // 32-row stages of the layer (M / 32)
     int n1, n2;                     // whole layer: a layer wider than 256 is a grid of 256 x 256 blocks, (n2 + 255) / 256 per row
     int wg0, nwg;                   // workgroups [wg0, wg0 + nwg) work on this layer: `split` per block, block-major
-    int accumulate;
+    int accumulate;                 // bit 0: add into C / colsum; bits 8-9 / 10-11: A / B are the three PLANES of a split operand (see copy_stage)
     int split;                      // 1: the block's one workgroup adds its result into C / colsum itself (no partial, no sum)
     int ws0;                        // split > 1: the layer's partial results start at workspace slot ws0
 };
@@ -141,15 +141,27 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(TnGroup grp_by_va
     const int ca = (n1 + 7) >> 3, cb = (n2 + 7) >> 3;             // live 16-byte chunks per row
     const t2_lds_ptr lds0 = (t2_lds_ptr)tsm;
 
+    // An operand given as PLANES (dhaug_tn_layer.planes_a / _b: the three distinct bf16 pieces [hi | mid | lo] of a split fp32 tensor,
+    // three rows per tensor row) is contracted over SIX virtual rows per tensor row, piece (0 0 1 1 0 2)[t] (order 1, the activation
+    // side of dhaug_split_bf16) or (0 1 0 1 2 0)[t] (order 2, the weight side) for virtual row 6 m + t -- the rows of the six-segment
+    // operand without their copies, in the same order (bit-identical sums): the repeated rows come out of L2, not out of HBM.
+    const int flags = L->accumulate;
+    const unsigned pmapA = ((flags >> 8) & 3) == 1 ? 0x850u : 0x244u, pmapB = ((flags >> 10) & 3) == 1 ? 0x850u : 0x244u;
+    const bool planesA = ((flags >> 8) & 3) != 0, planesB = ((flags >> 10) & 3) != 0;
+    auto real_row = [](long long rv, unsigned pmap) {
+        const unsigned r = (unsigned)rv, q = __umulhi(r, 0xAAAAAAABu) >> 2, t = r - 6u * q;
+        return (long long)(3u * q + ((pmap >> (2u * t)) & 3u));
+    };
     auto copy_stage = [&](int st) {
         const long long m0 = ms + (long long)st * T2_ROWS;
         const t2_lds_ptr base = lds0 + (st % T2_NSTG) * T2_STG;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {                             // 32 chunks per row: two rows per wave instruction
             const int row0 = (wave * 2 + i) * 2, row = row0 + (lane >> 5), c = (lane & 31) ^ t2_sw(row);
-            t2_copy16(c < ca ? static_cast<const void*>(A + (m0 + row) * lda + c * 8) : static_cast<const void*>(&g_t2_zero16),
+            const long long ra = planesA ? real_row(m0 + row, pmapA) : m0 + row, rb = planesB ? real_row(m0 + row, pmapB) : m0 + row;
+            t2_copy16(c < ca ? static_cast<const void*>(A + ra * lda + c * 8) : static_cast<const void*>(&g_t2_zero16),
                       base + row0 * 512);
-            t2_copy16(c < cb ? static_cast<const void*>(B + (m0 + row) * ldb + c * 8) : static_cast<const void*>(&g_t2_zero16),
+            t2_copy16(c < cb ? static_cast<const void*>(B + rb * ldb + c * 8) : static_cast<const void*>(&g_t2_zero16),
                       base + T2_HALF + row0 * 512);
         }
     };
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_group_kernel(TnGroup grp_by_va
         // 128-byte row pieces; no partial result, nothing for the summing launch to do
         float* C = L->C + (long long)256 * bi * L->ldc + 256 * bj;
         const long long ldc = L->ldc;
-        const int accm = L->accumulate;
+        const int accm = L->accumulate & 1;
         float* csum = (L->colsum != nullptr && bj == 0) ? L->colsum + 256 * bi : nullptr;
         // Adding into the slot: ALL of a 32-row tile's old values are requested before the first is used (written element by
         // element, `*d = *d + acc`, every one of a wave's 128 read-modify-writes waited for its own load -- vmcnt(0), i.e. for the
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(256) void tn_group_reduce_kernel(TnGroup g) {
     (void)g;
     const int abl = *(const int __attribute__((address_space(4)))*)(ka + __builtin_offsetof(TnGroup, abl));
     if (L->split == 1 && !(abl & 8)) return;                      // (its workgroups wrote the gradient slot themselves)
-    const int n1 = L->n1, n2 = L->n2, nwg = L->nwg, acc = L->accumulate;   // (split > 1: a single block, n1, n2 <= 256)
+    const int n1 = L->n1, n2 = L->n2, nwg = L->nwg, acc = L->accumulate & 1;   // (split > 1: a single block, n1, n2 <= 256)
     const float* p0 = ws + (long long)L->ws0 * T2_WS_STRIDE;
     float* C = L->C;
     const long long ldc = L->ldc;
@@ -356,7 +368,9 @@ int dhaug_gemm_tn_group_bf16_phase(const dhaug_tn_layer* layers, int n, float* w
         TnLayer& L = g.L[i];
         L.A = s.A; L.B = s.B; L.C = s.C; L.colsum = s.colsum_a;
         L.lda = s.lda; L.ldb = s.ldb; L.ldc = s.ldc; L.cs_rows = s.colsum_a != nullptr ? s.colsum_rows : 0;
-        L.nst = (int)(s.M / T2_ROWS); L.n1 = s.N1; L.n2 = s.N2; L.accumulate = s.accumulate;
+        DHAUG_CHECK(s.planes_a >= 0 && s.planes_a <= 2 && s.planes_b >= 0 && s.planes_b <= 2, DHAUG_EINVAL);
+        DHAUG_CHECK((s.planes_a == 0 && s.planes_b == 0) || (s.M % 6 == 0 && s.M < (1LL << 31)), DHAUG_EINVAL);   // six virtual rows per tensor row
+        L.nst = (int)(s.M / T2_ROWS); L.n1 = s.N1; L.n2 = s.N2; L.accumulate = (s.accumulate ? 1 : 0) | (s.planes_a << 8) | (s.planes_b << 10);
         nblk[i] = ((s.N1 + 255) / 256) * ((s.N2 + 255) / 256);
         wide = wide || nblk[i] > 1;
         blocks += nblk[i];

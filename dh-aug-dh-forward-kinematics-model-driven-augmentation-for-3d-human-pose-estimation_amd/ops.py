@@ -257,9 +257,34 @@ def split_bf16(src, mode, terms, pad_cols=None):
         ld = s.shape[1]
     rows, cols = s.shape
     pad_cols = ceil_to(cols, 16) if pad_cols is None else pad_cols
-    dst = torch.empty((rows, terms * pad_cols), dtype=BF16, device=s.device)
+    dst = torch.empty((rows, (3 if mode == 2 else terms) * pad_cols), dtype=BF16, device=s.device)
     _lib.call("dhaug_split_bf16", _p(s), ld, _p(dst), rows, cols, pad_cols, mode, terms, _stream())
     return dst
+
+
+def gemm_planes_ok(N, kp, bias=None, res_f32=None, dmask_f32=None, out=None):
+    """shapes dhaug_gemm_bf16x6_planes takes (the ping-pong tiles, a power-of-two piece width)"""
+    al = lambda t: t is None or (t.data_ptr() % 16 == 0)
+    row = lambda t: t is None or (t.stride(1) == 1 and t.stride(0) % 4 == 0)
+    return (N % 8 == 0 and kp >= 64 and (kp & (kp - 1)) == 0 and al(bias) and al(res_f32) and al(dmask_f32) and al(out)
+            and row(res_f32) and row(dmask_f32) and row(out))
+
+
+def gemm_nt_planes(A3, B6, N, kp, bias=None, res_f32=None, act=0, slope=0.0, dmask_f32=None, dmask_act=0, dmask_slope=0.0, out=None, x_order=0):
+    """fp32 (M, N) = act(x W^T + bias + res_f32), masked by dmask_f32, in the bf16x6 arithmetic with the activation side as planes:
+    A3 = split_bf16(x, 2, 6, kp) = [hi|mid|lo], B6 = split_bf16(W, 1, 6, kp) (dhaug_gemm_bf16x6_planes: bit-identical to gemm_nt on the
+    mode 0 split); x_order 1: the planes stand for the mode 1 operand, B6 = split_bf16(W, 0, 6, kp)."""
+    assert A3.dtype == BF16 and B6.dtype == BF16 and A3.is_cuda and B6.is_cuda and A3.stride(1) == 1 and B6.stride(1) == 1
+    M = A3.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A3.device)
+    assert out.dtype == torch.float32 and out.stride(1) == 1 and out.shape[0] == M
+    if bias is not None:
+        bias = _dev(bias, torch.float32, "gemm_nt_planes")
+    _lib.call("dhaug_gemm_bf16x6_planes", _p(A3), A3.stride(0), _p(B6), B6.stride(0), _p(bias), _p(res_f32),
+              0 if res_f32 is None else res_f32.stride(0), _p(dmask_f32), 0 if dmask_f32 is None else dmask_f32.stride(0), int(dmask_act),
+              float(dmask_slope), _p(out), out.stride(0), M, N, kp, int(x_order), act, float(slope), _stream())
+    return out
 
 
 def split_f16(src, mode, pad_cols=None):
@@ -541,6 +566,8 @@ def gemm_tn_group(items, max_workgroups=0, phase=0, workspace=None):
     # chunk they travel in has blocks enough to fill the card without splitting any over the batch; as 256 x 256 blocks, each an
     # item of its own, otherwise (a long batch of few wide layers: the blocks are split over the batch and summed)
     nblk = lambda it: ((it[2] + 255) // 256) * ((it[3] + 255) // 256)
+    # items may carry two more fields, (planes_a, planes_b): A / B as the three planes of a split operand (dhaug_tn_layer.planes_a / _b)
+    items = [tuple(it) if len(it) == 13 else tuple(it) + (0, 0) for it in items]
     if any(nblk(it) > 1 for it in items):
         flat = []
         for i0 in range(0, len(items), _lib.TN_GROUP_MAX):
@@ -548,12 +575,13 @@ def gemm_tn_group(items, max_workgroups=0, phase=0, workspace=None):
             if phase == 0 and sum(nblk(it) for it in chunk) >= TN_WIDE_MIN_BLOCKS:
                 flat.extend(chunk)
                 continue
-            for (A, B, N1, N2, out, cs, cr, accumulate, M, la, lb) in chunk:
+            for (A, B, N1, N2, out, cs, cr, accumulate, M, la, lb, pa, pb) in chunk:
+                assert (pa == 0 and pb == 0) or (N1 <= 256 and N2 <= 256), "a wide layer's operands as planes: not built"
                 for n0 in range(0, N1, 256):
                     for k0 in range(0, N2, 256):
                         c = cs[n0:] if (cs is not None and k0 == 0) else None
                         flat.append((A[:, n0:], B[:, k0:], min(256, N1 - n0), min(256, N2 - k0), out[n0:, k0:], c,
-                                     cr if c is not None else 0, accumulate, A.shape[0] if M is None else M, la, lb))
+                                     cr if c is not None else 0, accumulate, A.shape[0] if M is None else M, la, lb, pa, pb))
         items = flat
     assert phase == 0 or (len(items) <= _lib.TN_GROUP_MAX and workspace is not None)
     # the items of ONE launch are summed into their outputs concurrently (a block that is left with one workgroup adds its
@@ -577,7 +605,8 @@ def gemm_tn_group(items, max_workgroups=0, phase=0, workspace=None):
     for i0 in range(0, len(items), _lib.TN_GROUP_MAX):
         chunk = items[i0:i0 + _lib.TN_GROUP_MAX]
         arr = (_lib.TnLayer * len(chunk))()
-        for d, (A, B, N1, N2, out, cs, cr, accumulate, M, la, lb) in zip(arr, chunk):
+        for d, (A, B, N1, N2, out, cs, cr, accumulate, M, la, lb, pa, pb) in zip(arr, chunk):
+            d.planes_a, d.planes_b = int(pa), int(pb)
             assert A.dtype == BF16 and B.dtype == BF16 and out.dtype == torch.float32
             d.A, d.lda, d.B, d.ldb = _p(A), A.stride(0) if la is None else la, _p(B), B.stride(0) if lb is None else lb
             d.C, d.ldc, d.colsum_a, d.colsum_rows = _p(out), out.stride(0), _p(cs), cr

@@ -351,6 +351,12 @@ typedef struct dhaug_tn_layer {
     int32_t accumulate;         /* != 0: add into C / colsum_a, else overwrite */
     int32_t max_workgroups;     /* of layers[0]: the launch uses at most this many workgroups (0: one per CU) -- a launch that
                                    runs beside other kernels leaves them CUs */
+    int32_t planes_a, planes_b; /* 0: A / B is an ordinary (M, N) operand.  1 / 2: it is dhaug_split_bf16(x, mode 2, terms 6) seen as
+                                   (M / 2, ceil16 N) rows -- the three distinct pieces [hi | mid | lo] of every tensor row -- and the
+                                   contraction runs over M = 6 x (tensor rows) VIRTUAL rows, virtual row 6 m + t being piece
+                                   (0 0 1 1 0 2)[t] (1: the order of the mode 0 split) or (0 1 0 1 2 0)[t] (2: mode 1) of tensor row m:
+                                   the same sum, bit for bit, as over the mode 0 / mode 1 operand seen as (6 x rows, ceil16 N), from half
+                                   the bytes (the "bf16x6" weight gradients, autograd_ops._raw_outer).  M % 6 == 0 then. */
 } dhaug_tn_layer;
 int dhaug_gemm_tn_group_bf16(const dhaug_tn_layer* layers, int n, float* workspace, void* stream);
 /* The same in two calls: phase 1 launches the contractions (partial results into `workspace`), phase 2 the sums into the
@@ -375,6 +381,23 @@ int dhaug_cast_transpose_bf16(const float* src, int64_t ld_src, uint16_t* dst, i
  * 2^-24 (terms 6) relative.  dst is (rows, terms*pad_cols) contiguous. */
 int dhaug_split_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t rows, int64_t cols,
                      int64_t pad_cols, int mode, int terms, void* stream);
+/* (terms 6 only) mode 2: the three DISTINCT pieces once, row = [hi|mid|lo] (dst is (rows, 3*pad_cols)): half the bytes of mode 0.  The
+ * operand of dhaug_gemm_bf16x6_planes, which reads piece (0 0 1 1 0 2)[s] for K-segment s -- the mode 0 row without its copies. */
+
+/* c_f32[M,N] = act( X W^T + bias + residual_f32 ) * (dmask_f32 > 0 ? 1 : dneg) in the "bf16x6" arithmetic with the activation side as
+ * PLANES: A_planes = dhaug_split_bf16(x, mode 2, terms 6) = [hi|mid|lo] of kp columns each (lda >= 3 kp), B = dhaug_split_bf16(W, mode 1,
+ * terms 6) (ldb >= 6 kp) with x_order 0; x_order 1: the planes stand for the mode 1 operand and B is the mode 0 split (the backward
+ * chain: the cotangent is split once, in the layout the weight gradients contract it in).
+ * The same six product terms in the same order as dhaug_gemm_bf16 on the mode 0 / mode 1 operand (K = 6 kp) -- BIT-identical
+ * results -- but the split writes 6 instead of 12 bytes per value and the GEMM's re-reads of a piece come from L2 / MALL, not from HBM.
+ * kp = 64 * 2^j (a K-tile never straddles two pieces); runs on the 256 x 256 x 64 ping-pong tiles only (csrc/dhaug_gemm_p8.hip): N % 8 == 0,
+ * 16-byte aligned bias / residual / mask / output with row pitches % 4 == 0, DHAUG_EUNSUPPORTED otherwise (the caller then splits with
+ * mode 0 and calls dhaug_gemm_bf16).  dmask_act DHAUG_ACT_NONE: no mask.  Replaces, with the split, the fp32 layer products of the
+ * training passes, R/models_Fk_GAN/model_fk_gan_train.py:177-230. */
+int dhaug_gemm_bf16x6_planes(const uint16_t* A_planes, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias,
+                             const float* residual_f32, int64_t ld_res_f32, const float* dmask_f32, int64_t ld_dmask_f32, int dmask_act,
+                             float dmask_slope, float* c_f32, int64_t ldc_f32, int64_t M, int64_t N, int64_t kp, int x_order, int act,
+                             float slope, void* stream);
 
 /* The same split with IEEE-half pieces, x = hi + lo (22 significant bits; three product terms: mode 0 row = [hi|hi|lo], mode 1
  * [hi|lo|hi]): the operands of dhaug_gemm_f16x3.  |x| < 65 504. */

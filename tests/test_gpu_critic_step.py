@@ -481,3 +481,45 @@ def test_ragged_batch_keeps_every_saved_row(M, tag, monkeypatch):
     for k in ref[2]:
         if ref[2][k].numel() > 1:
             assert torch.equal(got[2][k], ref[2][k]) and torch.equal(allrows[2][k], ref[2][k]), (tag, k)
+
+
+@pytest.mark.parametrize("tag", ["d3", "d2"])
+def test_split_operands_as_planes_equal_six_segment_operands(M, tag):
+    """critic_step.PLANES: the fp32-grade ("bf16x6") step with every 256-wide operand split once into three planes -- layer products on
+    dhaug_gemm_bf16x6_planes, weight gradients over virtual rows -- is the step on six-segment operands bit for bit (same product terms, same
+    order), from fewer split launches moving half the bytes."""
+    B, D = 1536, 256
+    args = _args(B, D)
+    shapes = GU.shapes_d3(D) if tag == "d3" else GU.shapes_d2(D)
+    sd = GU.seeded_state_dict(shapes, 43)
+    data = _data(tag, B, 14)
+    assert M.cs.PLANES
+    from dhaug_amd import _lib
+    calls = {}
+    real = _lib.call
+    def spy(name, *a):
+        calls[name] = calls.get(name, 0) + 1
+        return real(name, *a)
+    _lib.call = spy
+    try:
+        W1, C1, g1, p1 = _run(M, tag, args, sd, "bf16x6", data, True)
+        with_planes = dict(calls)
+        calls.clear()
+        M.cs.PLANES = False
+        try:
+            W0, C0, g0, p0 = _run(M, tag, args, sd, "bf16x6", data, True)
+        finally:
+            M.cs.PLANES = True
+    finally:
+        _lib.call = real
+    assert with_planes.get("dhaug_gemm_bf16x6_planes", 0) >= 12 and calls.get("dhaug_gemm_bf16x6_planes", 0) == 0
+    print(tag, "split launches with planes / without:", with_planes["dhaug_split_bf16"], calls["dhaug_split_bf16"])
+    assert with_planes["dhaug_split_bf16"] <= calls["dhaug_split_bf16"]
+    assert W1 == W0 and C1 == C0
+    for k in g0:
+        if k.endswith("weight"):
+            assert torch.equal(g1[k], g0[k]), k
+            assert torch.equal(p1[k], p0[k]), k
+        else:                                                     # (bias gradients: dhaug_colsum_f32 adds its row slabs with atomics -- the same
+            scale = g0[k].abs().max().item() + 1e-12                  # cotangent bits summed in an order that varies from launch to launch)
+            assert (g1[k] - g0[k]).abs().max().item() <= 2e-6 * scale, k

@@ -199,3 +199,55 @@ def test_p8_column_tile_wholly_in_the_pad(ops):
     ops.gemm_nt(A, w, N, K, act=1, c_bf16=out, n_pad=272)
     assert maxabs(out[:, :N].float(), ref) <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
     assert out[:, N:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("M,N,kp,order", [(3000, 256, 256, 0), (3000, 256, 256, 1), (777, 1000, 1024, 0), (513, 64, 64, 1), (4096, 256, 128, 0)])
+def test_planes_operand_is_bit_identical_to_the_six_segment_operand(ops, M, N, kp, order):
+    """dhaug_gemm_bf16x6_planes: the activation side of a "bf16x6" product as the three distinct pieces [hi|mid|lo] (dhaug_split_bf16 mode 2) --
+    the same six product terms in the same order as the six-segment operand (mode 0 against mode 1 weights, or, x_order 1, mode 1 against mode 0
+    weights: the backward chain), so the same bits; plain, with bias + fp32 residual + activation, and with the fp32 mask."""
+    g = torch.Generator().manual_seed(5)
+    k = kp - (0 if kp < 1024 else 24)                             # (DenseDim 1000 padded to 1 024)
+    x = torch.randn(M, k, generator=g).cuda()
+    W = (torch.randn(N, k, generator=g) / k ** 0.5).cuda()
+    res, msk, bias = torch.randn(M, N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda(), torch.randn(N, generator=g).cuda()
+    A6, B6 = ops.split_bf16(x, order, 6, kp), ops.split_bf16(W, 1 - order, 6, kp)
+    A3 = ops.split_bf16(x, 2, 6, kp)
+    assert A3.shape == (M, 3 * kp) and torch.equal(A3[:, :kp], A6[:, :kp])
+    assert ops.gemm_planes_ok(N, kp, bias, res, msk)
+    _, want = ops.gemm_nt(A6, B6, N, 6 * kp, out_f32=True)
+    assert torch.equal(ops.gemm_nt_planes(A3, B6, N, kp, x_order=order), want)
+    ref = x.double().cpu() @ W.double().cpu().t()
+    assert maxabs(want, ref) <= 2e-6 * ref.abs().max().item()
+    _, want = ops.gemm_nt(A6, B6, N, 6 * kp, bias=bias, res_f32=res, act=2, slope=0.01, out_f32=True)
+    assert torch.equal(ops.gemm_nt_planes(A3, B6, N, kp, bias=bias, res_f32=res, act=2, slope=0.01, x_order=order), want)
+    want = ops.gemm_nt_dmask_f32(A6, B6, N, 6 * kp, msk, 1, 0.0, res_f32=res)
+    assert torch.equal(ops.gemm_nt_planes(A3, B6, N, kp, res_f32=res, dmask_f32=msk, dmask_act=1, x_order=order), want)
+    out = torch.full((M, N + 8), 7.0, device="cuda")              # into a column block of a wider buffer
+    ops.gemm_nt_planes(A3, B6, N, kp, res_f32=res, dmask_f32=msk, dmask_act=1, x_order=order, out=out[:, :N])
+    assert torch.equal(out[:, :N], want) and bool((out[:, N:] == 7.0).all())
+
+
+@pytest.mark.parametrize("pa,pb", [(2, 1), (2, 0), (0, 1)])
+def test_weight_gradient_contraction_over_planes_is_bit_identical(ops, pa, pb):
+    """dhaug_tn_layer.planes_a / _b: the grouped weight-gradient launch contracts the three planes of a split operand over six virtual rows per
+    tensor row, in the order of the six-segment operand's rows -- the same sums bit for bit, from half the bytes.  Several layers of a launch,
+    split over the batch and not, narrow and full width; against fp64 too."""
+    g = torch.Generator().manual_seed(9)
+    Mr = 4096 + 64
+    shapes = [(256, 256), (256, 64), (128, 256), (64, 128)]
+    items_p, items_6, refs = [], [], []
+    for N, K in shapes:
+        gt, xt = (torch.randn(Mr, N, generator=g) * 0.01).cuda(), torch.randn(Mr, K, generator=g).cuda()
+        g6, x6 = ops.split_bf16(gt, 1, 6, N), ops.split_bf16(xt, 0, 6, K)
+        g3, x3 = ops.split_bf16(gt, 2, 6, N), ops.split_bf16(xt, 2, 6, K)
+        o6, op = torch.zeros(N, K, device="cuda"), torch.zeros(N, K, device="cuda")
+        items_6.append((g6.view(6 * Mr, N), x6.view(6 * Mr, K), N, K, o6, None, 0, True, 6 * Mr, None, None))
+        items_p.append(((g3.view(3 * Mr, N) if pa else g6.view(6 * Mr, N)), (x3.view(3 * Mr, K) if pb else x6.view(6 * Mr, K)), N, K, op, None, 0,
+                        True, 6 * Mr, None, None, pa, pb))
+        refs.append((gt.double().cpu().t() @ xt.double().cpu(), o6, op))
+    ops.gemm_tn_group(items_6)
+    ops.gemm_tn_group(items_p)
+    for ref, o6, op in refs:
+        assert torch.equal(o6, op)
+        assert maxabs(op, ref) <= 3e-6 * ref.abs().max().item()
