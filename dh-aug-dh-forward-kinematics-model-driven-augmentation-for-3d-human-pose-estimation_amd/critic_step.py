@@ -65,6 +65,9 @@ SPLIT_CACHE = os.environ.get("DHAUG_NO_SPLIT_CACHE") is None
 # the layer products (ops.gemm_nt_planes) and the grouped weight-gradient launch read the pieces in the order of the six-segment operand --
 # bit-identical results.  DHAUG_X6_PLANES=0: six-segment operands everywhere.
 PLANES = os.environ.get("DHAUG_X6_PLANES", "1") != "0"
+# ... and a layer product whose RESULT is such an operand writes the result's planes itself (dhaug_gemm_bf16x6_planes, c_planes): bit for
+# bit the split of the fp32 result, without the split launch (DHAUG_X6_PLANES_OUT=0: split launches)
+PLANES_OUT = os.environ.get("DHAUG_X6_PLANES_OUT", "1") != "0"
 
 # bf16 operands that a kernel of the step writes beside its fp32 result anyway (the assembled real / fake rows, the penalty's cotangent,
 # the KCS operand) are registered as the casts of those tensors instead of being cast again (DHAUG_NO_SEED_CASTS=1: cast launches)
@@ -195,9 +198,18 @@ class _Math:
                     and ops.gemm_planes_ok(n, kp, bias, resc, mask if masked else None, out)):
                 swap = orient == "nn" and SPLIT_CACHE        # (the weights' operand copies as below)
                 Bop = A._w_nt(W, kp, self.prec) if orient == "nt" else A._w_nn(W, self.prec, 0 if swap else 1)
-                return ops.gemm_nt_planes(self.split0(a, k, 2), Bop, n, kp, bias=bias, res_f32=resc, act=act, slope=slope,
-                                          dmask_f32=mask if masked else None, dmask_act=mask_act if masked else NONE, dmask_slope=slope,
-                                          out=out, x_order=1 if swap else 0)
+                # a result that is itself an operand of that width (the next layer's input, sweep 4's) leaves the GEMM with its planes
+                # beside it -- registered as this step's split of the tensor: no split launch for it
+                emit = PLANES_OUT and SPLIT_CACHE and self.planes_ok(n) and ceil16(n) == n and (out is None or out.is_contiguous())
+                r = ops.gemm_nt_planes(self.split0(a, k, 2), Bop, n, kp, bias=bias, res_f32=resc, act=act, slope=slope,
+                                       dmask_f32=mask if masked else None, dmask_act=mask_act if masked else NONE, dmask_slope=slope,
+                                       out=out, x_order=1 if swap else 0, planes_out=emit)
+                if emit:
+                    y, yp = r
+                    self._splits.append((y.data_ptr(), y.shape[0], n, 2, yp))
+                    self._split_src.append(y)
+                    return y
+                return r
         # split-operand arithmetic, backward chain (orient "nn"): the cotangent is split ONCE, in the weight-side layout -- the
         # layout sweep 4 contracts it in (autograd_ops._raw_outer) -- and meets the weights in the activation-side layout
         swap = (not self.bf16) and orient == "nn" and SPLIT_CACHE

@@ -2538,8 +2538,8 @@ int dhaug_gemm_f16x3(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t 
 /* see include/dhaug.h */
 int dhaug_gemm_bf16x6_planes(const uint16_t* A_planes, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias,
                              const float* residual_f32, int64_t ld_res_f32, const float* dmask_f32, int64_t ld_dmask_f32, int dmask_act,
-                             float dmask_slope, float* c_f32, int64_t ldc_f32, int64_t M, int64_t N, int64_t kp, int x_order, int act,
-                             float slope, void* stream) {
+                             float dmask_slope, float* c_f32, int64_t ldc_f32, uint16_t* c_planes, int64_t ld_planes, int64_t M, int64_t N,
+                             int64_t kp, int x_order, int act, float slope, void* stream) {
     DHAUG_CHECK(M >= 0 && N >= 1 && kp >= 64 && (x_order == 0 || x_order == 1), DHAUG_EINVAL);
     DHAUG_CHECK(act >= DHAUG_ACT_NONE && act <= DHAUG_ACT_LRELU && dmask_act >= DHAUG_ACT_NONE && dmask_act <= DHAUG_ACT_LRELU, DHAUG_EINVAL);
     if (M == 0) return DHAUG_OK;
@@ -2557,6 +2557,10 @@ int dhaug_gemm_bf16x6_planes(const uint16_t* A_planes, int64_t lda, const uint16
                nullptr, 0, dneg, nullptr, nullptr, 0, dmask_f32, ld_dmask_f32};
     // dhaug_split_bf16 (terms 6): mode 0 is [hi | hi | mid | mid | hi | lo] = planes 0 0 1 1 0 2, mode 1 [hi | mid | hi | mid | lo | hi] = 0 1 0 1 2 0
     p.xp_lg = lg + 1; p.xp_map = x_order == 0 ? 0x850u : 0x244u; p.xp_kp = kp;
+    if (c_planes != nullptr) {
+        DHAUG_CHECK(ld_planes >= 3 * N && ld_planes % 8 == 0 && dhaug_aligned16(c_planes), DHAUG_EALIGN);
+        p.cp = c_planes; p.ldcp = ld_planes;
+    }
     DHAUG_CHECK(dhaug_p8_supported(p), DHAUG_EUNSUPPORTED);
     return dhaug_p8_launch((hipStream_t)stream, p);
 }

@@ -25,6 +25,9 @@ struct GemmArgs {
     // [hi | mid | lo] of xp_kp columns each (lda >= 3 xp_kp) and K = 6 xp_kp: K-segment s of the contraction reads plane
     // (xp_map >> 2 s) & 3.  xp_lg = 1 + log2(xp_kp / 64); 0: A is an ordinary K-wide operand.
     int xp_lg; unsigned xp_map; long long xp_kp;
+    // ... and its result once more as such planes (N == cp_kp columns per piece, ldcp >= 3 N): what dhaug_split_bf16(c_f32, mode 2) would
+    // make of it, written by the epilogue that has the values in registers -- the next layer's operand without a split launch
+    uint16_t* cp; long long ldcp;
 };
 
 // Up to eight independent GEMMs of ONE shape as one launch (dhaug_gemm_bf16_group)
@@ -39,7 +42,7 @@ template <class T> __device__ __forceinline__ T* as_global(T* q) { return (T*)(_
 __device__ __forceinline__ void globalize(GemmArgs& p) {
     p.A = as_global(p.A); p.B = as_global(p.B); p.bias = as_global(p.bias); p.res = as_global(p.res); p.resf = as_global(p.resf);
     p.cb = as_global(p.cb); p.cf = as_global(p.cf); p.dmask = as_global(p.dmask); p.dbits = as_global(p.dbits); p.dbits2 = as_global(p.dbits2);
-    p.dmaskf = as_global(p.dmaskf);
+    p.dmaskf = as_global(p.dmaskf); p.cp = as_global(p.cp);
 }
 
 // the member's arguments of a grouped launch, read from the kernarg segment with scalar loads (a by-value array indexed dynamically

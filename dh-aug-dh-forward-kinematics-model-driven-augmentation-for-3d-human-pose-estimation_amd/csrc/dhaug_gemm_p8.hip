@@ -334,6 +334,23 @@ __device__ __forceinline__ void p8_epilogue(const GemmArgs& p, const f32x4 (&acc
                             *reinterpret_cast<f32x4*>(p.cf + gm * p.ldcf + ncol) = v[it][0];
                             *reinterpret_cast<f32x4*>(p.cf + gm * p.ldcf + ncol + 4) = v[it][1];
                         }
+                        if (p.cp != nullptr) {                       // the three bf16 pieces of the fp32 result (split_kernel's arithmetic, elem.hip)
+                            uint32_t hi[4], mid[4], lo[4];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float xv = v[it][e >> 2][e & 3];
+                                const uint16_t h = dhaug_f32_to_bf16(xv);
+                                const float r1 = xv - dhaug_bf16_to_f32(h);
+                                const uint16_t m = dhaug_f32_to_bf16(r1);
+                                const uint16_t l = dhaug_f32_to_bf16(r1 - dhaug_bf16_to_f32(m));
+                                if (e & 1) { hi[e >> 1] |= (uint32_t)h << 16; mid[e >> 1] |= (uint32_t)m << 16; lo[e >> 1] |= (uint32_t)l << 16; }
+                                else { hi[e >> 1] = h; mid[e >> 1] = m; lo[e >> 1] = l; }
+                            }
+                            uint16_t* prow = p.cp + gm * p.ldcp + ncol;
+                            *reinterpret_cast<uint4*>(prow) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                            *reinterpret_cast<uint4*>(prow + p.N) = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+                            *reinterpret_cast<uint4*>(prow + 2 * p.N) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+                        }
                     } else if (col_pad) {
                         *reinterpret_cast<uint4*>(p.cb + gm * p.ldcb + ncol) = make_uint4(0u, 0u, 0u, 0u);
                     }
@@ -481,6 +498,7 @@ bool dhaug_p8_supported(const dhaug_gemm::GemmArgs& p) {
     if (p.dmask != nullptr && !(p.ld_dmask % 8 == 0 && al(p.dmask, 16))) return false;
     if (p.resf != nullptr && !(p.ld_resf % 4 == 0 && al(p.resf, 16))) return false;
     if (p.dmaskf != nullptr && !(p.ld_dmaskf % 4 == 0 && al(p.dmaskf, 16))) return false;
+    if (p.cp != nullptr && !(p.cf != nullptr && p.ldcp % 8 == 0 && p.ldcp >= 3 * p.N && al(p.cp, 16))) return false;
     return true;
 }
 

@@ -270,7 +270,8 @@ def gemm_planes_ok(N, kp, bias=None, res_f32=None, dmask_f32=None, out=None):
             and row(res_f32) and row(dmask_f32) and row(out))
 
 
-def gemm_nt_planes(A3, B6, N, kp, bias=None, res_f32=None, act=0, slope=0.0, dmask_f32=None, dmask_act=0, dmask_slope=0.0, out=None, x_order=0):
+def gemm_nt_planes(A3, B6, N, kp, bias=None, res_f32=None, act=0, slope=0.0, dmask_f32=None, dmask_act=0, dmask_slope=0.0, out=None, x_order=0,
+                   planes_out=False):
     """fp32 (M, N) = act(x W^T + bias + res_f32), masked by dmask_f32, in the bf16x6 arithmetic with the activation side as planes:
     A3 = split_bf16(x, 2, 6, kp) = [hi|mid|lo], B6 = split_bf16(W, 1, 6, kp) (dhaug_gemm_bf16x6_planes: bit-identical to gemm_nt on the
     mode 0 split); x_order 1: the planes stand for the mode 1 operand, B6 = split_bf16(W, 0, 6, kp)."""
@@ -281,10 +282,13 @@ def gemm_nt_planes(A3, B6, N, kp, bias=None, res_f32=None, act=0, slope=0.0, dma
     assert out.dtype == torch.float32 and out.stride(1) == 1 and out.shape[0] == M
     if bias is not None:
         bias = _dev(bias, torch.float32, "gemm_nt_planes")
+    # planes_out: the result once more as split_bf16(out, 2, 6, N) would make it (N a multiple of 8), written by the GEMM's epilogue
+    cp = torch.empty((M, 3 * N), dtype=BF16, device=A3.device) if planes_out else None
     _lib.call("dhaug_gemm_bf16x6_planes", _p(A3), A3.stride(0), _p(B6), B6.stride(0), _p(bias), _p(res_f32),
               0 if res_f32 is None else res_f32.stride(0), _p(dmask_f32), 0 if dmask_f32 is None else dmask_f32.stride(0), int(dmask_act),
-              float(dmask_slope), _p(out), out.stride(0), M, N, kp, int(x_order), act, float(slope), _stream())
-    return out
+              float(dmask_slope), _p(out), out.stride(0), _p(cp), 0 if cp is None else cp.stride(0), M, N, kp, int(x_order), act, float(slope),
+              _stream())
+    return (out, cp) if planes_out else out
 
 
 def split_f16(src, mode, pad_cols=None):

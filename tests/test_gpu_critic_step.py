@@ -513,8 +513,8 @@ def test_split_operands_as_planes_equal_six_segment_operands(M, tag):
     finally:
         _lib.call = real
     assert with_planes.get("dhaug_gemm_bf16x6_planes", 0) >= 12 and calls.get("dhaug_gemm_bf16x6_planes", 0) == 0
-    print(tag, "split launches with planes / without:", with_planes["dhaug_split_bf16"], calls["dhaug_split_bf16"])
-    assert with_planes["dhaug_split_bf16"] <= calls["dhaug_split_bf16"]
+    # (results that are operands themselves leave the GEMM with their planes: critic_step.PLANES_OUT)
+    assert M.cs.PLANES_OUT and with_planes["dhaug_split_bf16"] <= calls["dhaug_split_bf16"] - 8, (with_planes["dhaug_split_bf16"], calls["dhaug_split_bf16"])
     assert W1 == W0 and C1 == C0
     for k in g0:
         if k.endswith("weight"):

@@ -223,6 +223,8 @@ def test_planes_operand_is_bit_identical_to_the_six_segment_operand(ops, M, N, k
     assert torch.equal(ops.gemm_nt_planes(A3, B6, N, kp, bias=bias, res_f32=res, act=2, slope=0.01, x_order=order), want)
     want = ops.gemm_nt_dmask_f32(A6, B6, N, 6 * kp, msk, 1, 0.0, res_f32=res)
     assert torch.equal(ops.gemm_nt_planes(A3, B6, N, kp, res_f32=res, dmask_f32=msk, dmask_act=1, x_order=order), want)
+    got, planes = ops.gemm_nt_planes(A3, B6, N, kp, res_f32=res, dmask_f32=msk, dmask_act=1, x_order=order, planes_out=True)
+    assert torch.equal(got, want) and torch.equal(planes, ops.split_bf16(want, 2, 6, N))     # the result's own planes, from the epilogue
     out = torch.full((M, N + 8), 7.0, device="cuda")              # into a column block of a wider buffer
     ops.gemm_nt_planes(A3, B6, N, kp, res_f32=res, dmask_f32=msk, dmask_act=1, x_order=order, out=out[:, :N])
     assert torch.equal(out[:, :N], want) and bool((out[:, N:] == 7.0).all())
