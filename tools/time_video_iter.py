@@ -81,3 +81,23 @@ for kind, obj in getattr(fc, "items", []):
             torch.cuda.synchronize()
             ts.append((time.perf_counter() - t0) * 1e3)
         print("  chain %d alone: %.3f ms" % (i, min(ts)))
+# the same chains dealt to fewer streams (the chains of one stream one after the other): what the overlap of four is worth
+for kind, obj in getattr(fc, "items", []):
+    if kind == "graph":
+        continue
+    for part in ([[0], [1], [2], [3]], [[0, 2], [1, 3]], [[1, 2], [0, 3]], [[1], [0, 2, 3]], [[0, 1], [2, 3]], [[0, 1, 2, 3]]):
+        ts = []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for grp in part:
+                st = obj[grp[0]][0]
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    for i in grp:
+                        obj[i][1].replay()
+            for grp in part:
+                cur.wait_stream(obj[grp[0]][0])
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        print("  chains as %s: %.3f ms" % (part, min(ts)))
