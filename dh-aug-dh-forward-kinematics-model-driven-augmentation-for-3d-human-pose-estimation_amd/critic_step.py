@@ -210,6 +210,21 @@ class _Math:
                     self._split_src.append(y)
                     return y
                 return r
+        if (PLANES_OUT and SPLIT_CACHE and orient == "nt" and not self.bf16 and self.T == 6 and not self.planes_ok(k) and self.planes_ok(n)
+                and ceil16(n) == n and a.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1 and (out is None or out.is_contiguous())):
+            # a narrow input layer (30 / 48 -> DenseDim) whose result is an operand of plane width: the six-segment product on the same
+            # kernel, which writes the result's planes beside it
+            masked = mask is not None and mask_act != NONE
+            resc = res if (res is None or res.is_contiguous()) else res.contiguous()
+            if ((resc is None or resc.dtype == torch.float32) and (not masked or (mask.dtype == torch.float32 and mask.stride(1) == 1))
+                    and (out is None or (out.dtype == torch.float32 and out.stride(1) == 1))
+                    and ops.gemm_planes_ok(n, kp, bias, resc, mask if masked else None, out, six=True)):
+                y, yp = ops.gemm_nt_planes(self.split0(a, k, 0), A._w_nt(W, kp, self.prec), n, kp, bias=bias, res_f32=resc, act=act, slope=slope,
+                                           dmask_f32=mask if masked else None, dmask_act=mask_act if masked else NONE, dmask_slope=slope,
+                                           out=out, x_order=2, planes_out=True)
+                self._splits.append((y.data_ptr(), y.shape[0], n, 2, yp))
+                self._split_src.append(y)
+                return y
         # split-operand arithmetic, backward chain (orient "nn"): the cotangent is split ONCE, in the weight-side layout -- the
         # layout sweep 4 contracts it in (autograd_ops._raw_outer) -- and meets the weights in the activation-side layout
         swap = (not self.bf16) and orient == "nn" and SPLIT_CACHE

@@ -2540,14 +2540,15 @@ int dhaug_gemm_bf16x6_planes(const uint16_t* A_planes, int64_t lda, const uint16
                              const float* residual_f32, int64_t ld_res_f32, const float* dmask_f32, int64_t ld_dmask_f32, int dmask_act,
                              float dmask_slope, float* c_f32, int64_t ldc_f32, uint16_t* c_planes, int64_t ld_planes, int64_t M, int64_t N,
                              int64_t kp, int x_order, int act, float slope, void* stream) {
-    DHAUG_CHECK(M >= 0 && N >= 1 && kp >= 64 && (x_order == 0 || x_order == 1), DHAUG_EINVAL);
+    DHAUG_CHECK(M >= 0 && N >= 1 && x_order >= 0 && x_order <= 2 && kp >= (x_order == 2 ? 16 : 64), DHAUG_EINVAL);
     DHAUG_CHECK(act >= DHAUG_ACT_NONE && act <= DHAUG_ACT_LRELU && dmask_act >= DHAUG_ACT_NONE && dmask_act <= DHAUG_ACT_LRELU, DHAUG_EINVAL);
     if (M == 0) return DHAUG_OK;
     DHAUG_CHECK_PTR(A_planes); DHAUG_CHECK_PTR(B); DHAUG_CHECK_PTR(c_f32);
+    const bool six = x_order == 2;                                             // A is the ordinary six-segment operand (a narrow input layer)
     int lg = 0;
     while ((64ll << lg) < kp) ++lg;
-    DHAUG_CHECK((64ll << lg) == kp, DHAUG_EUNSUPPORTED);                       // 64, 128, 256, ... columns per piece
-    DHAUG_CHECK(lda % 8 == 0 && ldb % 8 == 0 && lda >= 3 * kp && ldb >= 6 * kp && dhaug_aligned16(A_planes) && dhaug_aligned16(B), DHAUG_EALIGN);
+    DHAUG_CHECK(six || (64ll << lg) == kp, DHAUG_EUNSUPPORTED);                // 64, 128, 256, ... columns per piece
+    DHAUG_CHECK(lda % 8 == 0 && ldb % 8 == 0 && lda >= (six ? 6 : 3) * kp && ldb >= 6 * kp && dhaug_aligned16(A_planes) && dhaug_aligned16(B), DHAUG_EALIGN);
     if (residual_f32) DHAUG_CHECK(ld_res_f32 >= N, DHAUG_EINVAL);
     if (dmask_act == DHAUG_ACT_NONE) dmask_f32 = nullptr;
     if (dmask_f32) DHAUG_CHECK(ld_dmask_f32 >= N, DHAUG_EINVAL);
@@ -2556,7 +2557,7 @@ int dhaug_gemm_bf16x6_planes(const uint16_t* A_planes, int64_t lda, const uint16
     GemmArgs p{A_planes, lda, B, ldb, bias, nullptr, 0, residual_f32, ld_res_f32, nullptr, 0, 0, c_f32, ldc_f32, M, N, 6 * kp, N, act, slope,
                nullptr, 0, dneg, nullptr, nullptr, 0, dmask_f32, ld_dmask_f32};
     // dhaug_split_bf16 (terms 6): mode 0 is [hi | hi | mid | mid | hi | lo] = planes 0 0 1 1 0 2, mode 1 [hi | mid | hi | mid | lo | hi] = 0 1 0 1 2 0
-    p.xp_lg = lg + 1; p.xp_map = x_order == 0 ? 0x850u : 0x244u; p.xp_kp = kp;
+    if (!six) { p.xp_lg = lg + 1; p.xp_map = x_order == 0 ? 0x850u : 0x244u; p.xp_kp = kp; }
     if (c_planes != nullptr) {
         DHAUG_CHECK(ld_planes >= 3 * N && ld_planes % 8 == 0 && dhaug_aligned16(c_planes), DHAUG_EALIGN);
         p.cp = c_planes; p.ldcp = ld_planes;

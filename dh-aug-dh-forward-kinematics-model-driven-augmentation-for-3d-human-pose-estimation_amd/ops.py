@@ -262,12 +262,13 @@ def split_bf16(src, mode, terms, pad_cols=None):
     return dst
 
 
-def gemm_planes_ok(N, kp, bias=None, res_f32=None, dmask_f32=None, out=None):
-    """shapes dhaug_gemm_bf16x6_planes takes (the ping-pong tiles, a power-of-two piece width)"""
+def gemm_planes_ok(N, kp, bias=None, res_f32=None, dmask_f32=None, out=None, six=False):
+    """shapes dhaug_gemm_bf16x6_planes takes (the ping-pong tiles; a power-of-two piece width, or -- six: the ordinary six-segment operand,
+    x_order 2 -- any width with 6 kp >= 128)"""
     al = lambda t: t is None or (t.data_ptr() % 16 == 0)
     row = lambda t: t is None or (t.stride(1) == 1 and t.stride(0) % 4 == 0)
-    return (N % 8 == 0 and kp >= 64 and (kp & (kp - 1)) == 0 and al(bias) and al(res_f32) and al(dmask_f32) and al(out)
-            and row(res_f32) and row(dmask_f32) and row(out))
+    wide = (6 * kp >= 128 and kp % 8 == 0) if six else (kp >= 64 and (kp & (kp - 1)) == 0)
+    return (N % 8 == 0 and wide and al(bias) and al(res_f32) and al(dmask_f32) and al(out) and row(res_f32) and row(dmask_f32) and row(out))
 
 
 def gemm_nt_planes(A3, B6, N, kp, bias=None, res_f32=None, act=0, slope=0.0, dmask_f32=None, dmask_act=0, dmask_slope=0.0, out=None, x_order=0,

@@ -392,7 +392,9 @@ int dhaug_split_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ro
  * results -- but the split writes 6 instead of 12 bytes per value and the GEMM's re-reads of a piece come from L2 / MALL, not from HBM.
  * kp = 64 * 2^j (a K-tile never straddles two pieces); runs on the 256 x 256 x 64 ping-pong tiles only (csrc/dhaug_gemm_p8.hip): N % 8 == 0,
  * 16-byte aligned bias / residual / mask / output with row pitches % 4 == 0, DHAUG_EUNSUPPORTED otherwise (the caller then splits with
- * mode 0 and calls dhaug_gemm_bf16).  dmask_act DHAUG_ACT_NONE: no mask.  c_planes (optional; ld_planes >= 3 N, % 8 == 0, 16-byte
+ * mode 0 and calls dhaug_gemm_bf16).  dmask_act DHAUG_ACT_NONE: no mask.
+ * x_order 2: A_planes is the ordinary six-segment operand (mode 0, lda >= 6 kp, any kp % 8 == 0 with 6 kp >= 128: a narrow input
+ * layer whose RESULT is wanted as planes).  c_planes (optional; ld_planes >= 3 N, % 8 == 0, 16-byte
  * aligned): the result once more as planes [hi|mid|lo] of N columns each -- bit for bit what dhaug_split_bf16(c_f32, mode 2, terms 6,
  * pad_cols N) makes of it, written by the epilogue that holds the values: the next layer's operand without a split launch.  Replaces, with the split, the fp32 layer products of the
  * training passes, R/models_Fk_GAN/model_fk_gan_train.py:177-230. */

@@ -253,3 +253,18 @@ def test_weight_gradient_contraction_over_planes_is_bit_identical(ops, pa, pb):
     for ref, o6, op in refs:
         assert torch.equal(o6, op)
         assert maxabs(op, ref) <= 3e-6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("M,N,k,kp", [(3000, 256, 30, 32), (2049, 256, 48, 48)])
+def test_six_segment_input_layer_writes_its_results_planes(ops, M, N, k, kp):
+    """dhaug_gemm_bf16x6_planes with x_order 2: a narrow input layer (30 / 48 -> DenseDim) on its ordinary six-segment operand, the result
+    also as planes -- same bits as dhaug_gemm_bf16 on the same operands, planes = the split of the result."""
+    g = torch.Generator().manual_seed(6)
+    x, W, bias = torch.randn(M, k, generator=g).cuda(), (torch.randn(N, k, generator=g) / k ** 0.5).cuda(), torch.randn(N, generator=g).cuda()
+    A6, B6 = ops.split_bf16(x, 0, 6, kp), ops.split_bf16(W, 1, 6, kp)
+    assert ops.gemm_planes_ok(N, kp, bias, six=True)
+    _, want = ops.gemm_nt(A6, B6, N, 6 * kp, bias=bias, act=1, out_f32=True)
+    got, planes = ops.gemm_nt_planes(A6, B6, N, kp, bias=bias, act=1, x_order=2, planes_out=True)
+    assert torch.equal(got, want) and torch.equal(planes, ops.split_bf16(want, 2, 6, N))
+    ref = torch.relu(x.double().cpu() @ W.double().cpu().t() + bias.double().cpu())
+    assert maxabs(want, ref) <= 2e-6 * ref.abs().max().item()
