@@ -998,3 +998,23 @@ def test_gen_tail_in_kernel_jitter(ops):
     assert (other[4] != sc).float().mean().item() > 0.99
     explicit = ops.gen_tail_forward_critics(head, bl, sc, True, None)
     assert maxabs(explicit[0], fake) == 0.0
+
+
+@pytest.mark.parametrize("M,N", [(196608, 256), (65536 + 2, 100), (9999, 256), (8192, 512)])
+def test_colsum_f32_vector_path(ops, M, N):
+    """dhaug_colsum_f32 on rows of whole 16-byte pieces (four columns per thread, four row pairs requested together): against fp64, a column
+    block of a wider buffer, accumulate, and the pairing of rows r and r + M/2 that keeps a WGAN critic's logit-bias gradient exactly zero."""
+    gen = torch.Generator().manual_seed(17)
+    X = torch.randn(M, N, generator=gen).cuda()
+    ref = X.double().sum(0).cpu()
+    tol = 3e-7 * M ** 0.5 * 4
+    assert maxabs(ops.colsum(X), ref) <= tol * 8
+    wide = torch.randn(M, N + 12, generator=gen).cuda()
+    blk = wide[:, 4:4 + N]                                        # (16-byte aligned column block, row pitch % 4 == 0: vector path)
+    assert maxabs(ops.colsum(blk), blk.double().sum(0).cpu()) <= tol * 8
+    out = torch.full((N,), 2.0, device="cuda")
+    ops.colsum(X, out=out, accumulate=True)
+    assert maxabs(out, ref + 2.0) <= tol * 8
+    if M % 2 == 0:
+        Y = X.clone(); Y[M // 2:] = -Y[:M // 2]                     # second half the exact negative of the first: every column sums to exactly 0
+        assert float(ops.colsum(Y).abs().max()) == 0.0
