@@ -45,6 +45,7 @@ SIGNATURES = {
     "dhaug_split_f16": [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp],
     "dhaug_gemm_bf16x6_planes": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _f32, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _f32, _vp],
     "dhaug_gemm_f16x3": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _f32, _vp],
+    "dhaug_gemm_f16x3_planes": [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _vp],
     "dhaug_colsum_f32": [_vp, _i64, _vp, _i64, _i64, _i32, _vp],
     "dhaug_colsum_bf16": [_vp, _i64, _vp, _i64, _i64, _i32, _vp],
     "dhaug_act_backward_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i32, _f32, _vp],

@@ -28,6 +28,15 @@ BF16 = torch.bfloat16
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 TERMS = {"bf16x3": 3, "bf16x6": 6}
 F16X3_LAYER = "f16x3l"     # forward-only layer arithmetic: IEEE-half pairs on dhaug_gemm_f16x3 (see _raw_linear)
+F16X3_PLANES = os.environ.get("DHAUG_F16X3_PLANES", "1") != "0"     # ... with the operand split written by the producing layer's epilogue
+
+
+def _pow2_width(k):
+    """piece width of an operand carried as planes: the power of two >= max(k, 64)"""
+    w = 64
+    while w < k:
+        w *= 2
+    return w
 # (activation-side segment, weight-side segment) holding (hi, mid|lo ...) for the TN products
 _SEG = {3: dict(hi=0, lo=2), 6: dict(hi=0, mid=2, lo=5)}
 _PAIRS = {3: (("hi", "hi"), ("hi", "lo"), ("lo", "hi")),
@@ -160,6 +169,24 @@ def _raw_linear(x, W, bias, res, act, slope, prec, out_f32):
         xf = x.float() if x.dtype == BF16 else x
         rf = res if (res is None or (res.dtype == torch.float32 and res.stride(-1) == 1)) else res.float().contiguous()
         if ops.gemm_f16x3_ok(N, 3 * Kp, bias, rf) and xf.dim() == 2 and xf.stride(1) == 1:
+            if F16X3_PLANES:
+                # the split left out of the chain of layers: a layer whose result is wide enough to be the next layer's operand writes the
+                # result's two pieces [hi | lo] from its epilogue (piece width: the next power of two -- 1 024 at DenseDim 1000) and hangs
+                # them on the tensor it returns; the next layer finds them there (a tensor made any other way has none and is split as before)
+                kp2 = _pow2_width(K)
+                have = getattr(x, "_dhaug_f16_planes", None)
+                if have is not None and (have.shape[1] != 2 * kp2 or have.shape[0] != xf.shape[0]):
+                    have = None
+                emit = _pow2_width(N) if N >= 64 else 0
+                if have is not None:
+                    r = ops.gemm_nt_f16x3_planes(have, _w_nt(W, kp2, prec), N, kp2, True, bias=bias, res_f32=rf, act=act, slope=slope, planes_kp=emit)
+                else:
+                    r = ops.gemm_nt_f16x3_planes(ops.split_f16(xf, 0, Kp), _w_nt(W, Kp, prec), N, Kp, False, bias=bias, res_f32=rf, act=act,
+                                                 slope=slope, planes_kp=emit)
+                if emit:
+                    r[0]._dhaug_f16_planes = r[1]
+                    return r[0]
+                return r
             return ops.gemm_nt_f16x3(ops.split_f16(xf, 0, Kp), _w_nt(W, Kp, prec), N, 3 * Kp, bias=bias, res_f32=rf, act=act, slope=slope)
         prec = "bf16x6"
     T = TERMS[prec]

@@ -93,10 +93,11 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ sr
         }
         const uint4 H = make_uint4(hi[0], hi[1], hi[2], hi[3]), Mi = make_uint4(mid[0], mid[1], mid[2], mid[3]),
                     L = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-        uint16_t* row = dst + r * (mode == 2 ? 3 : terms) * pad_cols + c;
+        uint16_t* row = dst + r * (mode == 2 ? (F16 ? 2 : 3) : terms) * pad_cols + c;
         auto put = [&](int t, const uint4& v) { *reinterpret_cast<uint4*>(row + t * pad_cols) = v; };
-        if (mode == 2) {                                           // the three distinct pieces once: [hi | mid | lo] (dhaug_gemm_bf16x6_planes)
-            put(0, H); put(1, Mi); put(2, L);
+        if (mode == 2) {                                           // the distinct pieces once: [hi | mid | lo] (dhaug_gemm_bf16x6_planes), [hi | lo] in IEEE half
+            put(0, H); put(1, Mi);
+            if (!F16) put(2, L);
         } else if (terms == 3) {
             put(0, H); put(1, mode == 0 ? H : Mi); put(2, mode == 0 ? Mi : H);
         } else if (mode == 0) {
@@ -709,7 +710,7 @@ int dhaug_split_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ro
 /* see include/dhaug.h */
 int dhaug_split_f16(const float* src, int64_t ld_src, uint16_t* dst, int64_t rows, int64_t cols, int64_t pad_cols, int mode,
                     void* stream) {
-    DHAUG_CHECK(rows >= 0 && cols >= 1 && pad_cols >= cols && ld_src >= cols && (mode == 0 || mode == 1), DHAUG_EINVAL);
+    DHAUG_CHECK(rows >= 0 && cols >= 1 && pad_cols >= cols && ld_src >= cols && (mode == 0 || mode == 1 || mode == 2), DHAUG_EINVAL);
     if (rows == 0) return DHAUG_OK;
     DHAUG_CHECK_PTR(src); DHAUG_CHECK_PTR(dst);
     DHAUG_CHECK(pad_cols % 8 == 0 && dhaug_aligned16(dst), DHAUG_EALIGN);

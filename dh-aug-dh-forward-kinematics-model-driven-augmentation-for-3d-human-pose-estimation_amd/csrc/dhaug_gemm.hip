@@ -2536,6 +2536,31 @@ int dhaug_gemm_f16x3(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t 
 }
 
 /* see include/dhaug.h */
+int dhaug_gemm_f16x3_planes(const uint16_t* A, int64_t lda, int a_planes, const uint16_t* B, int64_t ldb, const float* bias,
+                            const float* residual_f32, int64_t ld_res_f32, float* c_f32, int64_t ldc_f32, uint16_t* c_planes, int64_t ld_planes,
+                            int64_t planes_kp, int64_t M, int64_t N, int64_t kp, int act, float slope, void* stream) {
+    DHAUG_CHECK(M >= 0 && N >= 1 && kp >= 16 && kp % 8 == 0, DHAUG_EINVAL);
+    DHAUG_CHECK(act >= DHAUG_ACT_NONE && act <= DHAUG_ACT_LRELU, DHAUG_EINVAL);
+    if (M == 0) return DHAUG_OK;
+    DHAUG_CHECK_PTR(A); DHAUG_CHECK_PTR(B); DHAUG_CHECK_PTR(c_f32);
+    int lg = 0;
+    while ((64ll << lg) < kp) ++lg;
+    DHAUG_CHECK(!a_planes || (64ll << lg) == kp, DHAUG_EUNSUPPORTED);          // planes: 64, 128, 256, ... columns per piece
+    DHAUG_CHECK(lda % 8 == 0 && ldb % 8 == 0 && lda >= (a_planes ? 2 : 3) * kp && ldb >= 3 * kp && dhaug_aligned16(A) && dhaug_aligned16(B), DHAUG_EALIGN);
+    if (residual_f32) DHAUG_CHECK(ld_res_f32 >= N, DHAUG_EINVAL);
+    DHAUG_CHECK(ldc_f32 >= N, DHAUG_EINVAL);
+    GemmArgs p{A, lda, B, ldb, bias, nullptr, 0, residual_f32, ld_res_f32, nullptr, 0, 0, c_f32, ldc_f32, M, N, 3 * kp, N, act, slope,
+               nullptr, 0, 1.0f, nullptr, nullptr, 0};
+    if (a_planes) { p.xp_lg = lg + 1; p.xp_map = 0x10u; p.xp_kp = kp; }        // dhaug_split_f16 mode 0 is [hi | hi | lo] = pieces 0 0 1
+    if (c_planes != nullptr) {
+        DHAUG_CHECK(planes_kp >= N && planes_kp % 8 == 0 && ld_planes >= 2 * planes_kp && ld_planes % 8 == 0 && dhaug_aligned16(c_planes), DHAUG_EALIGN);
+        p.cp = c_planes; p.ldcp = ld_planes; p.cp_kp = planes_kp;
+    }
+    DHAUG_CHECK(dhaug_p8_supported(p), DHAUG_EUNSUPPORTED);
+    return dhaug_p8_launch_f16((hipStream_t)stream, p);
+}
+
+/* see include/dhaug.h */
 int dhaug_gemm_bf16x6_planes(const uint16_t* A_planes, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias,
                              const float* residual_f32, int64_t ld_res_f32, const float* dmask_f32, int64_t ld_dmask_f32, int dmask_act,
                              float dmask_slope, float* c_f32, int64_t ldc_f32, uint16_t* c_planes, int64_t ld_planes, int64_t M, int64_t N,
@@ -2560,7 +2585,7 @@ int dhaug_gemm_bf16x6_planes(const uint16_t* A_planes, int64_t lda, const uint16
     if (!six) { p.xp_lg = lg + 1; p.xp_map = x_order == 0 ? 0x850u : 0x244u; p.xp_kp = kp; }
     if (c_planes != nullptr) {
         DHAUG_CHECK(ld_planes >= 3 * N && ld_planes % 8 == 0 && dhaug_aligned16(c_planes), DHAUG_EALIGN);
-        p.cp = c_planes; p.ldcp = ld_planes;
+        p.cp = c_planes; p.ldcp = ld_planes; p.cp_kp = N;
     }
     DHAUG_CHECK(dhaug_p8_supported(p), DHAUG_EUNSUPPORTED);
     return dhaug_p8_launch((hipStream_t)stream, p);

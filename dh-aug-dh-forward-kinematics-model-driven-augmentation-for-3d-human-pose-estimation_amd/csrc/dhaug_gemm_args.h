@@ -23,11 +23,12 @@ struct GemmArgs {
                                                              // whose epilogue is nt_store_tile / the ping-pong kernel's
     // The ping-pong kernel only (dhaug_gemm_bf16x6_planes): A holds the THREE distinct bf16 pieces of a split fp32 operand as planes
     // [hi | mid | lo] of xp_kp columns each (lda >= 3 xp_kp) and K = 6 xp_kp: K-segment s of the contraction reads plane
-    // (xp_map >> 2 s) & 3.  xp_lg = 1 + log2(xp_kp / 64); 0: A is an ordinary K-wide operand.
+    // (xp_map >> 2 s) & 3.  xp_lg = 1 + log2(xp_kp / 64); 0: A is an ordinary K-wide operand.  IEEE-half operands (dhaug_gemm_f16x3_planes):
+    // two pieces [hi | lo], lda >= 2 xp_kp, K = 3 xp_kp, the result's planes likewise two.
     int xp_lg; unsigned xp_map; long long xp_kp;
     // ... and its result once more as such planes (N == cp_kp columns per piece, ldcp >= 3 N): what dhaug_split_bf16(c_f32, mode 2) would
     // make of it, written by the epilogue that has the values in registers -- the next layer's operand without a split launch
-    uint16_t* cp; long long ldcp;
+    uint16_t* cp; long long ldcp; long long cp_kp;          // (cp_kp >= N columns per piece, % 8 == 0; columns [N, cp_kp) are written as zeros)
 };
 
 // Up to eight independent GEMMs of ONE shape as one launch (dhaug_gemm_bf16_group)

@@ -218,7 +218,7 @@ struct P8 {
 // rows (residual, mask) is requested first, the rows are computed, then stored; a layer without residual / mask (MODE 0) has no wait at
 // all behind its stores.  (The first version loaded where it used: a full wait, i.e. a store round trip, per row group -- 21 000 clocks of
 // the tile's 82 000.)  MODE 1: bf16 residual / mask; MODE 2: fp32 ones as well (the split-operand arithmetic): fewer rows per group.
-template <int MODE>
+template <int MODE, bool F16>
 __device__ __forceinline__ void p8_epilogue(const GemmArgs& p, const f32x4 (&acc)[8][4], unsigned char* p8sm, int wave, int lane, long long m0,
                                             long long n0) {
     constexpr int CH = MODE == 0 ? 8 : (MODE == 1 ? 4 : 2);         // rows (per lane) whose operands travel together: registers
@@ -334,25 +334,38 @@ __device__ __forceinline__ void p8_epilogue(const GemmArgs& p, const f32x4 (&acc
                             *reinterpret_cast<f32x4*>(p.cf + gm * p.ldcf + ncol) = v[it][0];
                             *reinterpret_cast<f32x4*>(p.cf + gm * p.ldcf + ncol + 4) = v[it][1];
                         }
-                        if (p.cp != nullptr) {                       // the three bf16 pieces of the fp32 result (split_kernel's arithmetic, elem.hip)
+                        if (p.cp != nullptr) {                       // the pieces of the fp32 result (split_kernel's arithmetic, elem.hip)
                             uint32_t hi[4], mid[4], lo[4];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
                                 const float xv = v[it][e >> 2][e & 3];
-                                const uint16_t h = dhaug_f32_to_bf16(xv);
-                                const float r1 = xv - dhaug_bf16_to_f32(h);
-                                const uint16_t m = dhaug_f32_to_bf16(r1);
-                                const uint16_t l = dhaug_f32_to_bf16(r1 - dhaug_bf16_to_f32(m));
+                                uint16_t h, m, l = 0;
+                                if (F16) {
+                                    const _Float16 hh = (_Float16)xv;
+                                    const _Float16 mm2 = (_Float16)(xv - (float)hh);
+                                    h = __builtin_bit_cast(uint16_t, hh); m = __builtin_bit_cast(uint16_t, mm2);
+                                } else {
+                                    h = dhaug_f32_to_bf16(xv);
+                                    const float r1 = xv - dhaug_bf16_to_f32(h);
+                                    m = dhaug_f32_to_bf16(r1);
+                                    l = dhaug_f32_to_bf16(r1 - dhaug_bf16_to_f32(m));
+                                }
                                 if (e & 1) { hi[e >> 1] |= (uint32_t)h << 16; mid[e >> 1] |= (uint32_t)m << 16; lo[e >> 1] |= (uint32_t)l << 16; }
                                 else { hi[e >> 1] = h; mid[e >> 1] = m; lo[e >> 1] = l; }
                             }
                             uint16_t* prow = p.cp + gm * p.ldcp + ncol;
                             *reinterpret_cast<uint4*>(prow) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-                            *reinterpret_cast<uint4*>(prow + p.N) = make_uint4(mid[0], mid[1], mid[2], mid[3]);
-                            *reinterpret_cast<uint4*>(prow + 2 * p.N) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+                            *reinterpret_cast<uint4*>(prow + p.cp_kp) = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+                            if (!F16) *reinterpret_cast<uint4*>(prow + 2 * p.cp_kp) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
                         }
                     } else if (col_pad) {
                         *reinterpret_cast<uint4*>(p.cb + gm * p.ldcb + ncol) = make_uint4(0u, 0u, 0u, 0u);
+                    }
+                    if (!col_in && p.cp != nullptr && ncol < p.cp_kp) {  // the planes' pad columns: the next layer's K tail
+                        uint16_t* prow = p.cp + gm * p.ldcp + ncol;
+                        *reinterpret_cast<uint4*>(prow) = make_uint4(0u, 0u, 0u, 0u);
+                        *reinterpret_cast<uint4*>(prow + p.cp_kp) = make_uint4(0u, 0u, 0u, 0u);
+                        if (!F16) *reinterpret_cast<uint4*>(prow + 2 * p.cp_kp) = make_uint4(0u, 0u, 0u, 0u);
                     }
                 }
             }
@@ -430,9 +443,9 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, long long mb, long lo
     return;
 #endif
 
-    if (p.resf != nullptr || p.dmaskf != nullptr) p8_epilogue<2>(p, s.acc, p8sm, wave, lane, m0, n0);
-    else if (p.res != nullptr || p.dmask != nullptr) p8_epilogue<1>(p, s.acc, p8sm, wave, lane, m0, n0);
-    else p8_epilogue<0>(p, s.acc, p8sm, wave, lane, m0, n0);
+    if (p.resf != nullptr || p.dmaskf != nullptr) p8_epilogue<2, F16>(p, s.acc, p8sm, wave, lane, m0, n0);
+    else if (p.res != nullptr || p.dmask != nullptr) p8_epilogue<1, F16>(p, s.acc, p8sm, wave, lane, m0, n0);
+    else p8_epilogue<0, F16>(p, s.acc, p8sm, wave, lane, m0, n0);
     P8_STAMP(151)
 }
 
@@ -485,7 +498,9 @@ bool dhaug_p8_supported(const dhaug_gemm::GemmArgs& p) {
     const long long ldmax = p.lda > p.ldb ? p.lda : p.ldb;
     const auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
     const bool planes = p.xp_lg != 0;
-    if (planes && !(p.xp_lg >= 1 && p.xp_lg <= 8 && p.xp_kp == ((long long)P_BK << (p.xp_lg - 1)) && p.K == 6 * p.xp_kp && p.lda >= 3 * p.xp_kp))
+    // (six bf16 terms of three pieces, or -- the IEEE-half launcher -- three terms of two)
+    if (planes && !(p.xp_lg >= 1 && p.xp_lg <= 8 && p.xp_kp == ((long long)P_BK << (p.xp_lg - 1)) &&
+                    ((p.K == 6 * p.xp_kp && p.lda >= 3 * p.xp_kp) || (p.K == 3 * p.xp_kp && p.lda >= 2 * p.xp_kp))))
         return false;
     if (!(p.M > 0 && p.K >= 2 * P_BK && p.K % 8 == 0 && p.N % 8 == 0 && p.npad % 8 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && (planes || p.lda >= p.K) &&
           p.ldb >= p.K && ldmax * 2 * P_BM < (1ll << 31) && p.dbits == nullptr && p.dbits2 == nullptr && al(p.A, 16) && al(p.B, 16)))
@@ -498,7 +513,7 @@ bool dhaug_p8_supported(const dhaug_gemm::GemmArgs& p) {
     if (p.dmask != nullptr && !(p.ld_dmask % 8 == 0 && al(p.dmask, 16))) return false;
     if (p.resf != nullptr && !(p.ld_resf % 4 == 0 && al(p.resf, 16))) return false;
     if (p.dmaskf != nullptr && !(p.ld_dmaskf % 4 == 0 && al(p.dmaskf, 16))) return false;
-    if (p.cp != nullptr && !(p.cf != nullptr && p.ldcp % 8 == 0 && p.ldcp >= 3 * p.N && al(p.cp, 16))) return false;
+    if (p.cp != nullptr && !(p.cf != nullptr && p.ldcp % 8 == 0 && p.cp_kp % 8 == 0 && p.cp_kp >= p.N && p.ldcp >= 2 * p.cp_kp && al(p.cp, 16))) return false;
     return true;
 }
 

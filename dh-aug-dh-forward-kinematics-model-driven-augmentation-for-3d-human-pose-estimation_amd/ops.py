@@ -299,9 +299,25 @@ def split_f16(src, mode, pad_cols=None):
     assert s.dtype == torch.float32 and s.is_cuda and s.dim() == 2 and s.stride(1) == 1
     rows, cols = s.shape
     pad_cols = ceil_to(cols, 16) if pad_cols is None else pad_cols
-    dst = torch.empty((rows, 3 * pad_cols), dtype=torch.float16, device=s.device)
+    dst = torch.empty((rows, (2 if mode == 2 else 3) * pad_cols), dtype=torch.float16, device=s.device)
     _lib.call("dhaug_split_f16", _p(s), s.stride(0), _p(dst), rows, cols, pad_cols, mode, _stream())
     return dst
+
+
+def gemm_nt_f16x3_planes(A, B, N, kp, a_planes, bias=None, res_f32=None, act=0, slope=0.0, planes_kp=0):
+    """gemm_nt_f16x3 with the split left out of a chain of layers (dhaug_gemm_f16x3_planes): A = split_f16(x, 2, kp) = [hi|lo] (a_planes;
+    kp = 64 * 2^j) or the mode 0 operand; B = split_f16(W, 1, kp); planes_kp > 0: returns (out, planes) with planes = split_f16(out, 2,
+    planes_kp) written by the GEMM's epilogue."""
+    assert A.dtype == torch.float16 and B.dtype == torch.float16 and A.is_cuda and B.is_cuda and A.stride(1) == 1
+    M = A.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    cp = torch.empty((M, 2 * planes_kp), dtype=torch.float16, device=A.device) if planes_kp else None
+    if bias is not None:
+        bias = _dev(bias, torch.float32, "gemm_nt_f16x3_planes")
+    _lib.call("dhaug_gemm_f16x3_planes", _p(A), A.stride(0), int(bool(a_planes)), _p(B), B.stride(0), _p(bias), _p(res_f32),
+              0 if res_f32 is None else res_f32.stride(0), _p(out), out.stride(0), _p(cp), 0 if cp is None else cp.stride(0), int(planes_kp), M, N, kp,
+              act, float(slope), _stream())
+    return (out, cp) if planes_kp else out
 
 
 def gemm_f16x3_ok(N, K3, bias=None, res_f32=None):

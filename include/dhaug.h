@@ -404,7 +404,8 @@ int dhaug_gemm_bf16x6_planes(const uint16_t* A_planes, int64_t lda, const uint16
                              int64_t kp, int x_order, int act, float slope, void* stream);
 
 /* The same split with IEEE-half pieces, x = hi + lo (22 significant bits; three product terms: mode 0 row = [hi|hi|lo], mode 1
- * [hi|lo|hi]): the operands of dhaug_gemm_f16x3.  |x| < 65 504. */
+ * [hi|lo|hi]; mode 2: the two distinct pieces once, [hi|lo], dst (rows, 2*pad_cols)): the operands of dhaug_gemm_f16x3[_planes].
+ * |x| < 65 504. */
 int dhaug_split_f16(const float* src, int64_t ld_src, uint16_t* dst, int64_t rows, int64_t cols, int64_t pad_cols, int mode,
                     void* stream);
 
@@ -418,6 +419,17 @@ int dhaug_split_f16(const float* src, int64_t ld_src, uint16_t* dst, int64_t row
 int dhaug_gemm_f16x3(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias, const float* residual_f32,
                      int64_t ld_res_f32, float* c_f32, int64_t ldc_f32, int64_t M, int64_t N, int64_t K, int act, float slope,
                      void* stream);
+/* The same layer with the split LEFT OUT of the chain of layers: the activation side may come as the two distinct pieces [hi|lo] of kp
+ * columns each (a_planes != 0: A = dhaug_split_f16(x, mode 2), lda >= 2 kp, kp = 64 * 2^j -- DenseDim 1000 is padded to 1 024 --; the
+ * kernel reads piece (0 0 1)[s] for K-segment s of B = dhaug_split_f16(W, mode 1, pad kp); a_planes == 0: A is the mode 0 operand,
+ * lda >= 3 kp, any kp), and the result may be written once more as such pieces (c_planes, optional: planes_kp >= N columns per piece,
+ * ld_planes >= 2 planes_kp, columns [N, planes_kp) zero) -- bit for bit dhaug_split_f16(c_f32, mode 2, pad planes_kp), from the
+ * epilogue's registers: the next layer's operand without a split launch (4 instead of 6 bytes per value, read and written once).
+ * Same product terms in the same order as dhaug_gemm_f16x3 on the mode 0 operand of the same padded width: identical results.
+ * DHAUG_EUNSUPPORTED where the ping-pong kernel does not take the shape. */
+int dhaug_gemm_f16x3_planes(const uint16_t* A, int64_t lda, int a_planes, const uint16_t* B, int64_t ldb, const float* bias,
+                            const float* residual_f32, int64_t ld_res_f32, float* c_f32, int64_t ldc_f32, uint16_t* c_planes, int64_t ld_planes,
+                            int64_t planes_kp, int64_t M, int64_t N, int64_t kp, int act, float slope, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Fused multi-layer forward (one launch per network; activations stay in LDS)

@@ -268,3 +268,36 @@ def test_six_segment_input_layer_writes_its_results_planes(ops, M, N, k, kp):
     assert torch.equal(got, want) and torch.equal(planes, ops.split_bf16(want, 2, 6, N))
     ref = torch.relu(x.double().cpu() @ W.double().cpu().t() + bias.double().cpu())
     assert maxabs(want, ref) <= 2e-6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("M,N,K", [(3000, 1000, 1000), (513, 256, 256), (2048 + 7, 1000, 432)])
+def test_f16x3_layer_chain_without_split_launches(ops, M, N, K):
+    """dhaug_gemm_f16x3_planes: the activation side as its two distinct pieces [hi|lo] (piece width the next power of two: 1 024 at DenseDim
+    1000), the result's pieces written by the epilogue with zero pad columns -- same bits as dhaug_gemm_f16x3 on the mode 0 operand of the
+    same padded width; a second layer fed with the first one's planes equals the layer fed with a split launch."""
+    g = torch.Generator().manual_seed(4)
+    kp = 64
+    while kp < K:
+        kp *= 2
+    npw = 64
+    while npw < N:
+        npw *= 2
+    x = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias, res = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+    B3 = ops.split_f16(W, 1, kp)
+    A3, A2 = ops.split_f16(x, 0, kp), ops.split_f16(x, 2, kp)
+    assert A2.shape == (M, 2 * kp) and torch.equal(A2[:, :kp], A3[:, :kp]) and torch.equal(A2[:, kp:], A3[:, 2 * kp:])
+    want = ops.gemm_nt_f16x3(A3, B3, N, 3 * kp, bias=bias, res_f32=res, act=1)
+    got, planes = ops.gemm_nt_f16x3_planes(A2, B3, N, kp, True, bias=bias, res_f32=res, act=1, planes_kp=npw)
+    assert torch.equal(got, want)
+    assert torch.equal(planes, ops.split_f16(want, 2, npw)) and float(planes[:, N:npw].abs().max() if npw > N else 0.0) == 0.0
+    got0, planes0 = ops.gemm_nt_f16x3_planes(A3, B3, N, kp, False, bias=bias, res_f32=res, act=1, planes_kp=npw)   # six... the mode 0 operand in, planes out
+    assert torch.equal(got0, want) and torch.equal(planes0, planes)
+    ref = torch.relu(x.double().cpu() @ W.double().cpu().t() + bias.double().cpu() + res.double().cpu())
+    assert maxabs(want, ref) <= 3e-6 * max(1.0, ref.abs().max().item())
+    # the next layer from those planes
+    W2 = (torch.randn(256, N, generator=g) / N ** 0.5).cuda()
+    B2 = ops.split_f16(W2, 1, npw)
+    nxt = ops.gemm_nt_f16x3_planes(planes, B2, 256, npw, True)
+    assert torch.equal(nxt, ops.gemm_nt_f16x3(ops.split_f16(want, 0, npw), B2, 256, 3 * npw))
