@@ -92,6 +92,23 @@ def test_argument_errors_are_returned_not_thrown(built):
     mis = ctypes.c_void_p(ctypes.addressof(buf) + 4)
     assert L.dhaug_fk_forward(mis, mis, mis, mis, 1, 16, None) == -2                 # misaligned
     assert L.dhaug_gemm_bf16(mis, 8, mis, 8, None, None, 0, None, 0, None, 0, 0, None, 0, 4, 4, 24, 0, 0.0, None) in (-1, -3)
+    # the round-6 entries: argument checks of the planes products and of the contraction's planes fields (no launch is reached)
+    big = (ctypes.c_float * 4096)()
+    a16 = ctypes.c_void_p((ctypes.addressof(big) + 15) & ~15)
+    assert L.dhaug_gemm_bf16x6_planes(a16, 768, a16, 1536, None, None, 0, None, 0, 0, 0.0, a16, 256, None, 0, 4, 256, 256, 3, 0, 0.0, None) == -1      # x_order 3
+    assert L.dhaug_gemm_bf16x6_planes(a16, 768, a16, 1536, None, None, 0, None, 0, 0, 0.0, a16, 256, None, 0, 4, 256, 192, 0, 0, 0.0, None) == -3      # piece width not 64 * 2^j
+    assert L.dhaug_gemm_bf16x6_planes(a16, 512, a16, 1536, None, None, 0, None, 0, 0, 0.0, a16, 256, None, 0, 4, 256, 256, 0, 0, 0.0, None) == -2      # lda < 3 kp
+    assert L.dhaug_gemm_bf16x6_planes(a16, 768, a16, 1536, None, None, 0, None, 0, 0, 0.0, a16, 256, None, 0, 0, 256, 256, 0, 0, 0.0, None) == 0       # empty batch
+    assert L.dhaug_gemm_f16x3_planes(a16, 512, 1, a16, 768, None, None, 0, a16, 256, None, 0, 0, 4, 256, 200, 0, 0.0, None) == -3                        # planes need 64 * 2^j
+    assert L.dhaug_gemm_f16x3_planes(a16, 512, 1, a16, 768, None, None, 0, a16, 256, a16, 256, 256, 4, 256, 256, 0, 0.0, None) == -2                     # ld_planes < 2 planes_kp
+    assert L.dhaug_split_bf16(a16, 64, a16, 4, 64, 64, 2, 3, None) == -1                                                                                # mode 2 is a six-term layout
+    lay = (dhaug_amd._lib.TnLayer * 1)()
+    lay[0].A, lay[0].lda, lay[0].B, lay[0].ldb = a16.value, 64, a16.value, 64
+    lay[0].C, lay[0].ldc, lay[0].M, lay[0].N1, lay[0].N2 = a16.value, 64, 64, 64, 64
+    lay[0].planes_a = 3
+    assert L.dhaug_gemm_tn_group_bf16(lay, 1, a16, None) == -1                                                                                          # planes_a out of range
+    lay[0].planes_a, lay[0].M = 2, 64                                                                                                                    # planes: M must be 6 x rows
+    assert L.dhaug_gemm_tn_group_bf16(lay, 1, a16, None) == -1
     with pytest.raises(RuntimeError):
         dhaug_amd._lib.check(-2, "x")
 
