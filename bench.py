@@ -234,6 +234,9 @@ def main():
         # plain `python bench.py --gpus N`: this process becomes the launcher.  It has not touched the GPU (importing
         # torch does not initialise HIP) and never will: it starts N rank processes and relays rank 0's JSON line.
         sys.exit(launch_ranks(a.gpus))
+    # (the pool's host driver only supports dmabuf IPC: without this RCCL's first exchange fails with hipIpcGetMemHandle; it is exported
+    # on the boxes already -- kept here for a launcher that starts the ranks with a clean environment)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
