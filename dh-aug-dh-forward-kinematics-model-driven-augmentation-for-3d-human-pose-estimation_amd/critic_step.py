@@ -43,10 +43,13 @@ RANK1 = os.environ.get("DHAUG_NO_RANK1") is None
 # run (HBM-bound) beside the penalty and the launch-bound tangent sweep; the interpolated rows' part follows the tangents
 TN_SPLIT = os.environ.get("DHAUG_NO_TN_SPLIT") is None
 _TN_SIDE = {}
-# workgroups of sweep 4's side-stream part: it runs beside the penalty and the tangent sweep, whose kernels crawl while a
-# one-per-CU launch holds every CU (measured, iteration at B = 65 536: 256 -> 7.53 ms, 192 -> 7.44, 128 -> 7.31, 96 -> 7.28,
-# 80 -> 7.49, 64 -> 7.86: below ~90 the side part becomes the step's long pole)
-TN_SIDE_WGS = int(os.environ.get("DHAUG_TN_SIDE_WGS", "128"))
+# workgroups of sweep 4's side-stream part: it runs beside the penalty and the tangent sweep.  Round 4 measured an optimum near 100
+# (iteration at B = 65 536: 256 -> 7.53 ms, 192 -> 7.44, 128 -> 7.31, 96 -> 7.28, 80 -> 7.49, 64 -> 7.86: the tangent sweep's
+# launch-bound kernels crawled while a one-per-CU launch held every CU); since the tangent sweep runs as block / top-of-the-critic
+# launches (round 5) the side part is the longer of the two and wants the whole card -- round 6 (bench.py --workload gan_step), one box:
+# 96 -> 7.10 ms, 112 -> 6.91, 128 -> 6.64, 144 -> 6.67, 160 -> 6.60; another: 128 -> 6.49 (three runs), 160 -> 6.46, 192 -> 6.46,
+# 224 -> 6.39, 256 -> 6.40 (four runs, 6.35 - 6.44); the video iteration does not care (13.25 either way)
+TN_SIDE_WGS = int(os.environ.get("DHAUG_TN_SIDE_WGS", "256"))
 # the second part's contractions started beside what is left of the first (only the sums wait): measured 6.87 against 6.94 ms
 # per iteration -- the contractions are HBM-bound either way -- so it is an option, off
 TN_PHASED = os.environ.get("DHAUG_TN_PHASED") is not None
