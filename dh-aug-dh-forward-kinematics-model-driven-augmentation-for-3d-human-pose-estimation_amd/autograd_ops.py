@@ -152,16 +152,19 @@ def _operand(x, width):
     return ops.cast_pad_bf16(x, width)
 
 
-def _raw_linear(x, W, bias, res, act, slope, prec, out_f32):
+def _raw_linear(x, W, bias, res, act, slope, prec, out_f32, out=None):
     N, K = W.shape
     Kp = ceil16(K)
     if prec == "bf16":
         xb = _operand(x, Kp)
         rb = res if (res is not None and res.dtype == BF16) else None
         rf = res if (res is not None and res.dtype != BF16) else None
+        # out: a bf16 column block of a wider buffer (a branch's result written into its place in the concatenation; no column beyond
+        # the view's own is touched)
         cb, cf = ops.gemm_nt(xb, _w_nt(W, Kp, prec), N, Kp, bias=bias, res_bf16=rb, res_f32=rf, act=act, slope=slope,
-                             out_bf16=not out_f32, n_pad=ceil16(N), out_f32=out_f32)
+                             out_bf16=not out_f32, n_pad=ceil16(N), out_f32=out_f32, c_bf16=None if out_f32 else out)
         return cf if out_f32 else cb
+    assert out is None, "an output view is taken by the bf16 path only"
     if prec == F16X3_LAYER:
         # the fused parity programs' arithmetic (IEEE-half pairs, three product terms) as a layer GEMM on the ping-pong tiles: forward
         # passes without a graph at widths the fused programs do not cover (DenseDim 1000); a layer whose shape the kernel does not take
@@ -235,8 +238,8 @@ class LinearFn(torch.autograd.Function):
     """y = act(x W^T + bias + res).  x: fp32 (M,K) network input or bf16 (M,ceil16 K) hidden activation."""
 
     @staticmethod
-    def forward(ctx, x, W, bias, res, act, slope, prec, out_f32):
-        y = _raw_linear(x, W, bias, res, act, slope, prec, out_f32)
+    def forward(ctx, x, W, bias, res, act, slope, prec, out_f32, out=None):
+        y = _raw_linear(x, W, bias, res, act, slope, prec, out_f32, out)
         ctx.save_for_backward(x, W, y if act != ACT_NONE else None)
         ctx.cfg = (act, slope, prec, bias is not None, None if res is None else (res.dtype, res.shape))
         # gradient slots of a FusedAdam flat bucket (set by the optimizer), see backward
@@ -278,7 +281,7 @@ class LinearFn(torch.autograd.Function):
             gb = ColSumFn.apply(gz, N)
         if res_info is not None and ctx.needs_input_grad[3]:
             gres = gz if (gz.dtype == res_info[0] and gz.shape == res_info[1]) else ReshapeGradFn.apply(gz, res_info)
-        return gx, gW, gb, gres, None, None, None, None
+        return gx, gW, gb, gres, None, None, None, None, None
 
 
 class LinearTFn(torch.autograd.Function):
@@ -475,7 +478,11 @@ def res_block(x, W1, b1, W2, b2, act=ACT_RELU, slope=0.0, prec="bf16"):
     return linear(h, W2, b2, x, act, slope, prec)
 
 
-def linear(x, W, bias=None, res=None, act=ACT_NONE, slope=0.0, prec="bf16", out_f32=False):
+def linear(x, W, bias=None, res=None, act=ACT_NONE, slope=0.0, prec="bf16", out_f32=False, out=None):
+    """out (bf16 arithmetic, passes without a graph): write the result into this (M, N) column block of a wider bf16 buffer"""
+    if out is not None:
+        assert prec == "bf16" and not out_f32 and not torch.is_grad_enabled()
+        return LinearFn.apply(x, W, bias, res, act, slope, prec, False, out)
     return LinearFn.apply(x, W, bias, res, act, slope, prec, out_f32 or prec != "bf16")
 
 

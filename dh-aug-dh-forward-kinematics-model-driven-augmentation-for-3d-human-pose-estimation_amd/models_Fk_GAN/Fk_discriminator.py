@@ -28,11 +28,31 @@ def _no_graph(module, x):
     return not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters())))
 
 
-def _branch(x, first, blocks, prec):
+def _branch(x, first, blocks, prec, out=None):
+    """Linear + ReLU and the myResNet blocks of one input branch.  out: the branch's column block of the concatenation buffer (_cat_buffer):
+    the last layer writes its result there"""
     h = A.linear(x, first.weight, first.bias, None, A.ACT_RELU, 0.0, prec)
-    for b in blocks:
+    for b in (blocks if out is None else blocks[:-1]):
         h = b(h, prec)
+    if out is not None:
+        b = blocks[-1]
+        h1 = A.linear(h, b.fc1.weight, b.fc1.bias, None, A.ACT_RELU, 0.0, prec)
+        h = A.linear(h1, b.fc2.weight, b.fc2.bias, h, A.ACT_RELU, 0.0, prec, out=out)
     return h
+
+
+def _cat_buffer(n, Dw, x, prec):
+    """Passes without a graph in bf16 (the layer-by-layer forward at widths the fused programs do not cover: the reference's default
+    DenseDim 1000): the concatenation of n branch results as ONE buffer the branches' last layers write their column blocks into -- as the
+    training steps do -- instead of a torch.cat copy (262 MB and 224 us of a 4 ms forward at B = 65 536).  Returns the (M, ceil16(n Dw))
+    buffer and the n (M, Dw) views, or None where the blocks would not be 16-byte aligned / a graph is being built."""
+    if prec != "bf16" or torch.is_grad_enabled() or Dw % 8 != 0 or not x.is_cuda:
+        return None
+    M, total = x.shape[0], n * Dw
+    buf = torch.empty((M, A.ceil16(total)), dtype=torch.bfloat16, device=x.device)
+    if buf.shape[1] > total:
+        buf[:, total:].zero_()
+    return buf, [buf[:, i * Dw:(i + 1) * Dw] for i in range(n)]
 
 
 def _cat(outs, widths, prec):
@@ -79,11 +99,12 @@ class Fk_3D_Discriminator(nn.Module):
         p = forward_precision(p)
         if center:
             x = A.center_flip(x.reshape(-1, 16, 3), True, False).reshape(-1, 48)
-        k = _branch(A.KcsFn.apply(x, True), self.special_KCS_previous[0],
-                    (self.special_KCS_block1, self.special_KCS_block2, self.special_KCS_block3), p)
-        q = _branch(x, self.previous[0], (self.block1, self.block2, self.block3), p)
         Dw = self.args.Dis_DenseDim_3D
-        m = _cat((k, q), (Dw, Dw), p)
+        cb = _cat_buffer(2, Dw, x, p)
+        k = _branch(A.KcsFn.apply(x, True), self.special_KCS_previous[0],
+                    (self.special_KCS_block1, self.special_KCS_block2, self.special_KCS_block3), p, out=None if cb is None else cb[1][0])
+        q = _branch(x, self.previous[0], (self.block1, self.block2, self.block3), p, out=None if cb is None else cb[1][1])
+        m = _cat((k, q), (Dw, Dw), p) if cb is None else cb[0]
         m = A.linear(m, self.merge_previous[0].weight, self.merge_previous[0].bias, None, A.ACT_RELU, 0.0, p)
         m = self.merge_block1(m, p)
         return A.linear(m, self.output.weight, self.output.bias, None, A.ACT_NONE, 0.0, p, out_f32=True)

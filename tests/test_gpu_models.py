@@ -734,3 +734,33 @@ def test_parity_program_computes_kcs_itself(M):
         s3, s2 = M.dis.score_fake_pair(D3, D2, x3, kb, x2.reshape(300, 16, 2))
     assert ops._lib.CALLS[0] == calls + 1
     assert torch.equal(s3, got3) and torch.equal(s2, got2)
+
+
+@pytest.mark.parametrize("D,B", [(1000, 300), (200, 77), (40, 64)])
+def test_branch_results_written_into_the_concatenation(M, D, B):
+    """Fk_3D_Discriminator layer by layer in bf16 without a graph (widths the fused programs do not cover -- the reference's default 1000):
+    the branches' last layers write their column blocks of the concatenation buffer themselves (Fk_discriminator._cat_buffer) -- the same
+    logits bit for bit as the pass that concatenates with torch.cat (grad mode on: a graph could be built), and no cat copy launched."""
+    args = make_args(batch_size=B, Dis_DenseDim_3D=D)
+    d3 = M.dis.Fk_3D_Discriminator("cuda", args)
+    d3.load_state_dict(GU.seeded_state_dict(GU.shapes_d3(D), 71))
+    d3.precision = "bf16"
+    d3 = d3.cuda()
+    x = GU.synth_pose16(B, seed=5).cuda()
+    x = x - x[:, :1]
+    calls = []
+    real_cat = torch.cat
+    def spy(*a, **k):
+        calls.append(1)
+        return real_cat(*a, **k)
+    torch.cat = spy
+    try:
+        with torch.no_grad():
+            fast = d3(x)
+        n_fast = len(calls)
+        with torch.enable_grad():
+            slow = d3(x).detach()
+    finally:
+        torch.cat = real_cat
+    assert (n_fast == 0) == (D % 8 == 0) and len(calls) > n_fast
+    assert torch.equal(fast, slow)
