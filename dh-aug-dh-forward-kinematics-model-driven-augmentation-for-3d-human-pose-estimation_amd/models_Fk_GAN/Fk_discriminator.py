@@ -173,20 +173,23 @@ class Video_motion_Fk_3D_Discriminator(nn.Module):
         self.kcs_merge_block1 = myResNet(100)
         self.kcs_output = nn.Linear(100, 1)
 
-    def _b(self, x, name):
+    def _b(self, x, name, out=None):
         return _branch(x.contiguous(), getattr(self, name + "_previous")[0],
-                       [getattr(self, "%s_block%d" % (name, i)) for i in (1, 2, 3)], forward_precision(self.precision))
+                       [getattr(self, "%s_block%d" % (name, i)) for i in (1, 2, 3)], forward_precision(self.precision), out=out)
 
     def forward(self, input):
         R, p = self.video_frame_num, forward_precision(self.precision)
         x = input.reshape(-1, 48)
         kc = A.KcsFn.apply(x, False).reshape(-1, R * 15)
-        outs = [self._b(kc, "special_KCS"), self._b(_frame_diff(kc, R, 15), "diff_special_KCS")]
+        Dw = self.args.video_Dis_DenseDim_3D
+        cb = _cat_buffer(self.branch_num, Dw, kc, p)               # (passes without a graph in bf16: no torch.cat copy)
+        view = (lambda i: None) if cb is None else (lambda i: cb[1][i])
+        outs = [self._b(kc, "special_KCS", view(0)), self._b(_frame_diff(kc, R, 15), "diff_special_KCS", view(1))]
         if self.use_pos:
-            outs.append(self._b(x.reshape(-1, R * 48), "pos_3d"))
+            outs.append(self._b(x.reshape(-1, R * 48), "pos_3d", view(len(outs))))
         if self.use_diff:
-            outs.append(self._b(_frame_diff(x, R, 48), "diff_pos_3d"))
-        m = _cat(outs, [self.args.video_Dis_DenseDim_3D] * len(outs), p)
+            outs.append(self._b(_frame_diff(x, R, 48), "diff_pos_3d", view(len(outs))))
+        m = _cat(outs, [Dw] * len(outs), p) if cb is None else cb[0]
         m = A.linear(m, self.kcs_merge_previous[0].weight, self.kcs_merge_previous[0].bias, None, A.ACT_RELU, 0.0, p)
         m = self.kcs_merge_block1(m, p)
         return A.linear(m, self.kcs_output.weight, self.kcs_output.bias, None, A.ACT_NONE, 0.0, p, out_f32=True)
@@ -206,17 +209,19 @@ class Video_motion_Fk_2D_Discriminator(nn.Module):
         self.merge_block1 = myResNet(100)
         self.merge_output = nn.Linear(100, 1)
 
-    def _b(self, x, name):
+    def _b(self, x, name, out=None):
         return _branch(x.contiguous(), getattr(self, name + "_previous")[0],
-                       [getattr(self, "%s_block%d" % (name, i)) for i in (1, 2, 3)], forward_precision(self.precision))
+                       [getattr(self, "%s_block%d" % (name, i)) for i in (1, 2, 3)], forward_precision(self.precision), out=out)
 
     def forward(self, input):
         R, p = self.video_frame_num, forward_precision(self.precision)
         x = input.reshape(-1, 32)
-        a = self._b(x.reshape(-1, R * 32), "pos_2d")
-        b = self._b(_frame_diff(x.reshape(-1, 16, 2)[:, 0, :], R, 2), "root_diff_2d")
         Dw = self.args.video_Dis_DenseDim_2D
-        m = _cat((a, b), (Dw, Dw), p)
+        xa = x.reshape(-1, R * 32)
+        cb = _cat_buffer(2, Dw, xa, p)                             # (passes without a graph in bf16: no torch.cat copy)
+        a = self._b(xa, "pos_2d", None if cb is None else cb[1][0])
+        b = self._b(_frame_diff(x.reshape(-1, 16, 2)[:, 0, :], R, 2), "root_diff_2d", None if cb is None else cb[1][1])
+        m = _cat((a, b), (Dw, Dw), p) if cb is None else cb[0]
         m = A.linear(m, self.merge_previous[0].weight, self.merge_previous[0].bias, None, A.ACT_RELU, 0.0, p)
         m = self.merge_block1(m, p)
         return A.linear(m, self.merge_output.weight, self.merge_output.bias, None, A.ACT_NONE, 0.0, p, out_f32=True)

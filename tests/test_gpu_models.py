@@ -764,3 +764,33 @@ def test_branch_results_written_into_the_concatenation(M, D, B):
         torch.cat = real_cat
     assert (n_fast == 0) == (D % 8 == 0) and len(calls) > n_fast
     assert torch.equal(fast, slow)
+
+
+@pytest.mark.parametrize("D", [1000, 40])
+def test_motion_critics_write_their_branches_into_the_concatenation(M, D):
+    """the same for the motion critics (four / two branches, clips of nine frames): bf16 without a graph = the pass that uses torch.cat"""
+    B, R = 24, 9
+    args = make_args(batch_size=B, single_or_multi_train_mode="multi", architecture="3,3", video_Dis_DenseDim_3D=D, video_Dis_DenseDim_2D=D)
+    s3, s2 = _motion_shapes(D, R)
+    M3 = load(M.dis.Video_motion_Fk_3D_Discriminator("cuda", args, R), GU.seeded_state_dict(s3, 72), "bf16")
+    M2 = load(M.dis.Video_motion_Fk_2D_Discriminator("cuda", args, R), GU.seeded_state_dict(s2, 73), "bf16")
+    g = torch.Generator().manual_seed(3)
+    x3 = (GU.synth_pose16(B * R, seed=6).reshape(B, R, 16, 3)).cuda()
+    x2 = ((torch.rand(B, R, 16, 2, generator=g) - 0.5) * 1.2).cuda()
+    for net, x in ((M3, x3), (M2, x2)):
+        calls = []
+        real_cat = torch.cat
+        def spy(*a, **k):
+            calls.append(1)
+            return real_cat(*a, **k)
+        torch.cat = spy
+        try:
+            with torch.no_grad():
+                fast = net(x)
+            n_fast = len(calls)
+            with torch.enable_grad():
+                slow = net(x).detach()
+        finally:
+            torch.cat = real_cat
+        assert n_fast == 0 and len(calls) > 0
+        assert torch.equal(fast, slow)
