@@ -164,7 +164,7 @@ def _raw_linear(x, W, bias, res, act, slope, prec, out_f32, out=None):
         cb, cf = ops.gemm_nt(xb, _w_nt(W, Kp, prec), N, Kp, bias=bias, res_bf16=rb, res_f32=rf, act=act, slope=slope,
                              out_bf16=not out_f32, n_pad=ceil16(N), out_f32=out_f32, c_bf16=None if out_f32 else out)
         return cf if out_f32 else cb
-    assert out is None, "an output view is taken by the bf16 path only"
+    assert out is None or (prec == F16X3_LAYER and F16X3_PLANES), "an output view is taken by the bf16 and the f16x3 layer paths only"
     if prec == F16X3_LAYER:
         # the fused parity programs' arithmetic (IEEE-half pairs, three product terms) as a layer GEMM on the ping-pong tiles: forward
         # passes without a graph at widths the fused programs do not cover (DenseDim 1000); a layer whose shape the kernel does not take
@@ -180,17 +180,21 @@ def _raw_linear(x, W, bias, res, act, slope, prec, out_f32, out=None):
                 have = getattr(x, "_dhaug_f16_planes", None)
                 if have is not None and (have.shape[1] != 2 * kp2 or have.shape[0] != xf.shape[0]):
                     have = None
-                emit = _pow2_width(N) if N >= 64 else 0
+                emit = _pow2_width(N) if (N >= 64 and out is None) else 0       # (out: a block of a concatenation -- its consumer splits the whole)
                 if have is not None:
-                    r = ops.gemm_nt_f16x3_planes(have, _w_nt(W, kp2, prec), N, kp2, True, bias=bias, res_f32=rf, act=act, slope=slope, planes_kp=emit)
+                    r = ops.gemm_nt_f16x3_planes(have, _w_nt(W, kp2, prec), N, kp2, True, bias=bias, res_f32=rf, act=act, slope=slope, planes_kp=emit,
+                                                 out=out)
                 else:
                     r = ops.gemm_nt_f16x3_planes(ops.split_f16(xf, 0, Kp), _w_nt(W, Kp, prec), N, Kp, False, bias=bias, res_f32=rf, act=act,
-                                                 slope=slope, planes_kp=emit)
+                                                 slope=slope, planes_kp=emit, out=out)
                 if emit:
                     r[0]._dhaug_f16_planes = r[1]
                     return r[0]
                 return r
             return ops.gemm_nt_f16x3(ops.split_f16(xf, 0, Kp), _w_nt(W, Kp, prec), N, 3 * Kp, bias=bias, res_f32=rf, act=act, slope=slope)
+        if out is not None:                          # (a layer the kernel does not take, e.g. an unaligned bias: computed as usual, then placed)
+            out.copy_(_raw_linear(x, W, bias, res, act, slope, "bf16x6", True))
+            return out
         prec = "bf16x6"
     T = TERMS[prec]
     x3 = ops.split_bf16(x.float() if x.dtype == BF16 else x, 0, T, Kp)
@@ -481,8 +485,8 @@ def res_block(x, W1, b1, W2, b2, act=ACT_RELU, slope=0.0, prec="bf16"):
 def linear(x, W, bias=None, res=None, act=ACT_NONE, slope=0.0, prec="bf16", out_f32=False, out=None):
     """out (bf16 arithmetic, passes without a graph): write the result into this (M, N) column block of a wider bf16 buffer"""
     if out is not None:
-        assert prec == "bf16" and not out_f32 and not torch.is_grad_enabled()
-        return LinearFn.apply(x, W, bias, res, act, slope, prec, False, out)
+        assert prec in ("bf16", F16X3_LAYER) and not torch.is_grad_enabled()
+        return LinearFn.apply(x, W, bias, res, act, slope, prec, prec != "bf16", out)
     return LinearFn.apply(x, W, bias, res, act, slope, prec, out_f32 or prec != "bf16")
 
 

@@ -42,16 +42,21 @@ def _branch(x, first, blocks, prec, out=None):
 
 
 def _cat_buffer(n, Dw, x, prec):
-    """Passes without a graph in bf16 (the layer-by-layer forward at widths the fused programs do not cover: the reference's default
-    DenseDim 1000): the concatenation of n branch results as ONE buffer the branches' last layers write their column blocks into -- as the
+    """Passes without a graph in bf16 or as f16x3 layer GEMMs (the layer-by-layer forward at widths the fused programs do not cover: the
+    reference's default DenseDim 1000): the concatenation of n branch results as ONE buffer the branches' last layers write their column blocks into -- as the
     training steps do -- instead of a torch.cat copy (262 MB and 224 us of a 4 ms forward at B = 65 536).  Returns the (M, ceil16(n Dw))
     buffer and the n (M, Dw) views, or None where the blocks would not be 16-byte aligned / a graph is being built."""
-    if prec != "bf16" or torch.is_grad_enabled() or Dw % 8 != 0 or not x.is_cuda:
+    if torch.is_grad_enabled() or Dw % 8 != 0 or not x.is_cuda:
         return None
     M, total = x.shape[0], n * Dw
-    buf = torch.empty((M, A.ceil16(total)), dtype=torch.bfloat16, device=x.device)
-    if buf.shape[1] > total:
-        buf[:, total:].zero_()
+    if prec == A.F16X3_LAYER and A.F16X3_PLANES and A.ops.gemm_f16x3_ok(Dw, 3 * A.ceil16(Dw)):
+        buf = torch.empty((M, total), dtype=torch.float32, device=x.device)      # (fp32 activations: the layers' c_f32 takes a row pitch)
+    elif prec == "bf16":
+        buf = torch.empty((M, A.ceil16(total)), dtype=torch.bfloat16, device=x.device)
+        if buf.shape[1] > total:
+            buf[:, total:].zero_()
+    else:
+        return None
     return buf, [buf[:, i * Dw:(i + 1) * Dw] for i in range(n)]
 
 

@@ -304,13 +304,15 @@ def split_f16(src, mode, pad_cols=None):
     return dst
 
 
-def gemm_nt_f16x3_planes(A, B, N, kp, a_planes, bias=None, res_f32=None, act=0, slope=0.0, planes_kp=0):
+def gemm_nt_f16x3_planes(A, B, N, kp, a_planes, bias=None, res_f32=None, act=0, slope=0.0, planes_kp=0, out=None):
     """gemm_nt_f16x3 with the split left out of a chain of layers (dhaug_gemm_f16x3_planes): A = split_f16(x, 2, kp) = [hi|lo] (a_planes;
     kp = 64 * 2^j) or the mode 0 operand; B = split_f16(W, 1, kp); planes_kp > 0: returns (out, planes) with planes = split_f16(out, 2,
     planes_kp) written by the GEMM's epilogue."""
     assert A.dtype == torch.float16 and B.dtype == torch.float16 and A.is_cuda and B.is_cuda and A.stride(1) == 1
     M = A.shape[0]
-    out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    assert out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1      # (may be a column block of a wider buffer)
     cp = torch.empty((M, 2 * planes_kp), dtype=torch.float16, device=A.device) if planes_kp else None
     if bias is not None:
         bias = _dev(bias, torch.float32, "gemm_nt_f16x3_planes")

@@ -794,3 +794,33 @@ def test_motion_critics_write_their_branches_into_the_concatenation(M, D):
             torch.cat = real_cat
         assert n_fast == 0 and len(calls) > 0
         assert torch.equal(fast, slow)
+
+
+def test_f16x3_layer_path_writes_branches_into_the_concatenation(M, monkeypatch):
+    """the compliant arithmetic at DenseDim 1000 (f16x3 layer GEMMs, fp32 activations; passes without a graph): the branches' last layers
+    write their fp32 column blocks of the concatenation too -- same logits as the pass that concatenates with torch.cat, which is the one
+    the video_D1000 goldens pinned"""
+    D, B = 1000, 200
+    args = make_args(batch_size=B, Dis_DenseDim_3D=D)
+    d3 = M.dis.Fk_3D_Discriminator("cuda", args)
+    d3.load_state_dict(GU.seeded_state_dict(GU.shapes_d3(D), 74))
+    d3.precision = "f16x3"
+    d3 = d3.cuda()
+    x = GU.synth_pose16(B, seed=7).cuda()
+    x = x - x[:, :1]
+    calls = []
+    real_cat = torch.cat
+    def spy(*a, **k):
+        calls.append(1)
+        return real_cat(*a, **k)
+    torch.cat = spy
+    try:
+        with torch.no_grad():
+            fast = d3(x)
+            n_fast = len(calls)
+            monkeypatch.setattr(M.dis, "_cat_buffer", lambda *a: None)
+            slow = d3(x)
+    finally:
+        torch.cat = real_cat
+    assert n_fast == 0 and len(calls) > 0
+    assert torch.equal(fast, slow)
