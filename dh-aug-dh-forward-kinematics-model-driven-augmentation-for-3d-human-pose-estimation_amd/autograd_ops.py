@@ -171,6 +171,8 @@ def _raw_linear(x, W, bias, res, act, slope, prec, out_f32, out=None):
         # (the 100-wide merge block, the 1-wide logit layer, K < 48) runs in "bf16x6" -- fp32-grade either way
         xf = x.float() if x.dtype == BF16 else x
         rf = res if (res is None or (res.dtype == torch.float32 and res.stride(-1) == 1)) else res.float().contiguous()
+        if Kp < 48:                                  # (a 30- / 32-wide input layer: zero columns up to the kernel's shortest contraction, 3 x 48 --
+            Kp = 48                                  # the same products, and the layer writes its result's pieces like the others)
         if ops.gemm_f16x3_ok(N, 3 * Kp, bias, rf) and xf.dim() == 2 and xf.stride(1) == 1:
             if F16X3_PLANES:
                 # the split left out of the chain of layers: a layer whose result is wide enough to be the next layer's operand writes the

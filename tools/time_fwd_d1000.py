@@ -14,6 +14,9 @@ B, D = int(os.environ.get("PB", "65536")), 1000
 args = synth_args(B, D)
 d = T.my_get_poseFk_model(args, None, Forward_Kinematics_DH_Model(args, ["S1"], None))
 G, D3, D2 = d["model_G"], d["model_d3d"], d["model_d2d"]
+if os.environ.get("PREC"):                                # PREC=f16x3: the compliant arithmetic (f16x3 layer GEMMs at this width)
+    for net in (G, D3, D2):
+        net.precision = os.environ["PREC"]
 z = torch.randn(B, 128, device="cuda")
 x3 = torch.randn(B, 16, 3, device="cuda") * .3
 x2 = torch.rand(B, 16, 2, device="cuda") - .5
