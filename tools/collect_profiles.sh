@@ -5,8 +5,8 @@
 # gpurun_out/profiles/* there afterwards; <round>_STAMP.txt holds the collection time bench.py quotes as traffic_source).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT || exit 1
 R=${1:-r03}
-ONLY=${2:-all}                      # optional: the workloads to (re)collect, e.g. "step video" (tags: fwd fwd_parity step video d3 d3_parity fk; step_parity only when named)
-want() { { [ "$ONLY" = all ] && [ "$1" != step_parity ]; } || [[ " $ONLY " == *" $1 "* ]]; }
+ONLY=${2:-all}                      # optional: the workloads to (re)collect, e.g. "step video" (tags: fwd fwd_parity step video d3 d3_parity fk; step_parity, fwd_d1000, fwd_d1000_parity only when named)
+want() { { [ "$ONLY" = all ] && [ "$1" != step_parity ] && [ "$1" != fwd_d1000 ] && [ "$1" != fwd_d1000_parity ]; } || [[ " $ONLY " == *" $1 "* ]]; }
 O=gpurun_out/profiles
 mkdir -p $O
 B="python bench.py --no-cpu-baseline --no-extra --no-roofline --prewarm 0 --reps 1"
@@ -21,6 +21,9 @@ want fwd_parity && { stats fwd_parity $B --steps 100 --warmup 20 --precision par
 want step && { stats step $B --workload gan_step --steps 10 --warmup 5 --graph off || exit 1; }
 want video && { stats video $B --workload video --steps 5 --warmup 3 --graph off || exit 1; }
 want step_parity && { stats step_parity $B --workload gan_step --precision parity --steps 3 --warmup 2 --graph off || exit 1; }   # (bf16x6; not in "all")
+# the forward at the reference's default DenseDim 1000, layer by layer (bf16 / the compliant f16x3 layer GEMMs); only when named
+want fwd_d1000 && { stats fwd_d1000 python3 tools/time_fwd_d1000.py || exit 1; }
+want fwd_d1000_parity && { export PREC=f16x3; stats fwd_d1000_parity python3 tools/time_fwd_d1000.py || exit 1; unset PREC; }
 want d3 && { stats d3 python tools/prof_fused_d3.py bf16 || exit 1; }
 want d3_parity && { stats d3_parity python tools/prof_fused_d3.py f16x3 || exit 1; }
 want fk && { stats fk python tools/prof_fk.py || exit 1; }
